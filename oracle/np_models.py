@@ -1,0 +1,360 @@
+"""
+oracle/np_models.py -- CPU restatement (NumPy float64) of the reference's model graphs *as written*:
+ResNet-101 + FPN + PyramidROIAlign encoder, RoI head, caption decoders v2 (inject / merge) and v1
+(par-inject, T teacher-forced prefixes), their losses, gradients, Keras AMSGrad and greedy decode.
+
+*** TEST INFRASTRUCTURE, NOT PRODUCT CODE.  PARITY UNPINNED (see np_oracle.py header). ***
+
+Weights are a dict keyed '<keras layer name>/<weight name>' with Keras shapes
+(kernel HWIO / [in,out], LSTM gate blocks i,f,c,o).
+"""
+import numpy as np
+
+from . import np_oracle as O
+
+F64 = np.float64
+
+
+# --------------------------------------------------------------------------------------------
+# Encoder: ResNet-101 + FPN (feature_generation/dense_model.py:82-173, :1404-1427;
+# dense_img_cap_separate_models/modified_dense_model.py:1410-1433)
+# --------------------------------------------------------------------------------------------
+
+def _conv_bn(x, Wt, conv, bn, stride=1, padding='valid', act=True):
+    y = O.conv2d_nhwc(x, Wt[conv + '/kernel'], Wt[conv + '/bias'], stride, padding)
+    y = O.batchnorm_inference(y, Wt[bn + '/gamma'], Wt[bn + '/beta'],
+                              Wt[bn + '/moving_mean'], Wt[bn + '/moving_variance'])
+    return O.relu(y) if act else y
+
+
+def _bottleneck(x, Wt, stage, block, stride, shortcut_conv):
+    cn, bn = 'res%d%s_branch' % (stage, block), 'bn%d%s_branch' % (stage, block)
+    y = _conv_bn(x, Wt, cn + '2a', bn + '2a', stride=stride)            # stride on the first 1x1
+    y = _conv_bn(y, Wt, cn + '2b', bn + '2b', padding='same')
+    y = _conv_bn(y, Wt, cn + '2c', bn + '2c', act=False)
+    sc = _conv_bn(x, Wt, cn + '1', bn + '1', stride=stride, act=False) if shortcut_conv else x
+    return O.relu(y + sc)
+
+
+def resnet_graph(image, Wt, stage4_blocks=22):
+    """resnet_graph(input_image, 'resnet101', stage5=True) (dense_model.py:143-173).
+    stage4_blocks=22 is ResNet-101 (5 = the file's 'resnet50' option, used for fast tests)."""
+    x = np.pad(np.asarray(image, F64), ((0, 0), (3, 3), (3, 3), (0, 0)))   # ZeroPadding2D((3,3))
+    x = _conv_bn(x, Wt, 'conv1', 'bn_conv1', stride=2)
+    x = C1 = O.maxpool3x3s2_same(x)
+    x = _bottleneck(x, Wt, 2, 'a', 1, True)
+    x = _bottleneck(x, Wt, 2, 'b', 1, False)
+    x = C2 = _bottleneck(x, Wt, 2, 'c', 1, False)
+    x = _bottleneck(x, Wt, 3, 'a', 2, True)
+    for blk in 'bcd':
+        x = _bottleneck(x, Wt, 3, blk, 1, False)
+    C3 = x
+    x = _bottleneck(x, Wt, 4, 'a', 2, True)
+    for i in range(stage4_blocks):
+        x = _bottleneck(x, Wt, 4, chr(98 + i), 1, False)
+    C4 = x
+    x = _bottleneck(x, Wt, 5, 'a', 2, True)
+    x = _bottleneck(x, Wt, 5, 'b', 1, False)
+    x = C5 = _bottleneck(x, Wt, 5, 'c', 1, False)
+    return C1, C2, C3, C4, C5
+
+
+def fpn_graph(C2, C3, C4, C5, Wt):
+    """Top-down pathway (dense_model.py:1406-1423). Returns P2,P3,P4,P5,P6."""
+    def conv(x, name, padding='valid'):
+        return O.conv2d_nhwc(x, Wt[name + '/kernel'], Wt[name + '/bias'], 1, padding)
+    P5 = conv(C5, 'fpn_c5p5')
+    P4 = O.upsample2x(P5) + conv(C4, 'fpn_c4p4')
+    P3 = O.upsample2x(P4) + conv(C3, 'fpn_c3p3')
+    P2 = O.upsample2x(P3) + conv(C2, 'fpn_c2p2')
+    P2 = conv(P2, 'fpn_p2', 'same')
+    P3 = conv(P3, 'fpn_p3', 'same')
+    P4 = conv(P4, 'fpn_p4', 'same')
+    P5 = conv(P5, 'fpn_p5', 'same')
+    P6 = O.subsample2(P5)
+    return P2, P3, P4, P5, P6
+
+
+def encoder_features(images_u8, rois_px, Wt, mean_pixel, stage4_blocks=22, return_maps=False):
+    """generate_captions -> keras_model.predict for the GT-RoI variant
+    (modified_dense_model.py:1886-1923, :1522-1527): mold (no resize: the image is already the
+    model's size), ResNet+FPN, PyramidROIAlign on rois/[h,w,h,w].  images_u8 [B,H,W,3],
+    rois_px [B,R,4] (y1,x1,y2,x2).  Returns [B,R,7,7,256]."""
+    x = O.mold_image(images_u8, mean_pixel)
+    B, H, W, _ = x.shape
+    _, C2, C3, C4, C5 = resnet_graph(x, Wt, stage4_blocks)
+    P2, P3, P4, P5, _ = fpn_graph(C2, C3, C4, C5, Wt)
+    boxes = O.normalize_boxes(rois_px, H, W)
+    feats = O.pyramid_roi_align(boxes, [P2, P3, P4, P5], (H, W, 3), 7)
+    if return_maps:
+        return feats, (C2, C3, C4, C5, P2, P3, P4, P5)
+    return feats
+
+
+def image_level_features(roi_feats):
+    """feature_generation/generate_roi_features.py:60-75: mean over RoIs, flattened 12 544."""
+    return np.asarray(roi_feats, F64).mean(axis=0).reshape(-1)
+
+
+# --------------------------------------------------------------------------------------------
+# RoI head  mrcnn_class_conv1/bn1/conv2/bn2 (text_generation_model.py:250-262; _v2.py:141-150)
+# --------------------------------------------------------------------------------------------
+
+def roi_head_forward(feat, Wt):
+    """[R,7,7,256] -> conv7x7 valid -> BN -> ReLU -> conv1x1 -> BN -> ReLU -> squeeze -> [R,1024]."""
+    R = feat.shape[0]
+    x = np.asarray(feat, F64).reshape(R, -1)                       # (h,w,c) row-major == HWIO flatten
+    K1 = np.asarray(Wt['mrcnn_class_conv1/kernel'], F64).reshape(-1, 1024)
+    K2 = np.asarray(Wt['mrcnn_class_conv2/kernel'], F64).reshape(1024, 1024)
+    bn = lambda y, n: (np.asarray(Wt[n + '/gamma'], F64), np.asarray(Wt[n + '/beta'], F64),
+                       np.asarray(Wt[n + '/moving_mean'], F64),
+                       np.sqrt(np.asarray(Wt[n + '/moving_variance'], F64) + O.BN_EPS))
+    y1 = x @ K1 + np.asarray(Wt['mrcnn_class_conv1/bias'], F64)
+    g1, b1, m1, s1 = bn(y1, 'mrcnn_class_bn1')
+    n1 = (y1 - m1) / s1
+    a1 = O.relu(g1 * n1 + b1)
+    y2 = a1 @ K2 + np.asarray(Wt['mrcnn_class_conv2/bias'], F64)
+    g2, b2, m2, s2 = bn(y2, 'mrcnn_class_bn2')
+    n2 = (y2 - m2) / s2
+    f = O.relu(g2 * n2 + b2)
+    cache = dict(x=x, K1=K1, K2=K2, n1=n1, a1=a1, n2=n2, f=f, g1=g1, s1=s1, g2=g2, s2=s2)
+    return f, cache
+
+
+def roi_head_backward(df, cache):
+    """Gradients of the trainable head weights (v1 / joint model: kernels, biases, BN gamma/beta)."""
+    c = cache
+    dz2 = df * (c['f'] > 0)
+    G = {'mrcnn_class_bn2/gamma': (dz2 * c['n2']).sum(0), 'mrcnn_class_bn2/beta': dz2.sum(0)}
+    dy2 = dz2 * c['g2'] / c['s2']
+    G['mrcnn_class_conv2/kernel'] = (c['a1'].T @ dy2).reshape(1, 1, 1024, 1024)
+    G['mrcnn_class_conv2/bias'] = dy2.sum(0)
+    dz1 = (dy2 @ c['K2'].T) * (c['a1'] > 0)
+    G['mrcnn_class_bn1/gamma'] = (dz1 * c['n1']).sum(0)
+    G['mrcnn_class_bn1/beta'] = dz1.sum(0)
+    dy1 = dz1 * c['g1'] / c['s1']
+    G['mrcnn_class_conv1/kernel'] = (c['x'].T @ dy1).reshape(7, 7, 256, 1024)
+    G['mrcnn_class_conv1/bias'] = dy1.sum(0)
+    return G
+
+
+# --------------------------------------------------------------------------------------------
+# v2 decoder (Model 1 inject / Model 2 merge): text_generation_model_v2.py:140-166
+# --------------------------------------------------------------------------------------------
+
+def pad_sequences_pre(seqs, maxlen):
+    """keras pad_sequences defaults: padding='pre', truncating='pre', value 0, int32 (_v2.py:183)."""
+    out = np.zeros((len(seqs), maxlen), np.int32)
+    for i, s in enumerate(seqs):
+        s = list(s)[-maxlen:]
+        if s:
+            out[i, maxlen - len(s):] = s
+    return out
+
+
+def v2_expand_samples(captions, window):
+    """load_sequences + data_generator (_v2.py:128-137, :169-205): a caption of L word ids yields L
+    samples; sample j has prefix ids[:j] (the first one [0]) pre-padded/pre-truncated to `window`
+    and target ids[j].  Returns roi_index [N], words [N,window] int32, targets [N] int32."""
+    roi, seqs, tgt = [], [], []
+    for r, cap in enumerate(captions):
+        cap = [int(c) for c in cap]
+        for j in range(len(cap)):
+            roi.append(r)
+            seqs.append(cap[:j] if j > 0 else [0])
+            tgt.append(cap[j])
+    return np.array(roi, np.int32), pad_sequences_pre(seqs, window), np.array(tgt, np.int32)
+
+
+V2_WORD_LSTM = 'lstm_1'   # the unnamed KL.LSTM(1024) gets Keras' auto name (_v2.py:157)
+
+
+def v2_forward(Wt, feat, words, inject=True):
+    """build_model(...).predict([feat, words]) -> probs [B,V]; feat [B,7,7,256], words [B,Tw]."""
+    f, hc = roi_head_forward(feat, Wt)
+    emb, mask = O.embedding(words, Wt['imgcap_embedding_layer/embeddings'])
+    H, lc = O.lstm_forward(emb, mask, Wt[V2_WORD_LSTM + '/kernel'], Wt[V2_WORD_LSTM + '/recurrent_kernel'],
+                           Wt[V2_WORD_LSTM + '/bias'])
+    word = H[:, -1]                      # return_sequences=False: last output (carried through masks)
+    cat = np.concatenate([f, word], axis=1)          # Concatenate()([features, word]) -> [B,2048]
+    cache = dict(head=hc, lstm=lc, cat=cat)
+    if inject:
+        H2, ic = O.lstm_forward(cat[:, None, :], None, Wt['imgcap_lstm/kernel'],
+                                Wt['imgcap_lstm/recurrent_kernel'], Wt['imgcap_lstm/bias'])
+        top = H2[:, 0]
+        cache['inj'] = ic
+    else:
+        top = cat
+    logits = top @ np.asarray(Wt['imgcap_d1/kernel'], F64) + np.asarray(Wt['imgcap_d1/bias'], F64)
+    probs = O.softmax(logits)
+    cache.update(top=top, logits=logits, probs=probs)
+    return probs, cache
+
+
+def v2_loss_and_grads(Wt, feat, words, targets, inject=True):
+    """model.train_on_batch loss (mean over the batch of K.categorical_crossentropy, _v2.py:266-267)
+    and gradients of the trainable weights (word LSTM, imgcap_lstm, imgcap_d1; head and
+    embedding are trainable=False, _v2.py:142-156)."""
+    probs, c = v2_forward(Wt, feat, words, inject)
+    B = probs.shape[0]
+    loss = O.categorical_crossentropy(targets, probs).mean()
+    dlog = O.softmax_ce_grad_logits(targets, probs, np.full(B, 1.0 / B))
+    G = {'imgcap_d1/kernel': c['top'].T @ dlog, 'imgcap_d1/bias': dlog.sum(0)}
+    dtop = dlog @ np.asarray(Wt['imgcap_d1/kernel'], F64).T
+    if inject:
+        dcat3, dW, dU, db = O.lstm_backward(None, c['inj'], dh_last=dtop)
+        G['imgcap_lstm/kernel'], G['imgcap_lstm/recurrent_kernel'], G['imgcap_lstm/bias'] = dW, dU, db
+        dcat = dcat3[:, 0]
+    else:
+        dcat = dtop
+    dword = dcat[:, 1024:]
+    _, dW, dU, db = O.lstm_backward(None, c['lstm'], dh_last=dword)
+    G[V2_WORD_LSTM + '/kernel'], G[V2_WORD_LSTM + '/recurrent_kernel'], G[V2_WORD_LSTM + '/bias'] = dW, dU, db
+    return loss, G, probs
+
+
+def v2_greedy_decode(Wt, feat_one, window, steps):
+    """_v2.py:328-346 per RoI: prev=[zeros]; repeat PADDING_SIZE-1 times: predict on
+    pad_sequences([[argmax(p) for p in prev]]), append the probability row.  Returns the token ids
+    argmax'ed from every appended row (ids fed back) and the probability rows."""
+    ids, rows = [0], []
+    for _ in range(steps):
+        words = pad_sequences_pre([ids], window)
+        p, _ = v2_forward(Wt, feat_one[None], words)
+        rows.append(p[0])
+        ids.append(int(np.argmax(p[0])))
+    return np.array(ids[1:], np.int32), np.array(rows)
+
+
+# --------------------------------------------------------------------------------------------
+# v1 decoder (Model 3, par-inject): text_generation_model.py:130-294
+# --------------------------------------------------------------------------------------------
+
+def v1_word_model_forward(Wt, f, prefix):
+    """word_generation_model (text_generation_model.py:130-156): f [B,1024], prefix [B,T] float
+    token ids (0 = pad) -> probs [B,V]."""
+    emb, mask = O.embedding(prefix, Wt['imgcap_embedding_layer/embeddings'])
+    T = prefix.shape[1]
+    x = np.concatenate([emb, np.repeat(f[:, None, :], T, axis=1)], axis=2)      # [emb(300) | f(1024)]
+    H1, c1 = O.lstm_forward(x, mask, Wt['imgcap_lstm1/kernel'], Wt['imgcap_lstm1/recurrent_kernel'],
+                            Wt['imgcap_lstm1/bias'])
+    H2, c2 = O.lstm_forward(H1, mask, Wt['imgcap_lstm2/kernel'], Wt['imgcap_lstm2/recurrent_kernel'],
+                            Wt['imgcap_lstm2/bias'])
+    cat = np.concatenate([H2[:, -1], f], axis=1)                                 # [lstm2(512) | f(1024)]
+    z1 = cat @ np.asarray(Wt['imgcap_lstm_d1/kernel'], F64) + np.asarray(Wt['imgcap_lstm_d1/bias'], F64)
+    a1 = O.relu(z1)
+    logits = a1 @ np.asarray(Wt['imgcap_lstm_d2/kernel'], F64) + np.asarray(Wt['imgcap_lstm_d2/bias'], F64)
+    probs = O.softmax(logits)
+    return probs, dict(c1=c1, c2=c2, cat=cat, a1=a1, probs=probs, T=T)
+
+
+def v1_word_model_backward(Wt, dlog, c):
+    """Returns (df [B,1024], grads dict) for one word_model call."""
+    G = {'imgcap_lstm_d2/kernel': c['a1'].T @ dlog, 'imgcap_lstm_d2/bias': dlog.sum(0)}
+    dz1 = (dlog @ np.asarray(Wt['imgcap_lstm_d2/kernel'], F64).T) * (c['a1'] > 0)
+    G['imgcap_lstm_d1/kernel'] = c['cat'].T @ dz1
+    G['imgcap_lstm_d1/bias'] = dz1.sum(0)
+    dcat = dz1 @ np.asarray(Wt['imgcap_lstm_d1/kernel'], F64).T
+    dh2, df = dcat[:, :512].copy(), dcat[:, 512:].copy()
+    dH1, dW, dU, db = O.lstm_backward(None, c['c2'], dh_last=dh2)
+    G['imgcap_lstm2/kernel'], G['imgcap_lstm2/recurrent_kernel'], G['imgcap_lstm2/bias'] = dW, dU, db
+    dx, dW, dU, db = O.lstm_backward(dH1, c['c1'])
+    G['imgcap_lstm1/kernel'], G['imgcap_lstm1/recurrent_kernel'], G['imgcap_lstm1/bias'] = dW, dU, db
+    df += dx[:, :, 300:].sum(1)
+    return df, G
+
+
+def v1_prefixes(caps):
+    """build_roi_caption_model_training's Lambda (text_generation_model.py:180-185):
+    row j (1..T) = [c_0..c_{j-1}, 0, ...]."""
+    caps = np.asarray(caps, F64)
+    B, T = caps.shape
+    out = np.zeros((B, T, T))
+    for j in range(1, T + 1):
+        out[:, j - 1, :j] = caps[:, :j]
+    return out
+
+
+def v1_targets(caps):
+    """data_generator target ids (text_generation_model.py:352-357): caption shifted left by one,
+    last = 0; pads become class 0 (and *do* count in the loss)."""
+    caps = np.asarray(caps)
+    return np.concatenate([caps[:, 1:], np.zeros((caps.shape[0], 1))], axis=1).astype(np.int32)
+
+
+def v1_training_forward(Wt, feat, caps):
+    """build_lstm_model(..., 'training').predict([feat, caps]) -> [B,T,V] (dropout off)."""
+    f, hc = roi_head_forward(feat, Wt)
+    P = v1_prefixes(caps)
+    T = P.shape[1]
+    outs, caches = [], []
+    for j in range(T):
+        p, c = v1_word_model_forward(Wt, f, P[:, j])
+        outs.append(p)
+        caches.append(c)
+    return np.stack(outs, axis=1), dict(head=hc, f=f, caches=caches)
+
+
+def v1_loss_and_grads(Wt, feat, caps):
+    """roi_caption_loss (text_generation_model.py:286-294): every row has sum(y_true)=1>0, so the
+    loss is the mean CE over all B*T rows.  Gradients of all trainable weights (decoder + head)."""
+    probs, c = v1_training_forward(Wt, feat, caps)
+    tg = v1_targets(caps)
+    B, T, V = probs.shape
+    loss = O.categorical_crossentropy(tg, probs).mean()
+    G, df = {}, np.zeros_like(c['f'])
+    for j in range(T):
+        dlog = O.softmax_ce_grad_logits(tg[:, j], probs[:, j], np.full(B, 1.0 / (B * T)))
+        dfj, Gj = v1_word_model_backward(Wt, dlog, c['caches'][j])
+        df += dfj
+        for k, v in Gj.items():
+            G[k] = G.get(k, 0.0) + v
+    G.update(roi_head_backward(df, c['head']))
+    return loss, G, probs
+
+
+def v1_greedy_decode(Wt, feat, T):
+    """ROICaptionInferenceLayer (text_generation_model.py:192-232): start token 1; step j feeds
+    [prev..., 0...] and appends float(argmax).  T = config.PADDING_SIZE.
+    Returns probs [B,T,V] and ids [B,T]."""
+    f, _ = roi_head_forward(feat, Wt)
+    B = f.shape[0]
+    prev = np.ones((B, 1))
+    rows = []
+    for j in range(T):
+        ctx = np.concatenate([prev, np.zeros((B, T - j - 1))], axis=1)
+        p, _ = v1_word_model_forward(Wt, f, ctx)
+        rows.append(p)
+        prev = np.concatenate([prev, O.argmax_rows(p)[:, None].astype(F64)], axis=1)
+    return np.stack(rows, axis=1), prev[:, 1:].astype(np.int32)
+
+
+# --------------------------------------------------------------------------------------------
+# Optimizer over a weight dict, data-parallel averaging (parallel_model.py:58-102)
+# --------------------------------------------------------------------------------------------
+
+class AMSGrad:
+    """keras.optimizers.Adam(lr, amsgrad=True[, clipnorm]) over a dict of arrays."""
+
+    def __init__(self, lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, clipnorm=None):
+        self.lr, self.b1, self.b2, self.eps, self.clipnorm = lr, beta_1, beta_2, epsilon, clipnorm
+        self.t, self.state = 0, {}
+
+    def step(self, Wt, G):
+        self.t += 1
+        keys = sorted(G)
+        grads = [np.asarray(G[k], F64) for k in keys]
+        if self.clipnorm is not None:
+            grads, _ = O.clip_by_global_norm(grads, self.clipnorm)
+        for k, g in zip(keys, grads):
+            m, v, vh = self.state.get(k, (0.0, 0.0, 0.0))
+            p, m, v, vh = O.amsgrad_step(Wt[k], g, m, v, vh, self.t, self.lr, self.b1, self.b2, self.eps)
+            Wt[k] = p
+            self.state[k] = (m, v, vh)
+
+
+def data_parallel_mean(per_rank):
+    """ParallelModel semantics (parallel_model.py:93-101): mean over towers of the per-tower mean
+    loss => gradients are the plain average of the per-rank gradients."""
+    keys = per_rank[0].keys()
+    return {k: sum(np.asarray(g[k], F64) for g in per_rank) / len(per_rank) for k in keys}

@@ -1,0 +1,389 @@
+"""
+oracle/np_oracle.py -- CPU restatement (NumPy, float64) of the arithmetic primitives on the
+dense-captioning hot path of frosinastojanovska/image-captioning.
+
+*** TEST INFRASTRUCTURE, NOT PRODUCT CODE. ***
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+The product path (image-captioning_amd/) never imports it and fails loudly without its HIP library.
+
+*** PARITY UNPINNED. ***
+The reference's arithmetic lives in Keras 2.1.x / TensorFlow 1.x (un-vendored, un-pinned, not
+installable here: no network, Python 3.10).  The reference repo ships no tests, golden vectors or
+fixtures for this path.  This file restates the documented semantics of
+those libraries at the reference's call sites (cited per function, paths relative to
+/root/reference).  It is checked against analytic known-answer tests and an independent torch
+restatement (oracle/torch_ref.py), not against outputs of the reference itself.
+
+Everything is float64 unless a function says otherwise (box-coordinate arithmetic follows TF's
+float32 kernels so that index decisions -- pyramid level, out-of-range bins -- are bit-faithful).
+"""
+import numpy as np
+
+F64 = np.float64
+F32 = np.float32
+
+
+# --------------------------------------------------------------------------------------------
+# Convolution / normalisation / pooling  (feature_generation/dense_model.py:51-173, :1404-1427)
+# --------------------------------------------------------------------------------------------
+
+def same_pad(n, k, s):
+    """TF 'SAME' padding: total = max((ceil(n/s)-1)*s + k - n, 0); floor(total/2) goes before."""
+    out = -(-n // s)
+    total = max((out - 1) * s + k - n, 0)
+    return total // 2, total - total // 2
+
+
+def _resolve_pad(H, W, kh, kw, stride, padding):
+    if padding == 'same':
+        (pt, pb), (pl, pr) = same_pad(H, kh, stride), same_pad(W, kw, stride)
+    elif padding == 'valid':
+        pt = pb = pl = pr = 0
+    else:
+        pt, pb, pl, pr = padding
+    return pt, pb, pl, pr
+
+
+def conv2d_nhwc(x, w, b=None, stride=1, padding='valid'):
+    """Keras Conv2D, channels_last, kernel HWIO [kh,kw,cin,cout]
+    (dense_model.py:85-97 identity_block, :120-136 conv_block, :146-147 stem, :1406-1421 FPN).
+    padding: 'same' | 'valid' | (top, bottom, left, right)."""
+    x = np.asarray(x, F64)
+    w = np.asarray(w, F64)
+    N, H, W, C = x.shape
+    kh, kw, C2, O = w.shape
+    assert C == C2
+    pt, pb, pl, pr = _resolve_pad(H, W, kh, kw, stride, padding)
+    xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+    Ho = (H + pt + pb - kh) // stride + 1
+    Wo = (W + pl + pr - kw) // stride + 1
+    out = np.zeros((N * Ho * Wo, O), F64)
+    for ky in range(kh):
+        for kx in range(kw):
+            patch = xp[:, ky:ky + (Ho - 1) * stride + 1:stride, kx:kx + (Wo - 1) * stride + 1:stride, :]
+            out += patch.reshape(-1, C) @ w[ky, kx]
+    out = out.reshape(N, Ho, Wo, O)
+    if b is not None:
+        out = out + np.asarray(b, F64)
+    return out
+
+
+def conv2d_nhwc_loops(x, w, b=None, stride=1, padding='valid'):
+    """Loop-level twin of conv2d_nhwc for tiny shapes (self-check of the vectorised form)."""
+    x = np.asarray(x, F64)
+    w = np.asarray(w, F64)
+    N, H, W, C = x.shape
+    kh, kw, _, O = w.shape
+    pt, pb, pl, pr = _resolve_pad(H, W, kh, kw, stride, padding)
+    Ho = (H + pt + pb - kh) // stride + 1
+    Wo = (W + pl + pr - kw) // stride + 1
+    out = np.zeros((N, Ho, Wo, O), F64)
+    for n in range(N):
+        for oy in range(Ho):
+            for ox in range(Wo):
+                for o in range(O):
+                    acc = 0.0 if b is None else float(b[o])
+                    for ky in range(kh):
+                        iy = oy * stride + ky - pt
+                        if iy < 0 or iy >= H:
+                            continue
+                        for kx in range(kw):
+                            ix = ox * stride + kx - pl
+                            if ix < 0 or ix >= W:
+                                continue
+                            for c in range(C):
+                                acc += x[n, iy, ix, c] * w[ky, kx, c, o]
+                    out[n, oy, ox, o] = acc
+    return out
+
+
+BN_EPS = 1e-3  # Keras BatchNormalization default epsilon
+
+
+def batchnorm_inference(x, gamma, beta, mean, var, eps=BN_EPS):
+    """BatchNorm with training=False hard-coded (dense_model.py:51-61)."""
+    x = np.asarray(x, F64)
+    return np.asarray(gamma, F64) * (x - np.asarray(mean, F64)) / np.sqrt(np.asarray(var, F64) + eps) \
+        + np.asarray(beta, F64)
+
+
+def bn_scale_shift(gamma, beta, mean, var, conv_bias=None, eps=BN_EPS):
+    """y = scale*conv_nobias + shift  ==  BN(conv_nobias + bias).  float64; the product folds the
+    same way on the host (in float64) and hands float32 scale/shift to the kernel epilogue."""
+    scale = np.asarray(gamma, F64) / np.sqrt(np.asarray(var, F64) + eps)
+    b = 0.0 if conv_bias is None else np.asarray(conv_bias, F64)
+    shift = scale * (b - np.asarray(mean, F64)) + np.asarray(beta, F64)
+    return scale, shift
+
+
+def relu(x):
+    return np.maximum(x, 0.0)
+
+
+def maxpool3x3s2_same(x):
+    """KL.MaxPooling2D((3,3), strides=(2,2), padding='same') (dense_model.py:150).
+    TF SAME on even n: pad 0 before, 1 after; padded cells never win (-inf)."""
+    x = np.asarray(x, F64)
+    N, H, W, C = x.shape
+    pt, pb = same_pad(H, 3, 2)
+    pl, pr = same_pad(W, 3, 2)
+    xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)), constant_values=-np.inf)
+    Ho, Wo = -(-H // 2), -(-W // 2)
+    out = np.full((N, Ho, Wo, C), -np.inf)
+    for ky in range(3):
+        for kx in range(3):
+            out = np.maximum(out, xp[:, ky:ky + (Ho - 1) * 2 + 1:2, kx:kx + (Wo - 1) * 2 + 1:2, :])
+    return out
+
+
+def subsample2(x):
+    """KL.MaxPooling2D(pool_size=(1,1), strides=2) == every other pixel (dense_model.py:1423)."""
+    return np.asarray(x)[:, ::2, ::2, :]
+
+
+def upsample2x(x):
+    """KL.UpSampling2D(size=(2,2)): nearest neighbour (dense_model.py:1408)."""
+    return np.repeat(np.repeat(np.asarray(x), 2, axis=1), 2, axis=2)
+
+
+def mold_image(images_u8, mean_pixel):
+    """mold_image: float32(image) - MEAN_PIXEL (dense_model.py:2050-2055)."""
+    return np.asarray(images_u8).astype(F64) - np.asarray(mean_pixel, F64)
+
+
+# --------------------------------------------------------------------------------------------
+# RoIAlign  (feature_generation/dense_model.py:312-418)
+# --------------------------------------------------------------------------------------------
+
+def roi_levels(boxes_norm, image_shape):
+    """PyramidROIAlign level routing (dense_model.py:351-362), float32 like the TF graph:
+    level = clamp(4 + round_half_even(log(sqrt(h*w) / (224/sqrt(area))) / log(2)), 2, 5)."""
+    b = np.asarray(boxes_norm, F32)
+    h = b[..., 2] - b[..., 0]
+    w = b[..., 3] - b[..., 1]
+    area = F32(image_shape[0] * image_shape[1])
+    denom = F32(224.0) / np.sqrt(area, dtype=F32)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        ratio = np.sqrt(h * w, dtype=F32) / denom
+        lvl = np.log(ratio, dtype=F32) / np.log(F32(2.0), dtype=F32)
+    # tf.cast(tf.round(x), int32): round half to even; log(0) = -inf casts to INT_MIN in TF, the
+    # clamp then gives 2.  NaN (negative area) is undefined in TF; we map it to 2 as well.
+    r = np.rint(lvl)
+    r = np.where(np.isfinite(r), r, -100.0)
+    return np.minimum(5, np.maximum(2, 4 + r.astype(np.int64))).astype(np.int32)
+
+
+def crop_and_resize(image, boxes, box_ind, crop_size, extrapolation_value=0.0):
+    """tf.image.crop_and_resize(method='bilinear') (dense_model.py:378-380).
+    image [B,H,W,C]; boxes [N,4] (y1,x1,y2,x2) normalised; box_ind [N].
+    Sample coordinates are float32 in TF's kernel order (mul, div, mul, add -- no fma); the
+    interpolation itself is float64 here."""
+    image = np.asarray(image, F64)
+    boxes = np.asarray(boxes, F32)
+    B, H, W, C = image.shape
+    ch, cw = crop_size
+    N = boxes.shape[0]
+    out = np.full((N, ch, cw, C), extrapolation_value, F64)
+    for n in range(N):
+        y1, x1, y2, x2 = boxes[n]
+        bi = int(box_ind[n])
+        hs = (y2 - y1) * F32(H - 1) / F32(ch - 1) if ch > 1 else F32(0)
+        ws = (x2 - x1) * F32(W - 1) / F32(cw - 1) if cw > 1 else F32(0)
+        for y in range(ch):
+            in_y = (y1 * F32(H - 1) + F32(y) * hs) if ch > 1 else F32(0.5) * (y1 + y2) * F32(H - 1)
+            if not (in_y >= 0 and in_y <= H - 1):
+                continue
+            top, bot = int(np.floor(in_y)), int(np.ceil(in_y))
+            ly = F64(in_y - F32(top))
+            for x in range(cw):
+                in_x = (x1 * F32(W - 1) + F32(x) * ws) if cw > 1 else F32(0.5) * (x1 + x2) * F32(W - 1)
+                if not (in_x >= 0 and in_x <= W - 1):
+                    continue
+                left, right = int(np.floor(in_x)), int(np.ceil(in_x))
+                lx = F64(in_x - F32(left))
+                tl, tr = image[bi, top, left], image[bi, top, right]
+                bl, br = image[bi, bot, left], image[bi, bot, right]
+                t = tl + (tr - tl) * lx
+                bt = bl + (br - bl) * lx
+                out[n, y, x] = t + (bt - t) * ly
+    return out
+
+
+def pyramid_roi_align(boxes_norm, feature_maps, image_shape, pool=7):
+    """PyramidROIAlign.call (dense_model.py:339-415).  boxes_norm [B,R,4]; feature_maps = [P2..P5],
+    each [B,Hk,Wk,C].  Returns [B,R,pool,pool,C] (the reference re-packs it as [1,B*R,...] in
+    batch-then-box order, :413-415; same data)."""
+    boxes_norm = np.asarray(boxes_norm, F32)
+    B, R, _ = boxes_norm.shape
+    C = feature_maps[0].shape[-1]
+    lv = roi_levels(boxes_norm, image_shape)
+    out = np.zeros((B, R, pool, pool, C), F64)
+    for i, level in enumerate(range(2, 6)):
+        bi, ri = np.nonzero(lv == level)
+        if bi.size == 0:
+            continue
+        out[bi, ri] = crop_and_resize(feature_maps[i], boxes_norm[bi, ri], bi, (pool, pool))
+    return out
+
+
+def normalize_boxes(rois_px, h, w):
+    """rois / [h, w, h, w] with the *molded* image size (modified_dense_model.py:1522-1527)."""
+    return (np.asarray(rois_px, F32) / np.array([h, w, h, w], F32)).astype(F32)
+
+
+# --------------------------------------------------------------------------------------------
+# Dense / embedding / LSTM (Keras 2.1 semantics: SURVEY.md section 9.5, 9.6)
+# --------------------------------------------------------------------------------------------
+
+def hard_sigmoid(z):
+    """K.hard_sigmoid: clip(0.2*z + 0.5, 0, 1) -- Keras-2.1 LSTM default recurrent_activation."""
+    return np.clip(0.2 * z + 0.5, 0.0, 1.0)
+
+
+def hard_sigmoid_grad(z):
+    y = 0.2 * z + 0.5
+    return np.where((y >= 0.0) & (y <= 1.0), 0.2, 0.0)
+
+
+def embedding(ids, table):
+    """KL.Embedding(mask_zero=True): casts ids to int32 (truncation), mask = ids != 0
+    (text_generation_model.py:135-140; _v2.py:155-156)."""
+    ids = np.asarray(ids).astype(np.int32)
+    return np.asarray(table, F64)[ids], ids != 0
+
+
+def lstm_forward(x, mask, W, U, b, h0=None, c0=None):
+    """Keras LSTM (gate blocks i,f,c,o; hard-sigmoid gates; tanh) with mask carry.
+    x [B,T,I], mask [B,T] bool or None.  Returns (H [B,T,Uh] -- output per step with carry, zeros
+    before the first unmasked step --, cache)."""
+    x = np.asarray(x, F64)
+    B, T, _ = x.shape
+    Uh = U.shape[0]
+    W, U, b = np.asarray(W, F64), np.asarray(U, F64), np.asarray(b, F64)
+    h = np.zeros((B, Uh)) if h0 is None else np.asarray(h0, F64)
+    c = np.zeros((B, Uh)) if c0 is None else np.asarray(c0, F64)
+    if mask is None:
+        mask = np.ones((B, T), bool)
+    H = np.zeros((B, T, Uh))
+    cache = dict(x=x, mask=mask, W=W, U=U, steps=[])
+    for t in range(T):
+        z = x[:, t] @ W + h @ U + b
+        zi, zf, zc, zo = z[:, :Uh], z[:, Uh:2 * Uh], z[:, 2 * Uh:3 * Uh], z[:, 3 * Uh:]
+        i, f, g, o = hard_sigmoid(zi), hard_sigmoid(zf), np.tanh(zc), hard_sigmoid(zo)
+        cn = f * c + i * g
+        tc = np.tanh(cn)
+        hn = o * tc
+        m = mask[:, t][:, None]
+        cache['steps'].append((h, c, z, i, f, g, o, tc))
+        h = np.where(m, hn, h)
+        c = np.where(m, cn, c)
+        H[:, t] = h
+    cache['h_last'], cache['c_last'] = h, c
+    return H, cache
+
+
+def lstm_backward(dH, cache, dh_last=None):
+    """Backward of lstm_forward.  dH [B,T,Uh] gradient w.r.t. every step's output (or None),
+    dh_last [B,Uh] extra gradient on the final output.  Returns dx, dW, dU, db."""
+    x, mask, W, U = cache['x'], cache['mask'], cache['W'], cache['U']
+    B, T, _ = x.shape
+    Uh = U.shape[0]
+    dx = np.zeros_like(x)
+    dW, dU, db = np.zeros_like(W), np.zeros_like(U), np.zeros(4 * Uh)
+    dh = np.zeros((B, Uh)) if dh_last is None else np.asarray(dh_last, F64).copy()
+    dc = np.zeros((B, Uh))
+    for t in reversed(range(T)):
+        if dH is not None:
+            dh = dh + dH[:, t]
+        hp, cp, z, i, f, g, o, tc = cache['steps'][t]
+        m = mask[:, t][:, None].astype(F64)
+        dhn = dh * m
+        dcn = dc * m + dhn * o * (1.0 - tc * tc)
+        do = dhn * tc
+        dz = np.concatenate([
+            dcn * g * hard_sigmoid_grad(z[:, :Uh]),
+            dcn * cp * hard_sigmoid_grad(z[:, Uh:2 * Uh]),
+            dcn * i * (1.0 - g * g),
+            do * hard_sigmoid_grad(z[:, 3 * Uh:]),
+        ], axis=1)
+        dW += x[:, t].T @ dz
+        dU += hp.T @ dz
+        db += dz.sum(0)
+        dx[:, t] = dz @ W.T
+        dh = dh * (1.0 - m) + dz @ U.T
+        dc = dc * (1.0 - m) + dcn * f
+    return dx, dW, dU, db
+
+
+def softmax(z):
+    z = np.asarray(z, F64)
+    e = np.exp(z - z.max(-1, keepdims=True))
+    return e / e.sum(-1, keepdims=True)
+
+
+KERAS_EPS = 1e-7
+
+
+def categorical_crossentropy(target_ids, probs):
+    """K.categorical_crossentropy(target=one-hot, output=probs) per row (TF backend):
+    output /= sum(output); output = clip(output, 1e-7, 1-1e-7); -sum(target*log(output)).
+    Targets are one-hot in every reference call site, so they are passed as ids
+    (text_generation_model.py:286-294; _v2.py:267)."""
+    p = np.asarray(probs, F64)
+    p = p / p.sum(-1, keepdims=True)
+    p = np.clip(p, KERAS_EPS, 1.0 - KERAS_EPS)
+    idx = np.asarray(target_ids).astype(np.int64)
+    return -np.log(np.take_along_axis(p, idx[..., None], -1)[..., 0])
+
+
+def softmax_ce_grad_logits(target_ids, probs, upstream):
+    """d(sum_r upstream_r * CE_r)/d logits for softmax followed by categorical_crossentropy.
+    Unclipped rows: p - onehot (renormalisation is the identity on a softmax output); rows whose
+    target probability was clipped have zero gradient (tf.clip_by_value passes no gradient outside
+    its range)."""
+    p = np.asarray(probs, F64)
+    idx = np.asarray(target_ids).astype(np.int64)
+    pt = np.take_along_axis(p, idx[..., None], -1)[..., 0]
+    live = ((pt >= KERAS_EPS) & (pt <= 1.0 - KERAS_EPS)).astype(F64)
+    g = p.copy()
+    np.put_along_axis(g, idx[..., None], np.take_along_axis(g, idx[..., None], -1) - 1.0, -1)
+    return g * (live * np.asarray(upstream, F64))[..., None]
+
+
+def sparse_categorical_crossentropy_keras(target_ids, probs):
+    """K.sparse_categorical_crossentropy on probabilities (dense_img_cap/dense_model.py:943-945):
+    clip to [1e-7, 1-1e-7], logits = log(output), then TF sparse softmax-CE on those logits."""
+    p = np.clip(np.asarray(probs, F64), KERAS_EPS, 1.0 - KERAS_EPS)
+    lg = np.log(p)
+    lse = np.log(np.exp(lg - lg.max(-1, keepdims=True)).sum(-1)) + lg.max(-1)
+    idx = np.asarray(target_ids).astype(np.int64)
+    return lse - np.take_along_axis(lg, idx[..., None], -1)[..., 0]
+
+
+def argmax_rows(x):
+    """tf.argmax / np.argmax: lowest index among ties (text_generation_model.py:224)."""
+    return np.argmax(np.asarray(x), axis=-1).astype(np.int32)
+
+
+# --------------------------------------------------------------------------------------------
+# Optimizer (Keras 2.1 Adam with amsgrad=True; text_generation_model.py:425, _v2.py:266,
+# dense_img_cap/dense_model.py:1699)
+# --------------------------------------------------------------------------------------------
+
+def clip_by_global_norm(grads, clipnorm):
+    """Keras clipnorm: norm = sqrt(sum_i sum(g_i^2)); g *= clipnorm/norm when norm >= clipnorm."""
+    norm = np.sqrt(sum(float((np.asarray(g, F64) ** 2).sum()) for g in grads))
+    if norm >= clipnorm:
+        return [np.asarray(g, F64) * (clipnorm / norm) for g in grads], norm
+    return [np.asarray(g, F64) for g in grads], norm
+
+
+def amsgrad_step(p, g, m, v, vhat, t, lr=1e-3, b1=0.9, b2=0.999, eps=1e-7):
+    """One Keras Adam(amsgrad=True) update; t = iterations + 1 (1-based).  Returns new (p,m,v,vhat)."""
+    p, g, m, v, vhat = (np.asarray(a, F64) for a in (p, g, m, v, vhat))
+    lr_t = lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+    m = b1 * m + (1.0 - b1) * g
+    v = b2 * v + (1.0 - b2) * g * g
+    vhat = np.maximum(vhat, v)
+    p = p - lr_t * m / (np.sqrt(vhat) + eps)
+    return p, m, v, vhat
