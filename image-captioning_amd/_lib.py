@@ -1,0 +1,123 @@
+"""ctypes binding of libdcap_hip.so (the C-ABI in include/dcap.h).
+
+There is NO CPU fallback: if the library is missing, load() raises.  build it with
+`python __graft_entry__.py` (hipcc --offload-arch=gfx950).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdcap_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_int32_p = C.POINTER(C.c_int32)
+c_uint8_p = C.POINTER(C.c_uint8)
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("A", C.c_void_p), ("lda", C.c_int), ("a_trans", C.c_int),
+                ("a_gather", C.c_void_p),
+                ("B", C.c_void_p), ("ldb", C.c_int), ("b_trans", C.c_int),
+                ("C", C.c_void_p), ("ldc", C.c_int),
+                ("scale", C.c_void_p), ("shift", C.c_void_p),
+                ("residual", C.c_void_p), ("ldr", C.c_int),
+                ("relu", C.c_int), ("accumulate", C.c_int), ("split_k", C.c_int)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int),
+                ("Cout", C.c_int), ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int),
+                ("pad_t", C.c_int), ("pad_l", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
+                ("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p),
+                ("scale", C.c_void_p), ("shift", C.c_void_p),
+                ("residual", C.c_void_p), ("res_mode", C.c_int),
+                ("relu", C.c_int), ("split_k", C.c_int)]
+
+
+class RoiAlignDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("R", C.c_int), ("C", C.c_int), ("pool", C.c_int),
+                ("maps", C.c_void_p * 4), ("Hs", C.c_int * 4), ("Ws", C.c_int * 4),
+                ("boxes", C.c_void_p), ("image_area", C.c_float),
+                ("out", C.c_void_p), ("levels_out", C.c_void_p)]
+
+
+class LstmFwdDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("T", C.c_int), ("U", C.c_int),
+                ("z", C.c_void_p), ("U_rec", C.c_void_p), ("mask", C.c_void_p),
+                ("h_seq", C.c_void_p), ("c_seq", C.c_void_p)]
+
+
+class LstmBwdDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("T", C.c_int), ("U", C.c_int),
+                ("z", C.c_void_p), ("U_rec", C.c_void_p), ("mask", C.c_void_p),
+                ("h_seq", C.c_void_p), ("c_seq", C.c_void_p),
+                ("dh_seq", C.c_void_p), ("dh_last", C.c_void_p),
+                ("dz", C.c_void_p), ("dU_rec", C.c_void_p), ("accumulate_dU", C.c_int)]
+
+
+class SoftmaxCeDesc(C.Structure):
+    _fields_ = [("M", C.c_int), ("V", C.c_int), ("ld", C.c_int),
+                ("logits", C.c_void_p), ("targets", C.c_void_p),
+                ("probs", C.c_void_p), ("loss_rows", C.c_void_p), ("dlogits", C.c_void_p),
+                ("grad_scale", C.c_float)]
+
+
+class AmsgradDesc(C.Structure):
+    _fields_ = [("n", C.c_size_t), ("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p),
+                ("v", C.c_void_p), ("vhat", C.c_void_p),
+                ("lr_t", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("grad_scale", C.c_float), ("gnorm_sq", C.c_void_p), ("clipnorm", C.c_float)]
+
+
+# name -> (restype, argtypes): every symbol include/dcap.h declares
+SYMBOLS = {
+    "dc_version": (C.c_int, []),
+    "dc_last_error": (C.c_char_p, []),
+    "dc_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
+    "dc_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dc_conv2d_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
+    "dc_conv2d_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dc_maxpool3x3s2_same_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dc_mold_image_rgbx_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                         C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "dc_roi_align_pyramid_f32": (C.c_int, [C.POINTER(RoiAlignDesc), C.c_void_p]),
+    "dc_lstm_seq_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "dc_lstm_seq_fwd_f32": (C.c_int, [C.POINTER(LstmFwdDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dc_lstm_seq_bwd_f32": (C.c_int, [C.POINTER(LstmBwdDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dc_softmax_ce_f32": (C.c_int, [C.POINTER(SoftmaxCeDesc), C.c_void_p]),
+    "dc_argmax_rows_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "dc_colsum_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "dc_sumsq_f32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
+    "dc_mean_f32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "dc_amsgrad_step_f32": (C.c_int, [C.POINTER(AmsgradDesc), C.c_void_p]),
+}
+
+_lib = None
+
+
+class DcapError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Raises if it has not been built -- no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DcapError("%s is missing: build it with `python __graft_entry__.py` "
+                        "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().dc_last_error()
+        raise DcapError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else ""))

@@ -1,0 +1,135 @@
+// conv.hip -- dc_conv2d_nhwc_f32: NHWC convolution forward as an implicit GEMM on the fp32 MFMA main
+// loop (igemm_core.h): M = N*Ho*Wo output pixels, N = Cout, K = kh*kw*Cin; the A operand is the
+// im2col view gathered straight from the activation tensor into LDS tiles (never materialised),
+// B is the packed weight [Cout][K].  Frozen BN + bias + residual/upsample-add + ReLU ride in the
+// epilogue.  Plus the two bandwidth kernels of the stem: mold_image->RGBX and maxpool 3x3/s2 SAME.
+#include "igemm_core.h"
+#include <algorithm>
+
+namespace dcap {
+
+static int conv_validate(const dc_conv_desc* d, bool& stem) {
+    DC_REQUIRE(d != nullptr, DC_EINVAL, "dc_conv2d: null descriptor");
+    DC_REQUIRE(d->x && d->w && d->y, DC_EINVAL, "dc_conv2d: x, w, y must be non-null");
+    DC_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cout > 0 && d->Ho > 0 && d->Wo > 0, DC_EINVAL, "dc_conv2d: bad shape");
+    stem = (d->Cin == 4);
+    if (stem) {
+        DC_REQUIRE(d->kh == 7 && d->kw == 7 && d->stride == 2 && d->pad_t == 3 && d->pad_l == 3, DC_EINVAL,
+                   "dc_conv2d: Cin==4 is the RGBX stem path (7x7, stride 2, pad 3) only");
+    } else {
+        DC_REQUIRE(d->Cin % 32 == 0, DC_EINVAL, "dc_conv2d: Cin must be a multiple of 32 (got %d)", d->Cin);
+        DC_REQUIRE(d->kh >= 1 && d->kw >= 1 && d->stride >= 1, DC_EINVAL, "dc_conv2d: bad kernel/stride");
+    }
+    DC_REQUIRE((d->Ho - 1) * d->stride - d->pad_t + d->kh - 1 < d->H + d->kh && (d->Wo - 1) * d->stride - d->pad_l < d->W,
+               DC_EINVAL, "dc_conv2d: output size inconsistent with input/stride/pad");
+    DC_REQUIRE(aligned16(d->x) && aligned16(d->w), DC_EALIGN, "dc_conv2d: x and w must be 16-byte aligned");
+    DC_REQUIRE(d->res_mode >= 0 && d->res_mode <= 2 && (d->res_mode == 0 || d->residual), DC_EINVAL,
+               "dc_conv2d: res_mode/residual mismatch");
+    DC_REQUIRE(d->res_mode != 2 || ((d->Ho & 1) == 0 && (d->Wo & 1) == 0), DC_EINVAL,
+               "dc_conv2d: upsample-add needs even output size");
+    return DC_OK;
+}
+
+static inline void conv_dims(const dc_conv_desc* d, bool stem, int& M, int& N, int& K) {
+    M = d->N * d->Ho * d->Wo;
+    N = d->Cout;
+    K = stem ? 7 * 32 : d->kh * d->kw * d->Cin;
+}
+
+template <class AL>
+static int conv_dispatch(const AL& al, const DenseKC& bl, const Epilogue& ep, int M, int N, int K, const TileChoice& t, void* ws,
+                         size_t wsb, hipStream_t s) {
+    if (t.bm == 128 && t.bn == 128) return launch_igemm<128, 128, AL, DenseKC>(al, bl, ep, M, N, K, t.split, ws, wsb, s);
+    if (t.bm == 128 && t.bn == 64) return launch_igemm<128, 64, AL, DenseKC>(al, bl, ep, M, N, K, t.split, ws, wsb, s);
+    return launch_igemm<64, 64, AL, DenseKC>(al, bl, ep, M, N, K, t.split, ws, wsb, s);
+}
+
+// ---- maxpool 3x3 / stride 2 / TF SAME (pad only where the window leaves the image; padded cells never win)
+__global__ void maxpool3x3s2_kernel(const float4* __restrict__ x, float4* __restrict__ y, int N, int H, int W, int C4, int Ho, int Wo,
+                                    int pt, int pl) {
+    const long total = (long)N * Ho * Wo * C4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C4);
+        long p = idx / C4;
+        const int ox = (int)(p % Wo);
+        p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - pt + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - pl + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const float4 v = x[(((long)n * H + iy) * W + ix) * C4 + c];
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        y[idx] = m;
+    }
+}
+
+// ---- uint8 RGB -> float RGBX minus MEAN_PIXEL
+__global__ void mold_rgbx_kernel(const uint8_t* __restrict__ img, float4* __restrict__ out, long npix, float mr, float mg, float mb) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+        const uint8_t* p = img + 3 * i;
+        out[i] = make_float4((float)p[0] - mr, (float)p[1] - mg, (float)p[2] - mb, 0.f);
+    }
+}
+
+}  // namespace dcap
+
+using namespace dcap;
+
+extern "C" size_t dc_conv2d_workspace_bytes(const dc_conv_desc* d) {
+    bool stem;
+    if (conv_validate(d, stem)) return 0;
+    int M, N, K;
+    conv_dims(d, stem, M, N, K);
+    const TileChoice t = choose_tile(M, N, K, d->split_k);
+    return t.split > 1 ? (size_t)t.split * M * N * sizeof(float) : 0;
+}
+
+extern "C" int dc_conv2d_nhwc_f32(const dc_conv_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
+    bool stem;
+    int rc = conv_validate(d, stem);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int M, N, K;
+    conv_dims(d, stem, M, N, K);
+    const TileChoice t = choose_tile(M, N, K, d->split_k);
+    Epilogue ep{d->y, d->Cout, d->scale, d->shift, d->residual, d->Cout, d->res_mode, d->Ho, d->Wo, d->relu, 0};
+    DenseKC bl{d->w, K, N, nullptr};
+    if (stem) {
+        StemKC al{d->x, d->H, d->W, d->Ho, d->Wo, M};
+        return conv_dispatch(al, bl, ep, M, N, K, t, workspace, workspace_bytes, s);
+    }
+    Im2colKC al{d->x, d->H, d->W, d->Cin, d->Ho, d->Wo, d->stride, d->pad_t, d->pad_l, d->kw, d->Cin / 32, M};
+    return conv_dispatch(al, bl, ep, M, N, K, t, workspace, workspace_bytes, s);
+}
+
+extern "C" int dc_maxpool3x3s2_same_f32(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+    DC_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, DC_EINVAL, "dc_maxpool3x3s2: bad arguments");
+    DC_REQUIRE(aligned16(x) && aligned16(y), DC_EALIGN, "dc_maxpool3x3s2: pointers must be 16-byte aligned");
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const int pad_h = std::max((Ho - 1) * 2 + 3 - H, 0), pad_w = std::max((Wo - 1) * 2 + 3 - W, 0);
+    const long total = (long)N * Ho * Wo * (C / 4);
+    const int blocks = (int)std::min<long>((total + 255) / 256, (long)kNumCU * 8);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), N, H, W, C / 4, Ho, Wo, pad_h / 2, pad_w / 2);
+    return check_launch("maxpool3x3s2_kernel");
+}
+
+extern "C" int dc_mold_image_rgbx_f32(const uint8_t* img, float* out, int N, int H, int W, float mean_r, float mean_g, float mean_b,
+                                      void* stream) {
+    DC_REQUIRE(img && out && N > 0 && H > 0 && W > 0, DC_EINVAL, "dc_mold_image: bad arguments");
+    DC_REQUIRE(aligned16(out), DC_EALIGN, "dc_mold_image: out must be 16-byte aligned");
+    const long npix = (long)N * H * W;
+    const int blocks = (int)std::min<long>((npix + 255) / 256, (long)kNumCU * 8);
+    hipLaunchKernelGGL(mold_rgbx_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), img,
+                       reinterpret_cast<float4*>(out), npix, mean_r, mean_g, mean_b);
+    return check_launch("mold_rgbx_kernel");
+}

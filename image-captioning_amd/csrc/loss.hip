@@ -1,0 +1,231 @@
+// loss.hip -- vocabulary softmax + Keras categorical cross-entropy (forward + d/dlogits), greedy
+// argmax, column sums (bias gradients), reductions and the fused AMSGrad update.
+// All of these are HBM-bandwidth kernels: 16-byte accesses, wavefront (64-lane) shuffles for the
+// row reductions, one pass over the data wherever the maths allows.
+#include "dcap_internal.h"
+#include <algorithm>
+#include <math.h>
+
+namespace dcap {
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <bool IS_MAX>
+__device__ __forceinline__ float block_reduce(float v, float* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    v = IS_MAX ? wave_max(v) : wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < nw; ++i) r = IS_MAX ? fmaxf(r, red[i]) : r + red[i];
+    return r;
+}
+
+// One 256-thread block per row.  p = softmax(z); loss = -log(clip(p_t, 1e-7, 1-1e-7));
+// dz = grad_scale * (p - onehot) when p_t lies inside the clip range, else 0
+// (K.categorical_crossentropy's renormalisation p/sum(p) is the identity on a softmax row up to
+// fp32 rounding and is not repeated here).
+__global__ __launch_bounds__(256) void softmax_ce_kernel(dc_softmax_ce_desc d) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float* z = d.logits + (long)row * d.ld;
+    const int V = d.V, V4 = ((d.ld & 3) == 0) ? (V >> 2) : 0;
+    const float4* z4 = reinterpret_cast<const float4*>(z);
+    float mx = -INFINITY;
+    for (int i = tid; i < V4; i += 256) {
+        const float4 v = z4[i];
+        mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+    for (int i = 4 * V4 + tid; i < V; i += 256) mx = fmaxf(mx, z[i]);
+    mx = block_reduce<true>(mx, red);
+    float sum = 0.f;
+    for (int i = tid; i < V4; i += 256) {
+        const float4 v = z4[i];
+        sum += expf(v.x - mx) + expf(v.y - mx) + expf(v.z - mx) + expf(v.w - mx);
+    }
+    for (int i = 4 * V4 + tid; i < V; i += 256) sum += expf(z[i] - mx);
+    sum = block_reduce<false>(sum, red);
+    const float inv = 1.f / sum;
+    const int t = d.targets ? d.targets[row] : -1;
+    float pt = 1.f;
+    if (t >= 0 && t < V) pt = expf(z[t] - mx) * inv;
+    const bool live = (pt >= 1e-7f) && (pt <= 1.f - 1e-7f);
+    if (tid == 0 && d.loss_rows) d.loss_rows[row] = -logf(fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f));
+    if (!d.probs && !d.dlogits) return;
+    const float gs = live ? d.grad_scale : 0.f;
+    float* P = d.probs ? d.probs + (long)row * d.ld : nullptr;
+    float* G = d.dlogits ? d.dlogits + (long)row * d.ld : nullptr;
+    for (int i = tid; i < V4; i += 256) {
+        const float4 v = z4[i];
+        float4 p = make_float4(expf(v.x - mx) * inv, expf(v.y - mx) * inv, expf(v.z - mx) * inv, expf(v.w - mx) * inv);
+        if (P) reinterpret_cast<float4*>(P)[i] = p;
+        if (G) {
+            const int c = 4 * i;
+            float4 g = make_float4(gs * (p.x - (c == t ? 1.f : 0.f)), gs * (p.y - (c + 1 == t ? 1.f : 0.f)),
+                                   gs * (p.z - (c + 2 == t ? 1.f : 0.f)), gs * (p.w - (c + 3 == t ? 1.f : 0.f)));
+            reinterpret_cast<float4*>(G)[i] = g;
+        }
+    }
+    for (int i = 4 * V4 + tid; i < V; i += 256) {
+        const float p = expf(z[i] - mx) * inv;
+        if (P) P[i] = p;
+        if (G) G[i] = gs * (p - (i == t ? 1.f : 0.f));
+    }
+}
+
+// argmax with the lowest index winning ties (tf.argmax / np.argmax).
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int V, int ld, int32_t* __restrict__ out) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float* r = x + (long)row * ld;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i = tid; i < V; i += 256) {
+        const float v = r[i];
+        if (v > best || (v == best && i < idx)) { best = v; idx = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if ((tid & 63) == 0) { bv[tid >> 6] = best; bi[tid >> 6] = idx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        out[row] = (idx == 0x7fffffff) ? 0 : idx;      // all-NaN row: index 0 like np.argmax
+    }
+}
+
+// out[n] (+)= sum_m x[m][n]; block = 64 columns x 4 row lanes, rows summed in a fixed order.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int M, int N, int ld, float* __restrict__ out,
+                                                     int accumulate) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < N)
+        for (int m = rl; m < M; m += 4) s += x[(long)m * ld + c];
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < N) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        out[c] = accumulate ? out[c] + v : v;
+    }
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += x[i] * x[i];
+    s = block_reduce<false>(s, red);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+__global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (size_t i = threadIdx.x; i < n; i += 256) s += x[i];
+    s = block_reduce<false>(s, red);
+    if (threadIdx.x == 0) out[0] = s / (float)n;
+}
+
+__global__ __launch_bounds__(256) void amsgrad_kernel(dc_amsgrad_desc d) {
+    float gscale = d.grad_scale;
+    if (d.gnorm_sq && d.clipnorm > 0.f) {
+        const float norm = sqrtf(d.gnorm_sq[0]) * fabsf(d.grad_scale);
+        if (norm >= d.clipnorm) gscale *= d.clipnorm / norm;
+    }
+    const float b1 = d.beta1, b2 = d.beta2;
+    const size_t n4 = d.n >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 g = reinterpret_cast<const float4*>(d.g)[i];
+        float4 m = reinterpret_cast<float4*>(d.m)[i], v = reinterpret_cast<float4*>(d.v)[i];
+        float4 vh = reinterpret_cast<float4*>(d.vhat)[i], p = reinterpret_cast<float4*>(d.p)[i];
+#define DC_AMS(c)                                              \
+    {                                                          \
+        const float gg = g.c * gscale;                         \
+        m.c = b1 * m.c + (1.f - b1) * gg;                      \
+        v.c = b2 * v.c + (1.f - b2) * gg * gg;                 \
+        vh.c = fmaxf(vh.c, v.c);                               \
+        p.c -= d.lr_t * m.c / (sqrtf(vh.c) + d.eps);           \
+    }
+        DC_AMS(x) DC_AMS(y) DC_AMS(z) DC_AMS(w)
+        reinterpret_cast<float4*>(d.m)[i] = m;
+        reinterpret_cast<float4*>(d.v)[i] = v;
+        reinterpret_cast<float4*>(d.vhat)[i] = vh;
+        reinterpret_cast<float4*>(d.p)[i] = p;
+    }
+    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (size_t)gridDim.x * 256) {
+        const float gg = d.g[i] * gscale;
+        const float m = b1 * d.m[i] + (1.f - b1) * gg;
+        const float v = b2 * d.v[i] + (1.f - b2) * gg * gg;
+        const float vh = fmaxf(d.vhat[i], v);
+        d.m[i] = m; d.v[i] = v; d.vhat[i] = vh;
+        d.p[i] -= d.lr_t * m / (sqrtf(vh) + d.eps);
+    }
+}
+
+}  // namespace dcap
+
+using namespace dcap;
+
+extern "C" int dc_softmax_ce_f32(const dc_softmax_ce_desc* d, void* stream) {
+    DC_REQUIRE(d && d->logits && d->M > 0 && d->V > 0 && d->ld >= d->V, DC_EINVAL, "dc_softmax_ce: bad arguments");
+    DC_REQUIRE((d->ld & 3) != 0 || (aligned16(d->logits) && (!d->probs || aligned16(d->probs)) && (!d->dlogits || aligned16(d->dlogits))),
+               DC_EALIGN, "dc_softmax_ce: rows must be 16-byte aligned when ld %% 4 == 0");
+    DC_REQUIRE(d->targets || (!d->loss_rows && !d->dlogits), DC_EINVAL, "dc_softmax_ce: loss/gradient need targets");
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(d->M), dim3(256), 0, static_cast<hipStream_t>(stream), *d);
+    return check_launch("softmax_ce_kernel");
+}
+
+extern "C" int dc_argmax_rows_f32(const float* x, int M, int V, int ld, int32_t* out, void* stream) {
+    DC_REQUIRE(x && out && M > 0 && V > 0 && ld >= V, DC_EINVAL, "dc_argmax_rows: bad arguments");
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(M), dim3(256), 0, static_cast<hipStream_t>(stream), x, V, ld, out);
+    return check_launch("argmax_rows_kernel");
+}
+
+extern "C" int dc_colsum_f32(const float* x, int M, int N, int ld, float* out, int accumulate, void* stream) {
+    DC_REQUIRE(x && out && M > 0 && N > 0 && ld >= N, DC_EINVAL, "dc_colsum: bad arguments");
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), x, M, N, ld, out, accumulate);
+    return check_launch("colsum_kernel");
+}
+
+extern "C" int dc_sumsq_f32(const float* x, size_t n, float* out, int accumulate, void* stream) {
+    DC_REQUIRE(x && out && n > 0, DC_EINVAL, "dc_sumsq: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(out, 0, sizeof(float), s);
+        DC_REQUIRE(e == hipSuccess, DC_ELAUNCH, "dc_sumsq: memset failed: %s", hipGetErrorString(e));
+    }
+    const int blocks = (int)std::min<size_t>((n + 1023) / 1024, (size_t)kNumCU * 4);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, s, x, n, out);
+    return check_launch("sumsq_kernel");
+}
+
+extern "C" int dc_mean_f32(const float* x, size_t n, float* out, void* stream) {
+    DC_REQUIRE(x && out && n > 0, DC_EINVAL, "dc_mean: bad arguments");
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), x, n, out);
+    return check_launch("mean_kernel");
+}
+
+extern "C" int dc_amsgrad_step_f32(const dc_amsgrad_desc* d, void* stream) {
+    DC_REQUIRE(d && d->p && d->g && d->m && d->v && d->vhat && d->n > 0, DC_EINVAL, "dc_amsgrad_step: bad arguments");
+    DC_REQUIRE(aligned16(d->p) && aligned16(d->g) && aligned16(d->m) && aligned16(d->v) && aligned16(d->vhat), DC_EALIGN,
+               "dc_amsgrad_step: buffers must be 16-byte aligned");
+    const int blocks = (int)std::min<size_t>((d->n / 4 + 255) / 256 + 1, (size_t)kNumCU * 8);
+    hipLaunchKernelGGL(amsgrad_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), *d);
+    return check_launch("amsgrad_kernel");
+}

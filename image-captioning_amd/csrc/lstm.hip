@@ -1,0 +1,180 @@
+// lstm.hip -- Keras-2.1 LSTM recurrence over a whole sequence (forward and backward), time-major.
+// Per timestep: the skinny h_{t-1} * U_rec product runs on the MFMA GEMM (split-K so that a
+// B x 4U problem still covers the chip), then one fused pointwise kernel applies the hard-sigmoid /
+// tanh gates, the cell update and the Keras mask carry.  The caller batches the x * kernel + bias
+// projection for all T steps into one GEMM beforehand (dcap.h).
+#include "dcap_internal.h"
+#include <algorithm>
+
+namespace dcap {
+
+__device__ __forceinline__ float hard_sigmoid(float z) { return fminf(fmaxf(0.2f * z + 0.5f, 0.f), 1.f); }
+__device__ __forceinline__ float hard_sigmoid_grad(float z) {
+    const float y = 0.2f * z + 0.5f;
+    return (y >= 0.f && y <= 1.f) ? 0.2f : 0.f;   // tf.clip_by_value passes the gradient on [min, max]
+}
+
+// z_t holds the full pre-activation (x-projection + bias + h*U).  One thread per (b, unit).
+__global__ void lstm_gate_fwd_kernel(const float* __restrict__ z_t, const float* __restrict__ h_prev,
+                                     const float* __restrict__ c_prev, const uint8_t* __restrict__ mask_t,
+                                     float* __restrict__ h_t, float* __restrict__ c_t, int B, int U) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * U) return;
+    const int b = idx / U, u = idx - b * U;
+    const float* z = z_t + (long)b * 4 * U;
+    const float i = hard_sigmoid(z[u]), f = hard_sigmoid(z[U + u]), g = tanhf(z[2 * U + u]), o = hard_sigmoid(z[3 * U + u]);
+    const float hp = h_prev ? h_prev[idx] : 0.f, cp = c_prev ? c_prev[idx] : 0.f;
+    const float cn = f * cp + i * g;
+    const float hn = o * tanhf(cn);
+    const bool m = mask_t ? (mask_t[b] != 0) : true;
+    h_t[idx] = m ? hn : hp;
+    c_t[idx] = m ? cn : cp;
+}
+
+// dh_io: in = gradient arriving at h_t from step t+1 (recurrence + mask pass-through); out = the part
+// of it that passes straight to h_{t-1} through masked rows (the GEMM then adds dz*U^T on top).
+// dc_io: same for the cell state.
+__global__ void lstm_gate_bwd_kernel(const float* __restrict__ z_t, const float* __restrict__ c_prev,
+                                     const uint8_t* __restrict__ mask_t, const float* __restrict__ dh_out_t,
+                                     const float* __restrict__ dh_last, float* __restrict__ dh_io, float* __restrict__ dc_io,
+                                     float* __restrict__ dz_t, int B, int U) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * U) return;
+    const int b = idx / U, u = idx - b * U;
+    const float* z = z_t + (long)b * 4 * U;
+    const float zi = z[u], zf = z[U + u], zc = z[2 * U + u], zo = z[3 * U + u];
+    const float i = hard_sigmoid(zi), f = hard_sigmoid(zf), g = tanhf(zc), o = hard_sigmoid(zo);
+    const float cp = c_prev ? c_prev[idx] : 0.f;
+    const float tc = tanhf(f * cp + i * g);
+    float dh = dh_io[idx];
+    if (dh_out_t) dh += dh_out_t[idx];
+    if (dh_last) dh += dh_last[idx];
+    const float dc = dc_io[idx];
+    const bool m = mask_t ? (mask_t[b] != 0) : true;
+    float* dz = dz_t + (long)b * 4 * U;
+    if (m) {
+        const float dcn = dc + dh * o * (1.f - tc * tc);
+        dz[u] = dcn * g * hard_sigmoid_grad(zi);
+        dz[U + u] = dcn * cp * hard_sigmoid_grad(zf);
+        dz[2 * U + u] = dcn * i * (1.f - g * g);
+        dz[3 * U + u] = dh * tc * hard_sigmoid_grad(zo);
+        dh_io[idx] = 0.f;
+        dc_io[idx] = dcn * f;
+    } else {
+        dz[u] = 0.f; dz[U + u] = 0.f; dz[2 * U + u] = 0.f; dz[3 * U + u] = 0.f;
+        dh_io[idx] = dh;
+        dc_io[idx] = dc;
+    }
+}
+
+static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static dc_gemm_desc hU_desc(int B, int U, const float* h_prev, const float* U_rec, float* z_t) {
+    dc_gemm_desc g{};
+    g.M = B; g.N = 4 * U; g.K = U;
+    g.A = h_prev; g.lda = U; g.a_trans = 0;
+    g.B = U_rec; g.ldb = 4 * U; g.b_trans = 0;
+    g.C = z_t; g.ldc = 4 * U;
+    g.accumulate = 1;
+    return g;
+}
+
+static dc_gemm_desc dzUt_desc(int B, int U, const float* dz_t, const float* U_rec, float* dh) {
+    dc_gemm_desc g{};
+    g.M = B; g.N = U; g.K = 4 * U;
+    g.A = dz_t; g.lda = 4 * U; g.a_trans = 0;
+    g.B = U_rec; g.ldb = 4 * U; g.b_trans = 1;
+    g.C = dh; g.ldc = U;
+    g.accumulate = 1;
+    return g;
+}
+
+static dc_gemm_desc dU_desc(int B, int T, int U, const float* h_seq, const float* dz, float* dU, int accumulate) {
+    dc_gemm_desc g{};
+    g.M = U; g.N = 4 * U; g.K = (T - 1) * B;
+    g.A = h_seq; g.lda = U; g.a_trans = 1;            // rows t*B+b, t = 0..T-2  == h_{t-1} for steps 1..T-1
+    g.B = dz + (long)B * 4 * U; g.ldb = 4 * U; g.b_trans = 0;
+    g.C = dU; g.ldc = 4 * U;
+    g.accumulate = accumulate;
+    return g;
+}
+
+}  // namespace dcap
+
+using namespace dcap;
+
+extern "C" size_t dc_lstm_seq_workspace_bytes(int B, int T, int U) {
+    if (B <= 0 || T <= 0 || U <= 0) return 0;
+    dc_gemm_desc a = hU_desc(B, U, nullptr, nullptr, nullptr);
+    dc_gemm_desc b = dzUt_desc(B, U, nullptr, nullptr, nullptr);
+    size_t g = std::max(dc_gemm_workspace_bytes(&a), dc_gemm_workspace_bytes(&b));
+    if (T > 1) {
+        dc_gemm_desc c = dU_desc(B, T, U, nullptr, nullptr, nullptr, 0);
+        g = std::max(g, dc_gemm_workspace_bytes(&c));
+    }
+    return align_up(g) + 2 * align_up((size_t)B * U * sizeof(float));
+}
+
+extern "C" int dc_lstm_seq_fwd_f32(const dc_lstm_fwd_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
+    DC_REQUIRE(d && d->z && d->U_rec && d->h_seq && d->c_seq, DC_EINVAL, "dc_lstm_seq_fwd: null pointer");
+    DC_REQUIRE(d->B > 0 && d->T > 0 && d->U > 0 && (d->U & 3) == 0, DC_EINVAL, "dc_lstm_seq_fwd: bad B/T/U (U %% 4 == 0)");
+    DC_REQUIRE(workspace_bytes >= dc_lstm_seq_workspace_bytes(d->B, d->T, d->U) && (workspace || workspace_bytes == 0),
+               DC_EWORKSPACE, "dc_lstm_seq_fwd: workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int B = d->B, U = d->U, n = B * U, blocks = (n + 255) / 256;
+    for (int t = 0; t < d->T; ++t) {
+        float* z_t = d->z + (long)t * B * 4 * U;
+        const float* hp = t ? d->h_seq + (long)(t - 1) * n : nullptr;
+        const float* cp = t ? d->c_seq + (long)(t - 1) * n : nullptr;
+        if (t) {
+            dc_gemm_desc g = hU_desc(B, U, hp, d->U_rec, z_t);
+            int rc = dc_gemm_f32(&g, workspace, workspace_bytes, stream);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(lstm_gate_fwd_kernel, dim3(blocks), dim3(256), 0, s, z_t, hp, cp, d->mask ? d->mask + (long)t * B : nullptr,
+                           d->h_seq + (long)t * n, d->c_seq + (long)t * n, B, U);
+        int rc = check_launch("lstm_gate_fwd_kernel");
+        if (rc) return rc;
+    }
+    return DC_OK;
+}
+
+extern "C" int dc_lstm_seq_bwd_f32(const dc_lstm_bwd_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
+    DC_REQUIRE(d && d->z && d->U_rec && d->h_seq && d->c_seq && d->dz && d->dU_rec, DC_EINVAL, "dc_lstm_seq_bwd: null pointer");
+    DC_REQUIRE(d->B > 0 && d->T > 0 && d->U > 0 && (d->U & 3) == 0, DC_EINVAL, "dc_lstm_seq_bwd: bad B/T/U (U %% 4 == 0)");
+    DC_REQUIRE(workspace && workspace_bytes >= dc_lstm_seq_workspace_bytes(d->B, d->T, d->U), DC_EWORKSPACE,
+               "dc_lstm_seq_bwd: workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int B = d->B, U = d->U, T = d->T, n = B * U, blocks = (n + 255) / 256;
+    const size_t state_bytes = align_up((size_t)n * sizeof(float));
+    char* wsp = static_cast<char*>(workspace);
+    float* dh = reinterpret_cast<float*>(wsp);
+    float* dc = reinterpret_cast<float*>(wsp + state_bytes);
+    void* gws = wsp + 2 * state_bytes;
+    const size_t gws_bytes = workspace_bytes - 2 * state_bytes;
+    hipError_t e = hipMemsetAsync(wsp, 0, 2 * state_bytes, s);
+    DC_REQUIRE(e == hipSuccess, DC_ELAUNCH, "dc_lstm_seq_bwd: memset failed: %s", hipGetErrorString(e));
+    for (int t = T - 1; t >= 0; --t) {
+        const float* z_t = d->z + (long)t * B * 4 * U;
+        float* dz_t = d->dz + (long)t * B * 4 * U;
+        const float* cp = t ? d->c_seq + (long)(t - 1) * n : nullptr;
+        hipLaunchKernelGGL(lstm_gate_bwd_kernel, dim3(blocks), dim3(256), 0, s, z_t, cp, d->mask ? d->mask + (long)t * B : nullptr,
+                           d->dh_seq ? d->dh_seq + (long)t * n : nullptr, (t == T - 1) ? d->dh_last : nullptr, dh, dc, dz_t, B, U);
+        int rc = check_launch("lstm_gate_bwd_kernel");
+        if (rc) return rc;
+        if (t) {
+            dc_gemm_desc g = dzUt_desc(B, U, dz_t, d->U_rec, dh);
+            rc = dc_gemm_f32(&g, gws, gws_bytes, stream);
+            if (rc) return rc;
+        }
+    }
+    if (T > 1) {
+        dc_gemm_desc g = dU_desc(B, T, U, d->h_seq, d->dz, d->dU_rec, d->accumulate_dU);
+        return dc_gemm_f32(&g, gws, gws_bytes, stream);
+    }
+    if (!d->accumulate_dU) {
+        e = hipMemsetAsync(d->dU_rec, 0, (size_t)U * 4 * U * sizeof(float), s);
+        DC_REQUIRE(e == hipSuccess, DC_ELAUNCH, "dc_lstm_seq_bwd: memset failed: %s", hipGetErrorString(e));
+    }
+    return DC_OK;
+}

@@ -1,0 +1,266 @@
+"""Thin torch-tensor wrappers over the C-ABI (include/dcap.h).  torch is plumbing here: device memory,
+the current HIP stream and (elsewhere) torch.distributed; every arithmetic op is a dc_* kernel.
+All wrappers enqueue on torch's current stream and never synchronise.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (AmsgradDesc, ConvDesc, GemmDesc, LstmBwdDesc, LstmFwdDesc, RoiAlignDesc,
+                   SoftmaxCeDesc, check)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(t, dtype=torch.float32, name="tensor"):
+    if not t.is_cuda:
+        raise _lib.DcapError("%s must live on the GPU (no CPU path exists)" % name)
+    if t.dtype != dtype:
+        raise _lib.DcapError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if t.dim() > 0 and t.stride(-1) != 1:
+        raise _lib.DcapError("%s must be contiguous along its last dimension" % name)
+    return t
+
+
+class _Workspace:
+    """One grow-only scratch buffer per device (kernels never allocate)."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, nbytes, device):
+        if nbytes == 0:
+            return None, 0
+        b = self.buf.get(device)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            self.buf[device] = b
+        return b, b.numel()
+
+    def reserve(self, nbytes, device):
+        self.get(nbytes, device)
+
+
+WORKSPACE = _Workspace()
+
+
+def gemm(A, B, out=None, a_trans=False, b_trans=False, gather=None, scale=None, shift=None,
+         residual=None, relu=False, accumulate=False, split_k=0):
+    """out[M,N] = epilogue(op(A) @ op(B)); see dc_gemm_f32."""
+    lib = _lib.load()
+    _chk(A, name="A"), _chk(B, name="B")
+    if a_trans:
+        K, M = A.shape
+    elif gather is not None:
+        M, K = gather.numel(), A.shape[1]
+    else:
+        M, K = A.shape
+    N = B.shape[0] if b_trans else B.shape[1]
+    kb = B.shape[1] if b_trans else B.shape[0]
+    if kb != K:
+        raise _lib.DcapError("gemm: inner dimensions differ (%d vs %d)" % (K, kb))
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    _chk(out, name="out")
+    if tuple(out.shape) != (M, N):
+        raise _lib.DcapError("gemm: out has shape %s, expected %s" % (tuple(out.shape), (M, N)))
+    d = GemmDesc()
+    d.M, d.N, d.K = M, N, K
+    d.A, d.lda, d.a_trans = A.data_ptr(), A.stride(0), int(a_trans)
+    d.a_gather = None if gather is None else _chk(gather, torch.int32, "gather").data_ptr()
+    d.B, d.ldb, d.b_trans = B.data_ptr(), B.stride(0), int(b_trans)
+    d.C, d.ldc = out.data_ptr(), out.stride(0)
+    d.scale = None if scale is None else _chk(scale, name="scale").data_ptr()
+    d.shift = None if shift is None else _chk(shift, name="shift").data_ptr()
+    if residual is not None:
+        _chk(residual, name="residual")
+        d.residual, d.ldr = residual.data_ptr(), residual.stride(0)
+    d.relu, d.accumulate, d.split_k = int(relu), int(accumulate), int(split_k)
+    ws, wsb = WORKSPACE.get(lib.dc_gemm_workspace_bytes(C.byref(d)), A.device)
+    check(lib.dc_gemm_f32(C.byref(d), _ptr(ws), wsb, _stream()), "dc_gemm_f32")
+    return out
+
+
+def conv2d(x, w_packed, kh, kw, stride, pad_t, pad_l, Ho, Wo, scale=None, shift=None, residual=None,
+           res_mode=0, relu=False, out=None, split_k=0):
+    """NHWC conv forward with fused epilogue; see dc_conv2d_nhwc_f32.  x [N,H,W,Cin] contiguous."""
+    lib = _lib.load()
+    _chk(x, name="x"), _chk(w_packed, name="w")
+    N, H, W, Cin = x.shape
+    Cout = w_packed.shape[0]
+    if not x.is_contiguous() or not w_packed.is_contiguous():
+        raise _lib.DcapError("conv2d: x and w must be contiguous")
+    if out is None:
+        out = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+    d = ConvDesc()
+    d.N, d.H, d.W, d.Cin = N, H, W, Cin
+    d.Cout, d.kh, d.kw, d.stride, d.pad_t, d.pad_l, d.Ho, d.Wo = Cout, kh, kw, stride, pad_t, pad_l, Ho, Wo
+    d.x, d.w, d.y = x.data_ptr(), w_packed.data_ptr(), _chk(out, name="out").data_ptr()
+    d.scale = None if scale is None else scale.data_ptr()
+    d.shift = None if shift is None else shift.data_ptr()
+    d.residual = None if residual is None else _chk(residual, name="residual").data_ptr()
+    d.res_mode, d.relu, d.split_k = int(res_mode), int(relu), int(split_k)
+    ws, wsb = WORKSPACE.get(lib.dc_conv2d_workspace_bytes(C.byref(d)), x.device)
+    check(lib.dc_conv2d_nhwc_f32(C.byref(d), _ptr(ws), wsb, _stream()), "dc_conv2d_nhwc_f32")
+    return out
+
+
+def maxpool3x3s2_same(x, out=None):
+    lib = _lib.load()
+    _chk(x, name="x")
+    N, H, W, Cc = x.shape
+    if out is None:
+        out = torch.empty((N, (H + 1) // 2, (W + 1) // 2, Cc), dtype=torch.float32, device=x.device)
+    check(lib.dc_maxpool3x3s2_same_f32(_ptr(x), _ptr(out), N, H, W, Cc, _stream()), "dc_maxpool3x3s2_same_f32")
+    return out
+
+
+def mold_image_rgbx(img_u8, mean_pixel, out=None):
+    lib = _lib.load()
+    _chk(img_u8, torch.uint8, "images")
+    N, H, W, c = img_u8.shape
+    if c != 3 or not img_u8.is_contiguous():
+        raise _lib.DcapError("mold_image: images must be contiguous [N,H,W,3] uint8")
+    if out is None:
+        out = torch.empty((N, H, W, 4), dtype=torch.float32, device=img_u8.device)
+    check(lib.dc_mold_image_rgbx_f32(_ptr(img_u8), _ptr(out), N, H, W, float(mean_pixel[0]), float(mean_pixel[1]),
+                                     float(mean_pixel[2]), _stream()), "dc_mold_image_rgbx_f32")
+    return out
+
+
+def roi_align_pyramid(maps, boxes, image_area, pool=7, out=None, levels_out=None):
+    """maps: [P2,P3,P4,P5] each [B,H,W,C]; boxes [B,R,4] normalised float32 -> [B,R,pool,pool,C]."""
+    lib = _lib.load()
+    B, R, _ = boxes.shape
+    Cc = maps[0].shape[-1]
+    _chk(boxes, name="boxes")
+    if not boxes.is_contiguous():
+        raise _lib.DcapError("roi_align: boxes must be contiguous")
+    if out is None:
+        out = torch.empty((B, R, pool, pool, Cc), dtype=torch.float32, device=boxes.device)
+    d = RoiAlignDesc()
+    d.B, d.R, d.C, d.pool = B, R, Cc, pool
+    for i, m in enumerate(maps):
+        _chk(m, name="map")
+        if not m.is_contiguous() or m.shape[0] != B or m.shape[-1] != Cc:
+            raise _lib.DcapError("roi_align: feature maps must be contiguous [B,H,W,C]")
+        d.maps[i] = m.data_ptr()
+        d.Hs[i], d.Ws[i] = m.shape[1], m.shape[2]
+    d.boxes, d.image_area, d.out = boxes.data_ptr(), float(image_area), out.data_ptr()
+    d.levels_out = None if levels_out is None else _chk(levels_out, torch.int32, "levels").data_ptr()
+    check(lib.dc_roi_align_pyramid_f32(C.byref(d), _stream()), "dc_roi_align_pyramid_f32")
+    return out
+
+
+def lstm_seq_fwd(z, U_rec, mask, B, T, h_seq=None, c_seq=None):
+    """z [T*B,4U] (x-projection + bias, overwritten with the full pre-activation) -> h_seq, c_seq [T*B,U]."""
+    lib = _lib.load()
+    U = U_rec.shape[0]
+    _chk(z, name="z"), _chk(U_rec, name="U_rec")
+    if not z.is_contiguous() or not U_rec.is_contiguous() or tuple(z.shape) != (T * B, 4 * U):
+        raise _lib.DcapError("lstm_seq_fwd: z must be contiguous [T*B,4U], U_rec contiguous [U,4U]")
+    if h_seq is None:
+        h_seq = torch.empty((T * B, U), dtype=torch.float32, device=z.device)
+    if c_seq is None:
+        c_seq = torch.empty((T * B, U), dtype=torch.float32, device=z.device)
+    d = LstmFwdDesc()
+    d.B, d.T, d.U = B, T, U
+    d.z, d.U_rec = z.data_ptr(), U_rec.data_ptr()
+    d.mask = None if mask is None else _chk(mask, torch.uint8, "mask").data_ptr()
+    d.h_seq, d.c_seq = h_seq.data_ptr(), c_seq.data_ptr()
+    ws, wsb = WORKSPACE.get(lib.dc_lstm_seq_workspace_bytes(B, T, U), z.device)
+    check(lib.dc_lstm_seq_fwd_f32(C.byref(d), _ptr(ws), wsb, _stream()), "dc_lstm_seq_fwd_f32")
+    return h_seq, c_seq
+
+
+def lstm_seq_bwd(z, U_rec, mask, h_seq, c_seq, B, T, dh_seq=None, dh_last=None, dz=None, dU=None, accumulate_dU=False):
+    lib = _lib.load()
+    U = U_rec.shape[0]
+    if dz is None:
+        dz = torch.empty((T * B, 4 * U), dtype=torch.float32, device=z.device)
+    if dU is None:
+        dU = torch.empty((U, 4 * U), dtype=torch.float32, device=z.device)
+    d = LstmBwdDesc()
+    d.B, d.T, d.U = B, T, U
+    d.z, d.U_rec = _chk(z, name="z").data_ptr(), _chk(U_rec, name="U_rec").data_ptr()
+    d.mask = None if mask is None else _chk(mask, torch.uint8, "mask").data_ptr()
+    d.h_seq, d.c_seq = h_seq.data_ptr(), c_seq.data_ptr()
+    for name, t in (("dh_seq", dh_seq), ("dh_last", dh_last)):
+        if t is not None and not _chk(t, name=name).is_contiguous():
+            raise _lib.DcapError("lstm_seq_bwd: %s must be contiguous" % name)
+    d.dh_seq = None if dh_seq is None else dh_seq.data_ptr()
+    d.dh_last = None if dh_last is None else dh_last.data_ptr()
+    d.dz, d.dU_rec, d.accumulate_dU = dz.data_ptr(), _chk(dU, name="dU").data_ptr(), int(accumulate_dU)
+    ws, wsb = WORKSPACE.get(lib.dc_lstm_seq_workspace_bytes(B, T, U), z.device)
+    check(lib.dc_lstm_seq_bwd_f32(C.byref(d), _ptr(ws), wsb, _stream()), "dc_lstm_seq_bwd_f32")
+    return dz, dU
+
+
+def softmax_ce(logits, targets=None, probs=None, loss_rows=None, dlogits=None, grad_scale=1.0):
+    lib = _lib.load()
+    _chk(logits, name="logits")
+    d = SoftmaxCeDesc()
+    d.M, d.V, d.ld = logits.shape[0], logits.shape[1], logits.stride(0)
+    d.logits = logits.data_ptr()
+    d.targets = None if targets is None else _chk(targets, torch.int32, "targets").data_ptr()
+    for name, t in (("probs", probs), ("dlogits", dlogits)):
+        if t is not None and (_chk(t, name=name).stride(0) != logits.stride(0)):
+            raise _lib.DcapError("softmax_ce: %s must share the logits' row stride" % name)
+    d.probs = None if probs is None else probs.data_ptr()
+    d.loss_rows = None if loss_rows is None else _chk(loss_rows, name="loss_rows").data_ptr()
+    d.dlogits = None if dlogits is None else dlogits.data_ptr()
+    d.grad_scale = float(grad_scale)
+    check(lib.dc_softmax_ce_f32(C.byref(d), _stream()), "dc_softmax_ce_f32")
+
+
+def argmax_rows(x, out=None):
+    lib = _lib.load()
+    _chk(x, name="x")
+    if out is None:
+        out = torch.empty((x.shape[0],), dtype=torch.int32, device=x.device)
+    check(lib.dc_argmax_rows_f32(_ptr(x), x.shape[0], x.shape[1], x.stride(0), _ptr(out), _stream()), "dc_argmax_rows_f32")
+    return out
+
+
+def colsum(x, out=None, accumulate=False):
+    lib = _lib.load()
+    _chk(x, name="x")
+    if out is None:
+        out = torch.empty((x.shape[1],), dtype=torch.float32, device=x.device)
+    check(lib.dc_colsum_f32(_ptr(x), x.shape[0], x.shape[1], x.stride(0), _ptr(out), int(accumulate), _stream()), "dc_colsum_f32")
+    return out
+
+
+def sumsq(x, out=None, accumulate=False):
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty((1,), dtype=torch.float32, device=x.device)
+    check(lib.dc_sumsq_f32(_ptr(_chk(x, name="x")), x.numel(), _ptr(out), int(accumulate), _stream()), "dc_sumsq_f32")
+    return out
+
+
+def mean(x, out=None):
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty((1,), dtype=torch.float32, device=x.device)
+    check(lib.dc_mean_f32(_ptr(_chk(x, name="x")), x.numel(), _ptr(out), _stream()), "dc_mean_f32")
+    return out
+
+
+def amsgrad_step(p, g, m, v, vhat, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, gnorm_sq=None, clipnorm=0.0):
+    lib = _lib.load()
+    d = AmsgradDesc()
+    d.n = p.numel()
+    d.p, d.g, d.m, d.v, d.vhat = (_chk(t, name="amsgrad buffer").data_ptr() for t in (p, g, m, v, vhat))
+    d.lr_t, d.beta1, d.beta2, d.eps = float(lr_t), float(beta1), float(beta2), float(eps)
+    d.grad_scale = float(grad_scale)
+    d.gnorm_sq = None if gnorm_sq is None else gnorm_sq.data_ptr()
+    d.clipnorm = float(clipnorm or 0.0)
+    check(lib.dc_amsgrad_step_f32(C.byref(d), _stream()), "dc_amsgrad_step_f32")

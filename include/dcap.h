@@ -1,0 +1,225 @@
+/*
+ * dcap.h -- C-ABI of libdcap_hip.so: the MI355X (gfx950) kernels of the dense-captioning hot path.
+ *
+ * The reference (frosinastojanovska/image-captioning) has no FFI of its own: every arithmetic op on
+ * the path is a Keras-2.1 / TF-1.x call.  Each entry point below replaces one family of those call
+ * sites (cited as file:line relative to the reference root); the Python host side
+ * (the modules under image-captioning_amd/) binds them with ctypes and keeps the reference's module/function names.
+ * INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - return 0 on success, a negative DC_E* code otherwise; dc_last_error() gives a thread-local text;
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller;
+ *   - enqueue-only on `stream` (a hipStream_t passed as void*): no allocation, no synchronisation,
+ *     safe under hipGraph stream capture; stateless and re-entrant on distinct streams;
+ *   - scratch memory is a caller-provided workspace; dc_*_workspace_bytes() gives the size;
+ *   - tensors are row-major, activations NHWC, float32 unless stated.
+ */
+#ifndef DCAP_H
+#define DCAP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DC_OK            0
+#define DC_EINVAL       -1   /* bad shape / null pointer / unsupported combination */
+#define DC_EALIGN       -2   /* pointer or leading dimension not 16-byte aligned where required */
+#define DC_EWORKSPACE   -3   /* workspace too small */
+#define DC_ELAUNCH      -4   /* HIP launch error (text in dc_last_error) */
+
+int         dc_version(void);            /* 100*major + minor */
+const char* dc_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM  C[M,N] = epilogue(A[M,K] * B[K,N])            (fp32 in, fp32 MFMA accumulate)
+ * Replaces KL.Dense / the LSTM kernels' x.W products / the 7x7-valid + 1x1 RoI-head convs:
+ *   dense_img_cap_separate_models/text_generation_model.py:143-144,153-154,251-259
+ *   dense_img_cap_separate_models/text_generation_model_v2.py:141-150,157,163-164
+ * and their gradients (dgrad = dY*W^T: b_trans=1; wgrad = A^T*dY: a_trans=1).
+ *   a_trans=0: A is [M][lda] (K contiguous);   a_trans=1: A is [K][lda] (M contiguous)
+ *   b_trans=0: B is [K][ldb] (N contiguous, the Keras [in,out] kernel);  b_trans=1: B is [N][ldb]
+ *   a_gather (optional, a_trans=0): row m of A is A[a_gather[m]] -- the fused KL.Embedding lookup
+ *     (text_generation_model.py:135-140, _v2.py:155-156)
+ * epilogue: v = acc*scale[n] + shift[n] (each optional), += residual[m][n] (optional),
+ *           relu (optional), then C = v  or  C += v (accumulate).
+ * split_k > 1 partitions K over blockIdx.z through fp32 slabs in the workspace (deterministic
+ * reduction order); 0 lets the library choose.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int M, N, K;
+    const float*   A;  int lda;  int a_trans;
+    const int32_t* a_gather;
+    const float*   B;  int ldb;  int b_trans;
+    float*         C;  int ldc;
+    const float*   scale;
+    const float*   shift;
+    const float*   residual;  int ldr;
+    int relu;
+    int accumulate;
+    int split_k;
+} dc_gemm_desc;
+
+size_t dc_gemm_workspace_bytes(const dc_gemm_desc* d);
+int    dc_gemm_f32(const dc_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * conv2d NHWC forward as an implicit GEMM (LDS im2col tiles), fused frozen-BN / bias / residual /
+ * ReLU epilogue.  Replaces KL.Conv2D + BatchNorm(training=False) + Add + Activation('relu'):
+ *   feature_generation/dense_model.py:85-100 (identity_block), :120-139 (conv_block),
+ *   :146-149 (stem), :1406-1421 (FPN laterals / 3x3), UpSampling2D+Add :1407-1415 (res_mode 2).
+ *   x [N,H,W,Cin]; w PACKED [Cout][kh*kw*Cin] (cin fastest; dc_pack helper on the host side);
+ *   y [N,Ho,Wo,Cout];  y = relu?( scale[c]*conv + shift[c] + residual )
+ *   res_mode: 0 none, 1 residual [N,Ho,Wo,Cout], 2 residual [N,Ho/2,Wo/2,Cout] nearest-upsampled x2.
+ * Cin must be a multiple of 32, except the stem: Cin==4 (RGBX), kh==kw==7, stride 2, with w packed
+ * as [Cout][7][8][4] (kx==7 and c==3 entries zero).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int N, H, W, Cin;
+    int Cout, kh, kw, stride, pad_t, pad_l;
+    int Ho, Wo;
+    const float* x;
+    const float* w;
+    float*       y;
+    const float* scale;
+    const float* shift;
+    const float* residual;  int res_mode;
+    int relu;
+    int split_k;
+} dc_conv_desc;
+
+size_t dc_conv2d_workspace_bytes(const dc_conv_desc* d);
+int    dc_conv2d_nhwc_f32(const dc_conv_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+
+/* KL.MaxPooling2D((3,3), strides 2, 'same') (dense_model.py:150); C % 4 == 0. */
+int dc_maxpool3x3s2_same_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
+
+/* mold_image (dense_model.py:2050-2055) fused with the RGBX repack the stem kernel wants:
+ * out[n,h,w,0..2] = float(img_u8) - mean[c], out[...,3] = 0. */
+int dc_mold_image_rgbx_f32(const uint8_t* img, float* out, int N, int H, int W,
+                           float mean_r, float mean_g, float mean_b, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * PyramidROIAlign forward (feature_generation/dense_model.py:317-418): level routing
+ * k = clamp(4 + round_half_even(log2(sqrt(h*w) / (224/sqrt(image_area)))), 2, 5) and
+ * tf.image.crop_and_resize(bilinear, 1 sample per bin, extrapolation 0) in one gather kernel.
+ *   maps[l] = P(2+l) [B,Hl,Wl,C] (C % 4 == 0, C <= 256*4); boxes [B*R,4] normalised (y1,x1,y2,x2), batch-major;
+ *   out [B*R,pool,pool,C] in box order (the reference's final reorder, :397-411, is the identity
+ *   here because nothing is regrouped by level).  levels_out (optional) [B*R] int32.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int B, R, C, pool;
+    const float* maps[4];
+    int Hs[4], Ws[4];
+    const float* boxes;
+    float image_area;
+    float* out;
+    int32_t* levels_out;
+} dc_roialign_desc;
+
+int dc_roi_align_pyramid_f32(const dc_roialign_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Keras-2.1 LSTM over a whole sequence (gate blocks i,f,c,o; hard-sigmoid gates; tanh; mask carry).
+ * Replaces KL.LSTM: text_generation_model.py:141-142,150-151; _v2.py:157,163.
+ * Time-major: row (t*B + b).  The caller first computes zx = x*kernel + bias with dc_gemm_f32
+ * (optionally with the fused embedding gather); this call runs the recurrence:
+ *   z_t = zx_t + h_{t-1}*U ; i,f,o = hs(z) ; g = tanh(z_c) ; c' = f*c + i*g ; h' = o*tanh(c')
+ *   masked rows (mask[t*B+b]==0) carry h,c from t-1 (zeros before the first unmasked step).
+ * zx is updated IN PLACE to the full pre-activation z (saved for backward).
+ *   z [T*B][4U] in/out, U_rec [U][4U], mask [T*B] uint8 or NULL, h_seq/c_seq [T*B][U] out.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int B, T, U;
+    float* z;
+    const float* U_rec;
+    const uint8_t* mask;
+    float* h_seq;
+    float* c_seq;
+} dc_lstm_fwd_desc;
+
+size_t dc_lstm_seq_workspace_bytes(int B, int T, int U);
+int    dc_lstm_seq_fwd_f32(const dc_lstm_fwd_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward of the recurrence.  dh_seq [T*B][U] (may be NULL) is the gradient w.r.t. every step's
+ * output, dh_last [B][U] (may be NULL) an extra gradient on the last step's output.
+ * Outputs: dz [T*B][4U] (caller derives dkernel = x^T dz, dbias = colsum dz, dx = dz kernel^T with
+ * dc_gemm_f32 / dc_colsum_f32) and dU_rec [U][4U] (written, or accumulated if accumulate_dU). */
+typedef struct {
+    int B, T, U;
+    const float* z;
+    const float* U_rec;
+    const uint8_t* mask;
+    const float* h_seq;
+    const float* c_seq;
+    const float* dh_seq;
+    const float* dh_last;
+    float* dz;
+    float* dU_rec;
+    int accumulate_dU;
+} dc_lstm_bwd_desc;
+
+int dc_lstm_seq_bwd_f32(const dc_lstm_bwd_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * softmax + K.categorical_crossentropy (clip 1e-7) forward and d/dlogits in one pass per row.
+ * Replaces Dense(..., activation='softmax') + keras.losses.categorical_crossentropy /
+ * roi_caption_loss: text_generation_model.py:154,286-294; _v2.py:164,267.
+ *   logits [M][ld] (V valid columns); targets [M] int32 (the argmax of the reference's one-hot rows);
+ *   probs (optional) [M][ld]; loss_rows (optional) [M]; dlogits (optional, may alias logits) [M][ld]:
+ *   dlogits = grad_scale * (p - onehot) for rows whose target probability is inside [1e-7, 1-1e-7], else 0.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int M, V, ld;
+    const float* logits;
+    const int32_t* targets;
+    float* probs;
+    float* loss_rows;
+    float* dlogits;
+    float grad_scale;
+} dc_softmax_ce_desc;
+
+int dc_softmax_ce_f32(const dc_softmax_ce_desc* d, void* stream);
+
+/* tf.argmax over the last axis, lowest index wins ties (text_generation_model.py:222-225). */
+int dc_argmax_rows_f32(const float* x, int M, int V, int ld, int32_t* out, void* stream);
+
+/* out[n] (+)= sum_m x[m][n]  -- bias gradients. */
+int dc_colsum_f32(const float* x, int M, int N, int ld, float* out, int accumulate, void* stream);
+
+/* out[0] (+)= sum(x^2) -- global-norm clipping (Adam(clipnorm=0.5), dense_img_cap/dense_model.py:1699). */
+int dc_sumsq_f32(const float* x, size_t n, float* out, int accumulate, void* stream);
+
+/* mean of loss rows: out[0] = sum(x)/n. */
+int dc_mean_f32(const float* x, size_t n, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * keras.optimizers.Adam(amsgrad=True) fused over one flat parameter bucket
+ * (text_generation_model.py:425; _v2.py:266): with g' = g * grad_scale * clip,
+ *   m = b1*m + (1-b1)*g' ; v = b2*v + (1-b2)*g'^2 ; vhat = max(vhat, v) ; p -= lr_t*m/(sqrt(vhat)+eps)
+ * lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the caller.  If gnorm_sq (device scalar: sum of
+ * squares of the UNSCALED gradients) is non-NULL and clipnorm > 0, clip = clipnorm/norm when
+ * norm >= clipnorm (norm taken after grad_scale), else 1.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    size_t n;
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    float* vhat;
+    float lr_t, beta1, beta2, eps;
+    float grad_scale;
+    const float* gnorm_sq;
+    float clipnorm;
+} dc_amsgrad_desc;
+
+int dc_amsgrad_step_f32(const dc_amsgrad_desc* d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCAP_H */

@@ -1,0 +1,263 @@
+"""Kernel-level parity: every C-ABI entry point against the NumPy oracle on seeded inputs (-m gpu).
+Tolerances: fp32 MFMA accumulation vs float64 oracle => 2e-5 of the output scale unless stated
+(index outputs -- argmax, pyramid levels -- are bit-exact)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from image_captioning_amd import ops as _ops, _lib
+    _lib.load()
+    return _ops
+
+
+def dev(a, dtype=torch.float32):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device="cuda")
+
+
+def close(got, want, tol=2e-5):
+    got = got.detach().cpu().numpy().astype(np.float64)
+    want = np.asarray(want, np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    scale = max(1.0, float(np.abs(want).max()))
+    err = float(np.abs(got - want).max()) / scale
+    assert err < tol, "max err %.3e (scaled) exceeds %.1e" % (err, tol)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (100, 72, 300), (8, 1000, 1024), (260, 132, 68), (960, 256, 2048), (512, 1024, 960)])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_layouts(ops, M, N, K, ta, tb):
+    rng = np.random.default_rng(M * 7 + N * 3 + K + ta * 2 + tb)
+    A = rng.standard_normal((M, K))
+    B = rng.standard_normal((K, N))
+    a = dev(A.T if ta else A)
+    b = dev(B.T if tb else B)
+    close(ops.gemm(a, b, a_trans=bool(ta), b_trans=bool(tb)), A @ B)
+
+
+@pytest.mark.parametrize("split", [0, 1, 3, 8])
+def test_gemm_epilogue_splitk_accumulate(ops, split):
+    rng = np.random.default_rng(11 + split)
+    M, N, K = 64, 1024, 12544 // 4
+    A = rng.standard_normal((M, K))
+    B = rng.standard_normal((K, N)) / np.sqrt(K)
+    sc, sh = rng.uniform(0.5, 1.5, N), rng.standard_normal(N)
+    R = rng.standard_normal((M, N))
+    C0 = rng.standard_normal((M, N))
+    want = np.maximum((A @ B) * sc + sh + R, 0) + C0
+    out = dev(C0)
+    ops.gemm(dev(A), dev(B), out=out, scale=dev(sc), shift=dev(sh), residual=dev(R), relu=True, accumulate=True, split_k=split)
+    close(out, want)
+
+
+def test_gemm_gather_is_embedding_lookup(ops):
+    rng = np.random.default_rng(5)
+    V, E, N = 500, 300, 256
+    table = rng.standard_normal((V, E))
+    W = rng.standard_normal((E, N))
+    ids = rng.integers(0, V, 77)
+    got = ops.gemm(dev(table), dev(W), gather=dev(ids, torch.int32), shift=dev(np.ones(N)))
+    close(got, table[ids] @ W + 1.0)
+
+
+def test_gemm_strided_views(ops):
+    rng = np.random.default_rng(6)
+    big = rng.standard_normal((90, 1324))
+    W = rng.standard_normal((1324, 64))
+    a = dev(big)
+    close(ops.gemm(a[:, 300:], dev(W[300:])), big[:, 300:] @ W[300:])          # the RoI-feature half of lstm1.kernel
+    out = torch.zeros(90, 128, device="cuda")
+    ops.gemm(a, dev(W), out=out[:, 64:])
+    close(out[:, 64:], big @ W)
+    assert float(out[:, :64].abs().max()) == 0.0
+
+
+def test_gemm_rejects_bad_arguments(ops):
+    from image_captioning_amd._lib import DcapError
+    a = torch.zeros(8, 6, device="cuda")
+    b = torch.zeros(6, 8, device="cuda")
+    with pytest.raises(DcapError):
+        ops.gemm(a, b)                     # lda = 6 is not a multiple of 4
+    with pytest.raises(DcapError):
+        ops.gemm(torch.zeros(8, 8), torch.zeros(8, 8))     # CPU tensors: no fallback
+
+
+CONV_CASES = [
+    # N,H,W,Cin,Cout,k,stride,padding,res_mode,relu
+    (1, 16, 16, 64, 64, 1, 1, 'valid', 0, True),
+    (2, 16, 24, 64, 256, 1, 1, 'valid', 1, True),
+    (1, 32, 32, 256, 128, 1, 2, 'valid', 0, True),
+    (2, 12, 20, 64, 64, 3, 1, 'same', 0, True),
+    (1, 16, 16, 128, 128, 3, 1, 'same', 0, False),
+    (1, 8, 8, 512, 512, 3, 1, 'same', 0, True),          # small M, long K: split-K path
+    (1, 16, 16, 256, 256, 1, 1, 'valid', 2, False),      # FPN lateral + upsample-add
+    (3, 7, 7, 256, 1024, 7, 1, 'valid', 0, True),        # RoI head conv as a conv
+    (2, 64, 64, 64, 128, 3, 1, 'same', 1, True),         # 128-wide tiles
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_matches_oracle(ops, case):
+    from image_captioning_amd.packing import pack_conv_kernel
+    N, H, W, Cin, Cout, k, stride, padding, res_mode, relu = case
+    rng = np.random.default_rng(sum(int(v) * (i + 1) for i, v in enumerate(case) if not isinstance(v, str)))
+    x = rng.standard_normal((N, H, W, Cin))
+    w = rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)
+    sc, sh = rng.uniform(0.5, 1.5, Cout), rng.standard_normal(Cout)
+    y = O.conv2d_nhwc(x, w, None, stride, padding) * sc + sh
+    Ho, Wo = y.shape[1:3]
+    res = None
+    if res_mode == 1:
+        res = rng.standard_normal(y.shape)
+        y = y + res
+    elif res_mode == 2:
+        res = rng.standard_normal((N, Ho // 2, Wo // 2, Cout))
+        y = y + O.upsample2x(res)
+    if relu:
+        y = np.maximum(y, 0)
+    pt, pl = (O.same_pad(H, k, stride)[0], O.same_pad(W, k, stride)[0]) if padding == 'same' else (0, 0)
+    got = ops.conv2d(dev(x), dev(pack_conv_kernel(w)), k, k, stride, pt, pl, Ho, Wo, dev(sc), dev(sh),
+                     None if res is None else dev(res), res_mode, relu)
+    close(got, y)
+
+
+@pytest.mark.parametrize("N,H,W", [(1, 32, 32), (2, 64, 96)])
+def test_stem_mold_maxpool(ops, N, H, W):
+    from image_captioning_amd.packing import pack_stem_kernel
+    rng = np.random.default_rng(H)
+    img = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)
+    mean = [123.7, 116.8, 103.9]
+    w = rng.standard_normal((7, 7, 3, 64)) / 12.0
+    sc, sh = rng.uniform(0.5, 1.5, 64), rng.standard_normal(64)
+    x = O.mold_image(img, mean)
+    rgbx = ops.mold_image_rgbx(dev(img, torch.uint8), mean)
+    close(rgbx[..., :3], x, 1e-6)
+    assert float(rgbx[..., 3].abs().max()) == 0.0
+    y = np.maximum(O.conv2d_nhwc(x, w, None, 2, (3, 3, 3, 3)) * sc + sh, 0)
+    got = ops.conv2d(rgbx, dev(pack_stem_kernel(w)), 7, 7, 2, 3, 3, H // 2, W // 2, dev(sc), dev(sh), None, 0, True)
+    close(got, y)
+    close(ops.maxpool3x3s2_same(got), O.maxpool3x3s2_same(got.cpu().numpy().astype(np.float64)), 1e-7)
+
+
+def test_roi_align_pyramid(ops):
+    from image_captioning_amd import synth
+    rng = np.random.default_rng(3)
+    B, R, C, S = 2, 40, 256, 512
+    maps = [rng.standard_normal((B, S // s, S // s, C)) for s in (4, 8, 16, 32)]
+    rois = synth.rois(9, B, R, S, S, lo=16, hi=512)
+    rois[0, 0] = [0, 0, S, S]
+    rois[0, 1] = [100, 100, 100, 180]          # zero-area box
+    rois[1, 0] = [S - 40, S - 30, S, S]        # touches the border
+    boxes = O.normalize_boxes(rois, S, S)
+    want = O.pyramid_roi_align(boxes, maps, (S, S, 3), 7)
+    lv = torch.empty(B * R, dtype=torch.int32, device="cuda")
+    got = ops.roi_align_pyramid([dev(m) for m in maps], dev(boxes), S * S, 7, levels_out=lv)
+    np.testing.assert_array_equal(lv.cpu().numpy().reshape(B, R), O.roi_levels(boxes, (S, S, 3)))     # bit-exact routing
+    assert set(lv.cpu().numpy().tolist()) == {2, 3, 4, 5}
+    close(got, want, 1e-5)
+
+
+@pytest.mark.parametrize("B,T,I,U,masked", [(3, 4, 8, 4, True), (64, 10, 300, 128, True), (8, 15, 64, 512, False), (5, 1, 2048, 256, False)])
+def test_lstm_seq_forward_backward(ops, B, T, I, U, masked):
+    rng = np.random.default_rng(B + T + U)
+    x = rng.standard_normal((B, T, I))
+    W = rng.standard_normal((I, 4 * U)) / np.sqrt(I)
+    Ur = rng.standard_normal((U, 4 * U)) / np.sqrt(U)
+    b = 0.1 * rng.standard_normal(4 * U)
+    mask = None
+    if masked:
+        mask = rng.random((B, T)) > 0.3
+        mask[0] = False                                   # a fully masked row
+        mask[1] = True
+    H, cache = O.lstm_forward(x, mask, W, Ur, b)
+    dH = rng.standard_normal((B, T, U))
+    dlast = rng.standard_normal((B, U))
+    dx, dW, dU, db = O.lstm_backward(dH, cache, dh_last=dlast)
+    # device: time-major rows t*B+b
+    xt = dev(np.transpose(x, (1, 0, 2)).reshape(T * B, I))
+    z = ops.gemm(xt, dev(W), shift=dev(b))
+    mk = None if mask is None else dev(mask.T.reshape(-1), torch.uint8)
+    Ud = dev(Ur)
+    h_seq, c_seq = ops.lstm_seq_fwd(z, Ud, mk, B, T)
+    close(h_seq.view(T, B, U).permute(1, 0, 2), H)
+    dz, dUd = ops.lstm_seq_bwd(z, Ud, mk, h_seq, c_seq, B, T,
+                               dh_seq=dev(np.transpose(dH, (1, 0, 2)).reshape(T * B, U)), dh_last=dev(dlast))
+    close(dUd, dU, 5e-5)
+    close(ops.gemm(xt, dz, a_trans=True), dW, 5e-5)                          # dkernel = x^T dz
+    close(ops.colsum(dz), db, 5e-5)
+    close(ops.gemm(dz, dev(W), b_trans=True).view(T, B, I).permute(1, 0, 2), dx, 5e-5)   # dx = dz kernel^T
+
+
+@pytest.mark.parametrize("M,V", [(7, 1000), (64, 10000), (5, 1003)])
+def test_softmax_ce(ops, M, V):
+    rng = np.random.default_rng(V)
+    z = 3.0 * rng.standard_normal((M, V))
+    t = rng.integers(0, V, M)
+    z[0, t[0]] = -60.0                                    # target probability below 1e-7: clipped row
+    z[1, :] = -50.0
+    z[1, t[1]] = 50.0                                     # target probability above 1-1e-7: clipped row
+    p = O.softmax(z)
+    ld = (V + 3) // 4 * 4
+    zd = torch.zeros(M, ld, device="cuda")
+    zd[:, :V] = dev(z)
+    probs = torch.empty_like(zd)
+    dl = torch.empty_like(zd)
+    loss = torch.empty(M, device="cuda")
+    ops.softmax_ce(zd[:, :V], dev(t, torch.int32), probs[:, :V], loss, dl[:, :V], grad_scale=1.0 / M)
+    close(probs[:, :V], p, 1e-6)
+    close(loss, O.categorical_crossentropy(t, p), 1e-5)
+    close(dl[:, :V], O.softmax_ce_grad_logits(t, p, np.full(M, 1.0 / M)), 1e-6)
+    assert float(dl[0, :V].abs().max()) == 0.0 and float(dl[1, :V].abs().max()) == 0.0
+    close(ops.mean(loss), np.array([O.categorical_crossentropy(t, p).mean()]), 1e-5)
+
+
+def test_argmax_lowest_index_wins_ties(ops):
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((33, 10000)).astype(np.float32)
+    x[3, 77] = x[3, 9000] = 99.0
+    x[4, :] = 1.0
+    x[5, 9999] = 50.0
+    got = ops.argmax_rows(dev(x)).cpu().numpy()
+    np.testing.assert_array_equal(got, np.argmax(x, axis=1))
+    assert got[3] == 77 and got[4] == 0 and got[5] == 9999
+
+
+def test_colsum_sumsq(ops):
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((960, 1000))
+    close(ops.colsum(dev(x)), x.sum(0), 1e-5)
+    acc = dev(np.ones(1000))
+    ops.colsum(dev(x), out=acc, accumulate=True)
+    close(acc, x.sum(0) + 1, 1e-5)
+    close(ops.sumsq(dev(x)), np.array([(x ** 2).sum()]), 1e-5)
+
+
+@pytest.mark.parametrize("clip", [None, 0.5])
+def test_amsgrad_trajectory(ops, clip):
+    rng = np.random.default_rng(8)
+    n = 10007
+    p0 = rng.standard_normal(n)
+    p = dev(p0)
+    m = torch.zeros(n, device="cuda")
+    v = torch.zeros(n, device="cuda")
+    vh = torch.zeros(n, device="cuda")
+    P, Mm, Vv, Vh = p0.copy(), 0.0, 0.0, 0.0
+    for t in range(1, 6):
+        g = rng.standard_normal(n) * (0.3 ** t)
+        gg = g
+        if clip is not None:
+            (gg,), _ = O.clip_by_global_norm([g], clip)
+        P, Mm, Vv, Vh = O.amsgrad_step(P, gg, Mm, Vv, Vh, t)
+        gd = dev(g)
+        lr_t = 1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        ops.amsgrad_step(p, gd, m, v, vh, lr_t, gnorm_sq=ops.sumsq(gd) if clip else None, clipnorm=clip or 0.0)
+    close(p, P, 1e-6)
+    close(vh, Vh, 1e-5)
