@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""bench.py -- captions/sec of one dense-captioning TRAIN STEP on synthetic Visual-Genome-shaped data.
+
+Workload (BASELINE.json configs[2], and configs[3] at --gpus 8): per GPU `images_per_gpu` (2) synthetic
+1024x1024 images x 32 ground-truth RoIs x 15-token captions; one step =
+  frozen ResNet-101 + FPN forward -> PyramidROIAlign -> frozen RoI head -> v2-inject caption decoder
+  (word-LSTM-1024, inject-LSTM-256, Dense-V softmax, V = 10 000) forward + backward -> [RCCL gradient
+  all-reduce] -> Keras AMSGrad update.
+All arithmetic is fp32 (exact-f32 MFMA).  Inputs are resident in HBM before the timed region.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Rank 0 prints ONE JSON line (see the driver contract) with two extra objects:
+  roofline     -- the dominant kernel (the conv implicit-GEMM instantiation with the largest time share):
+                  algorithmic FLOPs per launch / mean launch time (HIP events on the launch stream, taken
+                  in this process right after the timed steps) against the fp32 MFMA peak (157.3 TFLOP/s);
+  cpu_baseline -- the reference-as-written algorithm (oracle/torch_ref.py, float32, all host threads)
+                  timed on a bounded sample (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+V2_INJECT_FWD_MF_PER_CAPTION = 310.3   # T=15, V=10k single pass
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--images-per-gpu", type=int, default=2)
+    ap.add_argument("--rois", type=int, default=32)
+    ap.add_argument("--tokens", type=int, default=15)
+    ap.add_argument("--vocab", type=int, default=10000)
+    ap.add_argument("--image-size", type=int, default=1024)
+    ap.add_argument("--stage4-blocks", type=int, default=22, help="22 = ResNet-101 (the benchmark config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-baseline-images", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Reference-as-written train step on the host (oracle/torch_ref.py), float32, all threads:
+    batch-1 ResNet-101+FPN (+ the RPN convs the reference always evaluates) per image, RoIAlign, then
+    every (prefix -> next word) sample recomputing RoI head + word LSTM; Keras AMSGrad."""
+    from oracle import torch_ref as TR
+    from image_captioning_amd import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    S, V, T, R = args.image_size, args.vocab, args.tokens, args.rois
+    encW = TR.to_t(synth.encoder_weights(0, args.stage4_blocks), torch.float32)
+    g = torch.Generator().manual_seed(0)
+    encW['_rpn'] = {'shared': 0.01 * torch.randn(512, 256, 3, 3, generator=g), 'cls': 0.01 * torch.randn(6, 512, 1, 1, generator=g),
+                    'bbox': 0.01 * torch.randn(12, 512, 1, 1, generator=g)}
+    W = dict(synth.head_weights(1), **synth.v2_weights(2, V))
+    W['imgcap_embedding_layer/embeddings'] = synth.embedding_matrix(3, V)
+    train = [k for k in W if k.split('/')[0] in ('lstm_1', 'imgcap_lstm', 'imgcap_d1')]
+    decW = TR.to_t(W, torch.float32, requires_grad=train)
+    imgs = synth.images(99, 1, S, S)
+    rois = synth.rois(98, 1, R, S, S)[0]
+    caps = synth.captions_v2(97, R, T, V, full=True)
+    state = {}
+    times = []
+    n_img = max(1, args.cpu_baseline_images)
+    for i in range(1 + n_img):                    # first image is the warm-up
+        t0 = time.perf_counter()
+        TR.cpu_baseline_step(encW, decW, imgs[0], rois, caps, [123.7, 116.8, 103.9], T, V, state, args.stage4_blocks)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times[1:]))
+    return {"value": R / med, "unit": "captions/s", "cores": cores, "kind": "port",
+            "sample": "%d timed step(s) of 1 image x %d RoI x %d tok (median %.2f s/step) after 1 warm-up; "
+                      "reference-as-written algorithm incl. dead RPN convs, torch-CPU fp32" % (n_img, R, T, med)}
+
+
+def main():
+    args = parse()
+    from image_captioning_amd import synth
+    from image_captioning_amd.parallel_model import init_process_group_from_env, ParallelModel
+    rank, world, local_rank = init_process_group_from_env()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    from image_captioning_amd.config import Config
+    from image_captioning_amd.modified_dense_model import DenseImageCapRCNN
+    from image_captioning_amd.text_generation_model_v2 import DenseCapConfig, build_model, Adam, SampleTables
+
+    S, V, T, R, B = args.image_size, args.vocab, args.tokens, args.rois, args.images_per_gpu
+
+    class EncCfg(Config):
+        NAME = "bench"
+        IMAGES_PER_GPU = B
+        IMAGE_MIN_DIM = S
+        IMAGE_MAX_DIM = S
+
+    enc = DenseImageCapRCNN("inference", EncCfg(), "logs", device=dev, stage4_blocks=args.stage4_blocks)
+    enc.set_weights(synth.encoder_weights(0, args.stage4_blocks))
+    cfg = DenseCapConfig(V, synth.embedding_matrix(3, V))
+    cfg.PADDING_SIZE = T
+    dec = build_model((7, 7, 256), (T,), cfg, 256, inject=True, device=dev, seed=0)
+    dec.compile(optimizer=Adam(amsgrad=True), loss="categorical_crossentropy")
+    if world > 1:
+        dec = ParallelModel(dec, world)
+
+    seed = 1234 + rank
+    images = torch.tensor(synth.images(seed, B, S, S), device=dev)
+    rois = synth.rois(seed + 1, B, R, S, S)
+    caps = synth.captions_v2(seed + 2, B * R, T, V, full=True)
+    tables = SampleTables.from_captions(caps, dev)
+    plan = enc.plan(B, S, S)
+    plan.images.copy_(images)
+    boxes = plan.normalize_boxes(rois)          # device-resident, normalised once
+    feat = torch.empty((B, R, 7, 7, 256), dtype=torch.float32, device=dev)
+    inner = dec.inner_model if world > 1 else dec
+
+    def step():
+        plan.forward(None)                       # images already resident in the plan's input buffer
+        plan.roi_features(boxes_norm=boxes, out=feat)
+        return inner.train_step(feat.view(B * R, 7, 7, 256), tables)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 2)):           # >= 2: the second call captures the encoder hipGraph
+        loss = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    captions = world * B * R * args.steps
+    final_loss = float(loss.item())
+
+    out = {
+        "metric": "captions/sec (train step) on 1024px x 32RoI x 15tok synth",
+        "value": captions / dt, "unit": "captions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2] (configs[3] at 8 GPUs): frozen ResNet-101+FPN fwd + PyramidROIAlign + "
+                               "RoI head + v2-inject decoder fwd/bwd + AMSGrad, %dx%d synth images, %d RoI/img, %d-token captions, V=%d"
+                               % (S, S, R, T, V),
+                   "images_per_gpu": B, "global_batch_images": B * world, "captions_per_step": B * R * world,
+                   "parallelism": "dp%d" % world, "stage4_blocks": args.stage4_blocks, "final_loss": final_loss},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        table = plan.conv_table()
+        times = dict(plan.time_convs(reps=3))
+        groups = {}
+        for name, fl, bm, bn, sk in table:
+            kind = "StemKC" if name == "conv1" else "Im2colKC"
+            key = "igemm_kernel<%d,%d,%s,DenseKC>" % (bm, bn, kind)
+            g = groups.setdefault(key, {"flops": 0.0, "ms": 0.0, "launches": 0})
+            g["flops"] += fl
+            g["ms"] += times[name]
+            g["launches"] += 1
+        dom = max(groups, key=lambda k: groups[k]["ms"])
+        g = groups[dom]
+        achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
+        conv_ms = sum(v["ms"] for v in groups.values())
+        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                           "launches_per_step": g["launches"], "gflop_per_launch": g["flops"] / g["launches"] / 1e9,
+                           "avg_launch_us": 1e3 * g["ms"] / g["launches"],
+                           "all_conv": {"gflop_per_step": plan.flops / 1e9, "ms_per_step": conv_ms,
+                                        "tflops": plan.flops / (conv_ms * 1e-3) / 1e12},
+                           "kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 4),
+                                           "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in groups.items()}}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

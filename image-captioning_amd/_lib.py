@@ -21,7 +21,7 @@ class GemmDesc(C.Structure):
                 ("B", C.c_void_p), ("ldb", C.c_int), ("b_trans", C.c_int),
                 ("C", C.c_void_p), ("ldc", C.c_int),
                 ("scale", C.c_void_p), ("shift", C.c_void_p),
-                ("residual", C.c_void_p), ("ldr", C.c_int),
+                ("residual", C.c_void_p), ("ldr", C.c_int), ("res_rows", C.c_int),
                 ("relu", C.c_int), ("accumulate", C.c_int), ("split_k", C.c_int)]
 
 
@@ -78,6 +78,7 @@ SYMBOLS = {
     "dc_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_conv2d_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "dc_conv2d_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dc_conv2d_tile_config": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dc_maxpool3x3s2_same_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dc_mold_image_rgbx_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.c_float, C.c_float, C.c_float, C.c_void_p]),
@@ -87,6 +88,7 @@ SYMBOLS = {
     "dc_lstm_seq_bwd_f32": (C.c_int, [C.POINTER(LstmBwdDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_softmax_ce_f32": (C.c_int, [C.POINTER(SoftmaxCeDesc), C.c_void_p]),
     "dc_argmax_rows_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "dc_gather_rows_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dc_colsum_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dc_sumsq_f32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
     "dc_mean_f32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),

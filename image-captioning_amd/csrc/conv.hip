@@ -93,6 +93,19 @@ extern "C" size_t dc_conv2d_workspace_bytes(const dc_conv_desc* d) {
     return t.split > 1 ? (size_t)t.split * M * N * sizeof(float) : 0;
 }
 
+extern "C" int dc_conv2d_tile_config(const dc_conv_desc* d, int* bm, int* bn, int* split_k) {
+    bool stem;
+    int rc = conv_validate(d, stem);
+    if (rc) return rc;
+    int M, N, K;
+    conv_dims(d, stem, M, N, K);
+    const TileChoice t = choose_tile(M, N, K, d->split_k);
+    if (bm) *bm = t.bm;
+    if (bn) *bn = t.bn;
+    if (split_k) *split_k = t.split;
+    return DC_OK;
+}
+
 extern "C" int dc_conv2d_nhwc_f32(const dc_conv_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
     bool stem;
     int rc = conv_validate(d, stem);

@@ -37,7 +37,6 @@ static int gemm_validate(const dc_gemm_desc* d) {
     DC_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, DC_EINVAL, "dc_gemm_f32: M,N,K must be positive (got %d,%d,%d)", d->M, d->N,
                d->K);
     DC_REQUIRE(d->A && d->B && d->C, DC_EINVAL, "dc_gemm_f32: A, B and C must be non-null");
-    DC_REQUIRE(!(d->a_gather && d->a_trans), DC_EINVAL, "dc_gemm_f32: a_gather needs a_trans == 0");
     DC_REQUIRE(d->lda >= (d->a_trans ? d->M : d->K) && d->ldb >= (d->b_trans ? d->K : d->N) && d->ldc >= d->N, DC_EINVAL,
                "dc_gemm_f32: leading dimension smaller than the row length");
     DC_REQUIRE((d->lda & 3) == 0 && (d->ldb & 3) == 0 && aligned16(d->A) && aligned16(d->B), DC_EALIGN,
@@ -64,16 +63,16 @@ extern "C" int dc_gemm_f32(const dc_gemm_desc* d, void* workspace, size_t worksp
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const TileChoice t = choose_tile(d->M, d->N, d->K, d->split_k);
-    Epilogue ep{d->C, d->ldc, d->scale, d->shift, d->residual, d->ldr, d->residual ? 1 : 0, 0, 0, d->relu, d->accumulate};
+    Epilogue ep{d->C, d->ldc, d->scale, d->shift, d->residual, d->ldr, d->residual ? (d->res_rows > 0 ? 3 : 1) : 0, d->res_rows, 0, d->relu, d->accumulate};
     if (!d->a_trans && !d->b_trans) {
-        return gemm_dispatch(DenseKC{d->A, d->lda, d->M, d->a_gather}, DenseMC{d->B, d->ldb, d->N}, ep, d, t, workspace,
+        return gemm_dispatch(DenseKC{d->A, d->lda, d->M, d->a_gather}, DenseMC{d->B, d->ldb, d->N, nullptr}, ep, d, t, workspace,
                              workspace_bytes, s);
     } else if (!d->a_trans && d->b_trans) {
         return gemm_dispatch(DenseKC{d->A, d->lda, d->M, d->a_gather}, DenseKC{d->B, d->ldb, d->N, nullptr}, ep, d, t,
                              workspace, workspace_bytes, s);
     } else if (d->a_trans && !d->b_trans) {
-        return gemm_dispatch(DenseMC{d->A, d->lda, d->M}, DenseMC{d->B, d->ldb, d->N}, ep, d, t, workspace, workspace_bytes, s);
+        return gemm_dispatch(DenseMC{d->A, d->lda, d->M, d->a_gather}, DenseMC{d->B, d->ldb, d->N, nullptr}, ep, d, t, workspace, workspace_bytes, s);
     }
-    return gemm_dispatch(DenseMC{d->A, d->lda, d->M}, DenseKC{d->B, d->ldb, d->N, nullptr}, ep, d, t, workspace, workspace_bytes,
+    return gemm_dispatch(DenseMC{d->A, d->lda, d->M, d->a_gather}, DenseKC{d->B, d->ldb, d->N, nullptr}, ep, d, t, workspace, workspace_bytes,
                          s);
 }

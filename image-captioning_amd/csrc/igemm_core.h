@@ -99,6 +99,7 @@ struct DenseMC {
     const float* p;
     long ld;
     int cols;
+    const int32_t* gather;   // optional: K row k is stored at row gather[k]
     template <int BT>
     struct State {
         int col;
@@ -114,8 +115,12 @@ struct DenseMC {
 #pragma unroll
         for (int i = 0; i < BT / 32; ++i) {
             const int k = k0 + kr + RPP * i;
-            r[i] = (k < kend && s.col < cols) ? load4_guard(p + (long)k * ld + s.col, cols - s.col)
-                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < kend && s.col < cols) {
+                const long src = gather ? (long)gather[k] : (long)k;
+                r[i] = load4_guard(p + src * ld + s.col, cols - s.col);
+            } else {
+                r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     }
     template <int BT>
@@ -230,7 +235,8 @@ struct Epilogue {
     const float* shift;
     const float* res;
     long ldr;
-    int res_mode;   // 0 none, 1 same rows, 2 rows are NHWC pixels and res is the 2x coarser map
+    int res_mode;   // 0 none, 1 same rows, 2 rows are NHWC pixels and res is the 2x coarser map,
+                    // 3 residual row = row % Ho (a per-RoI term broadcast over timesteps)
     int Ho, Wo;
     int relu;
     int accumulate;
@@ -244,6 +250,8 @@ struct Epilogue {
             const int y = rem / Wo, xx = rem - y * Wo;
             const long rr = ((long)n * (Ho >> 1) + (y >> 1)) * (Wo >> 1) + (xx >> 1);
             v += res[rr * ldr + col];
+        } else if (res_mode == 3) {
+            v += res[(long)(row % Ho) * ldr + col];
         }
         if (relu) v = fmaxf(v, 0.f);
         if (accumulate) v += C[(long)row * ldc + col];

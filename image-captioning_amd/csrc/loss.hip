@@ -126,6 +126,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     }
 }
 
+// one wave per row, float4 per lane
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int ld_src, const int32_t* __restrict__ idx,
+                                                          float* __restrict__ out, int ld_out, int n_rows, int w4) {
+    const int row = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (row >= n_rows) return;
+    const int s = idx[row];
+    float4* o = reinterpret_cast<float4*>(out + (long)row * ld_out);
+    if (s < 0) {
+        for (int c = lane; c < w4; c += 64) o[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        const float4* p = reinterpret_cast<const float4*>(src + (long)s * ld_src);
+        for (int c = lane; c < w4; c += 64) o[c] = p[c];
+    }
+}
+
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
     __shared__ float red[4];
     float s = 0.f;
@@ -195,6 +210,16 @@ extern "C" int dc_argmax_rows_f32(const float* x, int M, int V, int ld, int32_t*
     DC_REQUIRE(x && out && M > 0 && V > 0 && ld >= V, DC_EINVAL, "dc_argmax_rows: bad arguments");
     hipLaunchKernelGGL(argmax_rows_kernel, dim3(M), dim3(256), 0, static_cast<hipStream_t>(stream), x, V, ld, out);
     return check_launch("argmax_rows_kernel");
+}
+
+extern "C" int dc_gather_rows_f32(const float* src, int ld_src, const int32_t* idx, float* out, int ld_out, int n_rows, int width,
+                                  void* stream) {
+    DC_REQUIRE(src && idx && out && n_rows > 0 && width > 0, DC_EINVAL, "dc_gather_rows: bad arguments");
+    DC_REQUIRE((width & 3) == 0 && (ld_src & 3) == 0 && (ld_out & 3) == 0 && aligned16(src) && aligned16(out), DC_EALIGN,
+               "dc_gather_rows: width/ld must be multiples of 4 and pointers 16-byte aligned");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), src, ld_src, idx, out,
+                       ld_out, n_rows, width / 4);
+    return check_launch("gather_rows_kernel");
 }
 
 extern "C" int dc_colsum_f32(const float* x, int M, int N, int ld, float* out, int accumulate, void* stream) {

@@ -1,0 +1,221 @@
+"""Encoder plan: ResNet-101 + FPN + PyramidROIAlign on the GPU, built once per (batch, H, W).
+
+What the reference does with a Keras graph + predict() (feature_generation/dense_model.py:143-173
+resnet_graph, :1404-1427 FPN, :317-418 PyramidROIAlign; GT-RoI variant
+dense_img_cap_separate_models/modified_dense_model.py:1410-1433, :1522-1527) is here a flat list of
+pre-built kernel descriptors over pre-allocated, stage-wise recycled activation buffers:
+one dc_conv2d_nhwc_f32 launch per convolution with BN / bias / residual / ReLU / upsample-add fused
+into its epilogue, replayed from a hipGraph after the first call.  The RPN branch, whose output the
+GT-RoI path never reads (207.6 GF of dead work per image in the reference), is not evaluated.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import ConvDesc, check
+from .layers import resnet_fpn_convs
+from .packing import fold_bn, pack_conv_kernel, pack_stem_kernel
+
+
+class EncoderPlan:
+    def __init__(self, weights, batch, height, width, device, stage4_blocks=22,
+                 mean_pixel=(123.7, 116.8, 103.9), use_graph=True):
+        if height % 64 or width % 64:
+            raise ValueError("Image size must be dividable by 2 at least 6 times (got %dx%d)" % (height, width))
+        self.lib = _lib.load()
+        self.B, self.H, self.W = batch, height, width
+        self.device = torch.device(device)
+        self.mean_pixel = [float(v) for v in mean_pixel]
+        self.stage4_blocks = stage4_blocks
+        self.use_graph = use_graph
+        self._graph = None
+        self._warm = False
+        self._specs = {s.name: s for s in resnet_fpn_convs(stage4_blocks)}
+        self._w = {}
+        self._upload(weights)
+        self._build()
+
+    # ------------------------------------------------------------------ weights
+    def _upload(self, W):
+        dev = self.device
+        for s in self._specs.values():
+            k = np.asarray(W[s.name + "/kernel"], np.float32)
+            if tuple(k.shape) != (s.k, s.k, s.cin, s.cout):
+                raise ValueError("%s/kernel has shape %s, expected %s" % (s.name, k.shape, (s.k, s.k, s.cin, s.cout)))
+            packed = pack_stem_kernel(k) if s.name == "conv1" else pack_conv_kernel(k)
+            bias = np.asarray(W[s.name + "/bias"], np.float32)
+            if s.bn:
+                scale, shift = fold_bn(W[s.bn + "/gamma"], W[s.bn + "/beta"], W[s.bn + "/moving_mean"],
+                                       W[s.bn + "/moving_variance"], bias)
+                sc = torch.tensor(scale, device=dev)
+            else:
+                sc, shift = None, bias
+            self._w[s.name] = (torch.tensor(packed, device=dev), sc, torch.tensor(shift, device=dev))
+
+    # ------------------------------------------------------------------ plan
+    def _buf(self, h, w, c):
+        return torch.empty((self.B, h, w, c), dtype=torch.float32, device=self.device)
+
+    def _conv(self, name, x, y, residual=None, res_mode=0, relu=True):
+        s = self._specs[name]
+        wp, sc, sh = self._w[name]
+        N, H, W, Cin = x.shape
+        _, Ho, Wo, Cout = y.shape
+        d = ConvDesc()
+        d.N, d.H, d.W, d.Cin = N, H, W, Cin
+        if s.padding == "same":
+            pad = (s.k - 1) // 2 if s.stride == 1 else None
+            if pad is None:
+                raise ValueError("strided SAME conv is not on this path")
+        elif s.padding == "pad3":
+            pad = 3
+        else:
+            pad = 0
+        d.Cout, d.kh, d.kw, d.stride, d.pad_t, d.pad_l, d.Ho, d.Wo = Cout, s.k, s.k, s.stride, pad, pad, Ho, Wo
+        d.x, d.w, d.y = x.data_ptr(), wp.data_ptr(), y.data_ptr()
+        d.scale = None if sc is None else sc.data_ptr()
+        d.shift = sh.data_ptr()
+        d.residual = None if residual is None else residual.data_ptr()
+        d.res_mode, d.relu, d.split_k = res_mode, int(relu), 0
+        self._ws_bytes = max(self._ws_bytes, self.lib.dc_conv2d_workspace_bytes(C.byref(d)))
+        self._ops.append(("conv", d, name))
+        self.flops += 2.0 * N * Ho * Wo * Cout * s.k * s.k * s.cin
+
+    def _build(self):
+        B, H, W = self.B, self.H, self.W
+        self._ops, self._ws_bytes, self.flops = [], 0, 0.0
+        self.images = torch.empty((B, H, W, 3), dtype=torch.uint8, device=self.device)
+        rgbx = torch.empty((B, H, W, 4), dtype=torch.float32, device=self.device)
+        self._ops.append(("mold", self.images, rgbx))
+        c1 = self._buf(H // 2, W // 2, 64)
+        self._conv("conv1", rgbx, c1)
+        x = self._buf(H // 4, W // 4, 64)
+        self._ops.append(("pool", c1, x))
+
+        def stage(s, blocks, mid, cout, stride, x):
+            h, w = x.shape[1] // stride, x.shape[2] // stride
+            m1, m2, sc = self._buf(h, w, mid), self._buf(h, w, mid), self._buf(h, w, cout)
+            pp = [self._buf(h, w, cout), self._buf(h, w, cout)]
+            final = self._buf(h, w, cout)
+            for i, blk in enumerate(blocks):
+                cn = "res%d%s_branch" % (s, blk)
+                out = final if i == len(blocks) - 1 else pp[i & 1]
+                self._conv(cn + "2a", x, m1)
+                self._conv(cn + "2b", m1, m2)
+                if i == 0:
+                    self._conv(cn + "1", x, sc, relu=False)
+                    self._conv(cn + "2c", m2, out, residual=sc, res_mode=1)
+                else:
+                    self._conv(cn + "2c", m2, out, residual=x, res_mode=1)
+                x = out
+            return x
+
+        C2 = stage(2, "abc", 64, 256, 1, x)
+        C3 = stage(3, "abcd", 128, 512, 2, C2)
+        C4 = stage(4, ["a"] + [chr(98 + i) for i in range(self.stage4_blocks)], 256, 1024, 2, C3)
+        C5 = stage(5, "abc", 512, 2048, 2, C4)
+        self.C = (C2, C3, C4, C5)
+        t5, t4 = self._buf(H // 32, W // 32, 256), self._buf(H // 16, W // 16, 256)
+        t3, t2 = self._buf(H // 8, W // 8, 256), self._buf(H // 4, W // 4, 256)
+        self._conv("fpn_c5p5", C5, t5, relu=False)
+        self._conv("fpn_c4p4", C4, t4, residual=t5, res_mode=2, relu=False)
+        self._conv("fpn_c3p3", C3, t3, residual=t4, res_mode=2, relu=False)
+        self._conv("fpn_c2p2", C2, t2, residual=t3, res_mode=2, relu=False)
+        P2, P3 = self._buf(H // 4, W // 4, 256), self._buf(H // 8, W // 8, 256)
+        P4, P5 = self._buf(H // 16, W // 16, 256), self._buf(H // 32, W // 32, 256)
+        self._conv("fpn_p2", t2, P2, relu=False)
+        self._conv("fpn_p3", t3, P3, relu=False)
+        self._conv("fpn_p4", t4, P4, relu=False)
+        self._conv("fpn_p5", t5, P5, relu=False)
+        self.P = (P2, P3, P4, P5)
+        self._keep = (rgbx, c1)
+        # plan-owned split-K workspace: its address is baked into the captured hipGraph
+        self._ws = torch.empty(max(self._ws_bytes, 16), dtype=torch.uint8, device=self.device)
+
+    # ------------------------------------------------------------------ run
+    def _run_ops(self):
+        lib = self.lib
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        wsp, wsb = C.c_void_p(self._ws.data_ptr()), self._ws.numel()
+        for op in self._ops:
+            kind = op[0]
+            if kind == "conv":
+                rc = lib.dc_conv2d_nhwc_f32(C.byref(op[1]), wsp, wsb, stream)
+                if rc:
+                    check(rc, "dc_conv2d_nhwc_f32(%s)" % op[2])
+            elif kind == "mold":
+                ops.mold_image_rgbx(op[1], self.mean_pixel, out=op[2])
+            else:
+                ops.maxpool3x3s2_same(op[1], out=op[2])
+
+    def conv_table(self):
+        """[(layer, flops, bm, bn, split_k)] for every conv of the plan, in launch order."""
+        rows = []
+        for op in self._ops:
+            if op[0] != "conv":
+                continue
+            d, bm, bn, sk = op[1], C.c_int(), C.c_int(), C.c_int()
+            check(self.lib.dc_conv2d_tile_config(C.byref(d), C.byref(bm), C.byref(bn), C.byref(sk)), "dc_conv2d_tile_config")
+            s = self._specs[op[2]]
+            rows.append((op[2], 2.0 * d.N * d.Ho * d.Wo * d.Cout * s.k * s.k * s.cin, bm.value, bn.value, sk.value))
+        return rows
+
+    def time_convs(self, reps=3):
+        """Eager replay with a HIP event pair around every conv launch on the launch stream; returns
+        [(layer, mean milliseconds)] (the roofline leg of bench.py)."""
+        lib = self.lib
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        wsp, wsb = C.c_void_p(self._ws.data_ptr()), self._ws.numel()
+        convs = [op for op in self._ops if op[0] == "conv"]
+        acc = [0.0] * len(convs)
+        for _ in range(reps):
+            self._run_ops()
+            evs = []
+            for op in convs:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = lib.dc_conv2d_nhwc_f32(C.byref(op[1]), wsp, wsb, stream)
+                e1.record()
+                if rc:
+                    check(rc, "dc_conv2d_nhwc_f32(%s)" % op[2])
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            for i, (e0, e1) in enumerate(evs):
+                acc[i] += e0.elapsed_time(e1)
+        return [(op[2], a / reps) for op, a in zip(convs, acc)]
+
+    def forward(self, images_u8=None):
+        """images_u8: [B,H,W,3] uint8 torch tensor (any device) or None to reuse self.images.
+        Returns (P2, P3, P4, P5), plan-owned buffers valid until the next forward()."""
+        if images_u8 is not None:
+            self.images.copy_(images_u8, non_blocking=True)
+        if not self.use_graph:
+            self._run_ops()
+        elif self._graph is not None:
+            self._graph.replay()
+        elif not self._warm:
+            self._run_ops()                 # first call: eager (sets kernel attributes, sizes the workspace)
+            self._warm = True
+        else:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._run_ops()
+            self._graph = g
+            g.replay()
+        return self.P
+
+    def normalize_boxes(self, rois_px):
+        """rois / [h,w,h,w] in float32, as modified_dense_model.py:1522-1527 (the molded image's size,
+        no window/scale correction -- the reference's own quirk).  Returns a device tensor [B,R,4]."""
+        hw = np.array([self.H, self.W, self.H, self.W], np.float32)
+        if isinstance(rois_px, torch.Tensor):
+            rois_px = rois_px.detach().cpu().numpy()
+        return torch.tensor(np.asarray(rois_px, np.float32) / hw, device=self.device).contiguous()
+
+    def roi_features(self, rois_px=None, out=None, boxes_norm=None):
+        """rois_px [B,R,4] (y1,x1,y2,x2) pixels of the molded image (or boxes_norm from
+        normalize_boxes, device-resident) -> [B,R,7,7,256]."""
+        boxes = boxes_norm if boxes_norm is not None else self.normalize_boxes(rois_px)
+        return ops.roi_align_pyramid(list(self.P), boxes, float(self.H * self.W), 7, out=out)

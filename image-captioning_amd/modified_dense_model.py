@@ -1,0 +1,143 @@
+"""DenseImageCapRCNN: the RoI feature extractor behind the reference's own class interface
+(dense_img_cap_separate_models/modified_dense_model.py:1342 DenseImageCapRCNN, :1583 load_weights,
+:1806-1840 mold_inputs, :1886-1923 generate_captions; image-level variant
+feature_generation/dense_model.py:1868-1905).
+
+Only the GT-RoI inference variant (use_generated_rois=False, the one the caption decoders' data
+generators call) is on the hot path.  Proposal generation (RPN + ProposalLayer) and the joint
+training graph are SURVEY.md section 8(f) "next" rows and raise NotImplementedError here.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import utils
+from .encoder import EncoderPlan
+from .layers import resnet_fpn_convs
+
+
+class BatchNorm(object):
+    """Marker for the reference's BatchNorm(training=False) layer (modified_dense_model.py BatchNorm):
+    frozen statistics are folded into the conv epilogue (packing.fold_bn); nothing to run."""
+
+
+def compose_image_meta(image_id, image_shape, window):
+    return utils.compose_image_meta(image_id, image_shape, window)
+
+
+def mold_image(images, config):
+    return utils.mold_image(images, config)
+
+
+def load_weight_file(filepath):
+    """Checkpoint reader: '<layer>/<weight>' -> ndarray.  Native format is .npz with those keys;
+    Keras .h5 files need h5py (not in this image)."""
+    if filepath.endswith(".npz"):
+        with np.load(filepath) as z:
+            return {k: z[k] for k in z.files}
+    if filepath.endswith(".h5") or filepath.endswith(".hdf5"):
+        try:
+            import h5py  # noqa: F401
+        except ImportError as e:
+            raise ImportError("reading Keras HDF5 weights needs h5py, which this environment lacks; "
+                              "convert the file to .npz ('<layer>/<weight>' keys)") from e
+        out = {}
+        with h5py.File(filepath, "r") as f:
+            g = f["model_weights"] if "model_weights" in f else f
+            for layer in g:
+                for wname in g[layer].attrs.get("weight_names", []):
+                    wname = wname.decode() if isinstance(wname, bytes) else wname
+                    out[layer + "/" + wname.split("/")[-1].split(":")[0]] = np.asarray(g[layer][wname])
+        return out
+    raise ValueError("unknown weight file type: %s" % filepath)
+
+
+class DenseImageCapRCNN(object):
+    def __init__(self, mode, config, model_dir, use_generated_rois=False, device=None, stage4_blocks=22):
+        assert mode in ['training', 'inference']
+        if mode == 'training':
+            raise NotImplementedError("the joint training graph (dense_img_cap/dense_model.py) is a SURVEY 8(f) 'next' row")
+        if use_generated_rois:
+            raise NotImplementedError("RPN + ProposalLayer (use_generated_rois=True) is a SURVEY 8(f) 'next' row")
+        self.mode = mode
+        self.config = config
+        self.model_dir = model_dir
+        self.use_generated_rois = use_generated_rois
+        self.stage4_blocks = stage4_blocks
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self._weights = None
+        self._plans = {}
+
+    # ---- weights -------------------------------------------------------------------------
+    def weight_names(self):
+        names = []
+        for s in resnet_fpn_convs(self.stage4_blocks):
+            names += [s.name + "/kernel", s.name + "/bias"]
+            if s.bn:
+                names += [s.bn + "/" + w for w in ("gamma", "beta", "moving_mean", "moving_variance")]
+        return names
+
+    def set_weights(self, weights):
+        missing = [n for n in self.weight_names() if n not in weights]
+        if missing:
+            raise KeyError("encoder weights missing: %s ..." % missing[:5])
+        self._weights = {n: np.asarray(weights[n], np.float32) for n in self.weight_names()}
+        self._plans = {}
+
+    def load_weights(self, filepath, by_name=False, exclude=None):
+        """by_name loading as keras topology.load_weights_from_hdf5_group_by_name: layers absent from
+        the file keep their current values; `exclude` skips layers."""
+        loaded = load_weight_file(filepath)
+        cur = dict(self._weights or {})
+        for k, v in loaded.items():
+            if exclude and k.split("/")[0] in exclude:
+                continue
+            cur[k] = v
+        self.set_weights(cur)
+
+    # ---- plan ----------------------------------------------------------------------------
+    def plan(self, batch, h, w):
+        key = (batch, h, w)
+        if key not in self._plans:
+            if self._weights is None:
+                raise RuntimeError("load_weights()/set_weights() must be called before inference")
+            self._plans[key] = EncoderPlan(self._weights, batch, h, w, self.device, self.stage4_blocks,
+                                           self.config.MEAN_PIXEL)
+        return self._plans[key]
+
+    def extract_features(self, images_u8, rois_px):
+        """Device-resident fast path: images [B,H,W,3] uint8 (numpy or torch, already the model's
+        size), rois [B,R,4] pixels -> torch [B,R,7,7,256] on the GPU (no host round trip)."""
+        imgs = torch.as_tensor(images_u8)
+        B, H, W, _ = imgs.shape
+        p = self.plan(B, H, W)
+        p.forward(imgs)
+        return p.roi_features(rois_px)
+
+    # ---- reference API -------------------------------------------------------------------
+    def mold_inputs(self, images):
+        molded, metas, windows = [], [], []
+        for image in images:
+            m, window, scale, padding = utils.resize_image(image, min_dim=self.config.IMAGE_MIN_DIM,
+                                                           max_dim=self.config.IMAGE_MAX_DIM,
+                                                           padding=self.config.IMAGE_PADDING)
+            molded.append(m)                                # mean subtraction happens on the GPU
+            metas.append(compose_image_meta(0, image.shape, window))
+            windows.append(window)
+        return np.stack(molded), np.stack(metas), np.stack(windows)
+
+    def generate_captions(self, images, rois, verbose=0):
+        """images: list of [H,W,3] uint8; rois: [len(images), N, 4] (y1,x1,y2,x2) pixels.
+        Returns [{'features': float32 [N,7,7,256]}] like the reference (whose slice
+        features[i][1000*i:1000*(i+1)] only works for BATCH_SIZE == 1; image i > 0 gets its own RoIs here)."""
+        assert self.mode == "inference", "Create model in inference mode."
+        assert len(images) == self.config.BATCH_SIZE, "len(images) must be equal to BATCH_SIZE"
+        molded, metas, windows = self.mold_inputs(images)
+        rois = np.asarray(rois, np.float32)
+        feats = self.extract_features(molded, rois).cpu().numpy()
+        n = self.config.POST_NMS_ROIS_INFERENCE
+        return [{"features": feats[i][:n]} for i in range(len(images))]
+
+    def train(self, *a, **k):
+        raise NotImplementedError("joint training is a SURVEY 8(f) 'next' row")

@@ -52,12 +52,12 @@ WORKSPACE = _Workspace()
 
 
 def gemm(A, B, out=None, a_trans=False, b_trans=False, gather=None, scale=None, shift=None,
-         residual=None, relu=False, accumulate=False, split_k=0):
+         residual=None, res_rows=0, relu=False, accumulate=False, split_k=0):
     """out[M,N] = epilogue(op(A) @ op(B)); see dc_gemm_f32."""
     lib = _lib.load()
     _chk(A, name="A"), _chk(B, name="B")
     if a_trans:
-        K, M = A.shape
+        K, M = (gather.numel() if gather is not None else A.shape[0]), A.shape[1]
     elif gather is not None:
         M, K = gather.numel(), A.shape[1]
     else:
@@ -81,7 +81,7 @@ def gemm(A, B, out=None, a_trans=False, b_trans=False, gather=None, scale=None, 
     d.shift = None if shift is None else _chk(shift, name="shift").data_ptr()
     if residual is not None:
         _chk(residual, name="residual")
-        d.residual, d.ldr = residual.data_ptr(), residual.stride(0)
+        d.residual, d.ldr, d.res_rows = residual.data_ptr(), residual.stride(0), int(res_rows)
     d.relu, d.accumulate, d.split_k = int(relu), int(accumulate), int(split_k)
     ws, wsb = WORKSPACE.get(lib.dc_gemm_workspace_bytes(C.byref(d)), A.device)
     check(lib.dc_gemm_f32(C.byref(d), _ptr(ws), wsb, _stream()), "dc_gemm_f32")
@@ -226,6 +226,16 @@ def argmax_rows(x, out=None):
     if out is None:
         out = torch.empty((x.shape[0],), dtype=torch.int32, device=x.device)
     check(lib.dc_argmax_rows_f32(_ptr(x), x.shape[0], x.shape[1], x.stride(0), _ptr(out), _stream()), "dc_argmax_rows_f32")
+    return out
+
+
+def gather_rows(src, idx, out, width=None):
+    """out[n, :width] = src[idx[n], :width] (zeros where idx[n] < 0); out may be a column slice."""
+    lib = _lib.load()
+    _chk(src, name="src"), _chk(out, name="out"), _chk(idx, torch.int32, "idx")
+    width = out.shape[1] if width is None else width
+    check(lib.dc_gather_rows_f32(_ptr(src), src.stride(0), _ptr(idx), _ptr(out), out.stride(0), idx.numel(), width, _stream()),
+          "dc_gather_rows_f32")
     return out
 
 

@@ -1,0 +1,92 @@
+"""Data parallelism with the reference's ParallelModel semantics, MI355X-style.
+
+The reference (parallel_model.py:22-102) replicates the Keras graph on `gpu_count` towers inside one
+process, tf.split()s every input on axis 0, and reduces the towers' [1,1]-reshaped losses with
+tf.reduce_mean => the update uses the MEAN over towers of the per-tower gradients.
+Here each tower is one process on one GPU (torchrun / torch.distributed, backend "nccl" == RCCL over
+xGMI); the only exchange per step is one all-reduce(sum) of the flat gradient bucket
+(params.ParamStore.flat_grad), scaled by 1/world inside the fused AMSGrad kernel.  Weights and
+optimizer state are replicated; nothing else is communicated.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_process_group_from_env(backend=None):
+    """torchrun contract: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend)
+    return int(os.environ.get("RANK", "0")), world, int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def shard(x, rank, world):
+    """tf.split(x, gpu_count) on axis 0, keeping this rank's slice (parallel_model.py:60-62)."""
+    n = x.shape[0] if hasattr(x, "shape") else len(x)
+    if n % world:
+        raise ValueError("batch of %d does not split evenly over %d towers" % (n, world))
+    per = n // world
+    return x[rank * per:(rank + 1) * per]
+
+
+class GradAllReduce(object):
+    """Callable installed as model.grad_sync: sums the gradient bucket over ranks (in `buckets` chunks so
+    RCCL can pipeline them over all 7 xGMI links) and returns the scale (1/world) the optimizer applies."""
+
+    def __init__(self, group=None, bucket_bytes=64 << 20):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.bucket_elems = max(1, bucket_bytes // 4)
+
+    def __call__(self, flat_grad):
+        if self.world == 1:
+            return 1.0
+        n = flat_grad.numel()
+        for o in range(0, n, self.bucket_elems):
+            dist.all_reduce(flat_grad[o:min(n, o + self.bucket_elems)], op=dist.ReduceOp.SUM, group=self.group)
+        return 1.0 / self.world
+
+
+class ParallelModel(object):
+    """ParallelModel(keras_model, gpu_count): same constructor as the reference.  gpu_count must equal
+    the torch.distributed world size (one process per GPU).  Attribute access falls through to the
+    wrapped model (the reference's __getattribute__ trick, parallel_model.py:41-46)."""
+
+    def __init__(self, keras_model, gpu_count):
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        if gpu_count != world:
+            raise ValueError("gpu_count=%d but %d process(es) are running: launch one process per GPU "
+                             "(python -m torch.distributed.run --nproc-per-node %d ...)" % (gpu_count, world, gpu_count))
+        self.inner_model = keras_model
+        self.gpu_count = gpu_count
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        keras_model.grad_sync = GradAllReduce()
+        self.broadcast_weights()
+
+    def broadcast_weights(self):
+        """Towers share variables in the reference; here rank 0's weights seed every replica."""
+        if self.gpu_count > 1:
+            dist.broadcast(self.inner_model.store.flat, src=0)
+            for k in self.inner_model.store.frozen_names:
+                dist.broadcast(self.inner_model.store.w[k], src=0)
+            self.inner_model._weights_changed()
+
+    def __getattr__(self, name):
+        return getattr(self.inner_model, name)
+
+    def shard_inputs(self, inputs):
+        return [shard(x, self.rank, self.gpu_count) for x in inputs]
+
+    def train_on_batch(self, inputs, targets):
+        """Global batch in, split like tf.split; returns the mean over towers of the tower losses."""
+        loss = self.inner_model.train_on_batch(self.shard_inputs(inputs), shard(targets, self.rank, self.gpu_count))
+        if self.gpu_count > 1:
+            t = torch.tensor([loss], dtype=torch.float64, device=self.inner_model.device)
+            dist.all_reduce(t)
+            loss = float(t.item()) / self.gpu_count
+        return loss

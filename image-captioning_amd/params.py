@@ -1,0 +1,98 @@
+"""Flat parameter storage and the Keras-compatible AMSGrad optimizer.
+
+All trainable weights of a model live in ONE contiguous fp32 buffer (and so do their gradients and
+the Adam moments): the optimizer is a single fused kernel launch over the bucket, and data-parallel
+training all-reduces the gradient bucket directly (RCCL) with no flatten/unflatten copies.
+Per-weight tensors are views into the buckets; every offset is 16-byte aligned.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+class ParamStore:
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self._train, self._frozen = [], []           # (name, ndarray)
+        self.w, self.grad = {}, {}                    # name -> view
+        self.flat = self.flat_grad = None
+        self.trainable_names, self.frozen_names = [], []
+
+    def add(self, name, array, trainable):
+        (self._train if trainable else self._frozen).append((name, np.ascontiguousarray(array, np.float32)))
+
+    def finalize(self):
+        off, layout = 0, []
+        for name, a in self._train:
+            layout.append((name, off, a.shape))
+            off += (a.size + 3) // 4 * 4
+        self.n_train = off
+        flat = np.zeros(max(off, 4), np.float32)
+        for (name, o, shape), (_, a) in zip(layout, self._train):
+            flat[o:o + a.size] = a.reshape(-1)
+        self.flat = torch.tensor(flat, device=self.device)
+        self.flat_grad = torch.zeros_like(self.flat)
+        for name, o, shape in layout:
+            n = int(np.prod(shape))
+            self.w[name] = self.flat[o:o + n].view(*shape)
+            self.grad[name] = self.flat_grad[o:o + n].view(*shape)
+            self.trainable_names.append(name)
+        for name, a in self._frozen:
+            self.w[name] = torch.tensor(a, device=self.device)
+            self.frozen_names.append(name)
+        self._train = self._frozen = None
+        return self
+
+    def to_numpy(self):
+        return {k: v.detach().cpu().numpy() for k, v in self.w.items()}
+
+    def assign(self, name, array):
+        t = self.w[name]
+        a = np.asarray(array, np.float32)
+        if tuple(a.shape) != tuple(t.shape):
+            raise ValueError("shape mismatch for %s: %s vs %s" % (name, a.shape, tuple(t.shape)))
+        t.copy_(torch.tensor(a, device=self.device))
+
+
+class Adam:
+    """keras.optimizers.Adam(lr=0.001, beta_1=0.9, beta_2=0.999, epsilon=None -> K.epsilon()=1e-7,
+    decay=0., amsgrad=False, clipnorm=None) -- the reference uses amsgrad=True everywhere
+    (text_generation_model.py:425; _v2.py:266; dense_img_cap/dense_model.py:1699 adds clipnorm=0.5).
+    Semantics: t = iterations+1; lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m, v as usual;
+    vhat = max(vhat, v); p -= lr_t*m/(sqrt(vhat)+eps)."""
+
+    def __init__(self, lr=0.001, beta_1=0.9, beta_2=0.999, epsilon=None, decay=0.0, amsgrad=False, clipnorm=None):
+        if not amsgrad:
+            raise NotImplementedError("only the amsgrad=True variant the reference trains with is implemented")
+        if decay:
+            raise NotImplementedError("lr decay is not used by the reference")
+        self.lr, self.beta_1, self.beta_2 = lr, beta_1, beta_2
+        self.epsilon = 1e-7 if epsilon is None else epsilon
+        self.clipnorm = clipnorm
+        self.iterations = 0
+        self._state = None
+
+    def _init(self, store):
+        z = lambda: torch.zeros_like(store.flat)
+        self._state = (z(), z(), z())
+        self._gnorm = torch.zeros(1, dtype=torch.float32, device=store.device)
+
+    def lr_t(self):
+        t = self.iterations
+        return self.lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+
+    def apply(self, store, grad_scale=1.0):
+        """One update of every trainable weight from store.flat_grad (scaled by grad_scale, e.g.
+        1/world_size after a summing all-reduce)."""
+        if self._state is None:
+            self._init(store)
+        self.iterations += 1
+        m, v, vh = self._state
+        gn = None
+        if self.clipnorm:
+            gn = ops.sumsq(store.flat_grad, out=self._gnorm)
+        ops.amsgrad_step(store.flat, store.flat_grad, m, v, vh, self.lr_t(), self.beta_1, self.beta_2, self.epsilon,
+                         grad_scale=grad_scale, gnorm_sq=gn, clipnorm=self.clipnorm or 0.0)

@@ -1,0 +1,56 @@
+"""Vocabulary / caption encoding helpers (dense_img_cap_separate_models/preprocess.py:8-114).
+The reference tokenises with nltk.word_tokenize, which is not installable here; a regex tokenizer
+(words and single punctuation marks) stands in.  Data preparation is outside the hot path."""
+import re
+
+import numpy as np
+
+_TOKEN = re.compile(r"\w+|[^\w\s]")
+
+
+def word_tokenize(text):
+    return _TOKEN.findall(text)
+
+
+def load_corpus(tokens, embeddings, embeddings_dim):
+    """ids: 0 <unk>/pad (zero row), 1 <start>, 2 <end> (uniform(-0.5,0.5) rows), then the tokens."""
+    id_to_word = {0: '<unk>', 1: '<start>', 2: '<end>'}
+    word_to_id = {'<unk>': 0, '<start>': 1, '<end>': 2}
+    matrix = np.zeros((len(tokens) + 3, embeddings_dim))
+    matrix[1, :] = np.random.rand(embeddings_dim) - 0.5
+    matrix[2, :] = np.random.rand(embeddings_dim) - 0.5
+    for i, tok in enumerate(tokens):
+        id_to_word[i + 3] = tok
+        word_to_id[tok] = i + 3
+        matrix[i + 3, :] = embeddings[tok]
+    return word_to_id, id_to_word, matrix
+
+
+def encode_word(word, word_to_id):
+    return word_to_id.get(word, 0)
+
+
+def encode_caption(caption, word_to_id):
+    """v1: word ids, OOV dropped."""
+    ids = [encode_word(t, word_to_id) for t in word_tokenize(caption.lower())]
+    return np.array([i for i in ids if i != 0])
+
+
+def encode_word_v2(word, word_to_id):
+    vec = np.zeros(len(word_to_id))
+    vec[word_to_id[word] if word in word_to_id else word_to_id.get('<UNK>', word_to_id.get('<unk>', 0))] = 1
+    return vec
+
+
+def encode_caption_v2(caption, word_to_id):
+    """v2: one-hot rows, OOV (index 0) dropped... the reference drops rows whose element 0 is set."""
+    rows = [encode_word_v2(t, word_to_id) for t in word_tokenize(caption.lower())]
+    return np.array([r for r in rows if len(r) != 0 and r[0] != 1])
+
+
+def decode_word(vec, id_to_word):
+    return id_to_word[int(np.argmax(vec))]
+
+
+def decode_caption(vector, id_to_word):
+    return ''.join(decode_word(v, id_to_word) + ' ' for v in vector)

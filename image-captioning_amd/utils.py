@@ -1,0 +1,86 @@
+"""Dataset base class and image-molding helpers the hot path needs
+(dense_img_cap_separate_models/utils.py:187-287 Dataset, :290-340 resize_image;
+modified_dense_model.py:2028-2042 compose_image_meta, :2068-2073 mold_image).
+Box/anchor/NMS utilities of the reference's utils.py belong to the RPN path and are not here."""
+import numpy as np
+
+
+class Dataset(object):
+    """Image registry: add_image() records, prepare() assigns dense ids; sub-classes add
+    load_image / load_captions_and_rois."""
+
+    def __init__(self):
+        self._image_ids = []
+        self.image_info = []
+
+    def add_image(self, source, image_id, path, **kwargs):
+        info = {"id": image_id, "source": source, "path": path}
+        info.update(kwargs)
+        self.image_info.append(info)
+
+    def image_reference(self, image_id):
+        return ""
+
+    def prepare(self):
+        self.num_images = len(self.image_info)
+        self._image_ids = np.arange(self.num_images)
+
+    @property
+    def image_ids(self):
+        return self._image_ids
+
+    def source_image_link(self, image_id):
+        return self.image_info[image_id]["path"]
+
+    def load_image(self, image_id):
+        """[H,W,3] uint8.  The reference reads JPEGs with skimage (absent here); datasets that keep
+        decoded pixels put them under image_info[...]['pixels']."""
+        info = self.image_info[image_id]
+        if "pixels" in info:
+            img = np.asarray(info["pixels"])
+        else:
+            raise IOError("no JPEG decoder in this environment: provide 'pixels' for %r" % (info["path"],))
+        if img.ndim != 3:
+            img = np.stack([img] * 3, axis=-1)
+        return img
+
+    def load_captions_and_rois(self, image_id):
+        return np.empty([0, 0, 0, 0]), np.empty([0], np.float32)
+
+
+def resize_image(image, min_dim=None, max_dim=None, padding=False):
+    """Scale so the short side reaches min_dim (never down-scale for it) while the long side stays
+    within max_dim, then zero-pad to max_dim x max_dim.  Returns (image, window, scale, padding).
+    Synthetic 1024x1024 inputs take the scale == 1 path; other sizes use nearest-neighbour
+    resampling here (the reference calls scipy.misc.imresize, which no longer exists)."""
+    dtype = image.dtype
+    h, w = image.shape[:2]
+    window = (0, 0, h, w)
+    scale = 1
+    if min_dim:
+        scale = max(1, min_dim / min(h, w))
+    if max_dim:
+        if round(max(h, w) * scale) > max_dim:
+            scale = max_dim / max(h, w)
+    if scale != 1:
+        nh, nw = round(h * scale), round(w * scale)
+        yi = np.minimum((np.arange(nh) / scale).astype(int), h - 1)
+        xi = np.minimum((np.arange(nw) / scale).astype(int), w - 1)
+        image = image[yi][:, xi]
+    if padding:
+        h, w = image.shape[:2]
+        top = (max_dim - h) // 2
+        left = (max_dim - w) // 2
+        padding = [(top, max_dim - h - top), (left, max_dim - w - left), (0, 0)]
+        image = np.pad(image, padding, mode='constant', constant_values=0)
+        window = (top, left, h + top, w + left)
+    return image.astype(dtype), window, scale, padding
+
+
+def compose_image_meta(image_id, image_shape, window):
+    """[id, h, w, c, y1, x1, y2, x2]"""
+    return np.array([image_id] + list(image_shape) + list(window))
+
+
+def mold_image(images, config):
+    return images.astype(np.float32) - config.MEAN_PIXEL

@@ -43,7 +43,8 @@ const char* dc_last_error(void);
  *   a_trans=0: A is [M][lda] (K contiguous);   a_trans=1: A is [K][lda] (M contiguous)
  *   b_trans=0: B is [K][ldb] (N contiguous, the Keras [in,out] kernel);  b_trans=1: B is [N][ldb]
  *   a_gather (optional, a_trans=0): row m of A is A[a_gather[m]] -- the fused KL.Embedding lookup
- *     (text_generation_model.py:135-140, _v2.py:155-156)
+ *     (text_generation_model.py:135-140, _v2.py:155-156); with a_trans=1 it indexes the K rows
+ *     (A^T of a gathered matrix: the embedding-side wgrad)
  * epilogue: v = acc*scale[n] + shift[n] (each optional), += residual[m][n] (optional),
  *           relu (optional), then C = v  or  C += v (accumulate).
  * split_k > 1 partitions K over blockIdx.z through fp32 slabs in the workspace (deterministic
@@ -58,6 +59,7 @@ typedef struct {
     const float*   scale;
     const float*   shift;
     const float*   residual;  int ldr;
+    int res_rows;             /* >0: residual row = m % res_rows (per-RoI term broadcast over timesteps) */
     int relu;
     int accumulate;
     int split_k;
@@ -93,6 +95,10 @@ typedef struct {
 
 size_t dc_conv2d_workspace_bytes(const dc_conv_desc* d);
 int    dc_conv2d_nhwc_f32(const dc_conv_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Profiling aid: the block tile (bm x bn) and split-K factor dc_conv2d_nhwc_f32 picks for `d`, i.e.
+ * which igemm_kernel<bm,bn,...> instantiation runs (bench.py maps layers to rocprof kernel names). */
+int    dc_conv2d_tile_config(const dc_conv_desc* d, int* bm, int* bn, int* split_k);
 
 /* KL.MaxPooling2D((3,3), strides 2, 'same') (dense_model.py:150); C % 4 == 0. */
 int dc_maxpool3x3s2_same_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
@@ -186,6 +192,12 @@ int dc_softmax_ce_f32(const dc_softmax_ce_desc* d, void* stream);
 
 /* tf.argmax over the last axis, lowest index wins ties (text_generation_model.py:222-225). */
 int dc_argmax_rows_f32(const float* x, int M, int V, int ld, int32_t* out, void* stream);
+
+/* Row gather (data movement only): out[n][0:width] = idx[n] >= 0 ? src[idx[n]][0:width] : 0.
+ * Builds the Concatenate() operands of the decoders (text_generation_model.py:147-152; _v2.py:161)
+ * from per-RoI / per-timestep rows, and routes their gradients back (inverse index). width % 4 == 0. */
+int dc_gather_rows_f32(const float* src, int ld_src, const int32_t* idx, float* out, int ld_out,
+                       int n_rows, int width, void* stream);
 
 /* out[n] (+)= sum_m x[m][n]  -- bias gradients. */
 int dc_colsum_f32(const float* x, int M, int N, int ld, float* out, int accumulate, void* stream);
