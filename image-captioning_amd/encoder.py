@@ -56,7 +56,9 @@ class EncoderPlan:
 
     # ------------------------------------------------------------------ plan
     def _buf(self, h, w, c):
-        return torch.empty((self.B, h, w, c), dtype=torch.float32, device=self.device)
+        t = torch.empty((self.B, h, w, c), dtype=torch.float32, device=self.device)
+        self._bufs.append(t)          # descriptors hold raw pointers: the plan must own every buffer
+        return t
 
     def _conv(self, name, x, y, residual=None, res_mode=0, relu=True):
         s = self._specs[name]
@@ -85,7 +87,7 @@ class EncoderPlan:
 
     def _build(self):
         B, H, W = self.B, self.H, self.W
-        self._ops, self._ws_bytes, self.flops = [], 0, 0.0
+        self._ops, self._ws_bytes, self.flops, self._bufs = [], 0, 0.0, []
         self.images = torch.empty((B, H, W, 3), dtype=torch.uint8, device=self.device)
         rgbx = torch.empty((B, H, W, 4), dtype=torch.float32, device=self.device)
         self._ops.append(("mold", self.images, rgbx))
@@ -130,7 +132,7 @@ class EncoderPlan:
         self._conv("fpn_p4", t4, P4, relu=False)
         self._conv("fpn_p5", t5, P5, relu=False)
         self.P = (P2, P3, P4, P5)
-        self._keep = (rgbx, c1)
+        self._bufs.append(rgbx)
         # plan-owned split-K workspace: its address is baked into the captured hipGraph
         self._ws = torch.empty(max(self._ws_bytes, 16), dtype=torch.uint8, device=self.device)
 

@@ -272,4 +272,4 @@ def cpu_baseline_step(enc_W, dec_W, image_u8, rois_px, captions, mean_pixel, win
             vh = torch.maximum(vh, v)
             dec_W[k] -= lr_t * m / (vh.sqrt() + 1e-7)
             opt_state[k] = (m, v, vh)
-    return len(captions), float(loss)
+    return len(captions), float(loss.detach())
