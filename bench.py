@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-images", type=int, default=2)
+    ap.add_argument("--layer-table", default=None, help="write the per-layer conv timing table (TSV) to this path")
     return ap.parse_args()
 
 
@@ -182,6 +183,12 @@ def main():
             g["flops"] += fl
             g["ms"] += times[name]
             g["launches"] += 1
+        if args.layer_table:
+            with open(args.layer_table, "w") as f:
+                f.write("layer\tgflop\tbm\tbn\tsplit_k\tus\ttflops\n")
+                for name, fl, bm, bn, sk in table:
+                    f.write("%s\t%.3f\t%d\t%d\t%d\t%.1f\t%.1f\n" % (name, fl / 1e9, bm, bn, sk, 1e3 * times[name],
+                                                                    fl / (times[name] * 1e-3) / 1e12))
         dom = max(groups, key=lambda k: groups[k]["ms"])
         g = groups[dom]
         achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
