@@ -23,6 +23,10 @@ static int conv_validate(const dc_conv_desc* d, bool& stem) {
     DC_REQUIRE((d->Ho - 1) * d->stride - d->pad_t + d->kh - 1 < d->H + d->kh && (d->Wo - 1) * d->stride - d->pad_l < d->W,
                DC_EINVAL, "dc_conv2d: output size inconsistent with input/stride/pad");
     DC_REQUIRE(aligned16(d->x) && aligned16(d->w), DC_EALIGN, "dc_conv2d: x and w must be 16-byte aligned");
+    DC_REQUIRE((size_t)d->N * d->H * d->W * d->Cin * sizeof(float) < (size_t)0x80000000u &&
+                   (size_t)d->Cout * d->kh * d->kw * (stem ? 32 / 7.0 * 7 : d->Cin) * sizeof(float) < (size_t)0xFFFFFFFFu,
+               DC_EINVAL, "dc_conv2d: x must be < 2 GiB and w < 4 GiB (32-bit offsets)");
+    DC_REQUIRE(d->kh <= 8 && d->kw <= 8, DC_EINVAL, "dc_conv2d: kernel size up to 8x8");
     DC_REQUIRE(d->res_mode >= 0 && d->res_mode <= 2 && (d->res_mode == 0 || d->residual), DC_EINVAL,
                "dc_conv2d: res_mode/residual mismatch");
     DC_REQUIRE(d->res_mode != 2 || ((d->Ho & 1) == 0 && (d->Wo & 1) == 0), DC_EINVAL,
@@ -36,12 +40,14 @@ static inline void conv_dims(const dc_conv_desc* d, bool stem, int& M, int& N, i
     K = stem ? 7 * 32 : d->kh * d->kw * d->Cin;
 }
 
+using WeightKC = DenseKCT<true>;   // packed weights: K = kh*kw*Cin is a multiple of 32, rows 16-byte aligned
+
 template <class AL>
-static int conv_dispatch(const AL& al, const DenseKC& bl, const Epilogue& ep, int M, int N, int K, const TileChoice& t, void* ws,
+static int conv_dispatch(const AL& al, const WeightKC& bl, const Epilogue& ep, int M, int N, int K, const TileChoice& t, void* ws,
                          size_t wsb, hipStream_t s) {
-    if (t.bm == 128 && t.bn == 128) return launch_igemm<128, 128, AL, DenseKC>(al, bl, ep, M, N, K, t.split, ws, wsb, s);
-    if (t.bm == 128 && t.bn == 64) return launch_igemm<128, 64, AL, DenseKC>(al, bl, ep, M, N, K, t.split, ws, wsb, s);
-    return launch_igemm<64, 64, AL, DenseKC>(al, bl, ep, M, N, K, t.split, ws, wsb, s);
+    if (t.bm == 128 && t.bn == 128) return launch_igemm<128, 128, AL, WeightKC>(al, bl, ep, M, N, K, t.split, ws, wsb, s);
+    if (t.bm == 128 && t.bn == 64) return launch_igemm<128, 64, AL, WeightKC>(al, bl, ep, M, N, K, t.split, ws, wsb, s);
+    return launch_igemm<64, 64, AL, WeightKC>(al, bl, ep, M, N, K, t.split, ws, wsb, s);
 }
 
 // ---- maxpool 3x3 / stride 2 / TF SAME (pad only where the window leaves the image; padded cells never win)
@@ -114,13 +120,16 @@ extern "C" int dc_conv2d_nhwc_f32(const dc_conv_desc* d, void* workspace, size_t
     int M, N, K;
     conv_dims(d, stem, M, N, K);
     const TileChoice t = choose_tile(M, N, K, d->split_k);
-    Epilogue ep{d->y, d->Cout, d->scale, d->shift, d->residual, d->Cout, d->res_mode, d->Ho, d->Wo, d->relu, 0};
-    DenseKC bl{d->w, K, N, nullptr};
+    Epilogue ep{d->y, d->Cout, d->scale, d->shift, d->residual, d->Cout, d->res_mode, d->Ho, d->Wo, d->relu, 0, 0};
+    ep.vec4 = (d->Cout & 3) == 0 && aligned16(d->y) && (!d->residual || aligned16(d->residual)) && (!d->scale || aligned16(d->scale)) &&
+              (!d->shift || aligned16(d->shift));
+    WeightKC bl{d->w, K, N, nullptr};
     if (stem) {
-        StemKC al{d->x, d->H, d->W, d->Ho, d->Wo, M};
+        StemKC al{d->x, d->H, d->W, d->Ho, d->Wo, M, (unsigned)((size_t)d->N * d->H * d->W * 4 * sizeof(float))};
         return conv_dispatch(al, bl, ep, M, N, K, t, workspace, workspace_bytes, s);
     }
-    Im2colKC al{d->x, d->H, d->W, d->Cin, d->Ho, d->Wo, d->stride, d->pad_t, d->pad_l, d->kw, d->Cin / 32, M};
+    Im2colKC al{d->x, d->H, d->W, d->Cin, d->Ho, d->Wo, d->stride, d->pad_t, d->pad_l, d->kw, d->Cin / 32, M,
+                (unsigned)((size_t)d->N * d->H * d->W * d->Cin * sizeof(float))};
     return conv_dispatch(al, bl, ep, M, N, K, t, workspace, workspace_bytes, s);
 }
 

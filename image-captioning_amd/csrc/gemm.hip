@@ -25,11 +25,31 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int spli
 }
 
 template <class AL, class BL>
-static int gemm_dispatch(const AL& al, const BL& bl, const Epilogue& ep, const dc_gemm_desc* d, const TileChoice& t, void* ws,
-                         size_t wsb, hipStream_t s) {
+int gemm_dispatch(const AL& al, const BL& bl, const Epilogue& ep, const dc_gemm_desc* d, const TileChoice& t, void* ws,
+                  size_t wsb, hipStream_t s) {
     if (t.bm == 128 && t.bn == 128) return launch_igemm<128, 128, AL, BL>(al, bl, ep, d->M, d->N, d->K, t.split, ws, wsb, s);
     if (t.bm == 128 && t.bn == 64) return launch_igemm<128, 64, AL, BL>(al, bl, ep, d->M, d->N, d->K, t.split, ws, wsb, s);
     return launch_igemm<64, 64, AL, BL>(al, bl, ep, d->M, d->N, d->K, t.split, ws, wsb, s);
+}
+
+// ragged shapes (K % 32 != 0, or a K-major operand whose row length is not a multiple of 4): guarded
+// loaders, 64x64 tiles only
+template <class AL, class BL>
+static int gemm_ragged(const AL& al, const BL& bl, const Epilogue& ep, const dc_gemm_desc* d, const TileChoice& t, void* ws,
+                       size_t wsb, hipStream_t s) {
+    return launch_igemm<64, 64, AL, BL>(al, bl, ep, d->M, d->N, d->K, t.split, ws, wsb, s);
+}
+
+// fast TN / TT instantiations live in gemm_tn.hip (parallel compilation)
+int gemm_fast_tn(const dc_gemm_desc* d, const Epilogue& ep, const TileChoice& t, void* ws, size_t wsb, hipStream_t s);
+
+static bool gemm_is_fast(const dc_gemm_desc* d) {
+    // the fast loaders address with 32-bit byte offsets: operands (and a gathered table) must span < 4 GiB
+    const size_t a_span = (size_t)(d->a_trans ? d->K : d->M) * d->lda * sizeof(float);
+    const size_t b_span = (size_t)(d->b_trans ? d->N : d->K) * d->ldb * sizeof(float);
+    const size_t lim = (size_t)0xFFFFFFF0u;
+    return (d->K & 31) == 0 && (!d->a_trans || ((d->M & 3) == 0 && d->M >= 4)) && (d->b_trans || ((d->N & 3) == 0 && d->N >= 4)) &&
+           (d->a_gather || a_span < lim) && b_span < lim;
 }
 
 static int gemm_validate(const dc_gemm_desc* d) {
@@ -49,12 +69,22 @@ static int gemm_validate(const dc_gemm_desc* d) {
 
 using namespace dcap;
 
+#ifdef DCAP_STAMPS
+namespace dcap { __device__ unsigned long long g_dcap_stamps[6]; }
+extern "C" int dc_debug_stamps(unsigned long long* out, int reset) {
+    hipDeviceSynchronize();
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(dcap::g_dcap_stamps), sizeof(unsigned long long) * 6);
+    if (reset) { unsigned long long z[6] = {0, 0, 0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(dcap::g_dcap_stamps), z, sizeof(z)); }
+    return 0;
+}
+#endif
+
 extern "C" int dc_version(void) { return 1; }
 extern "C" const char* dc_last_error(void) { return g_err; }
 
 extern "C" size_t dc_gemm_workspace_bytes(const dc_gemm_desc* d) {
     if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
-    const TileChoice t = choose_tile(d->M, d->N, d->K, d->split_k);
+    const TileChoice t = choose_tile(d->M, d->N, d->K, d->split_k, gemm_is_fast(d));
     return t.split > 1 ? (size_t)t.split * d->M * d->N * sizeof(float) : 0;
 }
 
@@ -62,17 +92,24 @@ extern "C" int dc_gemm_f32(const dc_gemm_desc* d, void* workspace, size_t worksp
     int rc = gemm_validate(d);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const TileChoice t = choose_tile(d->M, d->N, d->K, d->split_k);
-    Epilogue ep{d->C, d->ldc, d->scale, d->shift, d->residual, d->ldr, d->residual ? (d->res_rows > 0 ? 3 : 1) : 0, d->res_rows, 0, d->relu, d->accumulate};
-    if (!d->a_trans && !d->b_trans) {
-        return gemm_dispatch(DenseKC{d->A, d->lda, d->M, d->a_gather}, DenseMC{d->B, d->ldb, d->N, nullptr}, ep, d, t, workspace,
-                             workspace_bytes, s);
-    } else if (!d->a_trans && d->b_trans) {
-        return gemm_dispatch(DenseKC{d->A, d->lda, d->M, d->a_gather}, DenseKC{d->B, d->ldb, d->N, nullptr}, ep, d, t,
-                             workspace, workspace_bytes, s);
-    } else if (d->a_trans && !d->b_trans) {
-        return gemm_dispatch(DenseMC{d->A, d->lda, d->M, d->a_gather}, DenseMC{d->B, d->ldb, d->N, nullptr}, ep, d, t, workspace, workspace_bytes, s);
+    const bool fast = gemm_is_fast(d);
+    const TileChoice t = choose_tile(d->M, d->N, d->K, d->split_k, fast);
+    Epilogue ep{d->C, d->ldc, d->scale, d->shift, d->residual, d->ldr, d->residual ? (d->res_rows > 0 ? 3 : 1) : 0, d->res_rows, 0, d->relu, d->accumulate, 0};
+    ep.vec4 = (d->N & 3) == 0 && (d->ldc & 3) == 0 && aligned16(d->C) && (!d->residual || ((d->ldr & 3) == 0 && aligned16(d->residual))) &&
+              (!d->scale || aligned16(d->scale)) && (!d->shift || aligned16(d->shift));
+    void* ws = workspace;
+    const size_t wsb = workspace_bytes;
+    if (fast) {
+        if (d->a_trans) return gemm_fast_tn(d, ep, t, ws, wsb, s);
+        if (!d->b_trans)
+            return gemm_dispatch(DenseKCT<true>{d->A, d->lda, d->M, d->a_gather}, DenseMCT<true>{d->B, d->ldb, d->N, nullptr}, ep, d, t, ws, wsb, s);
+        return gemm_dispatch(DenseKCT<true>{d->A, d->lda, d->M, d->a_gather}, DenseKCT<true>{d->B, d->ldb, d->N, nullptr}, ep, d, t, ws, wsb, s);
     }
-    return gemm_dispatch(DenseMC{d->A, d->lda, d->M, d->a_gather}, DenseKC{d->B, d->ldb, d->N, nullptr}, ep, d, t, workspace, workspace_bytes,
-                         s);
+    if (!d->a_trans && !d->b_trans)
+        return gemm_ragged(DenseKC{d->A, d->lda, d->M, d->a_gather}, DenseMC{d->B, d->ldb, d->N, nullptr}, ep, d, t, ws, wsb, s);
+    if (!d->a_trans && d->b_trans)
+        return gemm_ragged(DenseKC{d->A, d->lda, d->M, d->a_gather}, DenseKC{d->B, d->ldb, d->N, nullptr}, ep, d, t, ws, wsb, s);
+    if (d->a_trans && !d->b_trans)
+        return gemm_ragged(DenseMC{d->A, d->lda, d->M, d->a_gather}, DenseMC{d->B, d->ldb, d->N, nullptr}, ep, d, t, ws, wsb, s);
+    return gemm_ragged(DenseMC{d->A, d->lda, d->M, d->a_gather}, DenseKC{d->B, d->ldb, d->N, nullptr}, ep, d, t, ws, wsb, s);
 }

@@ -17,61 +17,95 @@
 // so the permuted K order is consistent.
 #pragma once
 #include "dcap_internal.h"
+#include <stdlib.h>
 
 namespace dcap {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// staging registers use the native vector type: HIP's float4 struct copies lower to memcpy, which kept
+// a pure load->LDS-store staging array in scratch
+typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4 f4_zero() { return (f4)(0.f); }
 
 constexpr int BK = 32;
 constexpr int LDKC = BK + 4;
 
 // ------------------------------------------------------------------------------------------------
-// Operand loaders.  load<BT>() fills this thread's BT/32 float4 registers for the K-tile starting
+// Operand loaders.  load<BT>() fills this thread's BT/32 f4 registers for the K-tile starting
 // at k0 (zero beyond the operand's edge), store<BT>() writes them into the LDS image.
 // ------------------------------------------------------------------------------------------------
 
 template <int BT>
-__device__ __forceinline__ void store_kc(float* S, const float4 (&r)[BT / 32], int tid) {
+__device__ __forceinline__ void store_kc(float* S, const f4 (&r)[BT / 32], int tid) {
     const int q = tid & 7, rr = tid >> 3;
 #pragma unroll
-    for (int i = 0; i < BT / 32; ++i) *reinterpret_cast<float4*>(&S[(rr + 32 * i) * LDKC + 4 * q]) = r[i];
+    for (int i = 0; i < BT / 32; ++i) *reinterpret_cast<f4*>(&S[(rr + 32 * i) * LDKC + 4 * q]) = r[i];
 }
 
 template <int BT>
-__device__ __forceinline__ void store_mc(float* S, const float4 (&r)[BT / 32], int tid) {
+__device__ __forceinline__ void store_mc(float* S, const f4 (&r)[BT / 32], int tid) {
     constexpr int QPR = BT / 4, RPP = 256 / QPR;
     const int q = tid % QPR, kr = tid / QPR;
 #pragma unroll
-    for (int i = 0; i < BT / 32; ++i) *reinterpret_cast<float4*>(&S[(kr + RPP * i) * (BT + 4) + 4 * q]) = r[i];
+    for (int i = 0; i < BT / 32; ++i) *reinterpret_cast<f4*>(&S[(kr + RPP * i) * (BT + 4) + 4 * q]) = r[i];
 }
 
-__device__ __forceinline__ float4 load4_guard(const float* a, int avail) {
+__device__ __forceinline__ f4 load4_guard(const float* a, int avail) {
     // avail = number of valid floats starting at a (>=1)
-    if (avail >= 4) return *reinterpret_cast<const float4*>(a);
-    float4 v = make_float4(a[0], 0.f, 0.f, 0.f);
+    if (avail >= 4) return *reinterpret_cast<const f4*>(a);
+    f4 v = f4_zero();
+    v.x = a[0];
     if (avail > 1) v.y = a[1];
     if (avail > 2) v.z = a[2];
     return v;
 }
 
+// Loaders come in two flavours.  FAST (host-checked: K % 32 == 0, 16-byte aligned rows, row length a
+// multiple of 4, operand < 4 GiB) is branch-free and nearly VALU-free per K-tile: every thread keeps a
+// 32-bit byte offset per staged row, computed once, and each K-tile only moves a block-uniform base
+// (SGPR) -- an s_memtime profile of the first version showed ~580 cycles of per-tile address arithmetic
+// per wave against 1024 cycles of MFMAs.  Rows beyond the operand's edge are CLAMPED to the last valid
+// row (they only feed outputs that are never stored), so every load is an unconditional
+// global_load_dwordx4.  The ragged flavour guards every access and zero-fills the K tail.
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// Raw buffer load with the hardware range check: byte offsets >= num_records return 0, which is how the
+// im2col halo (TF 'SAME' zero padding) is produced -- no select instructions on the loaded data.
+__device__ __forceinline__ f4 buf_f4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0));
+}
+constexpr unsigned kOobOffset = 0x80000000u;     // beyond any tensor the host admits (< 2 GiB)
+
+__device__ __forceinline__ f4 ldg_f4(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
 // rows x K, K contiguous; optional row gather (embedding lookup).
-struct DenseKC {
+template <bool FAST>
+struct DenseKCT {
     static constexpr bool KC = true;
+    // loads past the last K-tile are issued unconditionally (their data is never stored): keep them in range
+    __device__ __forceinline__ int kclamp(int k0, int kend) const { return FAST ? min(k0, kend - BK) : k0; }
     const float* p;
     long ld;
     int rows;
     const int32_t* gather;
     template <int BT>
     struct State {
-        const float* base[BT / 32];
+        const float* base[FAST ? 1 : BT / 32];
+        unsigned boff[FAST ? BT / 32 : 1];
     };
     template <int BT>
     __device__ __forceinline__ void init(State<BT>& s, int row0, int tid) const {
         const int rr = tid >> 3;
 #pragma unroll
         for (int i = 0; i < BT / 32; ++i) {
-            const int row = row0 + rr + 32 * i;
-            if (row < rows) {
+            int row = row0 + rr + 32 * i;
+            if constexpr (FAST) {
+                row = min(row, rows - 1);
+                const long src = gather ? (long)gather[row] : (long)row;
+                s.boff[i] = (unsigned)((src * ld + 4 * (tid & 7)) * 4);
+            } else if (row < rows) {
                 const long src = gather ? (long)gather[row] : (long)row;
                 s.base[i] = p + src * ld;
             } else {
@@ -80,22 +114,31 @@ struct DenseKC {
         }
     }
     template <int BT>
-    __device__ __forceinline__ void load(const State<BT>& s, float4 (&r)[BT / 32], int k0, int kend, int tid) const {
-        const int k = k0 + 4 * (tid & 7);
+    __device__ __forceinline__ void load(State<BT>& s, f4 (&r)[BT / 32], int k0, int kend, int tid) const {
+        if constexpr (FAST) {
+            const float* kb = p + k0;                         // block-uniform
 #pragma unroll
-        for (int i = 0; i < BT / 32; ++i) {
-            r[i] = (s.base[i] != nullptr && k < kend) ? load4_guard(s.base[i] + k, kend - k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < BT / 32; ++i) r[i] = ldg_f4(kb, s.boff[i]);
+        } else {
+            const int k = k0 + 4 * (tid & 7);
+#pragma unroll
+            for (int i = 0; i < BT / 32; ++i) {
+                r[i] = (s.base[i] != nullptr && k < kend) ? load4_guard(s.base[i] + k, kend - k) : f4_zero();
+            }
         }
     }
     template <int BT>
-    __device__ __forceinline__ void store(float* S, const float4 (&r)[BT / 32], int tid) const {
+    __device__ __forceinline__ void store(const State<BT>&, float* S, f4 (&r)[BT / 32], int tid) const {
         store_kc<BT>(S, r, tid);
     }
 };
+using DenseKC = DenseKCT<false>;
 
-// K x cols, cols contiguous (K-major operand).
-struct DenseMC {
+// K x cols, cols contiguous (K-major operand); optional gather of the K rows.
+template <bool FAST>
+struct DenseMCT {
     static constexpr bool KC = false;
+    __device__ __forceinline__ int kclamp(int k0, int kend) const { return FAST ? min(k0, kend - BK) : k0; }
     const float* p;
     long ld;
     int cols;
@@ -103,78 +146,108 @@ struct DenseMC {
     template <int BT>
     struct State {
         int col;
+        unsigned boff[BT / 32];
     };
     template <int BT>
     __device__ __forceinline__ void init(State<BT>& s, int col0, int tid) const {
-        s.col = col0 + 4 * (tid % (BT / 4));
+        constexpr int QPR = BT / 4, RPP = 256 / QPR;
+        s.col = col0 + 4 * (tid % QPR);
+        if constexpr (FAST) {
+            s.col = min(s.col, cols - 4);
+#pragma unroll
+            for (int i = 0; i < BT / 32; ++i) s.boff[i] = (unsigned)((((long)(tid / QPR) + RPP * i) * ld + s.col) * 4);
+        }
     }
     template <int BT>
-    __device__ __forceinline__ void load(const State<BT>& s, float4 (&r)[BT / 32], int k0, int kend, int tid) const {
+    __device__ __forceinline__ void load(State<BT>& s, f4 (&r)[BT / 32], int k0, int kend, int tid) const {
         constexpr int QPR = BT / 4, RPP = 256 / QPR;
         const int kr = tid / QPR;
+        if constexpr (FAST) {
+            if (gather == nullptr) {
+                const float* kb = p + (long)k0 * ld;          // block-uniform
+#pragma unroll
+                for (int i = 0; i < BT / 32; ++i) r[i] = ldg_f4(kb, s.boff[i]);
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < BT / 32; ++i) {
             const int k = k0 + kr + RPP * i;
-            if (k < kend && s.col < cols) {
+            if (FAST || (k < kend && s.col < cols)) {
                 const long src = gather ? (long)gather[k] : (long)k;
-                r[i] = load4_guard(p + src * ld + s.col, cols - s.col);
+                r[i] = FAST ? *reinterpret_cast<const f4*>(p + src * ld + s.col) : load4_guard(p + src * ld + s.col, cols - s.col);
             } else {
-                r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                r[i] = f4_zero();
             }
         }
     }
     template <int BT>
-    __device__ __forceinline__ void store(float* S, const float4 (&r)[BT / 32], int tid) const {
+    __device__ __forceinline__ void store(const State<BT>&, float* S, f4 (&r)[BT / 32], int tid) const {
         store_mc<BT>(S, r, tid);
     }
 };
+using DenseMC = DenseMCT<false>;
 
 // NHWC activations viewed as the im2col matrix [N*Ho*Wo][kh*kw*Cin] (cin fastest), Cin % 32 == 0:
 // one K-tile of 32 lies inside one (ky,kx) tap, so a row's 128 B are contiguous in memory.
+// Per thread and staged row: the byte offset of the output-aligned pixel (always inside the image) and a
+// bit mask of the taps that fall inside the image; per K-tile: one uniform tap offset.  Out-of-image
+// taps re-load the aligned pixel (valid memory) and are zeroed at store() time, after the MFMAs.
 struct Im2colKC {
     static constexpr bool KC = true;
+    __device__ __forceinline__ int kclamp(int k0, int) const { return k0; }     // range-checked buffer loads
     const float* x;
     int H, W, Cin, Ho, Wo, stride, pad_t, pad_l, kw, cin_tiles, M;
+    unsigned x_bytes;               // size of the activation tensor (buffer range for the zero-filling loads)
     template <int BT>
     struct State {
-        int iy0[BT / 32], ix0[BT / 32];
-        long nb[BT / 32];
+        __amdgpu_buffer_rsrc_t rsrc;
+        unsigned boff[BT / 32];     // ((n*H + oy*stride)*W + ox*stride)*Cin*4 + 16*(tid&7): the output-aligned pixel
+        unsigned mask[BT / 32];     // bit ky: row iy in range; bit 8+kx: column ix in range
+        int ky, kx, c;              // block-uniform position of the NEXT K-tile (incremental, no division)
     };
     template <int BT>
     __device__ __forceinline__ void init(State<BT>& s, int row0, int tid) const {
         const int rr = tid >> 3;
+        s.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)x_bytes, 0x00020000);
+        s.ky = -1;
 #pragma unroll
         for (int i = 0; i < BT / 32; ++i) {
-            const int m = row0 + rr + 32 * i;
-            if (m < M) {
-                const int n = m / (Ho * Wo), rem = m - n * (Ho * Wo);
-                const int oy = rem / Wo, ox = rem - oy * Wo;
-                s.iy0[i] = oy * stride - pad_t;
-                s.ix0[i] = ox * stride - pad_l;
-                s.nb[i] = (long)n * H;
-            } else {
-                s.iy0[i] = -(1 << 28);
-                s.ix0[i] = 0;
-                s.nb[i] = 0;
+            const int m = min(row0 + rr + 32 * i, M - 1);          // rows past M feed nothing that is stored
+            const int n = m / (Ho * Wo), rem = m - n * (Ho * Wo);
+            const int oy = rem / Wo, ox = rem - oy * Wo;
+            s.boff[i] = (unsigned)(((((long)n * H + oy * stride) * W + ox * stride) * Cin + 4 * (tid & 7)) * 4);
+            unsigned mk = 0;
+            for (int t = 0; t < 8; ++t) {
+                mk |= ((unsigned)(oy * stride - pad_t + t) < (unsigned)H) ? (1u << t) : 0u;
+                mk |= ((unsigned)(ox * stride - pad_l + t) < (unsigned)W) ? (1u << (8 + t)) : 0u;
             }
+            s.mask[i] = mk;
         }
     }
     template <int BT>
-    __device__ __forceinline__ void load(const State<BT>& s, float4 (&r)[BT / 32], int k0, int kend, int tid) const {
-        const int kt = k0 >> 5;                         // block-uniform
-        const int tap = kt / cin_tiles;
-        const int c = (kt - tap * cin_tiles) * 32 + 4 * (tid & 7);
-        const int ky = tap / kw, kx = tap - ky * kw;
+    __device__ __forceinline__ void load(State<BT>& s, f4 (&r)[BT / 32], int k0, int kend, int tid) const {
+        if (s.ky < 0) {                                   // first tile of this block (split-K start): one division
+            const int kt = k0 >> 5, tap = kt / cin_tiles;
+            s.c = (kt - tap * cin_tiles) * 32;
+            s.ky = tap / kw;
+            s.kx = tap - s.ky * kw;
+        }
+        const int ky = s.ky, kx = s.kx;
+        const int ubytes = (((ky - pad_t) * W + (kx - pad_l)) * Cin + s.c) * 4;      // block-uniform, may be negative
 #pragma unroll
         for (int i = 0; i < BT / 32; ++i) {
-            const int iy = s.iy0[i] + ky, ix = s.ix0[i] + kx;
-            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            r[i] = ok ? *reinterpret_cast<const float4*>(x + ((s.nb[i] + iy) * W + ix) * Cin + c)
-                      : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool in = ((s.mask[i] >> ky) & (s.mask[i] >> (8 + kx)) & 1u) != 0;
+            r[i] = buf_f4(s.rsrc, in ? s.boff[i] + (unsigned)ubytes : kOobOffset);     // out of image -> hardware zero
+        }
+        s.c += 32;
+        if (s.c == Cin) {
+            s.c = 0;
+            if (++s.kx == kw) { s.kx = 0; ++s.ky; }
         }
     }
     template <int BT>
-    __device__ __forceinline__ void store(float* S, const float4 (&r)[BT / 32], int tid) const {
+    __device__ __forceinline__ void store(const State<BT>&, float* S, f4 (&r)[BT / 32], int tid) const {
         store_kc<BT>(S, r, tid);
     }
 };
@@ -183,44 +256,43 @@ struct Im2colKC {
 // (kx == 7 is a zero-weight pad), so K = 7*8*4 = 224 and every load is one aligned pixel.
 struct StemKC {
     static constexpr bool KC = true;
+    __device__ __forceinline__ int kclamp(int k0, int) const { return k0; }
     const float* x;
     int H, W, Ho, Wo, M;
+    unsigned x_bytes;
     template <int BT>
     struct State {
-        int iy0[BT / 32], ix0[BT / 32];
-        long nb[BT / 32];
+        __amdgpu_buffer_rsrc_t rsrc;
+        unsigned boff[BT / 32];     // byte offset of pixel (oy*2, ox*2): always inside the image
+        unsigned mask[BT / 32];     // bits 0-6: row oy*2-3+ky in range; bit 8: this lane's column in range
     };
     template <int BT>
     __device__ __forceinline__ void init(State<BT>& s, int row0, int tid) const {
-        const int rr = tid >> 3;
+        const int rr = tid >> 3, q = tid & 7;
+        s.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)x_bytes, 0x00020000);
 #pragma unroll
         for (int i = 0; i < BT / 32; ++i) {
-            const int m = row0 + rr + 32 * i;
-            if (m < M) {
-                const int n = m / (Ho * Wo), rem = m - n * (Ho * Wo);
-                const int oy = rem / Wo, ox = rem - oy * Wo;
-                s.iy0[i] = oy * 2 - 3;
-                s.ix0[i] = ox * 2 - 3 + (tid & 7);
-                s.nb[i] = (long)n * H;
-            } else {
-                s.iy0[i] = -(1 << 28);
-                s.ix0[i] = 0;
-                s.nb[i] = 0;
-            }
+            const int m = min(row0 + rr + 32 * i, M - 1);
+            const int n = m / (Ho * Wo), rem = m - n * (Ho * Wo);
+            const int oy = rem / Wo, ox = rem - oy * Wo;
+            s.boff[i] = (unsigned)((((long)n * H + oy * 2) * W + ox * 2) * 16);
+            unsigned mk = ((unsigned)(ox * 2 - 3 + q) < (unsigned)W) ? (1u << 8) : 0u;
+            for (int t = 0; t < 7; ++t) mk |= ((unsigned)(oy * 2 - 3 + t) < (unsigned)H) ? (1u << t) : 0u;
+            s.mask[i] = mk;
         }
     }
     template <int BT>
-    __device__ __forceinline__ void load(const State<BT>& s, float4 (&r)[BT / 32], int k0, int kend, int tid) const {
+    __device__ __forceinline__ void load(State<BT>& s, f4 (&r)[BT / 32], int k0, int kend, int tid) const {
         const int ky = k0 >> 5;
+        const int ubytes = ((ky - 3) * W + ((tid & 7) - 3)) * 16;
 #pragma unroll
         for (int i = 0; i < BT / 32; ++i) {
-            const int iy = s.iy0[i] + ky, ix = s.ix0[i];
-            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            r[i] = ok ? *reinterpret_cast<const float4*>(x + ((s.nb[i] + iy) * W + ix) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool in = ((s.mask[i] >> ky) & (s.mask[i] >> 8) & 1u) != 0;
+            r[i] = buf_f4(s.rsrc, in ? s.boff[i] + (unsigned)ubytes : kOobOffset);
         }
     }
     template <int BT>
-    __device__ __forceinline__ void store(float* S, const float4 (&r)[BT / 32], int tid) const {
+    __device__ __forceinline__ void store(const State<BT>&, float* S, f4 (&r)[BT / 32], int tid) const {
         store_kc<BT>(S, r, tid);
     }
 };
@@ -240,6 +312,25 @@ struct Epilogue {
     int Ho, Wo;
     int relu;
     int accumulate;
+    int vec4;       // host-checked: C/res rows 16-byte aligned and N % 4 == 0 => 16-B epilogue accesses
+    // residual row pointer for output row `row` (nullptr when there is no residual)
+    __device__ __forceinline__ const float* res_row(int row) const {
+        if (res_mode == 1) return res + (long)row * ldr;
+        if (res_mode == 2) {
+            const int n = row / (Ho * Wo), rem = row - n * (Ho * Wo);
+            const int y = rem / Wo, xx = rem - y * Wo;
+            return res + (((long)n * (Ho >> 1) + (y >> 1)) * (Wo >> 1) + (xx >> 1)) * ldr;
+        }
+        if (res_mode == 3) return res + (long)(row % Ho) * ldr;
+        return nullptr;
+    }
+    __device__ __forceinline__ float finish(float v, float sc, float sh, const float* rr, float* crow, int col) const {
+        v = v * sc + sh;
+        if (rr) v += rr[col];
+        if (relu) v = fmaxf(v, 0.f);
+        if (accumulate) v += crow[col];
+        return v;
+    }
     __device__ __forceinline__ float apply(float v, int row, int col) const {
         if (scale) v *= scale[col];
         if (shift) v += shift[col];
@@ -262,42 +353,52 @@ struct Epilogue {
 // ------------------------------------------------------------------------------------------------
 // One K-tile of MFMAs from the LDS images.
 // ------------------------------------------------------------------------------------------------
+template <int BM, int BN, bool AKC, bool BKC, int TM, int TN>
+__device__ __forceinline__ void load_frags(const float* __restrict__ As, const float* __restrict__ Bs, float (&a)[TM][4],
+                                           float (&b)[TN][4], int c, int wm, int wn, int i, int h) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        if constexpr (AKC) {
+            const float4 t = *reinterpret_cast<const float4*>(&As[(wm + tm * 32 + i) * LDKC + 8 * c + 4 * h]);
+            a[tm][0] = t.x; a[tm][1] = t.y; a[tm][2] = t.z; a[tm][3] = t.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[tm][j] = As[(8 * c + 4 * h + j) * (BM + 4) + wm + tm * 32 + i];
+        }
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        if constexpr (BKC) {
+            const float4 t = *reinterpret_cast<const float4*>(&Bs[(wn + tn * 32 + i) * LDKC + 8 * c + 4 * h]);
+            b[tn][0] = t.x; b[tn][1] = t.y; b[tn][2] = t.z; b[tn][3] = t.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[tn][j] = Bs[(8 * c + 4 * h + j) * (BN + 4) + wn + tn * 32 + i];
+        }
+    }
+}
+
+// One K-tile: ALL fragment reads (4 chunks of 8 k) are issued first, then the 16*TM*TN MFMAs run
+// back to back with nothing to wait for; the next tile's global loads (issued before this call) and
+// the LDS latency of this burst are covered by the co-resident block's MFMAs.
 template <int BM, int BN, bool AKC, bool BKC>
 __device__ __forceinline__ void mma_tile(const float* __restrict__ As, const float* __restrict__ Bs,
                                          f32x16 (&acc)[BM / 64][BN / 64], int wm, int wn, int lane) {
     constexpr int TM = BM / 64, TN = BN / 64;
     const int i = lane & 31, h = lane >> 5;
+    float a[4][TM][4], b[4][TN][4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        float a[TM][4], b[TN][4];
+    for (int c = 0; c < 4; ++c) load_frags<BM, BN, AKC, BKC, TM, TN>(As, Bs, a[c], b[c], c, wm, wn, i, h);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            if constexpr (AKC) {
-                const float4 t = *reinterpret_cast<const float4*>(&As[(wm + tm * 32 + i) * LDKC + 8 * c + 4 * h]);
-                a[tm][0] = t.x; a[tm][1] = t.y; a[tm][2] = t.z; a[tm][3] = t.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) a[tm][j] = As[(8 * c + 4 * h + j) * (BM + 4) + wm + tm * 32 + i];
-            }
-        }
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            if constexpr (BKC) {
-                const float4 t = *reinterpret_cast<const float4*>(&Bs[(wn + tn * 32 + i) * LDKC + 8 * c + 4 * h]);
-                b[tn][0] = t.x; b[tn][1] = t.y; b[tn][2] = t.z; b[tn][3] = t.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) b[tn][j] = Bs[(8 * c + 4 * h + j) * (BN + 4) + wn + tn * 32 + i];
-            }
-        }
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], acc[tm][tn], 0, 0, 0);
-    }
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][tm][j], b[c][tn][j], acc[tm][tn], 0, 0, 0);
 }
 
 template <int BT, bool KC>
@@ -305,9 +406,16 @@ constexpr int lds_floats() {
     return KC ? BT * LDKC : BK * (BT + 4);
 }
 
+// K-tiles per barrier: the small tile runs two 32-deep K-tiles between barriers (half the
+// synchronisation points per MFMA); the larger tiles would no longer fit two blocks per CU.
+template <int BM, int BN>
+constexpr int tiles_per_sync() { return (BM * BN <= 64 * 64) ? 2 : 1; }
+
 template <int BM, int BN, class AL, class BL>
 constexpr size_t igemm_lds_bytes() {
-    return 2 * (size_t)(lds_floats<BM, AL::KC>() + lds_floats<BN, BL::KC>()) * sizeof(float);
+    constexpr size_t stages = 2 * tiles_per_sync<BM, BN>() * (size_t)(lds_floats<BM, AL::KC>() + lds_floats<BN, BL::KC>()) * sizeof(float);
+    constexpr size_t cimage = (size_t)BM * (BN + 4) * sizeof(float);     // epilogue transpose image
+    return stages > cimage ? stages : cimage;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -316,7 +424,7 @@ constexpr size_t igemm_lds_bytes() {
 // slab  partial[z][M][N]  and splitk_reduce_kernel applies the epilogue.
 // ------------------------------------------------------------------------------------------------
 template <int BM, int BN, class AL, class BL>
-__global__ __launch_bounds__(256) void igemm_kernel(AL al, BL bl, Epilogue ep, int M, int N, int K, int klen,
+__global__ __launch_bounds__(256, 2) void igemm_kernel(AL al, BL bl, Epilogue ep, int M, int N, int K, int klen,
                                                     float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -343,49 +451,149 @@ __global__ __launch_bounds__(256) void igemm_kernel(AL al, BL bl, Epilogue ep, i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-    float4 ra[BM / 32], rb[BN / 32];
+    constexpr int KT = tiles_per_sync<BM, BN>();
+    f4 ra[KT][BM / 32], rb[KT][BN / 32];
     const int nkt = (kend - kbeg + BK - 1) / BK;
-    if (nkt > 0) {
-        al.template load<BM>(sa, ra, kbeg, kend, tid);
-        bl.template load<BN>(sb, rb, kbeg, kend, tid);
-        al.template store<BM>(smem, ra, tid);
-        bl.template store<BN>(smem + A_FL, rb, tid);
+#pragma unroll
+    for (int j = 0; j < KT; ++j)
+        if (j < nkt) {
+            al.template load<BM>(sa, ra[j], kbeg + j * BK, kend, tid);
+            bl.template load<BN>(sb, rb[j], kbeg + j * BK, kend, tid);
+        }
+#pragma unroll
+    for (int j = 0; j < KT; ++j)
+        if (j < nkt) {
+            al.template store<BM>(sa, smem + j * STAGE, ra[j], tid);
+            bl.template store<BN>(sb, smem + j * STAGE + A_FL, rb[j], tid);
+        }
+    __syncthreads();
+#ifdef DCAP_STAMPS
+    // diagnostic build only (tools/micro): where does a wave's K-tile go?  s_memtime per phase, summed.
+    unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
+#define DC_STAMP(v) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define DC_STAMP(v)
+#endif
+    // f32 MFMAs execute on the SIMD's fp32 lanes: VALU instructions do NOT overlap them (tools/micro/
+    // coissue.hip: every extra VALU adds its full ~4 cycles per 64-cycle MFMA), so the loop keeps the
+    // per-tile VALU count minimal (32-bit offsets, uniform bases, hardware zero-fill) and only memory
+    // latency is left to hide behind the co-resident block's burst.
+    for (int kt = 0; kt < nkt; kt += KT) {
+        float* cur = smem + ((kt / KT) & 1) * (KT * STAGE);
+        float* nxt = smem + (((kt / KT) & 1) ^ 1) * (KT * STAGE);
+#ifdef DCAP_STAMPS
+        unsigned long long t0, t1, t2, t3, t4, t5;
+#endif
+        DC_STAMP(t0)
+        // unconditional (a conditional load merges with the old registers and the compiler then waits for
+        // the data right here): tiles past the end are clamped / range-checked and never stored
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            const int k0 = kbeg + (kt + KT + j) * BK;
+            al.template load<BM>(sa, ra[j], al.kclamp(k0, kend), kend, tid);
+            bl.template load<BN>(sb, rb[j], bl.kclamp(k0, kend), kend, tid);
+        }
+        DC_STAMP(t1)
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+            if (kt + j < nkt) mma_tile<BM, BN, AL::KC, BL::KC>(cur + j * STAGE, cur + j * STAGE + A_FL, acc, wm, wn, lane);
+        DC_STAMP(t2)
+#ifdef DCAP_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        DC_STAMP(t3)
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+            if (kt + KT + j < nkt) {
+                al.template store<BM>(sa, nxt + j * STAGE, ra[j], tid);
+                bl.template store<BN>(sb, nxt + j * STAGE + A_FL, rb[j], tid);
+            }
+        DC_STAMP(t4)
+        __syncthreads();
+        DC_STAMP(t5)
+#ifdef DCAP_STAMPS
+        st[0] += t1 - t0; st[1] += t2 - t1; st[2] += t3 - t2; st[3] += t4 - t3; st[4] += t5 - t4; st[5] += KT;
+#endif
+    }
+#ifdef DCAP_STAMPS
+    if (lane == 0 && blockIdx.x < 4096) {
+        extern __device__ unsigned long long g_dcap_stamps[6];
+        for (int q = 0; q < 6; ++q) atomicAdd(&g_dcap_stamps[q], st[q]);
+    }
+#endif
+
+    // ---- epilogue: transpose the accumulators through LDS so every lane owns 4 consecutive columns:
+    // 16-byte residual loads / output stores in full 256-512 B row segments instead of 4-byte accesses
+    // (the store tail of a wide 1x1 conv is issue-bound, not bandwidth-bound, with the raw MFMA layout).
+    constexpr int LDC = BN + 4;
+    float* Cs = smem;                       // all waves are past the loop's final barrier: LDS is free
+    {
+        const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Cs[(wm + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDC + wn + tn * 32 + i] = acc[tm][tn][r];
     }
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        float* cur = smem + (kt & 1) * STAGE;
-        float* nxt = smem + ((kt & 1) ^ 1) * STAGE;
-        const bool more = kt + 1 < nkt;
-        if (more) {
-            al.template load<BM>(sa, ra, kbeg + (kt + 1) * BK, kend, tid);
-            bl.template load<BN>(sb, rb, kbeg + (kt + 1) * BK, kend, tid);
-        }
-        mma_tile<BM, BN, AL::KC, BL::KC>(cur, cur + A_FL, acc, wm, wn, lane);
-        if (more) {
-            al.template store<BM>(nxt, ra, tid);
-            bl.template store<BN>(nxt + A_FL, rb, tid);
-        }
-        __syncthreads();
-    }
-
-    const int i = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int col = n0 + wn + tn * 32 + i;
-            if (col >= N) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row >= M) continue;
-                if (partial) {
-                    partial[((long)blockIdx.z * M + row) * N + col] = acc[tm][tn][r];
-                } else {
-                    ep.C[(long)row * ep.ldc + col] = ep.apply(acc[tm][tn][r], row, col);
-                }
+    constexpr int CPR = BN / 4, RPP = 256 / CPR;         // float4 columns per row, rows per pass
+    const int c4 = tid % CPR, rp = tid / CPR;
+    const int col = n0 + 4 * c4;
+    if (col >= N) return;
+    if (partial) {
+        float* prow = partial + (long)blockIdx.z * M * N;
+#pragma unroll 4
+        for (int p = 0; p < BM / RPP; ++p) {
+            const int lr = p * RPP + rp, row = m0 + lr;
+            if (row >= M) break;
+            const float4 v = *reinterpret_cast<const float4*>(&Cs[lr * LDC + 4 * c4]);
+            float* o = prow + (long)row * N + col;
+            if ((N & 3) == 0) {
+                *reinterpret_cast<float4*>(o) = v;
+            } else {
+                o[0] = v.x;
+                if (col + 1 < N) o[1] = v.y;
+                if (col + 2 < N) o[2] = v.z;
+                if (col + 3 < N) o[3] = v.w;
             }
         }
+        return;
+    }
+    const bool full = ep.vec4 && col + 3 < N;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (full) {
+        if (ep.scale) sc = *reinterpret_cast<const float4*>(ep.scale + col);
+        if (ep.shift) sh = *reinterpret_cast<const float4*>(ep.shift + col);
+    }
+#pragma unroll 4
+    for (int p = 0; p < BM / RPP; ++p) {
+        const int lr = p * RPP + rp, row = m0 + lr;
+        if (row >= M) break;
+        float4 v = *reinterpret_cast<const float4*>(&Cs[lr * LDC + 4 * c4]);
+        float* crow = ep.C + (long)row * ep.ldc;
+        const float* rr = ep.res_row(row);
+        if (full) {
+            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+            if (rr) {
+                const float4 q = *reinterpret_cast<const float4*>(rr + col);
+                v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+            }
+            if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (ep.accumulate) {
+                const float4 q = *reinterpret_cast<const float4*>(crow + col);
+                v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+            }
+            *reinterpret_cast<float4*>(crow + col) = v;
+        } else {
+#define DC_TAIL(j, e)                                                                                       \
+    if (col + j < N)                                                                                        \
+        crow[col + j] = ep.finish(e, ep.scale ? ep.scale[col + j] : 1.f, ep.shift ? ep.shift[col + j] : 0.f, rr, crow, col + j);
+            DC_TAIL(0, v.x) DC_TAIL(1, v.y) DC_TAIL(2, v.z) DC_TAIL(3, v.w)
+#undef DC_TAIL
+        }
+    }
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int splits, int M, int N, Epilogue ep);
@@ -407,11 +615,16 @@ int launch_igemm(const AL& al, const BL& bl, const Epilogue& ep, int M, int N, i
                    "igemm split-K needs %zu workspace bytes, got %zu", need, workspace_bytes);
         partial = static_cast<float*>(workspace);
     }
-    constexpr size_t lds = igemm_lds_bytes<BM, BN, AL, BL>();
+    size_t lds = igemm_lds_bytes<BM, BN, AL, BL>();
+    {   // experiment knob: DCAP_LDS_MIN=<bytes> raises the LDS request (caps resident blocks per CU)
+        static long lds_min = -1;
+        if (lds_min < 0) { const char* e = getenv("DCAP_LDS_MIN"); lds_min = e ? atol(e) : 0; }
+        if ((size_t)lds_min > lds) lds = (size_t)lds_min;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, AL, BL>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     dim3 grid(tiles, 1, split_k);
