@@ -63,6 +63,13 @@ class SoftmaxCeDesc(C.Structure):
                 ("grad_scale", C.c_float)]
 
 
+class BnReluDesc(C.Structure):
+    _fields_ = [("M", C.c_int), ("N", C.c_int), ("ld", C.c_int), ("acc", C.c_void_p),
+                ("bias", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p), ("var", C.c_void_p),
+                ("eps", C.c_float), ("y", C.c_void_p), ("dy", C.c_void_p), ("dacc", C.c_void_p),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dbias", C.c_void_p)]
+
+
 class AmsgradDesc(C.Structure):
     _fields_ = [("n", C.c_size_t), ("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p),
                 ("v", C.c_void_p), ("vhat", C.c_void_p),
@@ -89,6 +96,10 @@ SYMBOLS = {
     "dc_softmax_ce_f32": (C.c_int, [C.POINTER(SoftmaxCeDesc), C.c_void_p]),
     "dc_argmax_rows_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dc_gather_rows_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dc_bn_relu_fwd_f32": (C.c_int, [C.POINTER(BnReluDesc), C.c_void_p]),
+    "dc_bn_relu_bwd_f32": (C.c_int, [C.POINTER(BnReluDesc), C.c_void_p]),
+    "dc_relu_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dc_fold_time_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dc_colsum_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dc_sumsq_f32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
     "dc_mean_f32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),

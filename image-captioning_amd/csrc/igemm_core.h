@@ -648,8 +648,13 @@ struct TileChoice {
 inline TileChoice choose_tile(int M, int N, int K, int user_split, bool allow_128 = true) {
     auto nb = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     TileChoice t{64, 64, 1};
-    if (allow_128 && N >= 128 && nb(128, 128) >= 2 * kNumCU) t = {128, 128, 1};
-    else if (allow_128 && nb(128, 64) >= 2 * kNumCU) t = {128, 64, 1};
+    static int force = -1;       // experiment knob: DCAP_TILE=64|12864|128
+    if (force < 0) { const char* e = getenv("DCAP_TILE"); force = e ? atoi(e) : 0; }
+    if (force == 64 || !allow_128) t = {64, 64, 1};
+    else if (force == 12864) t = {128, 64, 1};
+    else if (force == 128) t = {128, 128, 1};
+    else if (N >= 128 && nb(128, 128) >= 2 * kNumCU) t = {128, 128, 1};
+    else if (nb(128, 64) >= 2 * kNumCU) t = {128, 64, 1};
     if (user_split > 0) {
         t.split = user_split;
     } else {

@@ -141,6 +141,61 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
     }
 }
 
+__global__ __launch_bounds__(256) void bn_relu_fwd_kernel(dc_bn_relu_desc d) {
+    const long total = (long)d.M * d.N;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int r = (int)(idx / d.N), c = (int)(idx - (long)r * d.N);
+        const float n = (d.acc[(long)r * d.ld + c] + d.bias[c] - d.mean[c]) / sqrtf(d.var[c] + d.eps);
+        d.y[(long)r * d.ld + c] = fmaxf(d.gamma[c] * n + d.beta[c], 0.f);
+    }
+}
+
+// block = 64 columns x 4 row lanes; one pass over the rows: writes dacc and reduces dgamma/dbeta/dbias
+__global__ __launch_bounds__(256) void bn_relu_bwd_kernel(dc_bn_relu_desc d) {
+    __shared__ float red[3][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    float sg = 0.f, sb = 0.f, sc = 0.f;
+    if (c < d.N) {
+        const float inv = 1.f / sqrtf(d.var[c] + d.eps), g = d.gamma[c], be = d.beta[c], off = d.bias[c] - d.mean[c];
+        for (int r = rl; r < d.M; r += 4) {
+            const float n = (d.acc[(long)r * d.ld + c] + off) * inv;
+            const float dz = (g * n + be > 0.f) ? d.dy[(long)r * d.ld + c] : 0.f;
+            const float da = dz * g * inv;
+            d.dacc[(long)r * d.ld + c] = da;
+            sg += dz * n; sb += dz; sc += da;
+        }
+    }
+    red[0][rl][threadIdx.x & 63] = sg; red[1][rl][threadIdx.x & 63] = sb; red[2][rl][threadIdx.x & 63] = sc;
+    __syncthreads();
+    if (rl == 0 && c < d.N) {
+        const int l = threadIdx.x;
+        d.dgamma[c] = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
+        d.dbeta[c] = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
+        d.dbias[c] = (red[2][0][l] + red[2][1][l]) + (red[2][2][l] + red[2][3][l]);
+    }
+}
+
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ out,
+                                                       int M, int N, int ld) {
+    const long total = (long)M * N;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int r = (int)(idx / N), c = (int)(idx - (long)r * N);
+        const long o = (long)r * ld + c;
+        out[o] = y[o] > 0.f ? dy[o] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void fold_time_kernel(const float* __restrict__ x, int T, int B, int N, int ld, float* __restrict__ out,
+                                                        int ld_out) {
+    const long total = (long)B * N;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int b = (int)(idx / N), c = (int)(idx - (long)b * N);
+        float s = 0.f;
+        for (int t = 0; t < T; ++t) s += x[((long)t * B + b) * ld + c];
+        out[(long)b * ld_out + c] = s;
+    }
+}
+
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
     __shared__ float red[4];
     float s = 0.f;
@@ -220,6 +275,43 @@ extern "C" int dc_gather_rows_f32(const float* src, int ld_src, const int32_t* i
     hipLaunchKernelGGL(gather_rows_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), src, ld_src, idx, out,
                        ld_out, n_rows, width / 4);
     return check_launch("gather_rows_kernel");
+}
+
+static int bn_relu_check(const dc_bn_relu_desc* d, bool bwd) {
+    DC_REQUIRE(d && d->acc && d->bias && d->gamma && d->beta && d->mean && d->var && d->M > 0 && d->N > 0 && d->ld >= d->N, DC_EINVAL,
+               "dc_bn_relu: bad arguments");
+    DC_REQUIRE(bwd ? (d->dy && d->dacc && d->dgamma && d->dbeta && d->dbias) : (d->y != nullptr), DC_EINVAL,
+               "dc_bn_relu: missing output pointers");
+    return DC_OK;
+}
+
+extern "C" int dc_bn_relu_fwd_f32(const dc_bn_relu_desc* d, void* stream) {
+    int rc = bn_relu_check(d, false);
+    if (rc) return rc;
+    const int blocks = (int)std::min<long>(((long)d->M * d->N + 255) / 256, (long)kNumCU * 8);
+    hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), *d);
+    return check_launch("bn_relu_fwd_kernel");
+}
+
+extern "C" int dc_bn_relu_bwd_f32(const dc_bn_relu_desc* d, void* stream) {
+    int rc = bn_relu_check(d, true);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3((d->N + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), *d);
+    return check_launch("bn_relu_bwd_kernel");
+}
+
+extern "C" int dc_relu_bwd_f32(const float* dy, const float* y, float* out, int M, int N, int ld, void* stream) {
+    DC_REQUIRE(dy && y && out && M > 0 && N > 0 && ld >= N, DC_EINVAL, "dc_relu_bwd: bad arguments");
+    const int blocks = (int)std::min<long>(((long)M * N + 255) / 256, (long)kNumCU * 8);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dy, y, out, M, N, ld);
+    return check_launch("relu_bwd_kernel");
+}
+
+extern "C" int dc_fold_time_f32(const float* x, int T, int B, int N, int ld, float* out, int ld_out, void* stream) {
+    DC_REQUIRE(x && out && T > 0 && B > 0 && N > 0 && ld >= N && ld_out >= N, DC_EINVAL, "dc_fold_time: bad arguments");
+    const int blocks = (int)std::min<long>(((long)B * N + 255) / 256, (long)kNumCU * 8);
+    hipLaunchKernelGGL(fold_time_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, T, B, N, ld, out, ld_out);
+    return check_launch("fold_time_kernel");
 }
 
 extern "C" int dc_colsum_f32(const float* x, int M, int N, int ld, float* out, int accumulate, void* stream) {

@@ -7,7 +7,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (AmsgradDesc, ConvDesc, GemmDesc, LstmBwdDesc, LstmFwdDesc, RoiAlignDesc,
+from ._lib import (AmsgradDesc, BnReluDesc, ConvDesc, GemmDesc, LstmBwdDesc, LstmFwdDesc, RoiAlignDesc,
                    SoftmaxCeDesc, check)
 
 
@@ -236,6 +236,56 @@ def gather_rows(src, idx, out, width=None):
     width = out.shape[1] if width is None else width
     check(lib.dc_gather_rows_f32(_ptr(src), src.stride(0), _ptr(idx), _ptr(out), out.stride(0), idx.numel(), width, _stream()),
           "dc_gather_rows_f32")
+    return out
+
+
+def _bn_desc(acc, bias, gamma, beta, mean, var, eps):
+    d = BnReluDesc()
+    d.M, d.N, d.ld = acc.shape[0], acc.shape[1], acc.stride(0)
+    d.acc = _chk(acc, name="acc").data_ptr()
+    d.bias, d.gamma, d.beta, d.mean, d.var = (_chk(t, name="bn param").data_ptr() for t in (bias, gamma, beta, mean, var))
+    d.eps = float(eps)
+    return d
+
+
+def bn_relu_fwd(acc, bias, gamma, beta, mean, var, out, eps=1e-3):
+    """out = relu(gamma*(acc + bias - mean)/sqrt(var+eps) + beta); acc/out [M,N] sharing a row stride."""
+    lib = _lib.load()
+    d = _bn_desc(acc, bias, gamma, beta, mean, var, eps)
+    if _chk(out, name="out").stride(0) != acc.stride(0):
+        raise _lib.DcapError("bn_relu_fwd: out must share acc's row stride")
+    d.y = out.data_ptr()
+    check(lib.dc_bn_relu_fwd_f32(C.byref(d), _stream()), "dc_bn_relu_fwd_f32")
+    return out
+
+
+def bn_relu_bwd(acc, bias, gamma, beta, mean, var, dy, dacc, dgamma, dbeta, dbias, eps=1e-3):
+    lib = _lib.load()
+    d = _bn_desc(acc, bias, gamma, beta, mean, var, eps)
+    for t in (dy, dacc):
+        if _chk(t, name="dy/dacc").stride(0) != acc.stride(0):
+            raise _lib.DcapError("bn_relu_bwd: dy and dacc must share acc's row stride")
+    d.dy, d.dacc = dy.data_ptr(), dacc.data_ptr()
+    d.dgamma, d.dbeta, d.dbias = (_chk(t, name="bn grad").data_ptr() for t in (dgamma, dbeta, dbias))
+    check(lib.dc_bn_relu_bwd_f32(C.byref(d), _stream()), "dc_bn_relu_bwd_f32")
+    return dacc
+
+
+def relu_bwd(dy, y, out):
+    """out = dy where y > 0 else 0 (all [M,N] with one row stride)."""
+    lib = _lib.load()
+    _chk(dy, name="dy"), _chk(y, name="y"), _chk(out, name="out")
+    if not (dy.stride(0) == y.stride(0) == out.stride(0)):
+        raise _lib.DcapError("relu_bwd: tensors must share a row stride")
+    check(lib.dc_relu_bwd_f32(_ptr(dy), _ptr(y), _ptr(out), y.shape[0], y.shape[1], y.stride(0), _stream()), "dc_relu_bwd_f32")
+    return out
+
+
+def fold_time(x, T, B, out):
+    """out[b] = sum_t x[t*B + b] (time-major rows)."""
+    lib = _lib.load()
+    _chk(x, name="x"), _chk(out, name="out")
+    check(lib.dc_fold_time_f32(_ptr(x), T, B, x.shape[1], x.stride(0), _ptr(out), out.stride(0), _stream()), "dc_fold_time_f32")
     return out
 
 

@@ -1,0 +1,347 @@
+"""Model 3 of the reference (par-inject: 2 x LSTM-512 + Dense-1024 + Dense-V on top of a TRAINABLE
+RoI head), behind its own module interface (dense_img_cap_separate_models/text_generation_model.py:
+DenseCapConfig :23-49, VisualGenomeDataset :52-127, word_generation_model :130-156,
+build_roi_caption_model_training :159-189, ROICaptionInferenceLayer :192-232, build_lstm_model :235-283,
+roi_caption_loss :286-294, create_roi_info :322-329, data_generator :332-371).
+
+The reference expands every caption into T zero-padded prefixes and runs the whole 2-layer LSTM over
+each of them (T^2 LSTM steps per RoI).  With Keras' mask carry a post-padded prefix ends in exactly the
+state the full caption has after that prefix, so ONE masked pass over the caption yields all T outputs:
+predict / train_on_batch here take the reference's batch layout ([feat f32[B,7,7,256], caps f32[B,T]],
+one-hot f64[B,T,V]) and return what the T-prefix graph returns (parity: tests/test_gpu_models.py against
+the as-written oracle), at 1/T of the LSTM work.  recurrent_dropout=0.2 of the reference is a
+training-time stochastic regulariser and is not applied (parity runs are dropout-off).
+"""
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import ops, synth
+from .config import Config
+from .keras_like import KerasLikeModel, ModelCheckpoint, CSVLogger  # noqa: F401
+from .params import ParamStore, Adam  # noqa: F401
+from .text_generation_model_v2 import pad_sequences
+from .utils import Dataset
+
+roi_caption_loss = "roi_caption_loss"     # marker accepted by compile(); the loss is built into the model
+
+
+class DenseCapConfig(Config):
+    NAME = "dense image captioning"
+    GPU_COUNT = 1
+    IMAGES_PER_GPU = 1
+    BATCH_SIZE = 10
+    STEPS_PER_EPOCH = 500
+    VALIDATION_STEPS = 50
+    PADDING_SIZE = 10
+
+    def __init__(self, vocab_size, embedding_weights, batch_size):
+        super(DenseCapConfig, self).__init__()
+        self.VOCABULARY_SIZE = vocab_size
+        self.EMBEDDING_WEIGHTS = embedding_weights
+        self.EMBEDDING_SIZE = embedding_weights.shape[1]
+        self.BATCH_SIZE = batch_size
+
+
+class VisualGenomeDataset(Dataset):
+    def __init__(self, words_to_ids, padding_size):
+        super(VisualGenomeDataset, self).__init__()
+        self.word_to_id = words_to_ids
+        self.padding_size = padding_size
+
+    def load_visual_genome(self, data_dir, image_ids, image_meta_file, data_file):
+        with open(data_file, 'r', encoding='utf-8') as doc:
+            regions = {x['id']: x['regions'] for x in json.load(doc)}
+        with open(image_meta_file, 'r', encoding='utf-8') as doc:
+            meta = {x['image_id']: x for x in json.load(doc)}
+        for i in image_ids:
+            self.add_image("VisualGenome", image_id=i, path=os.path.join(data_dir, '{}.jpg'.format(i)),
+                           width=meta[i]['width'], height=meta[i]['height'],
+                           rois=[[d['y'], d['x'], d['y'] + d['height'], d['x'] + d['width']] for d in regions[i]],
+                           captions=[[d['phrase']] for d in regions[i]])
+
+    def add_rois(self, rois):
+        self.rois = rois
+
+    def load_captions_and_rois(self, image_id):
+        """rois [N,4]; captions float32 [N,T] = [1(<start>), ids..., 2(<end>), 0-pad], truncated to T."""
+        info = self.image_info[image_id]
+        T = self.padding_size
+        rois, caps = [], []
+        for roi, caption in zip(info['rois'], info['captions']):
+            cap = self.encode_region_caption(caption[0])
+            if cap.size != 0:
+                rois.append(roi)
+                body = cap if len(cap) < (T - 2) else cap[:(T - 2)]
+                caps.append(np.hstack((np.array(1), body, np.array(2))))
+        captions = pad_sequences(caps, maxlen=T, padding='post', dtype='float').astype(np.float32)
+        return np.array(rois), captions
+
+    def load_original_captions_and_rois(self, image_id):
+        info = self.image_info[image_id]
+        return np.array(info['rois']), info['captions']
+
+    def encode_region_caption(self, caption):
+        from .preprocess import encode_caption
+        return encode_caption(caption, self.word_to_id)
+
+
+def create_roi_info(dataset):
+    roi = []
+    for image_id in dataset._image_ids:
+        _, captions = dataset.load_captions_and_rois(image_id)
+        for i in range(captions.shape[0]):
+            roi.append((image_id, i, captions[i]))
+    return roi
+
+
+def caption_targets(caps, vocab=None):
+    """Target ids of data_generator (:352-357): the caption shifted left by one, last = 0; pads are class 0.
+    With vocab given, returns the reference's one-hot float64 [B,T,V]."""
+    caps = np.asarray(caps)
+    ids = np.concatenate([caps[:, 1:], np.zeros((caps.shape[0], 1), caps.dtype)], axis=1).astype(np.int32)
+    return ids if vocab is None else np.eye(vocab)[ids]
+
+
+def data_generator(dataset, features_model, config, batch_size, shuffle=False):
+    """Infinite generator of ([feat f32[B,7,7,256], caps f32[B,T]], onehot f64[B,T,V])."""
+    from .generate_one_roi_features import generate_features
+    b = 0
+    roi_index = -1
+    roi_ids = np.arange(len(dataset.rois))
+    prev_im_id, prev_img_features = -1, None
+    while True:
+        roi_index = (roi_index + 1) % len(roi_ids)
+        if shuffle and roi_index == 0:
+            np.random.shuffle(roi_ids)
+        roi_id = roi_ids[roi_index]
+        try:
+            image_id, img_roi_id, cap = dataset.rois[roi_id]
+            if prev_im_id != image_id:
+                prev_img_features = generate_features(dataset, image_id, features_model)
+            roi_features = prev_img_features[img_roi_id]
+            prev_im_id = image_id
+            output_words = caption_targets(cap[None], config.VOCABULARY_SIZE)[0]
+            if b == 0:
+                batch_image_features = np.zeros((batch_size,) + roi_features.shape, dtype=roi_features.dtype)
+                batch_input_words = np.zeros((batch_size,) + cap.shape, dtype=cap.dtype)
+                batch_output_words = np.zeros((batch_size,) + output_words.shape, dtype=output_words.dtype)
+            batch_image_features[b] = roi_features
+            batch_input_words[b] = cap
+            batch_output_words[b] = output_words
+            b += 1
+        except Exception:
+            raise Exception('An error occurred while processing roi ' + str(roi_id))
+        if b >= batch_size:
+            yield [batch_image_features, batch_input_words], batch_output_words
+            b = 0
+
+
+def build_lstm_model(features_input, config, units, mode, device=None, seed=0):
+    assert mode in ['training', 'inference']
+    return CaptionModelV1(features_input, config, units, mode, device, seed)
+
+
+class CaptionModelV1(KerasLikeModel):
+    FEAT = 1024
+    D1 = 1024
+    HEAD = (("mrcnn_class_conv1", "mrcnn_class_bn1"), ("mrcnn_class_conv2", "mrcnn_class_bn2"))
+
+    def __init__(self, features_input, config, units, mode, device=None, seed=0):
+        self.features_input, self.config, self.units, self.mode = list(features_input), config, units, mode
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self.V, self.E, self.T = int(config.VOCABULARY_SIZE), int(config.EMBEDDING_SIZE), int(config.PADDING_SIZE)
+        if self.E % 4 or self.V % 4:
+            raise ValueError("EMBEDDING_SIZE and VOCABULARY_SIZE must be multiples of 4 (16-byte rows); pad the vocabulary")
+        pool, cin = self.features_input[0], self.features_input[2]
+        W = dict(synth.head_weights(seed + 1, pool, cin, self.FEAT))
+        W.update(synth.v1_weights(seed + 2, self.V, self.E, units, self.FEAT))
+        W['imgcap_embedding_layer/embeddings'] = np.asarray(config.EMBEDDING_WEIGHTS, np.float32)
+        st = ParamStore(self.device)
+        for k in sorted(W):
+            frozen = k.startswith('imgcap_embedding') or 'moving_' in k
+            st.add(k, W[k], not frozen)
+        self.store = st.finalize()
+        self.grad_sync = None
+        self._bufs = {}
+
+    def compile(self, optimizer, loss=None):
+        self.optimizer, self.loss = optimizer, loss
+
+    def _buf(self, key, shape, dtype=torch.float32):
+        b = self._bufs.get(key)
+        if b is None or tuple(b.shape) != tuple(shape):
+            b = torch.empty(shape, dtype=dtype, device=self.device)
+            self._bufs[key] = b
+        return b
+
+    # ---------------------------------------------------------------------------------- engine
+    def _head_forward(self, X):
+        w = self.store.w
+        R = X.shape[0]
+        x = X
+        for li, (conv, bn) in enumerate(self.HEAD):
+            k = w[conv + '/kernel']
+            acc = ops.gemm(x, k.view(-1, k.shape[-1]), out=self._buf('acc%d' % li, (R, self.FEAT)))
+            x = ops.bn_relu_fwd(acc, w[conv + '/bias'], w[bn + '/gamma'], w[bn + '/beta'], w[bn + '/moving_mean'],
+                                w[bn + '/moving_variance'], self._buf('hact%d' % li, (R, self.FEAT)))
+        return x
+
+    def _word_model(self, f, ids_tm, mask, B, T, want_grad_ctx=True):
+        """word_generation_model over time-major token ids: returns logits [T*B, V] (row t*B+b = output after
+        step t, i.e. for the prefix c_0..c_t)."""
+        w, u = self.store.w, self.units
+        W1 = w['imgcap_lstm1/kernel']
+        zf = ops.gemm(f, W1[self.E:], out=self._buf('zf', (B, 4 * u)))                       # per-RoI half of x.W
+        z1 = ops.gemm(w['imgcap_embedding_layer/embeddings'], W1[:self.E], gather=ids_tm, shift=w['imgcap_lstm1/bias'],
+                      residual=zf, res_rows=B, out=self._buf('z1', (T * B, 4 * u)))
+        h1, c1 = ops.lstm_seq_fwd(z1, w['imgcap_lstm1/recurrent_kernel'], mask, B, T, self._buf('h1', (T * B, u)),
+                                  self._buf('c1', (T * B, u)))
+        z2 = ops.gemm(h1, w['imgcap_lstm2/kernel'], shift=w['imgcap_lstm2/bias'], out=self._buf('z2', (T * B, 4 * u)))
+        h2, c2 = ops.lstm_seq_fwd(z2, w['imgcap_lstm2/recurrent_kernel'], mask, B, T, self._buf('h2', (T * B, u)),
+                                  self._buf('c2', (T * B, u)))
+        Wd1 = w['imgcap_lstm_d1/kernel']
+        zdf = ops.gemm(f, Wd1[u:], out=self._buf('zdf', (B, self.D1)))
+        a1 = ops.gemm(h2, Wd1[:u], shift=w['imgcap_lstm_d1/bias'], residual=zdf, res_rows=B, relu=True,
+                      out=self._buf('a1', (T * B, self.D1)))
+        Vp = (self.V + 3) // 4 * 4
+        logits = ops.gemm(a1, w['imgcap_lstm_d2/kernel'], shift=w['imgcap_lstm_d2/bias'],
+                          out=self._buf('logits', (T * B, Vp))[:, :self.V])
+        return logits
+
+    def _tables(self, caps):
+        caps = np.asarray(caps)
+        B, T = caps.shape
+        ids = caps.astype(np.int32)                        # Embedding casts float ids to int32
+        up = lambda a, dt: torch.tensor(np.ascontiguousarray(a), dtype=dt, device=self.device)
+        return up(ids.T.reshape(-1), torch.int32), up((ids != 0).T.reshape(-1), torch.uint8), B, T
+
+    def _forward_train(self, feat, caps, targets=None, want_probs=False, want_grad=False):
+        ids_tm, mask, B, T = self._tables(caps)
+        X = feat.reshape(B, -1)
+        f = self._head_forward(X)
+        logits = self._word_model(f, ids_tm, mask, B, T)
+        N = T * B
+        probs = self._buf('probs', tuple(self._bufs['logits'].shape))[:, :self.V] if want_probs else None
+        tg = loss_rows = None
+        if targets is not None:
+            tg = torch.tensor(np.ascontiguousarray(np.asarray(targets, np.int32).T.reshape(-1)), device=self.device)
+            loss_rows = self._buf('loss_rows', (N,))
+        ops.softmax_ce(logits, tg, probs, loss_rows, logits if want_grad else None, grad_scale=1.0 / N)
+        self._ctx = (X, f, ids_tm, mask, B, T)
+        return loss_rows, probs
+
+    def _backward(self):
+        w, g, u = self.store.w, self.store.grad, self.units
+        X, f, ids_tm, mask, B, T = self._ctx
+        bf = self._bufs
+        dlogits = bf['logits'][:, :self.V]
+        a1, h2, h1 = bf['a1'], bf['h2'], bf['h1']
+        N = T * B
+        ops.gemm(a1, dlogits, a_trans=True, out=g['imgcap_lstm_d2/kernel'])
+        ops.colsum(dlogits, out=g['imgcap_lstm_d2/bias'])
+        da1 = ops.gemm(dlogits, w['imgcap_lstm_d2/kernel'], b_trans=True, out=self._buf('da1', (N, self.D1)))
+        dz_d1 = ops.relu_bwd(da1, a1, da1)
+        Wd1, gWd1 = w['imgcap_lstm_d1/kernel'], g['imgcap_lstm_d1/kernel']
+        ops.gemm(h2, dz_d1, a_trans=True, out=gWd1[:u])
+        ops.colsum(dz_d1, out=g['imgcap_lstm_d1/bias'])
+        dzd_f = ops.fold_time(dz_d1, T, B, self._buf('dzd_f', (B, self.D1)))
+        ops.gemm(f, dzd_f, a_trans=True, out=gWd1[u:])
+        df = ops.gemm(dzd_f, Wd1[u:], b_trans=True, out=self._buf('df', (B, self.FEAT)))
+        dh2 = ops.gemm(dz_d1, Wd1[:u], b_trans=True, out=self._buf('dh2', (N, u)))
+        # lstm2
+        dz2, _ = ops.lstm_seq_bwd(bf['z2'], w['imgcap_lstm2/recurrent_kernel'], mask, h2, bf['c2'], B, T, dh_seq=dh2,
+                                  dz=self._buf('dz2', (N, 4 * u)), dU=g['imgcap_lstm2/recurrent_kernel'])
+        ops.gemm(h1, dz2, a_trans=True, out=g['imgcap_lstm2/kernel'])
+        ops.colsum(dz2, out=g['imgcap_lstm2/bias'])
+        dh1 = ops.gemm(dz2, w['imgcap_lstm2/kernel'], b_trans=True, out=self._buf('dh1', (N, u)))
+        # lstm1
+        dz1, _ = ops.lstm_seq_bwd(bf['z1'], w['imgcap_lstm1/recurrent_kernel'], mask, h1, bf['c1'], B, T, dh_seq=dh1,
+                                  dz=self._buf('dz1', (N, 4 * u)), dU=g['imgcap_lstm1/recurrent_kernel'])
+        W1, gW1 = w['imgcap_lstm1/kernel'], g['imgcap_lstm1/kernel']
+        ops.gemm(w['imgcap_embedding_layer/embeddings'], dz1, a_trans=True, gather=ids_tm, out=gW1[:self.E])
+        ops.colsum(dz1, out=g['imgcap_lstm1/bias'])
+        dzf = ops.fold_time(dz1, T, B, self._buf('dzf', (B, 4 * u)))
+        ops.gemm(f, dzf, a_trans=True, out=gW1[self.E:])
+        ops.gemm(dzf, W1[self.E:], b_trans=True, out=df, accumulate=True)
+        # trainable head (kernels, biases, BN gamma/beta; statistics frozen)
+        dy = df
+        inputs = [X, bf['hact0']]
+        for li in (1, 0):
+            conv, bn = self.HEAD[li]
+            dacc = ops.bn_relu_bwd(bf['acc%d' % li], w[conv + '/bias'], w[bn + '/gamma'], w[bn + '/beta'], w[bn + '/moving_mean'],
+                                   w[bn + '/moving_variance'], dy, self._buf('dacc%d' % li, (B, self.FEAT)),
+                                   g[bn + '/gamma'], g[bn + '/beta'], g[conv + '/bias'])
+            k, gk = w[conv + '/kernel'], g[conv + '/kernel']
+            ops.gemm(inputs[li], dacc, a_trans=True, out=gk.view(-1, gk.shape[-1]))
+            if li == 1:
+                dy = ops.gemm(dacc, k.view(-1, k.shape[-1]), b_trans=True, out=self._buf('dhact0', (B, self.FEAT)))
+
+    def train_step(self, feat, caps, targets):
+        if self.optimizer is None:
+            raise RuntimeError("compile(optimizer, loss) first")
+        loss_rows, _ = self._forward_train(feat, caps, targets, want_grad=True)
+        loss = ops.mean(loss_rows, out=self._buf('loss', (1,)))
+        self._backward()
+        scale = self.grad_sync(self.store.flat_grad) if self.grad_sync is not None else 1.0
+        self.optimizer.apply(self.store, grad_scale=scale)
+        return loss
+
+    # ---------------------------------------------------------------------------------- Keras surface
+    def _dev_feat(self, feat):
+        if isinstance(feat, torch.Tensor):
+            return feat.to(self.device, torch.float32).contiguous()
+        return torch.tensor(np.ascontiguousarray(feat, np.float32), device=self.device)
+
+    @staticmethod
+    def _target_ids(y):
+        y = np.asarray(y)
+        if y.ndim == 2:
+            return y.astype(np.int32)
+        if not (np.all(y.max(-1) == 1) and np.all(y.sum(-1) == 1)):
+            raise ValueError("targets must be one-hot rows (as the reference's data_generator yields)")
+        return y.argmax(-1).astype(np.int32)
+
+    def _unpack(self, probs_tm, B, T):
+        return probs_tm.view(T, B, self.V).permute(1, 0, 2).contiguous().cpu().numpy()
+
+    def predict(self, inputs, verbose=0):
+        if self.mode == 'inference':
+            return self.generate(inputs)[0]
+        feat, caps = inputs
+        _, probs = self._forward_train(self._dev_feat(feat), caps, want_probs=True)
+        B, T = np.asarray(caps).shape
+        return self._unpack(probs, B, T)
+
+    def train_on_batch(self, inputs, targets):
+        feat, caps = inputs
+        return float(self.train_step(self._dev_feat(feat), caps, self._target_ids(targets)).item())
+
+    def test_on_batch(self, inputs, targets):
+        feat, caps = inputs
+        loss_rows, _ = self._forward_train(self._dev_feat(feat), caps, self._target_ids(targets))
+        return float(ops.mean(loss_rows).item())
+
+    def generate(self, feat):
+        """ROICaptionInferenceLayer (:192-232): start token 1; step j feeds [prev..., 0...] through the word
+        model and appends float(argmax).  Returns (probs [B,T,V], ids [B,T])."""
+        feat = self._dev_feat(feat)
+        B, T = feat.shape[0], self.T
+        f = self._head_forward(feat.reshape(B, -1))
+        prefix = np.zeros((B, T), np.float32)
+        prefix[:, 0] = 1
+        rows, ids = [], np.zeros((B, T), np.int32)
+        for j in range(T):
+            ids_tm, mask, _, _ = self._tables(prefix)
+            logits = self._word_model(f, ids_tm, mask, B, T)
+            last = logits[(T - 1) * B:]                        # LSTM-2's last (carried) state = state after step j
+            probs = self._buf('gprobs', (B, (self.V + 3) // 4 * 4))[:, :self.V]
+            ops.softmax_ce(last, None, probs, None, None)
+            nxt = ops.argmax_rows(probs).cpu().numpy()
+            rows.append(probs.cpu().numpy())
+            ids[:, j] = nxt
+            if j + 1 < T:
+                prefix[:, j + 1] = nxt
+        return np.stack(rows, axis=1), ids

@@ -199,6 +199,36 @@ int dc_argmax_rows_f32(const float* x, int M, int V, int ld, int32_t* out, void*
 int dc_gather_rows_f32(const float* src, int ld_src, const int32_t* idx, float* out, int ld_out,
                        int n_rows, int width, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Trainable RoI head (v1 / joint model: TimeDistributed Conv2D + BatchNorm(training=False) + ReLU with
+ * trainable kernel, bias, gamma, beta; text_generation_model.py:251-262).  The conv itself is a
+ * dc_gemm_f32 without epilogue (acc = x*kernel); these two kernels apply / differentiate
+ *   n = (acc + bias - mean) / sqrt(var + eps),  y = relu(gamma*n + beta)        (eps = 1e-3)
+ * fwd: y [M][ld] from acc [M][ld].
+ * bwd: given dy (gradient w.r.t. y) and the saved acc: dacc [M][ld] (gradient w.r.t. acc, also the
+ *      conv-bias gradient's summand) and the column reductions dgamma, dbeta, dbias [N].
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int M, N, ld;
+    const float* acc;
+    const float* bias; const float* gamma; const float* beta; const float* mean; const float* var;
+    float eps;
+    float* y;              /* fwd out */
+    const float* dy;       /* bwd in  */
+    float* dacc;           /* bwd out */
+    float* dgamma; float* dbeta; float* dbias;   /* bwd out [N] */
+} dc_bn_relu_desc;
+
+int dc_bn_relu_fwd_f32(const dc_bn_relu_desc* d, void* stream);
+int dc_bn_relu_bwd_f32(const dc_bn_relu_desc* d, void* stream);
+
+/* out = (y > 0) ? dy : 0 over [M][N] (row strides ld): backward of Activation('relu') given its output. */
+int dc_relu_bwd_f32(const float* dy, const float* y, float* out, int M, int N, int ld, void* stream);
+
+/* out[b][n] = sum_t x[t*B + b][n]  (time-major fold: the per-RoI gradient of a term that was broadcast
+ * over timesteps -- RepeatVector(feature), text_generation_model.py:146). */
+int dc_fold_time_f32(const float* x, int T, int B, int N, int ld, float* out, int ld_out, void* stream);
+
 /* out[n] (+)= sum_m x[m][n]  -- bias gradients. */
 int dc_colsum_f32(const float* x, int M, int N, int ld, float* out, int accumulate, void* stream);
 

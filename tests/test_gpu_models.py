@@ -144,3 +144,60 @@ def test_full_size_properties(gpu):
     assert losses[0][-1] < losses[0][0]
     assert losses[0] == losses[1]
     np.testing.assert_array_equal(flats[0], flats[1])
+
+
+def make_v1(V, T, B, seed=0):
+    from image_captioning_amd import synth
+    from image_captioning_amd.text_generation_model import DenseCapConfig, build_lstm_model, Adam, roi_caption_loss
+    cfg = DenseCapConfig(V, synth.embedding_matrix(seed + 3, V), B)
+    cfg.PADDING_SIZE = T
+    model = build_lstm_model([7, 7, 256], cfg, 512, 'training', seed=seed)
+    model.compile(optimizer=Adam(amsgrad=True), loss=roi_caption_loss)
+    Wt = {k: v.astype(np.float64) for k, v in model.get_weights_dict().items()}
+    return model, Wt, cfg
+
+
+def test_v1_training_graph_matches_as_written_oracle(gpu):
+    """Model 3: the single masked pass == the reference's T-prefix TimeDistributed graph
+    (probabilities, roi_caption_loss, every gradient incl. the trainable RoI head, two AMSGrad steps)."""
+    from image_captioning_amd import synth
+    from image_captioning_amd.text_generation_model import caption_targets
+    V, T, B = 1000, 6, 4
+    model, Wt, cfg = make_v1(V, T, B)
+    rng = np.random.default_rng(21)
+    feat = rng.standard_normal((B, 7, 7, 256)).astype(np.float32)
+    caps = synth.captions_v1(22, B, T, V, lmin=1, lmax=3)
+    probs = model.predict([feat, caps])
+    want_p, _ = M.v1_training_forward(Wt, feat, caps)
+    assert probs.shape == (B, T, V)
+    assert np.abs(probs - want_p).max() < 1e-5
+    assert np.abs(np.log(probs + 1e-30) - np.log(want_p + 1e-30)).max() < 1e-3
+    np.testing.assert_array_equal(caption_targets(caps), M.v1_targets(caps))
+    onehot = caption_targets(caps, V)
+    opt = M.AMSGrad()
+    for step in range(2):
+        loss, G, _ = M.v1_loss_and_grads(Wt, feat, caps)
+        got = model.train_on_batch([feat, caps], onehot)
+        assert abs(got - loss) < 1e-4 * max(1.0, abs(loss))
+        assert set(G) == set(model.trainable_weights)
+        for k in G:
+            assert rel_err(model.store.grad[k].cpu().numpy(), G[k]) < 3e-4, (k, step)
+        opt.step(Wt, G)
+        for k in G:
+            assert np.abs(model.store.w[k].cpu().numpy() - Wt[k]).max() < 2e-5, (k, step)
+
+
+def test_v1_greedy_inference_ids_bit_exact(gpu):
+    from image_captioning_amd import synth
+    from image_captioning_amd.text_generation_model import DenseCapConfig, build_lstm_model
+    V, T, B = 1000, 6, 3
+    cfg = DenseCapConfig(V, synth.embedding_matrix(33, V), B)
+    cfg.PADDING_SIZE = T
+    model = build_lstm_model([7, 7, 256], cfg, 512, 'inference', seed=30)
+    Wt = {k: v.astype(np.float64) for k, v in model.get_weights_dict().items()}
+    feat = np.random.default_rng(31).standard_normal((B, 7, 7, 256)).astype(np.float32)
+    probs = model.predict(feat)
+    want_p, want_ids = M.v1_greedy_decode(Wt, feat, T)
+    _, ids = model.generate(feat)
+    np.testing.assert_array_equal(ids, want_ids)
+    assert np.abs(probs - want_p).max() < 1e-5

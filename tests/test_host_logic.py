@@ -1,0 +1,144 @@
+"""Host-side mirror of the reference interface (no GPU): Config values, datasets, sequence expansion,
+batch layouts of both data generators, sample tables, image molding, weight packing."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_models as M
+
+
+class FakeFeatures:
+    """Stands in for DenseImageCapRCNN in the generators: features = f(image id, roi index)."""
+    calls = 0
+
+    def generate_captions(self, images, rois, verbose=0):
+        FakeFeatures.calls += 1
+        n = rois.shape[1]
+        base = float(images[0][0, 0, 0])
+        return [{"features": (base + np.arange(n, dtype=np.float32))[:, None, None, None] * np.ones((n, 7, 7, 256), np.float32)}]
+
+
+def test_config_matches_reference_values():
+    from image_captioning_amd.config import Config
+    c = Config()
+    assert c.BATCH_SIZE == 2 and c.IMAGE_SHAPE.tolist() == [1024, 1024, 3]
+    assert c.BACKBONE_SHAPES.tolist() == [[256, 256], [128, 128], [64, 64], [32, 32], [16, 16]]
+    assert (c.POOL_SIZE, c.PADDING_SIZE, c.LEARNING_RATE, c.WEIGHT_DECAY) == (7, 15, 0.001, 0.0001)
+    assert c.MEAN_PIXEL.tolist() == [123.7, 116.8, 103.9] and c.RPN_ANCHOR_SCALES == (32, 64, 128, 256, 512)
+    assert (c.TRAIN_ROIS_PER_IMAGE, c.ROI_POSITIVE_RATIO, c.POST_NMS_ROIS_INFERENCE) == (200, 0.33, 1000)
+    from image_captioning_amd.text_generation_model_v2 import DenseCapConfig as C2
+    from image_captioning_amd.text_generation_model import DenseCapConfig as C1
+    E = np.zeros((12, 300), np.float32)
+    # v2 quirk kept: the class attribute BATCH_SIZE = 64 is shadowed by Config.__init__ (IMAGES_PER_GPU*GPU_COUNT = 1)
+    assert (C2(12, E).BATCH_SIZE, C2.BATCH_SIZE, C2(12, E).PADDING_SIZE, C2(12, E).EMBEDDING_SIZE) == (1, 64, 10, 300)
+    assert (C1(12, E, 256).BATCH_SIZE, C1(12, E, 256).PADDING_SIZE) == (256, 10)
+
+
+def _v2_dataset():
+    from image_captioning_amd.text_generation_model_v2 import VisualGenomeDataset
+    w2i = {"<unk>": 0, "<start>": 1, "<end>": 2, "a": 3, "red": 4, "car": 5, "dog": 6}
+    ds = VisualGenomeDataset(w2i, 10)
+    for i, caps in enumerate([["a red car", "dog"], ["a dog zebra"]]):
+        ds.add_image("VisualGenome", image_id=100 + i, path="none", width=8, height=8,
+                     rois=[[0, 0, 4, 4]] * len(caps), captions=[[c] for c in caps],
+                     pixels=np.full((8, 8, 3), 10 * (i + 1), np.uint8))
+    ds.prepare()
+    return ds
+
+
+def test_v2_sequences_and_generator_batch_layout():
+    from image_captioning_amd.text_generation_model_v2 import DenseCapConfig, data_generator, load_sequences
+    ds = _v2_dataset()
+    seqs = load_sequences(ds)
+    # "a red car" -> 3 samples, "dog" -> 1, "a dog zebra" (zebra OOV dropped) -> 2
+    assert [(s[0], s[1], s[2], s[3]) for s in seqs] == [(0, 0, [0], 3), (0, 0, [3], 4), (0, 0, [3, 4], 5), (0, 1, [0], 6),
+                                                        (1, 0, [0], 3), (1, 0, [3], 6)]
+    ds.add_sequences(seqs)
+    cfg = DenseCapConfig(7, np.zeros((7, 300), np.float32))
+    cfg.PADDING_SIZE = 4
+    FakeFeatures.calls = 0
+    gen = data_generator(ds, FakeFeatures(), cfg, 4)
+    (feat, words), y = next(gen)
+    assert feat.shape == (4, 7, 7, 256) and feat.dtype == np.float32
+    assert words.tolist() == [[0, 0, 0, 0], [0, 0, 0, 3], [0, 0, 3, 4], [0, 0, 0, 0]] and words.dtype == np.int32
+    assert y.shape == (4, 7) and y.dtype == np.float64 and y.argmax(1).tolist() == [3, 4, 5, 6]
+    assert feat[:, 0, 0, 0].tolist() == [10, 10, 10, 11]          # roi 0,0,0 then roi 1 of image 0
+    assert FakeFeatures.calls == 1                                  # features recomputed only on image change
+    (feat, words), y = next(gen)                                    # wraps around the sequence list
+    assert feat[:, 0, 0, 0].tolist() == [20, 20, 10, 10] and FakeFeatures.calls == 3
+    roi, w2, t2 = M.v2_expand_samples([[3, 4, 5], [6], [3, 6]], 4)  # the oracle's expansion agrees
+    assert w2[:4].tolist() == [[0, 0, 0, 0], [0, 0, 0, 3], [0, 0, 3, 4], [0, 0, 0, 0]] and t2.tolist() == [3, 4, 5, 6, 3, 6]
+
+
+def test_v1_dataset_and_generator_batch_layout():
+    from image_captioning_amd.text_generation_model import (DenseCapConfig, VisualGenomeDataset, caption_targets,
+                                                            create_roi_info, data_generator)
+    w2i = {"<unk>": 0, "<start>": 1, "<end>": 2, "a": 3, "red": 4, "car": 5, "dog": 6}
+    ds = VisualGenomeDataset(w2i, 5)
+    ds.add_image("VisualGenome", image_id=7, path="none", width=8, height=8, rois=[[0, 0, 4, 4], [1, 1, 3, 3]],
+                 captions=[["a red car dog a"], ["dog"]], pixels=np.full((8, 8, 3), 5, np.uint8))
+    ds.prepare()
+    rois, caps = ds.load_captions_and_rois(0)
+    assert caps.dtype == np.float32 and caps.tolist() == [[1, 3, 4, 5, 2], [1, 6, 2, 0, 0]]    # truncated to T-2 words
+    ds.add_rois(create_roi_info(ds))
+    cfg = DenseCapConfig(7, np.zeros((7, 300), np.float32), 2)
+    cfg.PADDING_SIZE = 5
+    (feat, words), y = next(data_generator(ds, FakeFeatures(), cfg, 2))
+    assert feat.shape == (2, 7, 7, 256) and words.tolist() == caps.tolist()
+    assert y.shape == (2, 5, 7) and y.dtype == np.float64
+    assert y.argmax(-1).tolist() == [[3, 4, 5, 2, 0], [6, 2, 0, 0, 0]]     # shifted left, pads -> class 0
+    np.testing.assert_array_equal(caption_targets(caps), M.v1_targets(caps))
+
+
+def test_sample_tables_single_pass_indexing():
+    from image_captioning_amd.text_generation_model_v2 import SampleTables
+    tb = SampleTables.from_captions([[5, 6, 7], [9], [3, 4]], "cpu")
+    assert (tb.Bw, tb.T, tb.N) == (3, 2, 6)
+    assert tb.ids_tm.tolist() == [5, 0, 3, 6, 0, 0]                 # time-major, last word never an input
+    assert tb.mask.tolist() == [1, 0, 1, 1, 0, 0]
+    assert tb.roi_idx.tolist() == [0, 0, 0, 1, 2, 2] and tb.targets.tolist() == [5, 6, 7, 9, 3, 4]
+    assert tb.hrow_idx.tolist() == [-1, 0, 3, -1, -1, 2]            # h after j tokens = row (j-1)*R + r
+    assert tb.inv_hrow.tolist() == [1, -1, 5, 2, -1, -1]
+    ts = SampleTables.from_samples(np.array([[0, 0, 3], [0, 3, 4]]), [4, 5], "cpu")
+    assert ts.ids_tm.tolist() == [0, 0, 0, 3, 3, 4] and ts.hrow_idx.tolist() == [4, 5]
+    with pytest.raises(ValueError):
+        SampleTables(np.zeros(2, np.int32), 1, 2, [0, 0], [1, 1], [3, 4], "cpu")   # one state row feeding two samples
+
+
+def test_resize_and_meta():
+    from image_captioning_amd import utils
+    img = np.ones((1024, 1024, 3), np.uint8)
+    out, window, scale, padding = utils.resize_image(img, 800, 1024, True)
+    assert out.shape == (1024, 1024, 3) and window == (0, 0, 1024, 1024) and scale == 1
+    out, window, scale, padding = utils.resize_image(np.ones((400, 200, 3), np.uint8), 800, 1024, True)
+    assert out.shape == (1024, 1024, 3) and scale == 1024 / 400 and window == (0, 256, 1024, 768)
+    assert utils.compose_image_meta(0, (400, 200, 3), window).tolist() == [0, 400, 200, 3, 0, 256, 1024, 768]
+
+
+def test_weight_packing_roundtrip():
+    from image_captioning_amd.packing import fold_bn, pack_conv_kernel, pack_stem_kernel
+    from oracle import np_oracle as O
+    rng = np.random.default_rng(0)
+    k = rng.standard_normal((3, 3, 8, 5)).astype(np.float32)
+    p = pack_conv_kernel(k)
+    assert p.shape == (5, 72) and p[2, (1 * 3 + 2) * 8 + 4] == k[1, 2, 4, 2]
+    s = pack_stem_kernel(rng.standard_normal((7, 7, 3, 4)).astype(np.float32)).reshape(4, 7, 8, 4)
+    assert np.all(s[:, :, 7, :] == 0) and np.all(s[:, :, :, 3] == 0)
+    g, b, m, v, cb = (rng.standard_normal(6) for _ in range(5))
+    sc, sh = fold_bn(g, b, m, np.abs(v) + 0.1, cb)
+    so, sho = O.bn_scale_shift(g, b, m, np.abs(v) + 0.1, cb)
+    np.testing.assert_allclose(sc, so, rtol=1e-6)
+    np.testing.assert_allclose(sh, sho, rtol=1e-6, atol=1e-7)
+
+
+def test_param_store_layout_on_cpu():
+    from image_captioning_amd.params import ParamStore
+    st = ParamStore("cpu")
+    st.add("a/kernel", np.arange(6, dtype=np.float32).reshape(2, 3), True)
+    st.add("b/bias", np.ones(5, np.float32), True)
+    st.add("emb", np.zeros((2, 2), np.float32), False)
+    st.finalize()
+    assert st.trainable_names == ["a/kernel", "b/bias"] and st.frozen_names == ["emb"]
+    assert st.flat.numel() == 8 + 8 and st.w["b/bias"].data_ptr() % 16 == st.flat.data_ptr() % 16     # 16-byte aligned views
+    st.grad["a/kernel"].fill_(2.0)
+    assert float(st.flat_grad[:6].sum()) == 12.0 and float(st.flat_grad[6:8].sum()) == 0.0
