@@ -178,7 +178,7 @@ def main():
         groups = {}
         for name, fl, bm, bn, sk in table:
             kind = "StemKC" if name == "conv1" else "Im2colKC"
-            key = "igemm_kernel<%d,%d,%s,DenseKC>" % (bm, bn, kind)
+            key = "igemm_kernel<%d, %d, dcap::%s, dcap::DenseKCT<true> >" % (bm, bn, kind)       # rocprof's spelling
             g = groups.setdefault(key, {"flops": 0.0, "ms": 0.0, "launches": 0})
             g["flops"] += fl
             g["ms"] += times[name]
@@ -193,8 +193,14 @@ def main():
         g = groups[dom]
         achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
         conv_ms = sum(v["ms"] for v in groups.values())
+        traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath):
+            for name, rec in json.load(open(tpath)).items():
+                if name.startswith("void dcap::" + dom[:40]):
+                    traffic = rec["hbm_bytes_per_launch_corrected"]
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                           "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                            "launches_per_step": g["launches"], "gflop_per_launch": g["flops"] / g["launches"] / 1e9,
                            "avg_launch_us": 1e3 * g["ms"] / g["launches"],
                            "all_conv": {"gflop_per_step": plan.flops / 1e9, "ms_per_step": conv_ms,

@@ -70,6 +70,15 @@ class BnReluDesc(C.Structure):
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dbias", C.c_void_p)]
 
 
+class ProposalDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("levels", C.c_int), ("anchors_per_loc", C.c_int),
+                ("heads", C.c_void_p * 5), ("Hs", C.c_int * 5), ("Ws", C.c_int * 5),
+                ("anchors", C.c_void_p), ("A_total", C.c_int), ("std_dev", C.c_float * 4),
+                ("image_h", C.c_float), ("image_w", C.c_float),
+                ("pre_nms_limit", C.c_int), ("proposal_count", C.c_int), ("nms_threshold", C.c_float),
+                ("proposals", C.c_void_p), ("scores_out", C.c_void_p), ("order_out", C.c_void_p), ("keep_out", C.c_void_p)]
+
+
 class AmsgradDesc(C.Structure):
     _fields_ = [("n", C.c_size_t), ("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p),
                 ("v", C.c_void_p), ("vhat", C.c_void_p),
@@ -90,6 +99,9 @@ SYMBOLS = {
     "dc_mold_image_rgbx_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "dc_roi_align_pyramid_f32": (C.c_int, [C.POINTER(RoiAlignDesc), C.c_void_p]),
+    "dc_subsample2_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dc_proposals_workspace_bytes": (C.c_size_t, [C.POINTER(ProposalDesc)]),
+    "dc_proposals_f32": (C.c_int, [C.POINTER(ProposalDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_lstm_seq_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "dc_lstm_seq_fwd_f32": (C.c_int, [C.POINTER(LstmFwdDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_lstm_seq_bwd_f32": (C.c_int, [C.POINTER(LstmBwdDesc), C.c_void_p, C.c_size_t, C.c_void_p]),

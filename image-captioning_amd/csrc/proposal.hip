@@ -1,0 +1,237 @@
+// proposal.hip -- RPN scoring + ProposalLayer on the device: fg-score softmax, top-k by one stable radix
+// sort per image (rocPRIM), box decode / clip / normalise in TF's float32 operation order, and
+// tf.image.non_max_suppression as a 64-bit suppression-mask kernel followed by a single-workgroup greedy
+// scan.  All index decisions (sort order, ties, IoU > threshold) are float32 like the TF graph.
+#include "dcap_internal.h"
+#include <string.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <algorithm>
+
+namespace dcap {
+
+static size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// scores[b][a] = softmax(class logits)[fg]; deltas[b][a][4] = bbox * std
+__global__ __launch_bounds__(256) void rpn_score_kernel(dc_proposal_desc d, int level, int level_off, float* __restrict__ scores,
+                                                        float* __restrict__ deltas, int* __restrict__ iota) {
+    const int H = d.Hs[level], W = d.Ws[level], A = d.anchors_per_loc;
+    const int per_img = H * W * A;
+    const long total = (long)d.B * per_img;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int b = (int)(idx / per_img), r = (int)(idx - (long)b * per_img);
+        const int cell = r / A, a = r - cell * A;
+        const float* h = d.heads[level] + ((long)b * H * W + cell) * (A * 6);
+        const float l0 = h[a * 2], l1 = h[a * 2 + 1];
+        const float m = fmaxf(l0, l1);
+        const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+        const long o = (long)b * d.A_total + level_off + r;
+        scores[o] = e1 / (e0 + e1);
+        const float* bb = h + A * 2 + a * 4;
+        float4 dl = make_float4(__fmul_rn(bb[0], d.std_dev[0]), __fmul_rn(bb[1], d.std_dev[1]), __fmul_rn(bb[2], d.std_dev[2]),
+                                __fmul_rn(bb[3], d.std_dev[3]));
+        reinterpret_cast<float4*>(deltas)[o] = dl;
+        if (b == 0) iota[level_off + r] = level_off + r;
+    }
+}
+
+// candidate i of image b: anchor order[i]; apply_box_deltas_graph + clip_boxes_graph + normalise (float32,
+// one rounding per TF op: no fma contraction)
+__global__ __launch_bounds__(256) void decode_kernel(dc_proposal_desc d, const int* __restrict__ order, const float* __restrict__ deltas,
+                                                     float4* __restrict__ boxes, int k) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= d.B * k) return;
+    const int b = idx / k, i = idx - b * k;
+    const int a = order[(long)b * d.A_total + i];
+    const float4 an = reinterpret_cast<const float4*>(d.anchors)[a];
+    const float4 dl = reinterpret_cast<const float4*>(deltas)[(long)b * d.A_total + a];
+    float h = __fsub_rn(an.z, an.x), w = __fsub_rn(an.w, an.y);
+    float cy = __fadd_rn(an.x, __fmul_rn(0.5f, h)), cx = __fadd_rn(an.y, __fmul_rn(0.5f, w));
+    cy = __fadd_rn(cy, __fmul_rn(dl.x, h));
+    cx = __fadd_rn(cx, __fmul_rn(dl.y, w));
+    h = __fmul_rn(h, expf(dl.z));
+    w = __fmul_rn(w, expf(dl.w));
+    float y1 = __fsub_rn(cy, __fmul_rn(0.5f, h)), x1 = __fsub_rn(cx, __fmul_rn(0.5f, w));
+    float y2 = __fadd_rn(y1, h), x2 = __fadd_rn(x1, w);
+    y1 = fmaxf(fminf(y1, d.image_h), 0.f); x1 = fmaxf(fminf(x1, d.image_w), 0.f);
+    y2 = fmaxf(fminf(y2, d.image_h), 0.f); x2 = fmaxf(fminf(x2, d.image_w), 0.f);
+    boxes[idx] = make_float4(__fdiv_rn(y1, d.image_h), __fdiv_rn(x1, d.image_w), __fdiv_rn(y2, d.image_h), __fdiv_rn(x2, d.image_w));
+}
+
+__device__ __forceinline__ bool iou_exceeds(const float4 a, const float4 b, float thr) {
+    const float ay0 = fminf(a.x, a.z), ay1 = fmaxf(a.x, a.z), ax0 = fminf(a.y, a.w), ax1 = fmaxf(a.y, a.w);
+    const float by0 = fminf(b.x, b.z), by1 = fmaxf(b.x, b.z), bx0 = fminf(b.y, b.w), bx1 = fmaxf(b.y, b.w);
+    const float area_a = __fmul_rn(__fsub_rn(ay1, ay0), __fsub_rn(ax1, ax0));
+    const float area_b = __fmul_rn(__fsub_rn(by1, by0), __fsub_rn(bx1, bx0));
+    if (area_a <= 0.f || area_b <= 0.f) return false;
+    const float ih = fmaxf(__fsub_rn(fminf(ay1, by1), fmaxf(ay0, by0)), 0.f);
+    const float iw = fmaxf(__fsub_rn(fminf(ax1, bx1), fmaxf(ax0, bx0)), 0.f);
+    const float inter = __fmul_rn(ih, iw);
+    return __fdiv_rn(inter, __fsub_rn(__fadd_rn(area_a, area_b), inter)) > thr;
+}
+
+// mask[b][i][w] bit j: candidate 64*w + j (ranked after i) overlaps candidate i by more than the threshold
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__ boxes, unsigned long long* __restrict__ mask, int k, int words,
+                                                      float thr) {
+    __shared__ float4 cb[64];
+    const int b = blockIdx.z, rowb = blockIdx.y, colb = blockIdx.x;
+    if (colb < rowb) return;
+    const float4* bx = boxes + (long)b * k;
+    const int cj = colb * 64 + threadIdx.x;
+    cb[threadIdx.x] = cj < k ? bx[cj] : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const int i = rowb * 64 + threadIdx.x;
+    if (i >= k) return;
+    const float4 me = bx[i];
+    unsigned long long bits = 0;
+    const int ncol = min(64, k - colb * 64);
+    for (int j = (rowb == colb) ? threadIdx.x + 1 : 0; j < ncol; ++j)
+        if (iou_exceeds(me, cb[j], thr)) bits |= 1ull << j;
+    mask[((long)b * k + i) * words + colb] = bits;
+}
+
+// one 64-thread workgroup per image walks the candidates in rank order
+__global__ __launch_bounds__(64) void nms_scan_kernel(const float4* __restrict__ boxes, const unsigned long long* __restrict__ mask, int k,
+                                                      int words, int count, float4* __restrict__ proposals, int* __restrict__ keep_out) {
+    extern __shared__ unsigned long long removed[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    for (int w = lane; w < words; w += 64) removed[w] = 0;
+    __syncthreads();
+    int kept = 0;
+    for (int i = 0; i < k && kept < count; ++i) {
+        const bool dead = (removed[i >> 6] >> (i & 63)) & 1ull;      // uniform
+        if (!dead) {
+            if (lane == 0) {
+                proposals[(long)b * count + kept] = boxes[(long)b * k + i];
+                if (keep_out) keep_out[(long)b * count + kept] = i;
+            }
+            ++kept;
+            const unsigned long long* row = mask + ((long)b * k + i) * words;
+            for (int w = (i >> 6) + lane; w < words; w += 64) removed[w] |= row[w];
+        }
+        __syncthreads();
+    }
+    for (int r = kept + lane; r < count; r += 64) {
+        proposals[(long)b * count + r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (keep_out) keep_out[(long)b * count + r] = -1;
+    }
+}
+
+__global__ void subsample2_kernel(const float4* __restrict__ x, float4* __restrict__ y, int N, int H, int W, int C4) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long total = (long)N * Ho * Wo * C4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C4);
+        long p = idx / C4;
+        const int ox = (int)(p % Wo);
+        p /= Wo;
+        const int oy = (int)(p % Ho), n = (int)(p / Ho);
+        y[idx] = x[(((long)n * H + oy * 2) * W + ox * 2) * C4 + c];
+    }
+}
+
+struct ProposalWs {
+    size_t scores, deltas, iota, keys, vals, boxes, mask, sort_tmp, total, sort_tmp_bytes;
+};
+
+static ProposalWs proposal_layout(const dc_proposal_desc* d) {
+    ProposalWs w{};
+    const int k = std::min(d->pre_nms_limit, d->A_total), words = (k + 63) / 64;
+    size_t o = 0;
+    w.scores = o; o += up256((size_t)d->B * d->A_total * 4);
+    w.deltas = o; o += up256((size_t)d->B * d->A_total * 16);
+    w.iota = o;   o += up256((size_t)d->A_total * 4);
+    w.keys = o;   o += up256((size_t)d->B * d->A_total * 4);
+    w.vals = o;   o += up256((size_t)d->B * d->A_total * 4);
+    w.boxes = o;  o += up256((size_t)d->B * k * 16);
+    w.mask = o;   o += up256((size_t)d->B * k * words * 8);
+    size_t tmp = 0;
+    (void)rocprim::radix_sort_pairs_desc(nullptr, tmp, (const float*)nullptr, (float*)nullptr, (const int*)nullptr, (int*)nullptr,
+                                         (size_t)d->A_total, 0, 32, (hipStream_t) nullptr, false);
+    w.sort_tmp = o; w.sort_tmp_bytes = tmp; o += up256(tmp);
+    w.total = o;
+    return w;
+}
+
+static int proposal_validate(const dc_proposal_desc* d) {
+    DC_REQUIRE(d && d->anchors && d->proposals, DC_EINVAL, "dc_proposals: null pointer");
+    DC_REQUIRE(d->B > 0 && d->levels >= 1 && d->levels <= 5 && d->anchors_per_loc > 0 && d->A_total > 0 && d->pre_nms_limit > 0 &&
+                   d->proposal_count > 0,
+               DC_EINVAL, "dc_proposals: bad sizes");
+    long a = 0;
+    for (int l = 0; l < d->levels; ++l) {
+        DC_REQUIRE(d->heads[l] && d->Hs[l] > 0 && d->Ws[l] > 0, DC_EINVAL, "dc_proposals: bad head %d", l);
+        a += (long)d->Hs[l] * d->Ws[l] * d->anchors_per_loc;
+    }
+    DC_REQUIRE(a == d->A_total, DC_EINVAL, "dc_proposals: A_total (%d) != sum of H*W*A over levels (%ld)", d->A_total, a);
+    DC_REQUIRE(aligned16(d->anchors) && aligned16(d->proposals), DC_EALIGN, "dc_proposals: anchors/proposals must be 16-byte aligned");
+    return DC_OK;
+}
+
+}  // namespace dcap
+
+using namespace dcap;
+
+extern "C" size_t dc_proposals_workspace_bytes(const dc_proposal_desc* d) {
+    if (proposal_validate(d)) return 0;
+    return proposal_layout(d).total;
+}
+
+extern "C" int dc_proposals_f32(const dc_proposal_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = proposal_validate(d);
+    if (rc) return rc;
+    const ProposalWs L = proposal_layout(d);
+    DC_REQUIRE(workspace && workspace_bytes >= L.total && aligned16(workspace), DC_EWORKSPACE,
+               "dc_proposals: needs %zu workspace bytes, got %zu", L.total, workspace_bytes);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    float* scores = reinterpret_cast<float*>(ws + L.scores);
+    float* deltas = reinterpret_cast<float*>(ws + L.deltas);
+    int* iota = reinterpret_cast<int*>(ws + L.iota);
+    float* keys = reinterpret_cast<float*>(ws + L.keys);
+    int* vals = reinterpret_cast<int*>(ws + L.vals);
+    float4* boxes = reinterpret_cast<float4*>(ws + L.boxes);
+    unsigned long long* mask = reinterpret_cast<unsigned long long*>(ws + L.mask);
+    const int k = std::min(d->pre_nms_limit, d->A_total), words = (k + 63) / 64;
+
+    int off = 0;
+    for (int l = 0; l < d->levels; ++l) {
+        const long n = (long)d->B * d->Hs[l] * d->Ws[l] * d->anchors_per_loc;
+        const int blocks = (int)std::min<long>((n + 255) / 256, (long)kNumCU * 8);
+        hipLaunchKernelGGL(rpn_score_kernel, dim3(blocks), dim3(256), 0, s, *d, l, off, scores, deltas, iota);
+        off += d->Hs[l] * d->Ws[l] * d->anchors_per_loc;
+    }
+    rc = check_launch("rpn_score_kernel");
+    if (rc) return rc;
+    for (int b = 0; b < d->B; ++b) {
+        size_t tmp = L.sort_tmp_bytes;
+        hipError_t e = rocprim::radix_sort_pairs_desc(ws + L.sort_tmp, tmp, (const float*)(scores + (long)b * d->A_total),
+                                                      keys + (long)b * d->A_total, (const int*)iota, vals + (long)b * d->A_total,
+                                                      (size_t)d->A_total, 0, 32, s, false);
+        DC_REQUIRE(e == hipSuccess, DC_ELAUNCH, "dc_proposals: radix sort failed: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(decode_kernel, dim3((d->B * k + 255) / 256), dim3(256), 0, s, *d, vals, deltas, boxes, k);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words, d->B), dim3(64), 0, s, boxes, mask, k, words, d->nms_threshold);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(d->B), dim3(64), (size_t)words * 8, s, boxes, mask, k, words, d->proposal_count,
+                       reinterpret_cast<float4*>(d->proposals), d->keep_out);
+    rc = check_launch("proposal kernels");
+    if (rc) return rc;
+    if (d->scores_out) {
+        hipError_t e = hipMemcpyAsync(d->scores_out, scores, (size_t)d->B * d->A_total * 4, hipMemcpyDeviceToDevice, s);
+        DC_REQUIRE(e == hipSuccess, DC_ELAUNCH, "dc_proposals: copy failed");
+    }
+    if (d->order_out) {
+        hipError_t e = hipMemcpy2DAsync(d->order_out, (size_t)k * 4, vals, (size_t)d->A_total * 4, (size_t)k * 4, d->B, hipMemcpyDeviceToDevice, s);
+        DC_REQUIRE(e == hipSuccess, DC_ELAUNCH, "dc_proposals: copy failed");
+    }
+    return DC_OK;
+}
+
+extern "C" int dc_subsample2_f32(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+    DC_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, DC_EINVAL, "dc_subsample2: bad arguments");
+    DC_REQUIRE(aligned16(x) && aligned16(y), DC_EALIGN, "dc_subsample2: pointers must be 16-byte aligned");
+    const long total = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+    const int blocks = (int)std::min<long>((total + 255) / 256, (long)kNumCU * 8);
+    hipLaunchKernelGGL(subsample2_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), N, H, W, C / 4);
+    return check_launch("subsample2_kernel");
+}

@@ -15,13 +15,15 @@ import torch
 
 from . import _lib, ops
 from ._lib import ConvDesc, check
-from .layers import resnet_fpn_convs
+from .layers import ConvSpec, resnet_fpn_convs
 from .packing import fold_bn, pack_conv_kernel, pack_stem_kernel
 
 
 class EncoderPlan:
     def __init__(self, weights, batch, height, width, device, stage4_blocks=22,
-                 mean_pixel=(123.7, 116.8, 103.9), use_graph=True):
+                 mean_pixel=(123.7, 116.8, 103.9), use_graph=True, rpn=None):
+        """rpn: None (GT-RoI variant: the RPN is never evaluated) or a dict with the config values the
+        proposal path needs: scales, ratios, strides, anchor_stride, bbox_std, nms_threshold, proposal_count."""
         if height % 64 or width % 64:
             raise ValueError("Image size must be dividable by 2 at least 6 times (got %dx%d)" % (height, width))
         self.lib = _lib.load()
@@ -33,6 +35,14 @@ class EncoderPlan:
         self._graph = None
         self._warm = False
         self._specs = {s.name: s for s in resnet_fpn_convs(stage4_blocks)}
+        self.rpn = rpn
+        if rpn is not None:
+            a = len(rpn["ratios"])
+            self._specs["rpn_conv_shared"] = ConvSpec("rpn_conv_shared", None, 3, 256, 512, 1, "same")
+            self._specs["rpn_head"] = ConvSpec("rpn_head", None, 1, 512, 6 * a, 1, "valid")      # class_raw ++ bbox_pred
+            weights = dict(weights)
+            weights["rpn_head/kernel"] = np.concatenate([weights["rpn_class_raw/kernel"], weights["rpn_bbox_pred/kernel"]], axis=3)
+            weights["rpn_head/bias"] = np.concatenate([weights["rpn_class_raw/bias"], weights["rpn_bbox_pred/bias"]])
         self._w = {}
         self._upload(weights)
         self._build()
@@ -132,6 +142,21 @@ class EncoderPlan:
         self._conv("fpn_p4", t4, P4, relu=False)
         self._conv("fpn_p5", t5, P5, relu=False)
         self.P = (P2, P3, P4, P5)
+        if self.rpn is not None:
+            from .utils import generate_pyramid_anchors
+            P6 = self._buf(H // 64, W // 64, 256)
+            self._ops.append(("sub2", P5, P6))
+            self.rpn_heads = []
+            for p in (P2, P3, P4, P5, P6):
+                sh = self._buf(p.shape[1], p.shape[2], 512)
+                hd = self._buf(p.shape[1], p.shape[2], 6 * len(self.rpn["ratios"]))
+                self._conv("rpn_conv_shared", p, sh)
+                self._conv("rpn_head", sh, hd, relu=False)
+                self.rpn_heads.append(hd)
+            shapes = [[-(-H // st), -(-W // st)] for st in self.rpn["strides"]]
+            anchors = generate_pyramid_anchors(self.rpn["scales"], self.rpn["ratios"], shapes, self.rpn["strides"],
+                                               self.rpn.get("anchor_stride", 1)).astype(np.float32)
+            self.anchors = torch.tensor(anchors, device=self.device)
         self._bufs.append(rgbx)
         # plan-owned split-K workspace: its address is baked into the captured hipGraph
         self._ws = torch.empty(max(self._ws_bytes, 16), dtype=torch.uint8, device=self.device)
@@ -149,6 +174,8 @@ class EncoderPlan:
                     check(rc, "dc_conv2d_nhwc_f32(%s)" % op[2])
             elif kind == "mold":
                 ops.mold_image_rgbx(op[1], self.mean_pixel, out=op[2])
+            elif kind == "sub2":
+                ops.subsample2(op[1], out=op[2])
             else:
                 ops.maxpool3x3s2_same(op[1], out=op[2])
 
@@ -207,6 +234,14 @@ class EncoderPlan:
             self._graph = g
             g.replay()
         return self.P
+
+    def proposals(self, debug=False):
+        """ProposalLayer on the RPN heads of the last forward(): normalised boxes [B,count,4], zero padded."""
+        if self.rpn is None:
+            raise RuntimeError("this plan was built without the RPN")
+        r = self.rpn
+        return ops.rpn_proposals(self.rpn_heads, self.anchors, (self.H, self.W), r["proposal_count"], r["nms_threshold"],
+                                 r.get("bbox_std", (0.1, 0.1, 0.2, 0.2)), anchors_per_loc=len(r["ratios"]), debug=debug)
 
     def normalize_boxes(self, rois_px):
         """rois / [h,w,h,w] in float32, as modified_dense_model.py:1522-1527 (the molded image's size,

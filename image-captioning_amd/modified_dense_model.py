@@ -3,9 +3,10 @@
 :1806-1840 mold_inputs, :1886-1923 generate_captions; image-level variant
 feature_generation/dense_model.py:1868-1905).
 
-Only the GT-RoI inference variant (use_generated_rois=False, the one the caption decoders' data
-generators call) is on the hot path.  Proposal generation (RPN + ProposalLayer) and the joint
-training graph are SURVEY.md section 8(f) "next" rows and raise NotImplementedError here.
+Inference variants: use_generated_rois=False (ground-truth RoIs: what the caption decoders' data
+generators call; the RPN is not evaluated) and use_generated_rois=True (RPN + ProposalLayer ->
+POST_NMS_ROIS_INFERENCE proposals, the feature_generation/ image-level path).  The joint training graph
+is a SURVEY.md section 8(f) "next" row and raises NotImplementedError.
 """
 import os
 
@@ -58,8 +59,6 @@ class DenseImageCapRCNN(object):
         assert mode in ['training', 'inference']
         if mode == 'training':
             raise NotImplementedError("the joint training graph (dense_img_cap/dense_model.py) is a SURVEY 8(f) 'next' row")
-        if use_generated_rois:
-            raise NotImplementedError("RPN + ProposalLayer (use_generated_rois=True) is a SURVEY 8(f) 'next' row")
         self.mode = mode
         self.config = config
         self.model_dir = model_dir
@@ -76,7 +75,18 @@ class DenseImageCapRCNN(object):
             names += [s.name + "/kernel", s.name + "/bias"]
             if s.bn:
                 names += [s.bn + "/" + w for w in ("gamma", "beta", "moving_mean", "moving_variance")]
+        if self.use_generated_rois:
+            for n in ("rpn_conv_shared", "rpn_class_raw", "rpn_bbox_pred"):
+                names += [n + "/kernel", n + "/bias"]
         return names
+
+    def _rpn_config(self):
+        if not self.use_generated_rois:
+            return None
+        c = self.config
+        return dict(scales=c.RPN_ANCHOR_SCALES, ratios=c.RPN_ANCHOR_RATIOS, strides=c.BACKBONE_STRIDES,
+                    anchor_stride=c.RPN_ANCHOR_STRIDE, bbox_std=[float(v) for v in c.RPN_BBOX_STD_DEV],
+                    nms_threshold=c.RPN_NMS_THRESHOLD, proposal_count=c.POST_NMS_ROIS_INFERENCE)
 
     def set_weights(self, weights):
         missing = [n for n in self.weight_names() if n not in weights]
@@ -103,16 +113,20 @@ class DenseImageCapRCNN(object):
             if self._weights is None:
                 raise RuntimeError("load_weights()/set_weights() must be called before inference")
             self._plans[key] = EncoderPlan(self._weights, batch, h, w, self.device, self.stage4_blocks,
-                                           self.config.MEAN_PIXEL)
+                                           self.config.MEAN_PIXEL, rpn=self._rpn_config())
         return self._plans[key]
 
-    def extract_features(self, images_u8, rois_px):
+    def extract_features(self, images_u8, rois_px=None):
         """Device-resident fast path: images [B,H,W,3] uint8 (numpy or torch, already the model's
-        size), rois [B,R,4] pixels -> torch [B,R,7,7,256] on the GPU (no host round trip)."""
+        size), rois [B,R,4] pixels (or None with use_generated_rois: the RPN's proposals)
+        -> torch [B,R,7,7,256] on the GPU (no host round trip)."""
         imgs = torch.as_tensor(images_u8)
         B, H, W, _ = imgs.shape
         p = self.plan(B, H, W)
         p.forward(imgs)
+        if self.use_generated_rois:
+            self.last_proposals = p.proposals()
+            return p.roi_features(boxes_norm=self.last_proposals)
         return p.roi_features(rois_px)
 
     # ---- reference API -------------------------------------------------------------------
@@ -127,14 +141,14 @@ class DenseImageCapRCNN(object):
             windows.append(window)
         return np.stack(molded), np.stack(metas), np.stack(windows)
 
-    def generate_captions(self, images, rois, verbose=0):
+    def generate_captions(self, images, rois=None, verbose=0):
         """images: list of [H,W,3] uint8; rois: [len(images), N, 4] (y1,x1,y2,x2) pixels.
         Returns [{'features': float32 [N,7,7,256]}] like the reference (whose slice
         features[i][1000*i:1000*(i+1)] only works for BATCH_SIZE == 1; image i > 0 gets its own RoIs here)."""
         assert self.mode == "inference", "Create model in inference mode."
         assert len(images) == self.config.BATCH_SIZE, "len(images) must be equal to BATCH_SIZE"
         molded, metas, windows = self.mold_inputs(images)
-        rois = np.asarray(rois, np.float32)
+        rois = None if self.use_generated_rois else np.asarray(rois, np.float32)
         feats = self.extract_features(molded, rois).cpu().numpy()
         n = self.config.POST_NMS_ROIS_INFERENCE
         return [{"features": feats[i][:n]} for i in range(len(images))]

@@ -7,7 +7,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (AmsgradDesc, BnReluDesc, ConvDesc, GemmDesc, LstmBwdDesc, LstmFwdDesc, RoiAlignDesc,
+from ._lib import (AmsgradDesc, BnReluDesc, ConvDesc, ProposalDesc, GemmDesc, LstmBwdDesc, LstmFwdDesc, RoiAlignDesc,
                    SoftmaxCeDesc, check)
 
 
@@ -157,6 +157,50 @@ def roi_align_pyramid(maps, boxes, image_area, pool=7, out=None, levels_out=None
     d.levels_out = None if levels_out is None else _chk(levels_out, torch.int32, "levels").data_ptr()
     check(lib.dc_roi_align_pyramid_f32(C.byref(d), _stream()), "dc_roi_align_pyramid_f32")
     return out
+
+
+def subsample2(x, out=None):
+    lib = _lib.load()
+    _chk(x, name="x")
+    N, H, W, Cc = x.shape
+    if out is None:
+        out = torch.empty((N, (H + 1) // 2, (W + 1) // 2, Cc), dtype=torch.float32, device=x.device)
+    check(lib.dc_subsample2_f32(_ptr(x), _ptr(out), N, H, W, Cc, _stream()), "dc_subsample2_f32")
+    return out
+
+
+def rpn_proposals(heads, anchors, image_hw, proposal_count, nms_threshold, std_dev=(0.1, 0.1, 0.2, 0.2), pre_nms_limit=6000,
+                  anchors_per_loc=3, out=None, debug=False):
+    """heads: per-level fused RPN head outputs [B,H,W,A*6]; anchors [A_total,4] float32 device tensor.
+    Returns proposals [B,count,4] (normalised, zero padded) and, with debug, (scores, order, keep)."""
+    lib = _lib.load()
+    B = heads[0].shape[0]
+    d = ProposalDesc()
+    d.B, d.levels, d.anchors_per_loc = B, len(heads), anchors_per_loc
+    for i, h in enumerate(heads):
+        if not _chk(h, name="head").is_contiguous() or h.shape[-1] != anchors_per_loc * 6:
+            raise _lib.DcapError("rpn_proposals: heads must be contiguous [B,H,W,A*6]")
+        d.heads[i] = h.data_ptr()
+        d.Hs[i], d.Ws[i] = h.shape[1], h.shape[2]
+    d.anchors, d.A_total = _chk(anchors, name="anchors").data_ptr(), anchors.shape[0]
+    for i in range(4):
+        d.std_dev[i] = float(std_dev[i])
+    d.image_h, d.image_w = float(image_hw[0]), float(image_hw[1])
+    d.pre_nms_limit, d.proposal_count, d.nms_threshold = int(pre_nms_limit), int(proposal_count), float(nms_threshold)
+    dev = heads[0].device
+    if out is None:
+        out = torch.empty((B, proposal_count, 4), dtype=torch.float32, device=dev)
+    d.proposals = out.data_ptr()
+    extra = None
+    if debug:
+        k = min(pre_nms_limit, anchors.shape[0])
+        extra = (torch.empty((B, anchors.shape[0]), dtype=torch.float32, device=dev),
+                 torch.empty((B, k), dtype=torch.int32, device=dev),
+                 torch.empty((B, proposal_count), dtype=torch.int32, device=dev))
+        d.scores_out, d.order_out, d.keep_out = (t.data_ptr() for t in extra)
+    ws, wsb = WORKSPACE.get(lib.dc_proposals_workspace_bytes(C.byref(d)), dev)
+    check(lib.dc_proposals_f32(C.byref(d), _ptr(ws), wsb, _stream()), "dc_proposals_f32")
+    return (out, extra) if debug else out
 
 
 def lstm_seq_fwd(z, U_rec, mask, B, T, h_seq=None, c_seq=None):

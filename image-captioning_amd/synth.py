@@ -63,6 +63,16 @@ def encoder_weights(seed=0, stage4_blocks=22):
     return W
 
 
+def rpn_weights(seed=4, anchors_per_loc=3, depth=256):
+    """rpn_graph's three convolutions (feature_generation/dense_model.py:701-725)."""
+    rng = np.random.default_rng(seed)
+    W = {}
+    conv_weights(rng, "rpn_conv_shared", 3, depth, 512, W)
+    conv_weights(rng, "rpn_class_raw", 1, 512, 2 * anchors_per_loc, W)
+    conv_weights(rng, "rpn_bbox_pred", 1, 512, 4 * anchors_per_loc, W)
+    return W
+
+
 def head_weights(seed=1, pool=7, cin=256, width=1024):
     rng = np.random.default_rng(seed)
     W = {}

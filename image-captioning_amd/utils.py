@@ -84,3 +84,25 @@ def compose_image_meta(image_id, image_shape, window):
 
 def mold_image(images, config):
     return images.astype(np.float32) - config.MEAN_PIXEL
+
+
+def generate_anchors(scales, ratios, shape, feature_stride, anchor_stride):
+    """Anchors of one pyramid level, [H*W*len(ratios), (y1,x1,y2,x2)] in image pixels, ordered
+    (y, x, ratio) -- the order rpn_graph's reshape gives the RPN outputs (utils.py:333-369)."""
+    scales, ratios = np.meshgrid(np.array(scales), np.array(ratios))
+    scales, ratios = scales.flatten(), ratios.flatten()
+    heights, widths = scales / np.sqrt(ratios), scales * np.sqrt(ratios)
+    ys = np.arange(0, shape[0], anchor_stride) * feature_stride
+    xs = np.arange(0, shape[1], anchor_stride) * feature_stride
+    xs, ys = np.meshgrid(xs, ys)
+    bw, cx = np.meshgrid(widths, xs)
+    bh, cy = np.meshgrid(heights, ys)
+    centers = np.stack([cy, cx], axis=2).reshape([-1, 2])
+    sizes = np.stack([bh, bw], axis=2).reshape([-1, 2])
+    return np.concatenate([centers - 0.5 * sizes, centers + 0.5 * sizes], axis=1)
+
+
+def generate_pyramid_anchors(scales, ratios, feature_shapes, feature_strides, anchor_stride):
+    """All levels concatenated, scale i on level i (utils.py:372-389)."""
+    return np.concatenate([generate_anchors(scales[i], ratios, feature_shapes[i], feature_strides[i], anchor_stride)
+                           for i in range(len(scales))], axis=0)

@@ -128,6 +128,40 @@ typedef struct {
 
 int dc_roi_align_pyramid_f32(const dc_roialign_desc* d, void* stream);
 
+/* KL.MaxPooling2D(pool_size=(1,1), strides=2): P6 = every other pixel of P5 (dense_model.py:1423). */
+int dc_subsample2_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * RPN scores + ProposalLayer (feature_generation/dense_model.py:684-725, :221-305): per image
+ *   fg score = softmax(class logits)[1] per anchor, deltas *= RPN_BBOX_STD_DEV,
+ *   tf.nn.top_k(scores, pre_nms_limit) (stable: lower anchor index first among ties),
+ *   apply_box_deltas -> clip to the image -> normalise by [h,w,h,w] (float32, TF's operation order),
+ *   tf.image.non_max_suppression(threshold) -> first `proposal_count` survivors, zero padded.
+ * heads[l] = the fused RPN head output of pyramid level l, NHWC [B,Hl,Wl,A*6]: channels a*2+{bg,fg}
+ * (rpn_class_raw) followed by A*2 + a*4 + {dy,dx,dh,dw} (rpn_bbox_pred); anchors [A_total,4] pixels in
+ * generate_pyramid_anchors order (level, y, x, ratio).
+ * Optional outputs for tests: scores_out [B,A_total], order_out [B,pre_nms_limit] (anchor index of each
+ * sorted candidate), keep_out [B,proposal_count] (candidate rank of each kept box, -1 padded).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int B, levels, anchors_per_loc;
+    const float* heads[5];
+    int Hs[5], Ws[5];
+    const float* anchors;
+    int A_total;
+    float std_dev[4];
+    float image_h, image_w;
+    int pre_nms_limit, proposal_count;
+    float nms_threshold;
+    float* proposals;
+    float* scores_out;
+    int32_t* order_out;
+    int32_t* keep_out;
+} dc_proposal_desc;
+
+size_t dc_proposals_workspace_bytes(const dc_proposal_desc* d);
+int    dc_proposals_f32(const dc_proposal_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Keras-2.1 LSTM over a whole sequence (gate blocks i,f,c,o; hard-sigmoid gates; tanh; mask carry).
  * Replaces KL.LSTM: text_generation_model.py:141-142,150-151; _v2.py:157,163.

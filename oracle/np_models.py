@@ -358,3 +358,41 @@ def data_parallel_mean(per_rank):
     loss => gradients are the plain average of the per-rank gradients."""
     keys = per_rank[0].keys()
     return {k: sum(np.asarray(g[k], F64) for g in per_rank) / len(per_rank) for k in keys}
+
+
+# --------------------------------------------------------------------------------------------
+# RPN + proposals: the image-level variant named by north_star
+# (feature_generation/dense_model.py:684-725 rpn_graph, :1425-1455, :221-305; generate_roi_features.py:60-75)
+# --------------------------------------------------------------------------------------------
+
+def rpn_forward(P, Wt):
+    """rpn_graph on one feature map [B,H,W,256] -> (probs [B,H*W*A,2], bbox [B,H*W*A,4])."""
+    shared = O.relu(O.conv2d_nhwc(P, Wt['rpn_conv_shared/kernel'], Wt['rpn_conv_shared/bias'], 1, 'same'))
+    cls = O.conv2d_nhwc(shared, Wt['rpn_class_raw/kernel'], Wt['rpn_class_raw/bias'])
+    box = O.conv2d_nhwc(shared, Wt['rpn_bbox_pred/kernel'], Wt['rpn_bbox_pred/bias'])
+    B = P.shape[0]
+    return O.softmax(cls.reshape(B, -1, 2)), box.reshape(B, -1, 4)
+
+
+def rpn_proposals(maps5, Wt, config_like, image_hw):
+    """maps5 = [P2..P6]; returns (proposals [B,count,4] normalised float32, scores [B,A], deltas [B,A,4])."""
+    outs = [rpn_forward(p, Wt) for p in maps5]
+    probs = np.concatenate([o[0] for o in outs], axis=1)
+    bbox = np.concatenate([o[1] for o in outs], axis=1)
+    H, W = image_hw
+    shapes = [[-(-H // s), -(-W // s)] for s in config_like['strides']]
+    anchors = O.generate_pyramid_anchors(config_like['scales'], config_like['ratios'], shapes, config_like['strides'], 1)
+    props = [O.proposal_layer(probs[b, :, 1], bbox[b], anchors, image_hw, config_like['count'], config_like['nms'])[0]
+             for b in range(probs.shape[0])]
+    return np.stack(props), probs[:, :, 1], bbox, anchors
+
+
+def image_level_encoder_features(images_u8, Wt, mean_pixel, config_like, stage4_blocks=22):
+    """feature_generation variant: RoIs from the RPN; returns ([B,count,7,7,256], proposals)."""
+    x = O.mold_image(images_u8, mean_pixel)
+    B, H, W, _ = x.shape
+    _, C2, C3, C4, C5 = resnet_graph(x, Wt, stage4_blocks)
+    P2, P3, P4, P5, P6 = fpn_graph(C2, C3, C4, C5, Wt)
+    props, scores, bbox, anchors = rpn_proposals([P2, P3, P4, P5, P6], Wt, config_like, (H, W))
+    feats = O.pyramid_roi_align(props, [P2, P3, P4, P5], (H, W, 3), 7)
+    return feats, props, (scores, bbox, anchors)

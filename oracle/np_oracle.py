@@ -387,3 +387,98 @@ def amsgrad_step(p, g, m, v, vhat, t, lr=1e-3, b1=0.9, b2=0.999, eps=1e-7):
     vhat = np.maximum(vhat, v)
     p = p - lr_t * m / (np.sqrt(vhat) + eps)
     return p, m, v, vhat
+
+
+# --------------------------------------------------------------------------------------------
+# RPN anchors and ProposalLayer (feature_generation/utils.py:333-389; dense_model.py:180-305)
+# --------------------------------------------------------------------------------------------
+
+def generate_anchors(scales, ratios, shape, feature_stride, anchor_stride):
+    """utils.generate_anchors: [H*W*len(ratios), (y1,x1,y2,x2)] float64, index = (y*W + x)*R + ratio."""
+    scales, ratios = np.meshgrid(np.array(scales), np.array(ratios))
+    scales, ratios = scales.flatten(), ratios.flatten()
+    heights = scales / np.sqrt(ratios)
+    widths = scales * np.sqrt(ratios)
+    shifts_y = np.arange(0, shape[0], anchor_stride) * feature_stride
+    shifts_x = np.arange(0, shape[1], anchor_stride) * feature_stride
+    shifts_x, shifts_y = np.meshgrid(shifts_x, shifts_y)
+    box_widths, box_centers_x = np.meshgrid(widths, shifts_x)
+    box_heights, box_centers_y = np.meshgrid(heights, shifts_y)
+    box_centers = np.stack([box_centers_y, box_centers_x], axis=2).reshape([-1, 2])
+    box_sizes = np.stack([box_heights, box_widths], axis=2).reshape([-1, 2])
+    return np.concatenate([box_centers - 0.5 * box_sizes, box_centers + 0.5 * box_sizes], axis=1)
+
+
+def generate_pyramid_anchors(scales, ratios, feature_shapes, feature_strides, anchor_stride):
+    return np.concatenate([generate_anchors(scales[i], ratios, feature_shapes[i], feature_strides[i], anchor_stride)
+                           for i in range(len(scales))], axis=0)
+
+
+def apply_box_deltas_f32(boxes, deltas):
+    """apply_box_deltas_graph in float32, operation by operation (no fma)."""
+    b, d = np.asarray(boxes, F32), np.asarray(deltas, F32)
+    h = b[:, 2] - b[:, 0]
+    w = b[:, 3] - b[:, 1]
+    cy = b[:, 0] + F32(0.5) * h
+    cx = b[:, 1] + F32(0.5) * w
+    cy = cy + d[:, 0] * h
+    cx = cx + d[:, 1] * w
+    h = h * np.exp(d[:, 2], dtype=F32)
+    w = w * np.exp(d[:, 3], dtype=F32)
+    y1 = cy - F32(0.5) * h
+    x1 = cx - F32(0.5) * w
+    return np.stack([y1, x1, y1 + h, x1 + w], axis=1).astype(F32)
+
+
+def clip_boxes_f32(boxes, window):
+    wy1, wx1, wy2, wx2 = (F32(v) for v in window)
+    b = np.asarray(boxes, F32)
+    return np.stack([np.maximum(np.minimum(b[:, 0], wy2), wy1), np.maximum(np.minimum(b[:, 1], wx2), wx1),
+                     np.maximum(np.minimum(b[:, 2], wy2), wy1), np.maximum(np.minimum(b[:, 3], wx2), wx1)], axis=1)
+
+
+def nms_tf(boxes, scores, max_output_size, iou_threshold):
+    """tf.image.non_max_suppression (TF 1.x kernel), float32: candidates in descending score order (stable),
+    a candidate is kept unless its IoU with an already kept box exceeds the threshold."""
+    b = np.asarray(boxes, F32)
+    order = np.argsort(-np.asarray(scores, F32), kind='stable')
+    ymin, ymax = np.minimum(b[:, 0], b[:, 2]), np.maximum(b[:, 0], b[:, 2])
+    xmin, xmax = np.minimum(b[:, 1], b[:, 3]), np.maximum(b[:, 1], b[:, 3])
+    area = (ymax - ymin) * (xmax - xmin)
+    keep = []
+    thr = F32(iou_threshold)
+    for i in order:
+        if len(keep) >= max_output_size:
+            break
+        ok = True
+        for j in reversed(keep):
+            if area[i] <= 0 or area[j] <= 0:
+                continue
+            ih = np.maximum(np.minimum(ymax[i], ymax[j]) - np.maximum(ymin[i], ymin[j]), F32(0))
+            iw = np.maximum(np.minimum(xmax[i], xmax[j]) - np.maximum(xmin[i], xmin[j]), F32(0))
+            inter = ih * iw
+            if inter / (area[i] + area[j] - inter) > thr:
+                ok = False
+                break
+        if ok:
+            keep.append(int(i))
+    return np.array(keep, np.int32)
+
+
+def proposal_layer(scores, deltas, anchors, image_hw, proposal_count, nms_threshold, bbox_std=(0.1, 0.1, 0.2, 0.2),
+                   pre_nms_limit=6000):
+    """ProposalLayer.call for one image: scores [A] (fg prob), deltas [A,4], anchors [A,4] pixels.
+    Returns normalised proposals [proposal_count,4] (zero padded), float32.  Index decisions (top-k order,
+    clipping, NMS) are float32 as in the TF graph; tf.nn.top_k puts the lower index first among ties."""
+    scores = np.asarray(scores, F32)
+    d = np.asarray(deltas, F32) * np.asarray(bbox_std, F32)
+    k = min(pre_nms_limit, anchors.shape[0])
+    ix = np.argsort(-scores, kind='stable')[:k]
+    boxes = apply_box_deltas_f32(np.asarray(anchors, F32)[ix], d[ix])
+    h, w = image_hw
+    boxes = clip_boxes_f32(boxes, (0, 0, h, w))
+    nb = (boxes / np.array([h, w, h, w], F32)).astype(F32)
+    keep = nms_tf(nb, scores[ix], proposal_count, nms_threshold)
+    out = np.zeros((proposal_count, 4), F32)
+    out[:len(keep)] = nb[keep]
+    return out, ix, keep

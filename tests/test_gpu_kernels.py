@@ -261,3 +261,38 @@ def test_amsgrad_trajectory(ops, clip):
         ops.amsgrad_step(p, gd, m, v, vh, lr_t, gnorm_sq=ops.sumsq(gd) if clip else None, clipnorm=clip or 0.0)
     close(p, P, 1e-6)
     close(vh, Vh, 1e-5)
+
+
+def test_subsample2(ops):
+    x = np.random.default_rng(0).standard_normal((2, 8, 6, 8))
+    close(ops.subsample2(dev(x)), O.subsample2(x), 1e-7)
+
+
+@pytest.mark.parametrize("B,S", [(1, 256), (2, 128)])
+def test_rpn_proposals_bit_exact_given_scores(ops, B, S):
+    """ProposalLayer: the top-k order (ties included) and the NMS survivors are bit-exact against the float32
+    oracle when both start from the same fp32 scores (the device's own softmax output); box coordinates agree to
+    the last bit of exp()."""
+    rng = np.random.default_rng(S)
+    strides, scales, ratios = [4, 8, 16, 32, 64], (32, 64, 128, 256, 512), [0.5, 1, 2]
+    shapes = [[S // s, S // s] for s in strides]
+    heads = [rng.standard_normal((B, h, w, 18)).astype(np.float32) for h, w in shapes]
+    for hd in heads:
+        hd[..., 6:] *= 0.5
+    heads[0][0, 0, 0, :6] = heads[0][0, 0, 1, :6]              # exact score ties between neighbouring anchors
+    anchors = O.generate_pyramid_anchors(scales, ratios, shapes, strides, 1).astype(np.float32)
+    count, pre = 100, 600
+    props, (scores, order, keep) = ops.rpn_proposals([dev(h) for h in heads], dev(anchors), (S, S), count, 0.7,
+                                                     pre_nms_limit=pre, debug=True)
+    scores, order, keep, props = scores.cpu().numpy(), order.cpu().numpy(), keep.cpu().numpy(), props.cpu().numpy()
+    cls = np.concatenate([h[..., :6].reshape(B, -1, 2) for h in heads], axis=1)
+    box = np.concatenate([h[..., 6:].reshape(B, -1, 4) for h in heads], axis=1)
+    assert np.abs(scores - O.softmax(cls)[:, :, 1]).max() < 1e-6
+    for b in range(B):
+        want, ix, kp = O.proposal_layer(scores[b], box[b], anchors, (S, S), count, 0.7, pre_nms_limit=pre)
+        np.testing.assert_array_equal(order[b], ix)
+        np.testing.assert_array_equal(keep[b][:len(kp)], kp)
+        assert np.all(keep[b][len(kp):] == -1)
+        # box values: the device's expf and numpy's float32 exp may differ in the last bit
+        np.testing.assert_allclose(props[b], want, rtol=3e-7, atol=1e-7)
+        assert np.all(props[b][len(kp):] == 0)                       # zero padding

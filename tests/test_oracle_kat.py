@@ -191,3 +191,27 @@ def test_dp_mean_equals_single_rank_on_concatenated_batch():
     Gm = M.data_parallel_mean(parts)
     for k in Gall:
         np.testing.assert_allclose(Gm[k], Gall[k], rtol=1e-9, atol=1e-12)
+
+
+def test_anchor_layout_and_counts():
+    a = O.generate_pyramid_anchors((32, 64, 128, 256, 512), [0.5, 1, 2], [[256, 256], [128, 128], [64, 64], [32, 32], [16, 16]],
+                                   [4, 8, 16, 32, 64], 1)
+    assert a.shape == (261888, 4)                         # SURVEY: 261 888 anchors at 1024x1024
+    # first cell of P2: centre (0,0); ratio 0.5 -> h = 32/sqrt(.5), w = 32*sqrt(.5)
+    h, w = 32 / np.sqrt(0.5), 32 * np.sqrt(0.5)
+    np.testing.assert_allclose(a[0], [-h / 2, -w / 2, h / 2, w / 2])
+    np.testing.assert_allclose(a[1], [-16, -16, 16, 16])  # ratio 1
+    np.testing.assert_allclose(a[3], [-h / 2, 4 - w / 2, h / 2, 4 + w / 2])   # next x (stride 4), ratio 0.5
+
+
+def test_box_deltas_clip_and_nms():
+    boxes = np.array([[0, 0, 10, 10]], np.float32)
+    np.testing.assert_allclose(O.apply_box_deltas_f32(boxes, np.zeros((1, 4))), boxes)
+    out = O.apply_box_deltas_f32(boxes, np.array([[0.1, -0.2, np.log(2.0), 0.0]]))
+    np.testing.assert_allclose(out, [[-4, -2, 16, 8]], rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(O.clip_boxes_f32(out, (0, 0, 12, 12)), [[0, 0, 12, 8]], atol=1e-5)
+    b = np.array([[0, 0, 10, 10], [0, 0, 10, 9], [20, 20, 30, 30], [0, 0, 10, 6.9], [5, 5, 5, 9]], np.float32)
+    s = np.array([0.9, 0.8, 0.7, 0.6, 0.5], np.float32)
+    assert O.nms_tf(b, s, 10, 0.7).tolist() == [0, 2, 3, 4]        # IoU(0,1)=0.9 > 0.7 suppressed; 0.69 kept; zero area kept
+    assert O.nms_tf(b, s, 2, 0.7).tolist() == [0, 2]
+    assert O.nms_tf(b, np.array([0.5, 0.5, 0.5, 0.5, 0.5], np.float32), 1, 0.7).tolist() == [0]   # ties: lowest index first
