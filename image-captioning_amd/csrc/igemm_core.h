@@ -203,7 +203,7 @@ struct Im2colKC {
     struct State {
         __amdgpu_buffer_rsrc_t rsrc;
         unsigned boff[BT / 32];     // ((n*H + oy*stride)*W + ox*stride)*Cin*4 + 16*(tid&7): the output-aligned pixel
-        unsigned mask[BT / 32];     // bit ky: row iy in range; bit 8+kx: column ix in range
+        unsigned long long mask[BT / 32];     // bit (ky*kw + kx): that tap of this output pixel lies inside the image
         int ky, kx, c;              // block-uniform position of the NEXT K-tile (incremental, no division)
     };
     template <int BT>
@@ -217,11 +217,14 @@ struct Im2colKC {
             const int n = m / (Ho * Wo), rem = m - n * (Ho * Wo);
             const int oy = rem / Wo, ox = rem - oy * Wo;
             s.boff[i] = (unsigned)(((((long)n * H + oy * stride) * W + ox * stride) * Cin + 4 * (tid & 7)) * 4);
-            unsigned mk = 0;
+            unsigned ym = 0, xm = 0;
             for (int t = 0; t < 8; ++t) {
-                mk |= ((unsigned)(oy * stride - pad_t + t) < (unsigned)H) ? (1u << t) : 0u;
-                mk |= ((unsigned)(ox * stride - pad_l + t) < (unsigned)W) ? (1u << (8 + t)) : 0u;
+                ym |= ((unsigned)(oy * stride - pad_t + t) < (unsigned)H) ? (1u << t) : 0u;
+                xm |= ((unsigned)(ox * stride - pad_l + t) < (unsigned)W) ? (1u << t) : 0u;
             }
+            unsigned long long mk = 0;
+            for (int ty = 0; ty < 8; ++ty)
+                if ((ym >> ty) & 1u) mk |= (unsigned long long)(xm & ((1u << kw) - 1u)) << (ty * kw);
             s.mask[i] = mk;
         }
     }
@@ -235,9 +238,10 @@ struct Im2colKC {
         }
         const int ky = s.ky, kx = s.kx;
         const int ubytes = (((ky - pad_t) * W + (kx - pad_l)) * Cin + s.c) * 4;      // block-uniform, may be negative
+        const int tap = ky * kw + kx;                                                  // block-uniform
 #pragma unroll
         for (int i = 0; i < BT / 32; ++i) {
-            const bool in = ((s.mask[i] >> ky) & (s.mask[i] >> (8 + kx)) & 1u) != 0;
+            const bool in = ((s.mask[i] >> tap) & 1ull) != 0;
             r[i] = buf_f4(s.rsrc, in ? s.boff[i] + (unsigned)ubytes : kOobOffset);     // out of image -> hardware zero
         }
         s.c += 32;
@@ -615,12 +619,7 @@ int launch_igemm(const AL& al, const BL& bl, const Epilogue& ep, int M, int N, i
                    "igemm split-K needs %zu workspace bytes, got %zu", need, workspace_bytes);
         partial = static_cast<float*>(workspace);
     }
-    size_t lds = igemm_lds_bytes<BM, BN, AL, BL>();
-    {   // experiment knob: DCAP_LDS_MIN=<bytes> raises the LDS request (caps resident blocks per CU)
-        static long lds_min = -1;
-        if (lds_min < 0) { const char* e = getenv("DCAP_LDS_MIN"); lds_min = e ? atol(e) : 0; }
-        if ((size_t)lds_min > lds) lds = (size_t)lds_min;
-    }
+    constexpr size_t lds = igemm_lds_bytes<BM, BN, AL, BL>();
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, AL, BL>),

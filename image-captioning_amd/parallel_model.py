@@ -15,14 +15,23 @@ import torch.distributed as dist
 
 
 def init_process_group_from_env(backend=None):
-    """torchrun contract: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT."""
+    """torchrun contract: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT.  One process per GPU:
+    the device is bound (cuda:LOCAL_RANK) BEFORE the RCCL communicator is created.  DCAP_DIST_BACKEND=gloo
+    rehearses the multi-process path on a box with fewer GPUs than ranks (ranks then share devices)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if backend is None:
+        backend = os.environ.get("DCAP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if torch.cuda.is_available():
+        n = torch.cuda.device_count()
+        if backend == "nccl" and local_rank >= n:
+            raise RuntimeError("LOCAL_RANK %d but only %d GPU(s) visible" % (local_rank, n))
+        local_rank = local_rank % max(n, 1)
+        torch.cuda.set_device(local_rank)
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend)
-    return int(os.environ.get("RANK", "0")), world, int(os.environ.get("LOCAL_RANK", "0"))
+    return rank, world, local_rank
 
 
 def shard(x, rank, world):
