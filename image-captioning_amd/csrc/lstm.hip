@@ -67,6 +67,86 @@ __global__ void lstm_gate_bwd_kernel(const float* __restrict__ z_t, const float*
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused forward timestep (U % 32 == 0): z_t = zx_t + h_{t-1} * U_rec, gates, cell update, mask carry in ONE
+// launch.  Block = 32 batch rows x 8 units (= 32 columns: 4 gates x 8 units), 4 waves that split K = U
+// four ways; every wave streams its K range straight from global/L2 into MFMA fragments (one 16-byte load
+// of h per 4 MFMAs, one dword of U_rec per MFMA, prefetched 4 chunks ahead; SGPR-advanced bases: no
+// per-chunk VALU), the four partial 32x32 tiles meet in LDS and the 256 threads finish the gate math.
+// Replaces {split-K GEMM + slab reduce + gate kernel} = 3 launches and ~16 MB of slab traffic per step.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void lstm_step_fused_kernel(float* __restrict__ z_t, const float* __restrict__ U_rec,
+                                                              const float* __restrict__ h_prev, const float* __restrict__ c_prev,
+                                                              const uint8_t* __restrict__ mask_t, float* __restrict__ h_t,
+                                                              float* __restrict__ c_t, int B, int U) {
+    __shared__ float part[4][32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int u0 = blockIdx.x * 8, r0 = blockIdx.y * 32;
+    const int i = lane & 31, h = lane >> 5;
+    const int kq = U / 4, kbeg = wave * kq;
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // A: h_prev[row][k], lane (row i, half h) takes k = 8c + 4h .. +3 ; B: U_rec[k][col], col i -> gate i>>3, unit u0 + (i&7)
+    const int arow = min(r0 + i, B - 1);
+    const float* ap = h_prev + (long)arow * U + kbeg + 4 * h;
+    const float* bp = U_rec + (long)(kbeg + 4 * h) * (4 * U) + (i >> 3) * U + u0 + (i & 7);
+    constexpr int PF = 4;
+    const int nch = kq / 8;
+    f4_t a[PF];
+    float b[PF][4];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        const int c = min(p, nch - 1);
+        a[p] = *reinterpret_cast<const f4_t*>(ap + 8 * c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[p][j] = bp[(long)(8 * c + j) * (4 * U)];
+    }
+    for (int c0 = 0; c0 < nch; c0 += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const f4_t av = a[p];
+            const float b0 = b[p][0], b1 = b[p][1], b2 = b[p][2], b3 = b[p][3];
+            const int cn = min(c0 + p + PF, nch - 1);                 // prefetch (clamped: extra loads are discarded)
+            a[p] = *reinterpret_cast<const f4_t*>(ap + 8 * cn);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[p][j] = bp[(long)(8 * cn + j) * (4 * U)];
+            if (c0 + p < nch) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b3, acc, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * h][i] = acc[r];
+    __syncthreads();
+    // gate math: thread -> (row tid>>3, unit tid&7)
+    const int row = tid >> 3, uu = tid & 7;
+    const int brow = r0 + row;
+    if (brow >= B) return;
+    float zg[4];
+    float* zrow = z_t + (long)brow * 4 * U + u0 + uu;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int col = g * 8 + uu;
+        zg[g] = zrow[(long)g * U] + ((part[0][row][col] + part[1][row][col]) + (part[2][row][col] + part[3][row][col]));
+        zrow[(long)g * U] = zg[g];
+    }
+    const long o = (long)brow * U + u0 + uu;
+    const float ig = hard_sigmoid(zg[0]), fg = hard_sigmoid(zg[1]), gg = tanhf(zg[2]), og = hard_sigmoid(zg[3]);
+    const float hp = h_prev[o], cp = c_prev[o];
+    const float cn = fg * cp + ig * gg;
+    const float hn = og * tanhf(cn);
+    const bool m = mask_t ? (mask_t[brow] != 0) : true;
+    h_t[o] = m ? hn : hp;
+    c_t[o] = m ? cn : cp;
+}
+
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static dc_gemm_desc hU_desc(int B, int U, const float* h_prev, const float* U_rec, float* z_t) {
@@ -126,6 +206,13 @@ extern "C" int dc_lstm_seq_fwd_f32(const dc_lstm_fwd_desc* d, void* workspace, s
         float* z_t = d->z + (long)t * B * 4 * U;
         const float* hp = t ? d->h_seq + (long)(t - 1) * n : nullptr;
         const float* cp = t ? d->c_seq + (long)(t - 1) * n : nullptr;
+        if (t && (U & 31) == 0) {
+            hipLaunchKernelGGL(lstm_step_fused_kernel, dim3(U / 8, (B + 31) / 32), dim3(256), 0, s, z_t, d->U_rec, hp, cp,
+                               d->mask ? d->mask + (long)t * B : nullptr, d->h_seq + (long)t * n, d->c_seq + (long)t * n, B, U);
+            int rc = check_launch("lstm_step_fused_kernel");
+            if (rc) return rc;
+            continue;
+        }
         if (t) {
             dc_gemm_desc g = hU_desc(B, U, hp, d->U_rec, z_t);
             int rc = dc_gemm_f32(&g, workspace, workspace_bytes, stream);
