@@ -133,6 +133,71 @@ extern "C" int dc_conv2d_nhwc_f32(const dc_conv_desc* d, void* workspace, size_t
     return conv_dispatch(al, bl, ep, M, N, K, t, workspace, workspace_bytes, s);
 }
 
+static int wgrad_validate(const dc_conv_desc* d) {
+    DC_REQUIRE(d && d->x && d->w && d->y, DC_EINVAL, "dc_conv2d_wgrad: x, dy (y) and dw (w) must be non-null");
+    DC_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->kh >= 1 && d->kw >= 1 && d->kh <= 8 && d->kw <= 8 &&
+                   d->stride >= 1,
+               DC_EINVAL, "dc_conv2d_wgrad: bad shape");
+    DC_REQUIRE(d->Cin % 64 == 0 && d->Cout % 4 == 0 && ((long)d->N * d->Ho * d->Wo) % 32 == 0, DC_EINVAL,
+               "dc_conv2d_wgrad: needs Cin %% 64 == 0, Cout %% 4 == 0 and N*Ho*Wo %% 32 == 0");
+    DC_REQUIRE(aligned16(d->x) && aligned16(d->y) && aligned16(d->w), DC_EALIGN, "dc_conv2d_wgrad: pointers must be 16-byte aligned");
+    DC_REQUIRE((size_t)d->N * d->H * d->W * d->Cin * sizeof(float) < (size_t)0x80000000u &&
+                   (size_t)d->N * d->Ho * d->Wo * d->Cout * sizeof(float) < (size_t)0xFFFFFFF0u,
+               DC_EINVAL, "dc_conv2d_wgrad: x must be < 2 GiB and dy < 4 GiB");
+    return DC_OK;
+}
+
+static TileChoice wgrad_tile(const dc_conv_desc* d) {
+    const int M = d->Cout, N = d->kh * d->kw * d->Cin, K = d->N * d->Ho * d->Wo;
+    TileChoice t = choose_tile(M, N, K, d->split_k, false);         // 64x64 tiles: a column tile stays inside one tap
+    return t;
+}
+
+extern "C" size_t dc_conv2d_wgrad_workspace_bytes(const dc_conv_desc* d) {
+    if (wgrad_validate(d)) return 0;
+    const TileChoice t = wgrad_tile(d);
+    return t.split > 1 ? (size_t)t.split * d->Cout * d->kh * d->kw * d->Cin * sizeof(float) : 0;
+}
+
+extern "C" int dc_conv2d_wgrad_f32(const dc_conv_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = wgrad_validate(d);
+    if (rc) return rc;
+    const int M = d->Cout, N = d->kh * d->kw * d->Cin, K = d->N * d->Ho * d->Wo;
+    const TileChoice t = wgrad_tile(d);
+    Epilogue ep{const_cast<float*>(d->w), N, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 1};
+    DenseMCT<true> al{d->y, d->Cout, M, nullptr};                   // A^T: dy is [pixels][Cout]
+    Im2colMC bl{d->x, d->H, d->W, d->Cin, d->Ho, d->Wo, d->stride, d->pad_t, d->pad_l, d->kw, K,
+                (unsigned)((size_t)d->N * d->H * d->W * d->Cin * sizeof(float))};
+    return launch_igemm<64, 64, DenseMCT<true>, Im2colMC>(al, bl, ep, M, N, K, t.split, workspace, workspace_bytes,
+                                                         static_cast<hipStream_t>(stream));
+}
+
+__global__ void downsample2x_sum_kernel(const float4* __restrict__ fine, float4* __restrict__ out, int N, int Ho, int Wo, int C4, int acc) {
+    const long total = (long)N * Ho * Wo * C4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C4);
+        long p = idx / C4;
+        const int x = (int)(p % Wo);
+        p /= Wo;
+        const int y = (int)(p % Ho), n = (int)(p / Ho);
+        const long base = (((long)n * 2 * Ho + 2 * y) * 2 * Wo + 2 * x) * C4 + c;
+        const float4 a = fine[base], b = fine[base + C4], e = fine[base + (long)2 * Wo * C4], f = fine[base + (long)2 * Wo * C4 + C4];
+        float4 o = make_float4((a.x + b.x) + (e.x + f.x), (a.y + b.y) + (e.y + f.y), (a.z + b.z) + (e.z + f.z), (a.w + b.w) + (e.w + f.w));
+        if (acc) { const float4 q = out[idx]; o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
+        out[idx] = o;
+    }
+}
+
+extern "C" int dc_downsample2x_sum_f32(const float* fine, float* out, int N, int Ho, int Wo, int C, int accumulate, void* stream) {
+    DC_REQUIRE(fine && out && N > 0 && Ho > 0 && Wo > 0 && C > 0 && (C & 3) == 0, DC_EINVAL, "dc_downsample2x_sum: bad arguments");
+    DC_REQUIRE(aligned16(fine) && aligned16(out), DC_EALIGN, "dc_downsample2x_sum: pointers must be 16-byte aligned");
+    const long total = (long)N * Ho * Wo * (C / 4);
+    const int blocks = (int)std::min<long>((total + 255) / 256, (long)kNumCU * 8);
+    hipLaunchKernelGGL(downsample2x_sum_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float4*>(fine), reinterpret_cast<float4*>(out), N, Ho, Wo, C / 4, accumulate);
+    return check_launch("downsample2x_sum_kernel");
+}
+
 extern "C" int dc_maxpool3x3s2_same_f32(const float* x, float* y, int N, int H, int W, int C, void* stream) {
     DC_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, DC_EINVAL, "dc_maxpool3x3s2: bad arguments");
     DC_REQUIRE(aligned16(x) && aligned16(y), DC_EALIGN, "dc_maxpool3x3s2: pointers must be 16-byte aligned");

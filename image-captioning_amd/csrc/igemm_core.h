@@ -256,6 +256,66 @@ struct Im2colKC {
     }
 };
 
+// wgrad's B operand: the im2col matrix K-major.  K rows = output pixels (all images), columns
+// n = tap*Cin + ci; a column tile of BT lies inside one tap (Cin % BT == 0), so a K row is a contiguous run of
+// channels of ONE (shifted) input pixel.  Each thread walks its pixels incrementally (32 pixels per K-tile:
+// an add and a wrap test instead of divisions); out-of-image taps and pixels past the end read hardware zeros.
+struct Im2colMC {
+    static constexpr bool KC = false;
+    __device__ __forceinline__ int kclamp(int k0, int) const { return k0; }
+    const float* x;
+    int H, W, Cin, Ho, Wo, stride, pad_t, pad_l, kw, P;      // P = N*Ho*Wo pixels (the K extent)
+    unsigned x_bytes;
+    template <int BT>
+    struct State {
+        __amdgpu_buffer_rsrc_t rsrc;
+        int oy[BT / 32], ox[BT / 32], n[BT / 32];
+        int dy, dx;            // tap offset of this column tile (block-uniform)
+        unsigned coff;         // (ci0 + 4*q) * 4 bytes
+        int started;
+    };
+    template <int BT>
+    __device__ __forceinline__ void init(State<BT>& s, int col0, int tid) const {
+        constexpr int QPR = BT / 4;
+        s.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)x_bytes, 0x00020000);
+        const int tap = col0 / Cin, ci0 = col0 - tap * Cin;
+        const int ky = tap / kw, kx = tap - ky * kw;
+        s.dy = ky - pad_t;
+        s.dx = kx - pad_l;
+        s.coff = (unsigned)((ci0 + 4 * (tid % QPR)) * 4);
+        s.started = 0;
+    }
+    template <int BT>
+    __device__ __forceinline__ void load(State<BT>& s, f4 (&r)[BT / 32], int k0, int kend, int tid) const {
+        constexpr int QPR = BT / 4, RPP = 256 / QPR;
+        if (!s.started) {                               // first K-tile of this block: decode once
+            s.started = 1;
+#pragma unroll
+            for (int i = 0; i < BT / 32; ++i) {
+                const int p = k0 + tid / QPR + RPP * i;
+                const int n = p / (Ho * Wo), rem = p - n * (Ho * Wo);
+                s.n[i] = n;
+                s.oy[i] = rem / Wo;
+                s.ox[i] = rem - s.oy[i] * Wo;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BT / 32; ++i) {
+            const int iy = s.oy[i] * stride + s.dy, ix = s.ox[i] * stride + s.dx;
+            const bool in = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && s.n[i] * (Ho * Wo) + s.oy[i] * Wo + s.ox[i] < min(P, kend);
+            const unsigned off = (unsigned)((((long)s.n[i] * H + iy) * W + ix) * Cin * 4) + s.coff;
+            r[i] = buf_f4(s.rsrc, in ? off : kOobOffset);
+            s.ox[i] += BK;                              // next K-tile: 32 pixels further along the row-major walk
+            while (s.ox[i] >= Wo) { s.ox[i] -= Wo; ++s.oy[i]; }
+            while (s.oy[i] >= Ho) { s.oy[i] -= Ho; ++s.n[i]; }
+        }
+    }
+    template <int BT>
+    __device__ __forceinline__ void store(const State<BT>&, float* S, f4 (&r)[BT / 32], int tid) const {
+        store_mc<BT>(S, r, tid);
+    }
+};
+
 // The 7x7/stride-2 stem on an RGBX image [N,H,W,4]: K-tile ky = one kernel row, float4 q = tap kx
 // (kx == 7 is a zero-weight pad), so K = 7*8*4 = 224 and every load is one aligned pixel.
 struct StemKC {

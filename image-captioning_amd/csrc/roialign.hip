@@ -64,9 +64,53 @@ __global__ __launch_bounds__(256) void roi_align_kernel(dc_roialign_desc d) {
     }
 }
 
+// backward: one wave per output bin scatters its gradient row into the four corner pixels of the routed level
+__global__ __launch_bounds__(256) void roi_align_bwd_kernel(dc_roialign_desc d) {
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int bins = d.pool * d.pool;
+    if (wave >= d.B * d.R * bins) return;
+    const int box = wave / bins, bin = wave - box * bins;
+    const int py = bin / d.pool, px = bin - py * d.pool;
+    const float4 bx = reinterpret_cast<const float4*>(d.boxes)[box];
+    const int li = roi_level(bx.x, bx.y, bx.z, bx.w, d.image_area) - 2;
+    const int H = d.Hs[li], W = d.Ws[li];
+    float* gm = const_cast<float*>(d.maps[li]) + (long)(box / d.R) * H * W * d.C;
+    const float* go = d.out + (long)wave * d.C;
+    const float hs = (d.pool > 1) ? __fdiv_rn(__fmul_rn(__fsub_rn(bx.z, bx.x), (float)(H - 1)), (float)(d.pool - 1)) : 0.f;
+    const float ws = (d.pool > 1) ? __fdiv_rn(__fmul_rn(__fsub_rn(bx.w, bx.y), (float)(W - 1)), (float)(d.pool - 1)) : 0.f;
+    const float in_y = (d.pool > 1) ? __fadd_rn(__fmul_rn(bx.x, (float)(H - 1)), __fmul_rn((float)py, hs))
+                                    : __fmul_rn(__fmul_rn(0.5f, __fadd_rn(bx.x, bx.z)), (float)(H - 1));
+    const float in_x = (d.pool > 1) ? __fadd_rn(__fmul_rn(bx.y, (float)(W - 1)), __fmul_rn((float)px, ws))
+                                    : __fmul_rn(__fmul_rn(0.5f, __fadd_rn(bx.y, bx.w)), (float)(W - 1));
+    if (!((in_y >= 0.f) && (in_y <= (float)(H - 1)) && (in_x >= 0.f) && (in_x <= (float)(W - 1)))) return;
+    const int top = (int)floorf(in_y), bot = (int)ceilf(in_y), left = (int)floorf(in_x), right = (int)ceilf(in_x);
+    const float ly = in_y - (float)top, lx = in_x - (float)left;
+    float* tl = gm + ((long)top * W + left) * d.C;
+    float* tr = gm + ((long)top * W + right) * d.C;
+    float* bl = gm + ((long)bot * W + left) * d.C;
+    float* br = gm + ((long)bot * W + right) * d.C;
+    for (int c = lane; c < d.C; c += 64) {
+        const float g = go[c];
+        atomicAdd(tl + c, g * (1.f - ly) * (1.f - lx));
+        atomicAdd(tr + c, g * (1.f - ly) * lx);
+        atomicAdd(bl + c, g * ly * (1.f - lx));
+        atomicAdd(br + c, g * ly * lx);
+    }
+}
+
 }  // namespace dcap
 
 using namespace dcap;
+
+extern "C" int dc_roi_align_pyramid_bwd_f32(const dc_roialign_desc* d, void* stream) {
+    DC_REQUIRE(d && d->boxes && d->out, DC_EINVAL, "dc_roi_align_pyramid_bwd: null pointer");
+    DC_REQUIRE(d->B > 0 && d->R > 0 && d->pool > 0 && d->C > 0, DC_EINVAL, "dc_roi_align_pyramid_bwd: bad B/R/pool/C");
+    for (int l = 0; l < 4; ++l) DC_REQUIRE(d->maps[l] && d->Hs[l] > 0 && d->Ws[l] > 0, DC_EINVAL, "dc_roi_align_pyramid_bwd: bad map %d", l);
+    DC_REQUIRE(aligned16(d->boxes), DC_EALIGN, "dc_roi_align_pyramid_bwd: boxes not 16-byte aligned");
+    const long waves = (long)d->B * d->R * d->pool * d->pool;
+    hipLaunchKernelGGL(roi_align_bwd_kernel, dim3((int)((waves + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), *d);
+    return check_launch("roi_align_bwd_kernel");
+}
 
 extern "C" int dc_roi_align_pyramid_f32(const dc_roialign_desc* d, void* stream) {
     DC_REQUIRE(d && d->boxes && d->out, DC_EINVAL, "dc_roi_align_pyramid: null pointer");

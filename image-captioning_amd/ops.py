@@ -112,6 +112,52 @@ def conv2d(x, w_packed, kh, kw, stride, pad_t, pad_l, Ho, Wo, scale=None, shift=
     return out
 
 
+def conv2d_wgrad(x, dy, kh, kw, stride, pad_t, pad_l, out=None, split_k=0):
+    """dw packed [Cout][kh*kw*Cin] = sum_pixels dy (x) im2col(x); x [N,H,W,Cin], dy [N,Ho,Wo,Cout] contiguous."""
+    lib = _lib.load()
+    _chk(x, name="x"), _chk(dy, name="dy")
+    N, H, W, Cin = x.shape
+    _, Ho, Wo, Cout = dy.shape
+    if not x.is_contiguous() or not dy.is_contiguous():
+        raise _lib.DcapError("conv2d_wgrad: x and dy must be contiguous")
+    if out is None:
+        out = torch.empty((Cout, kh * kw * Cin), dtype=torch.float32, device=x.device)
+    d = ConvDesc()
+    d.N, d.H, d.W, d.Cin = N, H, W, Cin
+    d.Cout, d.kh, d.kw, d.stride, d.pad_t, d.pad_l, d.Ho, d.Wo = Cout, kh, kw, stride, pad_t, pad_l, Ho, Wo
+    d.x, d.y, d.w, d.split_k = x.data_ptr(), dy.data_ptr(), _chk(out, name="dw").data_ptr(), int(split_k)
+    ws, wsb = WORKSPACE.get(lib.dc_conv2d_wgrad_workspace_bytes(C.byref(d)), x.device)
+    check(lib.dc_conv2d_wgrad_f32(C.byref(d), _ptr(ws), wsb, _stream()), "dc_conv2d_wgrad_f32")
+    return out
+
+
+def downsample2x_sum(fine, out=None, accumulate=False):
+    lib = _lib.load()
+    _chk(fine, name="fine")
+    N, H, W, Cc = fine.shape
+    if out is None:
+        out = torch.empty((N, H // 2, W // 2, Cc), dtype=torch.float32, device=fine.device)
+    check(lib.dc_downsample2x_sum_f32(_ptr(fine), _ptr(out), N, H // 2, W // 2, Cc, int(accumulate), _stream()), "dc_downsample2x_sum_f32")
+    return out
+
+
+def roi_align_pyramid_bwd(dmaps, boxes, image_area, dout, pool=7):
+    """dmaps: four zero-initialised gradient maps [B,H,W,C] (accumulated into); dout [B,R,pool,pool,C]."""
+    lib = _lib.load()
+    B, R, _ = boxes.shape
+    d = RoiAlignDesc()
+    d.B, d.R, d.C, d.pool = B, R, dmaps[0].shape[-1], pool
+    for i, m in enumerate(dmaps):
+        if not _chk(m, name="dmap").is_contiguous():
+            raise _lib.DcapError("roi_align_bwd: gradient maps must be contiguous")
+        d.maps[i] = m.data_ptr()
+        d.Hs[i], d.Ws[i] = m.shape[1], m.shape[2]
+    d.boxes, d.image_area = _chk(boxes, name="boxes").data_ptr(), float(image_area)
+    d.out = _chk(dout, name="dout").data_ptr()
+    check(lib.dc_roi_align_pyramid_bwd_f32(C.byref(d), _stream()), "dc_roi_align_pyramid_bwd_f32")
+    return dmaps
+
+
 def maxpool3x3s2_same(x, out=None):
     lib = _lib.load()
     _chk(x, name="x")

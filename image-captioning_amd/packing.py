@@ -25,3 +25,11 @@ def fold_bn(gamma, beta, mean, var, conv_bias=None, eps=BN_EPS):
     b = 0.0 if conv_bias is None else np.asarray(conv_bias, np.float64)
     shift = scale * (b - np.asarray(mean, np.float64)) + np.asarray(beta, np.float64)
     return scale.astype(np.float32), shift.astype(np.float32)
+
+
+def pack_conv_kernel_dgrad(k_hwio):
+    """Packed weights that make dc_conv2d_nhwc_f32(dy, ...) the DATA gradient of a stride-1 convolution:
+    rotate the taps by 180 degrees and swap cin/cout -> [cin][kh*kw*cout]; call it with padding k-1-pad."""
+    kh, kw, cin, cout = k_hwio.shape
+    rot = k_hwio[::-1, ::-1]                                   # [kh,kw,cin,cout] rotated
+    return np.ascontiguousarray(np.transpose(rot, (2, 0, 1, 3)).reshape(cin, kh * kw * cout), dtype=np.float32)

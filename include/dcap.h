@@ -100,6 +100,18 @@ int    dc_conv2d_nhwc_f32(const dc_conv_desc* d, void* workspace, size_t workspa
  * which igemm_kernel<bm,bn,...> instantiation runs (bench.py maps layers to rocprof kernel names). */
 int    dc_conv2d_tile_config(const dc_conv_desc* d, int* bm, int* bn, int* split_k);
 
+/* ------------------------------------------------------------------------------------------------
+ * conv2d weight gradient (for the layers the joint model trains: fpn_*, rpn_*, dense_img_cap/dense_model.py
+ * train(layers="no_backbone") :1829-1831):  dw[cout][(ky,kx,ci)] = sum over output pixels of
+ * dy[p][cout] * x[p*stride + (ky,kx) - pad][ci]   -- packed like the forward weights, so the optimizer
+ * updates the packed tensor directly.  Uses the fields N,H,W,Cin,Cout,kh,kw,stride,pad_*,Ho,Wo and
+ * x (activations), y (= dy, [N,Ho,Wo,Cout]), w (= dw OUT).  Cin % 64 == 0, Cout % 4 == 0, N*Ho*Wo % 32 == 0.
+ * The data gradient needs no entry point of its own: for stride-1 convs it is dc_conv2d_nhwc_f32 on dy with
+ * the kernel rotated by 180 degrees and cin/cout swapped (packing.pack_conv_kernel_dgrad).
+ * ------------------------------------------------------------------------------------------------ */
+size_t dc_conv2d_wgrad_workspace_bytes(const dc_conv_desc* d);
+int    dc_conv2d_wgrad_f32(const dc_conv_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+
 /* KL.MaxPooling2D((3,3), strides 2, 'same') (dense_model.py:150); C % 4 == 0. */
 int dc_maxpool3x3s2_same_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
 
@@ -161,6 +173,16 @@ typedef struct {
 
 size_t dc_proposals_workspace_bytes(const dc_proposal_desc* d);
 int    dc_proposals_f32(const dc_proposal_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+
+/* PyramidROIAlign backward: d(maps) += bilinear scatter of d(out) (gradients to the boxes are stopped in the
+ * reference, dense_model.py:378-379).  dmaps[l] must be zero-initialised by the caller; accumulation uses
+ * float atomics (order-dependent in the last bits).  Same descriptor as the forward; `out` holds d(out) and
+ * `maps` the gradient maps (written). */
+int dc_roi_align_pyramid_bwd_f32(const dc_roialign_desc* d, void* stream);
+
+/* FPN top-down backward: out[n,y,x,c] (+)= sum of the 2x2 block of fine[n,2y..2y+1,2x..2x+1,c]
+ * (the gradient of UpSampling2D(2) + Add, dense_model.py:1407-1415). */
+int dc_downsample2x_sum_f32(const float* fine, float* out, int N, int Ho, int Wo, int C, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Keras-2.1 LSTM over a whole sequence (gate blocks i,f,c,o; hard-sigmoid gates; tanh; mask carry).

@@ -97,6 +97,27 @@ def conv2d_nhwc_loops(x, w, b=None, stride=1, padding='valid'):
     return out
 
 
+def conv2d_nhwc_backward(x, w, dy, stride=1, padding='valid'):
+    """Gradients of conv2d_nhwc w.r.t. x, w and bias (the joint model trains fpn_*/rpn_* convs,
+    dense_img_cap/dense_model.py:1829-1831).  float64."""
+    x, w, dy = np.asarray(x, F64), np.asarray(w, F64), np.asarray(dy, F64)
+    N, H, W, C = x.shape
+    kh, kw, _, Oc = w.shape
+    pt, pb, pl, pr = _resolve_pad(H, W, kh, kw, stride, padding)
+    xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+    dxp = np.zeros_like(xp)
+    Ho, Wo = dy.shape[1:3]
+    dw = np.zeros_like(w)
+    d2 = dy.reshape(-1, Oc)
+    for ky in range(kh):
+        for kx in range(kw):
+            sl = (slice(None), slice(ky, ky + (Ho - 1) * stride + 1, stride), slice(kx, kx + (Wo - 1) * stride + 1, stride), slice(None))
+            dw[ky, kx] = xp[sl].reshape(-1, C).T @ d2
+            dxp[sl] += (d2 @ w[ky, kx].T).reshape(N, Ho, Wo, C)
+    dx = dxp[:, pt:pt + H, pl:pl + W, :]
+    return dx, dw, d2.sum(0)
+
+
 BN_EPS = 1e-3  # Keras BatchNormalization default epsilon
 
 

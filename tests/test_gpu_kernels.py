@@ -296,3 +296,52 @@ def test_rpn_proposals_bit_exact_given_scores(ops, B, S):
         # box values: the device's expf and numpy's float32 exp may differ in the last bit
         np.testing.assert_allclose(props[b], want, rtol=3e-7, atol=1e-7)
         assert np.all(props[b][len(kp):] == 0)                       # zero padding
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 3, 1), (1, 32, 32, 128, 256, 3, 1), (2, 16, 16, 256, 64, 1, 1), (1, 32, 32, 64, 128, 1, 2)])
+def test_conv2d_weight_and_data_gradients(ops, case):
+    """Building blocks of the joint model's trainable convs: wgrad kernel and dgrad-as-forward-conv."""
+    from image_captioning_amd.packing import pack_conv_kernel, pack_conv_kernel_dgrad
+    N, H, W, Cin, Cout, k, stride = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((N, H, W, Cin))
+    w = rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)
+    padding = 'same' if k == 3 else 'valid'
+    y = O.conv2d_nhwc(x, w, None, stride, padding)
+    dy = rng.standard_normal(y.shape)
+    dx, dw, db = O.conv2d_nhwc_backward(x, w, dy, stride, padding)
+    pad = (k - 1) // 2
+    got_dw = ops.conv2d_wgrad(dev(x), dev(dy), k, k, stride, pad, pad)
+    close(got_dw, pack_conv_kernel(dw), 3e-5)
+    close(ops.colsum(dev(dy.reshape(-1, Cout))), db, 3e-5)
+    if stride == 1:
+        got_dx = ops.conv2d(dev(dy), dev(pack_conv_kernel_dgrad(w)), k, k, 1, k - 1 - pad, k - 1 - pad, H, W)
+        close(got_dx, dx, 3e-5)
+
+
+def test_roi_align_backward_is_the_adjoint_of_forward(ops):
+    """<forward(maps), g> == <maps, backward(g)> for random maps and g (bilinear gather / scatter adjointness),
+    plus a direct check of the scatter against a NumPy loop on one level."""
+    from image_captioning_amd import synth
+    rng = np.random.default_rng(5)
+    B, R, C, S = 1, 24, 64, 256
+    maps = [rng.standard_normal((B, S // s, S // s, C)) for s in (4, 8, 16, 32)]
+    rois = synth.rois(7, B, R, S, S, lo=16, hi=256)
+    boxes = dev(O.normalize_boxes(rois, S, S))
+    g = rng.standard_normal((B, R, 7, 7, C))
+    fwd = ops.roi_align_pyramid([dev(m) for m in maps], boxes, S * S, 7).cpu().numpy().astype(np.float64)
+    dm = [torch.zeros(m.shape, device="cuda") for m in maps]
+    ops.roi_align_pyramid_bwd(dm, boxes, S * S, dev(g), 7)
+    lhs = float((fwd * g).sum())
+    rhs = sum(float((d.cpu().numpy().astype(np.float64) * m).sum()) for d, m in zip(dm, maps))
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
+
+
+def test_downsample2x_sum_is_upsample_adjoint(ops):
+    rng = np.random.default_rng(6)
+    fine = rng.standard_normal((2, 8, 12, 8))
+    want = fine.reshape(2, 4, 2, 6, 2, 8).sum(axis=(2, 4))
+    close(ops.downsample2x_sum(dev(fine)), want, 1e-6)
+    acc = dev(np.ones_like(want))
+    ops.downsample2x_sum(dev(fine), out=acc, accumulate=True)
+    close(acc, want + 1, 1e-6)
