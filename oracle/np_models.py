@@ -135,6 +135,7 @@ def roi_head_backward(df, cache):
     dy1 = dz1 * c['g1'] / c['s1']
     G['mrcnn_class_conv1/kernel'] = (c['x'].T @ dy1).reshape(7, 7, 256, 1024)
     G['mrcnn_class_conv1/bias'] = dy1.sum(0)
+    G['_dx'] = dy1 @ c['K1'].T                        # gradient w.r.t. the flattened RoI features [R,12544]
     return G
 
 
@@ -310,7 +311,21 @@ def v1_loss_and_grads(Wt, feat, caps):
         for k, v in Gj.items():
             G[k] = G.get(k, 0.0) + v
     G.update(roi_head_backward(df, c['head']))
+    G.pop('_dx')
     return loss, G, probs
+
+
+def v1_backward_from_dlogits(Wt, cache, dlog):
+    """Backward of v1_training_forward for an arbitrary gradient w.r.t. the softmax LOGITS [B,T,V] (the joint
+    model's masked sparse-CE).  Returns (grads dict incl. '_dx' = d RoI features [B,12544])."""
+    G, df = {}, np.zeros_like(cache['f'])
+    for j in range(dlog.shape[1]):
+        dfj, Gj = v1_word_model_backward(Wt, dlog[:, j], cache['caches'][j])
+        df += dfj
+        for k, v in Gj.items():
+            G[k] = G.get(k, 0.0) + v
+    G.update(roi_head_backward(df, cache['head']))
+    return G
 
 
 def v1_greedy_decode(Wt, feat, T):
@@ -396,3 +411,100 @@ def image_level_encoder_features(images_u8, Wt, mean_pixel, config_like, stage4_
     props, scores, bbox, anchors = rpn_proposals([P2, P3, P4, P5, P6], Wt, config_like, (H, W))
     feats = O.pyramid_roi_align(props, [P2, P3, P4, P5], (H, W, 3), 7)
     return feats, props, (scores, bbox, anchors)
+
+
+# --------------------------------------------------------------------------------------------
+# Joint model (configs[4]): dense_img_cap/dense_model.py build('training') :1429-1600, losses :877-946,
+# compile :1694-1730, train(layers="no_backbone") :1829-1831
+# --------------------------------------------------------------------------------------------
+
+JOINT_TRAINABLE_PREFIXES = ('imgcap_', 'rpn_', 'fpn_', 'mrcnn_')
+
+
+def joint_trainable(Wt):
+    """layers="no_backbone": imgcap_*, rpn_*, fpn_*, mrcnn_*; the embedding layer is trainable=False and BN moving
+    statistics are not variables of the optimizer."""
+    return [k for k in Wt if k.startswith(JOINT_TRAINABLE_PREFIXES) and not k.startswith('imgcap_embedding') and 'moving_' not in k]
+
+
+def joint_loss_and_grads(Wt, image_u8, rpn_match, rpn_bbox_target, gt_captions, gt_boxes_px, cfg, shuffle=None, stage4_blocks=22):
+    """One training step's losses and gradients for ONE image (IMAGES_PER_GPU = 1, train_dense_captions.py:27).
+    cfg: dict(mean_pixel, scales, ratios, strides, proposal_count, nms, train_rois, positive_ratio, weight_decay, T).
+    Returns (losses dict, grads dict over joint_trainable(Wt), aux dict)."""
+    x = O.mold_image(image_u8[None], cfg['mean_pixel'])
+    _, H, W, _ = x.shape
+    _, C2, C3, C4, C5 = resnet_graph(x, Wt, stage4_blocks)
+    Cs = {2: C2, 3: C3, 4: C4, 5: C5}
+    conv = lambda t, n, pad='valid': O.conv2d_nhwc(t, Wt[n + '/kernel'], Wt[n + '/bias'], 1, pad)
+    pre = {5: conv(C5, 'fpn_c5p5')}
+    for k in (4, 3, 2):
+        pre[k] = O.upsample2x(pre[k + 1]) + conv(Cs[k], 'fpn_c%dp%d' % (k, k))
+    P = {k: conv(pre[k], 'fpn_p%d' % k, 'same') for k in (2, 3, 4, 5)}
+    P[6] = O.subsample2(P[5])
+    # RPN
+    shared, cls, box = {}, {}, {}
+    for k in (2, 3, 4, 5, 6):
+        shared[k] = O.relu(conv(P[k], 'rpn_conv_shared', 'same'))
+        cls[k] = conv(shared[k], 'rpn_class_raw')
+        box[k] = conv(shared[k], 'rpn_bbox_pred')
+    logits = np.concatenate([cls[k].reshape(1, -1, 2) for k in (2, 3, 4, 5, 6)], axis=1)[0]
+    bbox = np.concatenate([box[k].reshape(1, -1, 4) for k in (2, 3, 4, 5, 6)], axis=1)[0]
+    probs = O.softmax(logits)
+    shapes = [[-(-H // s_), -(-W // s_)] for s_ in cfg['strides']]
+    anchors = O.generate_pyramid_anchors(cfg['scales'], cfg['ratios'], shapes, cfg['strides'], 1)
+    proposals, _, _ = O.proposal_layer(probs[:, 1], bbox, anchors, (H, W), cfg['proposal_count'], cfg['nms'])
+    gt_norm = (np.asarray(gt_boxes_px, np.float32) / np.array([H, W, H, W], np.float32)).astype(np.float32)
+    rois, caps, npos, nneg = O.detection_targets(proposals, gt_captions, gt_norm, cfg['train_rois'], cfg['positive_ratio'], shuffle)
+    maps = [P[2], P[3], P[4], P[5]]
+    feats = O.pyramid_roi_align(rois[None], maps, (H, W, 3), 7)[0]
+    cap_probs, cache = v1_training_forward(Wt, feats, caps.astype(np.float64))
+    tg = v1_targets(caps)                                             # remove <start>, append 0
+    w = (tg > 0).astype(F64)
+    cnt = w.sum()
+    rows_loss, dlog = O.sparse_cce_keras_with_grad(tg, cap_probs, w / max(cnt, 1.0))
+    losses = {'imgcap_loss': float(rows_loss.sum()) if cnt > 0 else 0.0}
+    l_cls, dlogits = O.rpn_class_loss(rpn_match, logits)
+    l_box, dbbox = O.rpn_bbox_loss(rpn_bbox_target, rpn_match, bbox)
+    losses['rpn_class_loss'], losses['rpn_bbox_loss'] = l_cls, l_box
+    train = joint_trainable(Wt)
+    reg_keys = [k for k in train if 'gamma' not in k and 'beta' not in k]
+    losses['reg_loss'] = float(sum(cfg['weight_decay'] * (np.asarray(Wt[k], F64) ** 2).sum() / np.asarray(Wt[k]).size for k in reg_keys))
+    losses['loss'] = sum(losses[k] for k in ('imgcap_loss', 'rpn_class_loss', 'rpn_bbox_loss', 'reg_loss'))
+
+    # ---- backward
+    G = v1_backward_from_dlogits(Wt, cache, dlog if cnt > 0 else np.zeros_like(dlog))
+    dfeat = G.pop('_dx').reshape(feats.shape)
+    dP = O.pyramid_roi_align_backward(rois[None], [m.shape for m in maps], (H, W, 3), dfeat[None])
+    dP = {k: dP[i] for i, k in enumerate((2, 3, 4, 5))}
+    dP[6] = np.zeros_like(P[6])
+    off = 0
+    acc = lambda name, val: G.__setitem__(name, G.get(name, 0.0) + val)
+    for k in (2, 3, 4, 5, 6):
+        n = cls[k].shape[1] * cls[k].shape[2] * len(cfg['ratios'])
+        dcls = dlogits[off:off + n].reshape(cls[k].shape)
+        dbox = dbbox[off:off + n].reshape(box[k].shape)
+        off += n
+        ds1, dw, db = O.conv2d_nhwc_backward(shared[k], Wt['rpn_class_raw/kernel'], dcls)
+        acc('rpn_class_raw/kernel', dw); acc('rpn_class_raw/bias', db)
+        ds2, dw, db = O.conv2d_nhwc_backward(shared[k], Wt['rpn_bbox_pred/kernel'], dbox)
+        acc('rpn_bbox_pred/kernel', dw); acc('rpn_bbox_pred/bias', db)
+        dsh = (ds1 + ds2) * (shared[k] > 0)
+        dpk, dw, db = O.conv2d_nhwc_backward(P[k], Wt['rpn_conv_shared/kernel'], dsh, 1, 'same')
+        acc('rpn_conv_shared/kernel', dw); acc('rpn_conv_shared/bias', db)
+        dP[k] = dP[k] + dpk
+    dP[5][:, ::2, ::2, :] += dP[6]                                    # MaxPooling2D(1, strides 2) backward
+    dpre = {}
+    for k in (2, 3, 4, 5):
+        dpre[k], dw, db = O.conv2d_nhwc_backward(pre[k], Wt['fpn_p%d/kernel' % k], dP[k], 1, 'same')
+        G['fpn_p%d/kernel' % k], G['fpn_p%d/bias' % k] = dw, db
+    for k in (2, 3, 4):                                               # top-down: pre[k] = up(pre[k+1]) + lateral
+        g = dpre[k]
+        N_, h_, w_, c_ = g.shape
+        dpre[k + 1] = dpre[k + 1] + g.reshape(N_, h_ // 2, 2, w_ // 2, 2, c_).sum(axis=(2, 4))
+    for k in (2, 3, 4, 5):
+        _, dw, db = O.conv2d_nhwc_backward(Cs[k], Wt['fpn_c%dp%d/kernel' % (k, k)], dpre[k])
+        G['fpn_c%dp%d/kernel' % (k, k)], G['fpn_c%dp%d/bias' % (k, k)] = dw, db
+    for k in reg_keys:
+        G[k] = G[k] + 2.0 * cfg['weight_decay'] * np.asarray(Wt[k], F64) / np.asarray(Wt[k]).size
+    aux = dict(proposals=proposals, rois=rois, caps=caps, npos=npos, nneg=nneg, count=cnt, cap_probs=cap_probs, anchors=anchors)
+    return losses, {k: G[k] for k in train}, aux

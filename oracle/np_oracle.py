@@ -503,3 +503,145 @@ def proposal_layer(scores, deltas, anchors, image_hw, proposal_count, nms_thresh
     out = np.zeros((proposal_count, 4), F32)
     out[:len(keep)] = nb[keep]
     return out, ix, keep
+
+
+# --------------------------------------------------------------------------------------------
+# Joint model pieces (dense_img_cap/dense_model.py): RoIAlign backward, detection targets, RPN losses
+# --------------------------------------------------------------------------------------------
+
+def crop_and_resize_backward(image_shape, boxes, box_ind, dout):
+    """d(image) of crop_and_resize (bilinear scatter; no gradient to the boxes, dense_model.py:378-379)."""
+    B, H, W, C = image_shape
+    boxes = np.asarray(boxes, F32)
+    N, ch, cw, _ = dout.shape
+    dimg = np.zeros(image_shape, F64)
+    for n in range(N):
+        y1, x1, y2, x2 = boxes[n]
+        bi = int(box_ind[n])
+        hs = (y2 - y1) * F32(H - 1) / F32(ch - 1) if ch > 1 else F32(0)
+        ws = (x2 - x1) * F32(W - 1) / F32(cw - 1) if cw > 1 else F32(0)
+        for y in range(ch):
+            in_y = (y1 * F32(H - 1) + F32(y) * hs) if ch > 1 else F32(0.5) * (y1 + y2) * F32(H - 1)
+            if not (in_y >= 0 and in_y <= H - 1):
+                continue
+            top, bot = int(np.floor(in_y)), int(np.ceil(in_y))
+            ly = F64(in_y - F32(top))
+            for x in range(cw):
+                in_x = (x1 * F32(W - 1) + F32(x) * ws) if cw > 1 else F32(0.5) * (x1 + x2) * F32(W - 1)
+                if not (in_x >= 0 and in_x <= W - 1):
+                    continue
+                left, right = int(np.floor(in_x)), int(np.ceil(in_x))
+                lx = F64(in_x - F32(left))
+                g = dout[n, y, x]
+                dimg[bi, top, left] += g * (1 - ly) * (1 - lx)
+                dimg[bi, top, right] += g * (1 - ly) * lx
+                dimg[bi, bot, left] += g * ly * (1 - lx)
+                dimg[bi, bot, right] += g * ly * lx
+    return dimg
+
+
+def pyramid_roi_align_backward(boxes_norm, map_shapes, image_shape, dout):
+    boxes_norm = np.asarray(boxes_norm, F32)
+    lv = roi_levels(boxes_norm, image_shape)
+    grads = [np.zeros(s, F64) for s in map_shapes]
+    for i, level in enumerate(range(2, 6)):
+        bi, ri = np.nonzero(lv == level)
+        if bi.size:
+            grads[i] += crop_and_resize_backward(map_shapes[i], boxes_norm[bi, ri], bi, dout[bi, ri])
+    return grads
+
+
+def overlaps_f32(boxes1, boxes2):
+    """overlaps_graph (dense_img_cap/dense_model.py:421-447), float32: IoU matrix [len(b1), len(b2)] (0/0 -> nan like TF)."""
+    b1, b2 = np.asarray(boxes1, F32)[:, None, :], np.asarray(boxes2, F32)[None, :, :]
+    y1, x1 = np.maximum(b1[..., 0], b2[..., 0]), np.maximum(b1[..., 1], b2[..., 1])
+    y2, x2 = np.minimum(b1[..., 2], b2[..., 2]), np.minimum(b1[..., 3], b2[..., 3])
+    inter = np.maximum(x2 - x1, F32(0)) * np.maximum(y2 - y1, F32(0))
+    a1 = (b1[..., 2] - b1[..., 0]) * (b1[..., 3] - b1[..., 1])
+    a2 = (b2[..., 2] - b2[..., 0]) * (b2[..., 3] - b2[..., 1])
+    with np.errstate(divide='ignore', invalid='ignore'):
+        return (inter / (a1 + a2 - inter)).astype(F32)
+
+
+def detection_targets(proposals, gt_captions, gt_boxes, train_rois, positive_ratio, shuffle=None):
+    """detection_targets_graph (dense_img_cap/dense_model.py:450-528) for one image.  proposals [N,4] and
+    gt_boxes [G,4] normalised (zero rows = padding), gt_captions [G,T].  `shuffle(indices)` stands for
+    tf.random_shuffle (identity when None: the reference's choice is non-deterministic).
+    Returns rois [train_rois,4] float32 and captions [train_rois,T] (zero padded)."""
+    p = np.asarray(proposals, F32)
+    p = p[np.abs(p).sum(1) > 0]
+    gb = np.asarray(gt_boxes, F32)
+    nz = np.abs(gb).sum(1) > 0
+    gb, gc = gb[nz], np.asarray(gt_captions)[nz]
+    ov = overlaps_f32(p, gb)
+    iou_max = ov.max(axis=1) if gb.shape[0] else np.zeros(len(p), F32)
+    pos = np.nonzero(iou_max >= 0.5)[0]
+    neg = np.nonzero(iou_max < 0.5)[0]
+    sh = shuffle if shuffle is not None else (lambda a: a)
+    pcount = int(train_rois * positive_ratio)
+    pos = sh(pos)[:pcount]
+    ncount = int((1.0 / positive_ratio) * len(pos)) - len(pos)
+    neg = sh(neg)[:ncount]
+    assign = ov[pos].argmax(axis=1) if len(pos) else np.zeros(0, np.int64)
+    rois = np.zeros((train_rois, 4), F32)
+    caps = np.zeros((train_rois, gc.shape[1]), gc.dtype)
+    rois[:len(pos)] = p[pos]
+    rois[len(pos):len(pos) + len(neg)] = p[neg]
+    caps[:len(pos)] = gc[assign]
+    return rois, caps, len(pos), len(neg)
+
+
+def rpn_class_loss(rpn_match, logits):
+    """rpn_class_loss_graph (:877-900): sparse softmax CE on non-neutral anchors, mean.  Returns (loss, dlogits)."""
+    m = np.asarray(rpn_match).reshape(-1)
+    lg = np.asarray(logits, F64).reshape(-1, 2)
+    idx = np.nonzero(m != 0)[0]
+    d = np.zeros_like(lg)
+    if idx.size == 0:
+        return 0.0, d.reshape(np.shape(logits))
+    cls = (m[idx] == 1).astype(np.int64)
+    z = lg[idx]
+    p = softmax(z)
+    loss = -np.log(p[np.arange(len(idx)), cls]).mean()
+    g = p.copy()
+    g[np.arange(len(idx)), cls] -= 1.0
+    d[idx] = g / len(idx)
+    return loss, d.reshape(np.shape(logits))
+
+
+def rpn_bbox_loss(target_deltas, rpn_match, rpn_bbox):
+    """rpn_bbox_loss_graph (:903-933): smooth-L1 between the first P target rows and the deltas of the P
+    positive anchors (in anchor order), mean over all 4P elements.  Returns (loss, d rpn_bbox)."""
+    m = np.asarray(rpn_match).reshape(-1)
+    bb = np.asarray(rpn_bbox, F64).reshape(-1, 4)
+    idx = np.nonzero(m == 1)[0]
+    d = np.zeros_like(bb)
+    if idx.size == 0:
+        return 0.0, d.reshape(np.shape(rpn_bbox))
+    t = np.asarray(target_deltas, F64)[:len(idx)]
+    diff = t - bb[idx]
+    ad = np.abs(diff)
+    lt = ad < 1.0
+    loss = np.where(lt, 0.5 * ad ** 2, ad - 0.5).mean()
+    g = np.where(lt, -diff, -np.sign(diff)) / diff.size
+    d[idx] = g
+    return loss, d.reshape(np.shape(rpn_bbox))
+
+
+def sparse_cce_keras_with_grad(target_ids, probs, weights):
+    """K.sparse_categorical_crossentropy(target, probs) (dense_img_cap/dense_model.py:943-945) per row, times
+    `weights`, and the gradient of sum(weights*loss) w.r.t. the softmax LOGITS that produced probs:
+    q = clip(p,1e-7,1-1e-7); loss = -log q_t + log sum(q)."""
+    p = np.asarray(probs, F64)
+    idx = np.asarray(target_ids).astype(np.int64)
+    w = np.asarray(weights, F64)
+    q = np.clip(p, KERAS_EPS, 1.0 - KERAS_EPS)
+    u = ((p >= KERAS_EPS) & (p <= 1.0 - KERAS_EPS)).astype(F64)
+    S = q.sum(-1)
+    qt = np.take_along_axis(q, idx[..., None], -1)[..., 0]
+    loss = -np.log(qt) + np.log(S)
+    g = u / S[..., None]
+    ut = np.take_along_axis(u, idx[..., None], -1)[..., 0]
+    np.put_along_axis(g, idx[..., None], np.take_along_axis(g, idx[..., None], -1) - (ut / qt)[..., None], -1)
+    dz = p * (g - (g * p).sum(-1, keepdims=True))
+    return loss * w, dz * w[..., None]

@@ -273,3 +273,59 @@ def cpu_baseline_step(enc_W, dec_W, image_u8, rois_px, captions, mean_pixel, win
             dec_W[k] -= lr_t * m / (vh.sqrt() + 1e-7)
             opt_state[k] = (m, v, vh)
     return len(captions), float(loss.detach())
+
+
+# ------------------------------------------------------------------ joint model (autograd cross-check)
+
+def joint_loss(Wt, image_u8, rpn_match, rpn_bbox_target, rois, caps, mean_pixel, ratios, weight_decay, stage4_blocks=22):
+    """Total loss of the joint model for one image given the (non-differentiable) detection targets `rois`/`caps`:
+    imgcap sparse-CE (target > 0) + RPN class + RPN bbox + L2/size regulariser.  float64 tensors in Wt."""
+    x = torch.tensor(image_u8[None].astype(np.float64)) - torch.tensor(np.asarray(mean_pixel, np.float64))
+    H, W = image_u8.shape[:2]
+    xin = x.permute(0, 3, 1, 2)
+    xin = F.pad(xin, (3, 3, 3, 3))
+    t = torch.relu(bn4(conv(xin, Wt, 'conv1', 2), Wt, 'bn_conv1'))
+    t = F.max_pool2d(F.pad(t, (0, 1, 0, 1), value=float('-inf')), 3, 2)
+    t = bottleneck(t, Wt, 2, 'a', 1, True); t = bottleneck(t, Wt, 2, 'b', 1, False); C2 = t = bottleneck(t, Wt, 2, 'c', 1, False)
+    t = bottleneck(t, Wt, 3, 'a', 2, True)
+    for b in 'bcd':
+        t = bottleneck(t, Wt, 3, b, 1, False)
+    C3 = t
+    t = bottleneck(t, Wt, 4, 'a', 2, True)
+    for i in range(stage4_blocks):
+        t = bottleneck(t, Wt, 4, chr(98 + i), 1, False)
+    C4 = t
+    t = bottleneck(t, Wt, 5, 'a', 2, True); t = bottleneck(t, Wt, 5, 'b', 1, False); C5 = bottleneck(t, Wt, 5, 'c', 1, False)
+    up = lambda q: F.interpolate(q, scale_factor=2, mode='nearest')
+    p5 = conv(C5, Wt, 'fpn_c5p5'); p4 = up(p5) + conv(C4, Wt, 'fpn_c4p4'); p3 = up(p4) + conv(C3, Wt, 'fpn_c3p3'); p2 = up(p3) + conv(C2, Wt, 'fpn_c2p2')
+    P = [conv(p2, Wt, 'fpn_p2', 1, 'same'), conv(p3, Wt, 'fpn_p3', 1, 'same'), conv(p4, Wt, 'fpn_p4', 1, 'same'), conv(p5, Wt, 'fpn_p5', 1, 'same')]
+    P6 = P[3][:, :, ::2, ::2]
+    logits, bbox = [], []
+    for p in P + [P6]:
+        sh = torch.relu(conv(p, Wt, 'rpn_conv_shared', 1, 'same'))
+        logits.append(conv(sh, Wt, 'rpn_class_raw').permute(0, 2, 3, 1).reshape(-1, 2))
+        bbox.append(conv(sh, Wt, 'rpn_bbox_pred').permute(0, 2, 3, 1).reshape(-1, 4))
+    logits, bbox = torch.cat(logits), torch.cat(bbox)
+    m = torch.tensor(np.asarray(rpn_match).reshape(-1))
+    idx = torch.nonzero(m != 0).squeeze(1)
+    l_cls = F.cross_entropy(logits[idx], (m[idx] == 1).long()) if idx.numel() else logits.sum() * 0
+    pidx = torch.nonzero(m == 1).squeeze(1)
+    if pidx.numel():
+        diff = (torch.tensor(np.asarray(rpn_bbox_target, np.float64))[:pidx.numel()] - bbox[pidx]).abs()
+        l_box = torch.where(diff < 1.0, 0.5 * diff ** 2, diff - 0.5).mean()
+    else:
+        l_box = bbox.sum() * 0
+    maps = [q.permute(0, 2, 3, 1) for q in P]
+    feats = pyramid_roi_align(torch.tensor(np.asarray(rois, np.float32)), maps, (H, W))
+    capt = torch.tensor(np.asarray(caps, np.float64))
+    probs = v1_training_forward(Wt, feats, capt)
+    tg = torch.cat([capt[:, 1:], capt.new_zeros(capt.shape[0], 1)], 1).long()
+    q = torch.clamp(probs, KERAS_EPS, 1 - KERAS_EPS)
+    rows = -torch.log(q.gather(-1, tg.unsqueeze(-1)).squeeze(-1)) + torch.log(q.sum(-1))
+    w = (tg > 0).double()
+    l_cap = (rows * w).sum() / w.sum().clamp(min=1.0)
+    reg = 0
+    for k, v in Wt.items():
+        if v.requires_grad and 'gamma' not in k and 'beta' not in k:
+            reg = reg + weight_decay * (v ** 2).sum() / v.numel()
+    return l_cap + l_cls + l_box + reg, dict(imgcap_loss=float(l_cap), rpn_class_loss=float(l_cls), rpn_bbox_loss=float(l_box), reg_loss=float(reg))

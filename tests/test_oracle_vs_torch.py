@@ -99,3 +99,36 @@ def test_amsgrad_trajectory_matches_torch_adam():
         topt.step()
     # torch: max over bias-corrected... (v-hat of raw v, then /bias2) -- identical algebra at eps=0
     np.testing.assert_allclose(Wd['p'], tp.detach().numpy(), rtol=1e-9)
+
+
+def test_joint_model_losses_and_gradients():
+    """configs[4] joint model (FPN + RPN + RoIAlign + trainable head + Model-3 decoder, three losses + L2/size):
+    the oracle's hand-written backward against torch autograd on a 128x128 image."""
+    S, V, T = 128, 24, 5
+    Wt = dict(synth.encoder_weights(0, 1), **synth.rpn_weights(4))
+    Wt['rpn_conv_shared/kernel'] = Wt['rpn_conv_shared/kernel'] * np.float32(0.05)
+    Wt['rpn_bbox_pred/kernel'] = Wt['rpn_bbox_pred/kernel'] * np.float32(0.3)
+    Wt.update(synth.head_weights(1))
+    Wt.update(synth.v1_weights(2, V))
+    Wt['imgcap_embedding_layer/embeddings'] = synth.embedding_matrix(3, V)
+    img = synth.images(7, 1, S, S)[0]
+    rng = np.random.default_rng(8)
+    gt_boxes = np.array([[10, 12, 70, 90], [40, 30, 120, 128], [0, 0, 50, 40]], np.float32)
+    gt_caps = synth.captions_v1(9, 3, T, V, lmin=1, lmax=3)
+    A = (32 * 32 + 16 * 16 + 8 * 8 + 4 * 4 + 2 * 2) * 3
+    match = np.zeros(A, np.int32)
+    match[rng.choice(A, 40, replace=False)] = np.where(rng.random(40) < 0.4, 1, -1)
+    tdelta = rng.standard_normal((64, 4))
+    cfg = dict(mean_pixel=[123.7, 116.8, 103.9], scales=(32, 64, 128, 256, 512), ratios=[0.5, 1, 2], strides=[4, 8, 16, 32, 64],
+               proposal_count=60, nms=0.7, train_rois=12, positive_ratio=0.33, weight_decay=1e-4, T=T)
+    losses, G, aux = M.joint_loss_and_grads(Wt, img, match, tdelta, gt_caps, gt_boxes, cfg, stage4_blocks=1)
+    assert aux['count'] > 0, "no positive RoI: the caption loss is not exercised"
+    train = M.joint_trainable(Wt)
+    assert set(G) == set(train) and any(k.startswith('fpn_') for k in train) and any(k.startswith('rpn_') for k in train)
+    Tt = TR.to_t(Wt, requires_grad=train)
+    total, parts = TR.joint_loss(Tt, img, match, tdelta, aux['rois'], aux['caps'], cfg['mean_pixel'], cfg['ratios'], 1e-4, 1)
+    total.backward()
+    for k, v in parts.items():
+        np.testing.assert_allclose(losses[k], v, rtol=1e-9, atol=1e-12, err_msg=k)
+    for k in train:
+        np.testing.assert_allclose(G[k], Tt[k].grad.numpy(), rtol=1e-6, atol=1e-11, err_msg=k)
