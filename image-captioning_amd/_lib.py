@@ -32,7 +32,7 @@ class ConvDesc(C.Structure):
                 ("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p),
                 ("scale", C.c_void_p), ("shift", C.c_void_p),
                 ("residual", C.c_void_p), ("res_mode", C.c_int),
-                ("relu", C.c_int), ("split_k", C.c_int)]
+                ("relu", C.c_int), ("split_k", C.c_int), ("accumulate", C.c_int)]
 
 
 class RoiAlignDesc(C.Structure):
@@ -60,7 +60,7 @@ class SoftmaxCeDesc(C.Structure):
     _fields_ = [("M", C.c_int), ("V", C.c_int), ("ld", C.c_int),
                 ("logits", C.c_void_p), ("targets", C.c_void_p),
                 ("probs", C.c_void_p), ("loss_rows", C.c_void_p), ("dlogits", C.c_void_p),
-                ("grad_scale", C.c_float)]
+                ("grad_scale", C.c_float), ("row_weights", C.c_void_p), ("keras_sparse", C.c_int)]
 
 
 class BnReluDesc(C.Structure):
@@ -72,11 +72,19 @@ class BnReluDesc(C.Structure):
 
 class ProposalDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("levels", C.c_int), ("anchors_per_loc", C.c_int),
-                ("heads", C.c_void_p * 5), ("Hs", C.c_int * 5), ("Ws", C.c_int * 5),
+                ("heads", C.c_void_p * 5), ("Hs", C.c_int * 5), ("Ws", C.c_int * 5), ("head_stride", C.c_int),
                 ("anchors", C.c_void_p), ("A_total", C.c_int), ("std_dev", C.c_float * 4),
                 ("image_h", C.c_float), ("image_w", C.c_float),
                 ("pre_nms_limit", C.c_int), ("proposal_count", C.c_int), ("nms_threshold", C.c_float),
                 ("proposals", C.c_void_p), ("scores_out", C.c_void_p), ("order_out", C.c_void_p), ("keep_out", C.c_void_p)]
+
+
+class RpnLossDesc(C.Structure):
+    _fields_ = [("levels", C.c_int), ("anchors_per_loc", C.c_int), ("head_stride", C.c_int),
+                ("heads", C.c_void_p * 5), ("dheads", C.c_void_p * 5), ("Hs", C.c_int * 5), ("Ws", C.c_int * 5),
+                ("n_sel", C.c_int), ("n_pos", C.c_int),
+                ("sel_level", C.c_void_p), ("sel_index", C.c_void_p), ("sel_match", C.c_void_p),
+                ("target_deltas", C.c_void_p), ("losses", C.c_void_p)]
 
 
 class AmsgradDesc(C.Structure):
@@ -114,6 +122,11 @@ SYMBOLS = {
     "dc_gather_rows_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dc_bn_relu_fwd_f32": (C.c_int, [C.POINTER(BnReluDesc), C.c_void_p]),
     "dc_bn_relu_bwd_f32": (C.c_int, [C.POINTER(BnReluDesc), C.c_void_p]),
+    "dc_conv_weight_dgrad_pack_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dc_rpn_loss_grad_f32": (C.c_int, [C.POINTER(RpnLossDesc), C.c_void_p]),
+    "dc_scatter2_add_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dc_l2_reg_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "dc_axpy_f32": (C.c_int, [C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_relu_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dc_fold_time_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dc_colsum_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),

@@ -138,8 +138,7 @@ static int wgrad_validate(const dc_conv_desc* d) {
     DC_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->kh >= 1 && d->kw >= 1 && d->kh <= 8 && d->kw <= 8 &&
                    d->stride >= 1,
                DC_EINVAL, "dc_conv2d_wgrad: bad shape");
-    DC_REQUIRE(d->Cin % 64 == 0 && d->Cout % 4 == 0 && ((long)d->N * d->Ho * d->Wo) % 32 == 0, DC_EINVAL,
-               "dc_conv2d_wgrad: needs Cin %% 64 == 0, Cout %% 4 == 0 and N*Ho*Wo %% 32 == 0");
+    DC_REQUIRE(d->Cin % 64 == 0 && d->Cout % 4 == 0, DC_EINVAL, "dc_conv2d_wgrad: needs Cin %% 64 == 0 and Cout %% 4 == 0 (pad the head)");
     DC_REQUIRE(aligned16(d->x) && aligned16(d->y) && aligned16(d->w), DC_EALIGN, "dc_conv2d_wgrad: pointers must be 16-byte aligned");
     DC_REQUIRE((size_t)d->N * d->H * d->W * d->Cin * sizeof(float) < (size_t)0x80000000u &&
                    (size_t)d->N * d->Ho * d->Wo * d->Cout * sizeof(float) < (size_t)0xFFFFFFF0u,
@@ -164,12 +163,64 @@ extern "C" int dc_conv2d_wgrad_f32(const dc_conv_desc* d, void* workspace, size_
     if (rc) return rc;
     const int M = d->Cout, N = d->kh * d->kw * d->Cin, K = d->N * d->Ho * d->Wo;
     const TileChoice t = wgrad_tile(d);
-    Epilogue ep{const_cast<float*>(d->w), N, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 1};
-    DenseMCT<true> al{d->y, d->Cout, M, nullptr};                   // A^T: dy is [pixels][Cout]
+    Epilogue ep{const_cast<float*>(d->w), N, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, d->accumulate, 1};
     Im2colMC bl{d->x, d->H, d->W, d->Cin, d->Ho, d->Wo, d->stride, d->pad_t, d->pad_l, d->kw, K,
                 (unsigned)((size_t)d->N * d->H * d->W * d->Cin * sizeof(float))};
-    return launch_igemm<64, 64, DenseMCT<true>, Im2colMC>(al, bl, ep, M, N, K, t.split, workspace, workspace_bytes,
-                                                         static_cast<hipStream_t>(stream));
+    if (K % 32 == 0) {
+        DenseMCT<true> al{d->y, d->Cout, M, nullptr};               // A^T: dy is [pixels][Cout]
+        return launch_igemm<64, 64, DenseMCT<true>, Im2colMC>(al, bl, ep, M, N, K, t.split, workspace, workspace_bytes,
+                                                             static_cast<hipStream_t>(stream));
+    }
+    DenseMCT<false> al{d->y, d->Cout, M, nullptr};                  // pixel count not a multiple of the K-tile (tiny pyramid levels)
+    return launch_igemm<64, 64, DenseMCT<false>, Im2colMC>(al, bl, ep, M, N, K, t.split, workspace, workspace_bytes,
+                                                          static_cast<hipStream_t>(stream));
+}
+
+// packed forward weights [Cout][kh*kw*Cin] -> data-gradient weights [Cin][kh*kw*Cout], taps rotated by 180 degrees
+__global__ void dgrad_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int kh, int kw, int Cin) {
+    const long total = (long)Cout * kh * kw * Cin;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(idx % Cout);
+        long r = idx / Cout;
+        const int tap = (int)(r % (kh * kw));
+        const int ci = (int)(r / (kh * kw));
+        const int ky = tap / kw, kx = tap - ky * kw;
+        out[idx] = w[((long)co * kh * kw + (kh - 1 - ky) * kw + (kw - 1 - kx)) * Cin + ci];
+    }
+}
+
+__global__ void scatter2_add_kernel(const float4* __restrict__ coarse, float4* __restrict__ fine, int N, int Hc, int Wc, int C4) {
+    const long total = (long)N * Hc * Wc * C4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C4);
+        long p = idx / C4;
+        const int x = (int)(p % Wc);
+        p /= Wc;
+        const int y = (int)(p % Hc), n = (int)(p / Hc);
+        const long o = (((long)n * 2 * Hc + 2 * y) * 2 * Wc + 2 * x) * C4 + c;
+        float4 f = fine[o];
+        const float4 q = coarse[idx];
+        f.x += q.x; f.y += q.y; f.z += q.z; f.w += q.w;
+        fine[o] = f;
+    }
+}
+
+extern "C" int dc_conv_weight_dgrad_pack_f32(const float* w, float* out, int Cout, int kh, int kw, int Cin, void* stream) {
+    DC_REQUIRE(w && out && Cout > 0 && kh > 0 && kw > 0 && Cin > 0, DC_EINVAL, "dc_conv_weight_dgrad_pack: bad arguments");
+    const long total = (long)Cout * kh * kw * Cin;
+    const int blocks = (int)std::min<long>((total + 255) / 256, (long)kNumCU * 8);
+    hipLaunchKernelGGL(dgrad_pack_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w, out, Cout, kh, kw, Cin);
+    return check_launch("dgrad_pack_kernel");
+}
+
+extern "C" int dc_scatter2_add_f32(const float* coarse, float* fine, int N, int Hc, int Wc, int C, void* stream) {
+    DC_REQUIRE(coarse && fine && N > 0 && Hc > 0 && Wc > 0 && C > 0 && (C & 3) == 0, DC_EINVAL, "dc_scatter2_add: bad arguments");
+    DC_REQUIRE(aligned16(coarse) && aligned16(fine), DC_EALIGN, "dc_scatter2_add: pointers must be 16-byte aligned");
+    const long total = (long)N * Hc * Wc * (C / 4);
+    const int blocks = (int)std::min<long>((total + 255) / 256, (long)kNumCU * 8);
+    hipLaunchKernelGGL(scatter2_add_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float4*>(coarse), reinterpret_cast<float4*>(fine), N, Hc, Wc, C / 4);
+    return check_launch("scatter2_add_kernel");
 }
 
 __global__ void downsample2x_sum_kernel(const float4* __restrict__ fine, float4* __restrict__ out, int N, int Ho, int Wo, int C4, int acc) {

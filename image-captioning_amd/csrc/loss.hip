@@ -60,9 +60,42 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(dc_softmax_ce_desc d) {
     float pt = 1.f;
     if (t >= 0 && t < V) pt = expf(z[t] - mx) * inv;
     const bool live = (pt >= 1e-7f) && (pt <= 1.f - 1e-7f);
-    if (tid == 0 && d.loss_rows) d.loss_rows[row] = -logf(fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f));
+    const float rw = d.row_weights ? d.row_weights[row] : 1.f;
+    if (d.keras_sparse) {
+        // q = clip(p); S = sum q; U = sum over unclipped of p_k^2-free term: we need  c = sum_k g_k p_k  with
+        // g_k = u_k (1/S - [k==t]/q_t)
+        float sq = 0.f, sup = 0.f;
+        for (int i = tid; i < V; i += 256) {
+            const float p = expf(z[i] - mx) * inv;
+            const bool u = (p >= 1e-7f) && (p <= 1.f - 1e-7f);
+            sq += fminf(fmaxf(p, 1e-7f), 1.f - 1e-7f);
+            sup += u ? p : 0.f;
+        }
+        const float S = block_reduce<false>(sq, red);
+        const float UP = block_reduce<false>(sup, red);
+        const float qt = fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f);
+        if (tid == 0 && d.loss_rows) d.loss_rows[row] = rw * (-logf(qt) + logf(S));
+        if (!d.probs && !d.dlogits) return;
+        const float invS = 1.f / S;
+        const float c = UP * invS - (live ? pt / qt : 0.f);
+        float* P = d.probs ? d.probs + (long)row * d.ld : nullptr;
+        float* G = d.dlogits ? d.dlogits + (long)row * d.ld : nullptr;
+        const float gsr = d.grad_scale * rw;
+        for (int i = tid; i < V; i += 256) {
+            const float p = expf(z[i] - mx) * inv;
+            if (P) P[i] = p;
+            if (G) {
+                const bool u = (p >= 1e-7f) && (p <= 1.f - 1e-7f);
+                float g = u ? invS : 0.f;
+                if (i == t && live) g -= 1.f / qt;
+                G[i] = gsr * p * (g - c);
+            }
+        }
+        return;
+    }
+    if (tid == 0 && d.loss_rows) d.loss_rows[row] = rw * -logf(fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f));
     if (!d.probs && !d.dlogits) return;
-    const float gs = live ? d.grad_scale : 0.f;
+    const float gs = live ? d.grad_scale * rw : 0.f;
     float* P = d.probs ? d.probs + (long)row * d.ld : nullptr;
     float* G = d.dlogits ? d.dlogits + (long)row * d.ld : nullptr;
     for (int i = tid; i < V4; i += 256) {
@@ -196,12 +229,31 @@ __global__ __launch_bounds__(256) void fold_time_kernel(const float* __restrict_
     }
 }
 
+__global__ __launch_bounds__(256) void axpy_kernel(float a, const float* __restrict__ x, float* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] += a * x[i];
+}
+
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
     __shared__ float red[4];
     float s = 0.f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += x[i] * x[i];
     s = block_reduce<false>(s, red);
     if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+// L2 weight regulariser of the joint model over the flat parameter bucket: coef[i] = WEIGHT_DECAY / size(tensor of i)
+// for regularised tensors, 0 elsewhere (BN gamma/beta, padding).  grad += 2*coef*w ; loss += sum coef*w^2.
+__global__ __launch_bounds__(256) void l2_reg_kernel(const float* __restrict__ w, const float* __restrict__ coef, float* __restrict__ g,
+                                                     size_t n, float* __restrict__ loss) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float c = coef[i], x = w[i];
+        if (g) g[i] += 2.f * c * x;
+        s += c * x * x;
+    }
+    s = block_reduce<false>(s, red);
+    if (threadIdx.x == 0 && loss) atomicAdd(loss, s);
 }
 
 __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
@@ -330,6 +382,25 @@ extern "C" int dc_sumsq_f32(const float* x, size_t n, float* out, int accumulate
     const int blocks = (int)std::min<size_t>((n + 1023) / 1024, (size_t)kNumCU * 4);
     hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, s, x, n, out);
     return check_launch("sumsq_kernel");
+}
+
+extern "C" int dc_l2_reg_f32(const float* w, const float* coef, float* grad, size_t n, float* loss, void* stream) {
+    DC_REQUIRE(w && coef && n > 0 && (grad || loss), DC_EINVAL, "dc_l2_reg: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (loss) {
+        hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), s);
+        DC_REQUIRE(e == hipSuccess, DC_ELAUNCH, "dc_l2_reg: memset failed: %s", hipGetErrorString(e));
+    }
+    const int blocks = (int)std::min<size_t>((n + 1023) / 1024, (size_t)kNumCU * 4);
+    hipLaunchKernelGGL(l2_reg_kernel, dim3(blocks), dim3(256), 0, s, w, coef, grad, n, loss);
+    return check_launch("l2_reg_kernel");
+}
+
+extern "C" int dc_axpy_f32(float a, const float* x, float* y, size_t n, void* stream) {
+    DC_REQUIRE(x && y && n > 0, DC_EINVAL, "dc_axpy: bad arguments");
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, (size_t)kNumCU * 8);
+    hipLaunchKernelGGL(axpy_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a, x, y, n);
+    return check_launch("axpy_kernel");
 }
 
 extern "C" int dc_mean_f32(const float* x, size_t n, float* out, void* stream) {

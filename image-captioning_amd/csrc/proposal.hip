@@ -20,7 +20,8 @@ __global__ __launch_bounds__(256) void rpn_score_kernel(dc_proposal_desc d, int 
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int b = (int)(idx / per_img), r = (int)(idx - (long)b * per_img);
         const int cell = r / A, a = r - cell * A;
-        const float* h = d.heads[level] + ((long)b * H * W + cell) * (A * 6);
+        const int hstride = d.head_stride > 0 ? d.head_stride : A * 6;
+        const float* h = d.heads[level] + ((long)b * H * W + cell) * hstride;
         const float l0 = h[a * 2], l1 = h[a * 2 + 1];
         const float m = fmaxf(l0, l1);
         const float e0 = expf(l0 - m), e1 = expf(l1 - m);
@@ -129,6 +130,45 @@ __global__ void subsample2_kernel(const float4* __restrict__ x, float4* __restri
     }
 }
 
+// RPN losses and their gradients w.r.t. the padded head outputs, one thread per selected (non-neutral) anchor.
+// class: sparse softmax CE over {bg, fg}, mean over the n_sel anchors; bbox: smooth-L1 against the target rows
+// of the positive anchors (in anchor order), mean over 4*n_pos elements.  Loss sums use float atomics on 2 words.
+__global__ __launch_bounds__(256) void rpn_loss_grad_kernel(dc_rpn_loss_desc d) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.n_sel) return;
+    const int l = d.sel_level[i], idx = d.sel_index[i], m = d.sel_match[i];
+    const int A = d.anchors_per_loc;
+    const int cell = idx / A, a = idx - cell * A;
+    const float* h = d.heads[l] + (long)cell * d.head_stride;
+    float* g = d.dheads[l] + (long)cell * d.head_stride;
+    const float l0 = h[a * 2], l1 = h[a * 2 + 1];
+    const float mx = fmaxf(l0, l1);
+    const float e0 = expf(l0 - mx), e1 = expf(l1 - mx), inv = 1.f / (e0 + e1);
+    const float p0 = e0 * inv, p1 = e1 * inv;
+    const int cls = (m == 1) ? 1 : 0;
+    const float invn = 1.f / (float)d.n_sel;
+    g[a * 2] = (p0 - (cls == 0 ? 1.f : 0.f)) * invn;
+    g[a * 2 + 1] = (p1 - (cls == 1 ? 1.f : 0.f)) * invn;
+    atomicAdd(&d.losses[0], -logf(cls ? p1 : p0) * invn);
+    if (m == 1) {
+        // rank of this positive among the positives = number of positives before it in sel (sel is in anchor order)
+        int rank = 0;
+        for (int j = 0; j < i; ++j) rank += (d.sel_match[j] == 1);
+        const float* t = d.target_deltas + (long)rank * 4;
+        const float* bb = h + A * 2 + a * 4;
+        float* gb = g + A * 2 + a * 4;
+        const float invp = 1.f / (4.f * (float)d.n_pos);
+        float ls = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float diff = t[k] - bb[k], ad = fabsf(diff);
+            if (ad < 1.f) { ls += 0.5f * ad * ad; gb[k] = -diff * invp; }
+            else { ls += ad - 0.5f; gb[k] = (diff > 0.f ? -1.f : 1.f) * invp; }
+        }
+        atomicAdd(&d.losses[1], ls * invp);
+    }
+}
+
 struct ProposalWs {
     size_t scores, deltas, iota, keys, vals, boxes, mask, sort_tmp, total, sort_tmp_bytes;
 };
@@ -162,6 +202,7 @@ static int proposal_validate(const dc_proposal_desc* d) {
         DC_REQUIRE(d->heads[l] && d->Hs[l] > 0 && d->Ws[l] > 0, DC_EINVAL, "dc_proposals: bad head %d", l);
         a += (long)d->Hs[l] * d->Ws[l] * d->anchors_per_loc;
     }
+    DC_REQUIRE(d->head_stride == 0 || d->head_stride >= d->anchors_per_loc * 6, DC_EINVAL, "dc_proposals: head_stride too small");
     DC_REQUIRE(a == d->A_total, DC_EINVAL, "dc_proposals: A_total (%d) != sum of H*W*A over levels (%ld)", d->A_total, a);
     DC_REQUIRE(aligned16(d->anchors) && aligned16(d->proposals), DC_EALIGN, "dc_proposals: anchors/proposals must be 16-byte aligned");
     return DC_OK;
@@ -224,6 +265,19 @@ extern "C" int dc_proposals_f32(const dc_proposal_desc* d, void* workspace, size
         DC_REQUIRE(e == hipSuccess, DC_ELAUNCH, "dc_proposals: copy failed");
     }
     return DC_OK;
+}
+
+extern "C" int dc_rpn_loss_grad_f32(const dc_rpn_loss_desc* d, void* stream) {
+    DC_REQUIRE(d && d->losses && d->levels >= 1 && d->levels <= 5 && d->anchors_per_loc > 0 && d->head_stride >= d->anchors_per_loc * 6,
+               DC_EINVAL, "dc_rpn_loss_grad: bad descriptor");
+    DC_REQUIRE(d->n_sel == 0 || (d->sel_level && d->sel_index && d->sel_match), DC_EINVAL, "dc_rpn_loss_grad: missing selection");
+    DC_REQUIRE(d->n_pos == 0 || d->target_deltas, DC_EINVAL, "dc_rpn_loss_grad: missing target deltas");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(d->losses, 0, 2 * sizeof(float), s);
+    DC_REQUIRE(e == hipSuccess, DC_ELAUNCH, "dc_rpn_loss_grad: memset failed");
+    if (d->n_sel == 0) return DC_OK;
+    hipLaunchKernelGGL(rpn_loss_grad_kernel, dim3((d->n_sel + 255) / 256), dim3(256), 0, s, *d);
+    return check_launch("rpn_loss_grad_kernel");
 }
 
 extern "C" int dc_subsample2_f32(const float* x, float* y, int N, int H, int W, int C, void* stream) {

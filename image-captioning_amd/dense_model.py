@@ -1,0 +1,538 @@
+"""The joint dense-captioning model (configs[4]) behind the reference's own module interface:
+dense_img_cap/dense_model.py  (DenseImageCapRCNN :1408, build('training') :1429-1600, compile :1694-1730,
+train :1810-1888, data_generator :1260-1403, build_rpn_targets :1095-1183, detection_targets_graph :450-528,
+rpn_class_loss_graph :877-900, rpn_bbox_loss_graph :903-933, imgcap_caption_loss_graph :936-946).
+
+One train step on the GPU (IMAGES_PER_GPU = 1 like train_dense_captions.py:27):
+
+  frozen ResNet-101  ->  FPN (trainable)  ->  RPN on P2..P6 (trainable)  ->  ProposalLayer (2000 boxes)
+  -> detection targets (<= TRAIN_ROIS_PER_IMAGE RoIs, positives carry their GT caption)
+  -> PyramidROIAlign -> trainable RoI head -> Model-3 decoder
+  losses: masked sparse CE over caption positions with target > 0, RPN class CE, RPN smooth-L1, L2(w)/size(w)
+  backward: decoder + head (text_generation_model.CaptionModelV1) -> RoIAlign scatter -> RPN and FPN convolutions
+  (data gradients = forward conv kernel on rotated weights, weight gradients = dc_conv2d_wgrad_f32)
+  Adam(amsgrad, clipnorm 0.5) over ONE flat bucket holding every trainable weight.
+
+Trainable set = train(layers="no_backbone"): imgcap_*, rpn_*, fpn_*, mrcnn_* (dense_model.py:1829-1831).
+The detection-target sampling uses tf.random_shuffle in the reference (order is not reproducible there); here a seeded
+numpy permutation on the host, the only host round trip of the step (2000x4 floats down, 200x4 up).
+"""
+import os
+import re
+
+import numpy as np
+import torch
+
+from . import ops, synth, utils
+from .encoder import EncoderPlan, fuse_rpn_head
+from .layers import resnet_fpn_convs
+from .modified_dense_model import load_weight_file
+from .packing import pack_conv_kernel
+from .params import Adam
+from .text_generation_model import CaptionModelV1, caption_targets
+
+FPN_CONVS = (("fpn_c5p5", 1, 2048), ("fpn_c4p4", 1, 1024), ("fpn_c3p3", 1, 512), ("fpn_c2p2", 1, 256),
+             ("fpn_p2", 3, 256), ("fpn_p3", 3, 256), ("fpn_p4", 3, 256), ("fpn_p5", 3, 256))
+HEAD_PAD = 20            # 2A + 4A = 18 RPN head channels padded to a multiple of 4 (A = 3 anchors per location)
+
+
+# ------------------------------------------------------------------------------------------------
+# host-side target building (the reference does these in numpy / TF ops on tiny tensors)
+# ------------------------------------------------------------------------------------------------
+
+def compute_overlaps(boxes1, boxes2):
+    """IoU matrix [len(boxes1), len(boxes2)] of (y1,x1,y2,x2) boxes (utils.compute_overlaps of the reference)."""
+    b1 = np.asarray(boxes1, np.float64)[:, None, :]
+    b2 = np.asarray(boxes2, np.float64)[None, :, :]
+    ih = np.clip(np.minimum(b1[..., 2], b2[..., 2]) - np.maximum(b1[..., 0], b2[..., 0]), 0, None)
+    iw = np.clip(np.minimum(b1[..., 3], b2[..., 3]) - np.maximum(b1[..., 1], b2[..., 1]), 0, None)
+    inter = ih * iw
+    area = lambda b: (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1])
+    return inter / (area(b1) + area(b2) - inter)
+
+
+def build_rpn_targets(image_shape, anchors, gt_captions, gt_boxes, config, rng=np.random):
+    """rpn_match [A] int32 (1 positive / -1 negative / 0 neutral) and rpn_bbox [RPN_TRAIN_ANCHORS_PER_IMAGE, 4]
+    (dense_model.py:1095-1183): negatives IoU < 0.3, every GT box claims its best anchor(s), IoU >= 0.7 positive;
+    positives are capped at half the budget, negatives fill the rest; deltas of the positives (anchor order)
+    against their best GT box, divided by RPN_BBOX_STD_DEV."""
+    budget = config.RPN_TRAIN_ANCHORS_PER_IMAGE
+    match = np.zeros(anchors.shape[0], np.int32)
+    deltas = np.zeros((budget, 4))
+    iou = compute_overlaps(anchors, gt_boxes)
+    best_gt = iou.argmax(axis=1)
+    best_iou = iou[np.arange(iou.shape[0]), best_gt]
+    match[best_iou < 0.3] = -1
+    match[np.argwhere(iou == iou.max(axis=0))[:, 0]] = 1
+    match[best_iou >= 0.7] = 1
+    pos = np.where(match == 1)[0]
+    surplus = len(pos) - budget // 2
+    if surplus > 0:
+        match[rng.choice(pos, surplus, replace=False)] = 0
+    neg = np.where(match == -1)[0]
+    surplus = len(neg) - (budget - int(np.sum(match == 1)))
+    if surplus > 0:
+        match[rng.choice(neg, surplus, replace=False)] = 0
+    pos = np.where(match == 1)[0]
+    a, g = anchors[pos].astype(np.float64), np.asarray(gt_boxes, np.float64)[best_gt[pos]]
+    ah, aw, gh, gw = a[:, 2] - a[:, 0], a[:, 3] - a[:, 1], g[:, 2] - g[:, 0], g[:, 3] - g[:, 1]
+    d = np.stack([((g[:, 0] + 0.5 * gh) - (a[:, 0] + 0.5 * ah)) / ah, ((g[:, 1] + 0.5 * gw) - (a[:, 1] + 0.5 * aw)) / aw,
+                  np.log(gh / ah), np.log(gw / aw)], axis=1) / np.asarray(config.RPN_BBOX_STD_DEV, np.float64)
+    deltas[:len(pos)] = d
+    return match, deltas
+
+
+def box_iou_f32(boxes1, boxes2):
+    """overlaps_graph (:421-447) in float32 like the TF graph."""
+    f = np.float32
+    b1, b2 = np.asarray(boxes1, f)[:, None, :], np.asarray(boxes2, f)[None, :, :]
+    ih = np.maximum(np.minimum(b1[..., 2], b2[..., 2]) - np.maximum(b1[..., 0], b2[..., 0]), f(0))
+    iw = np.maximum(np.minimum(b1[..., 3], b2[..., 3]) - np.maximum(b1[..., 1], b2[..., 1]), f(0))
+    inter = iw * ih
+    a1 = (b1[..., 2] - b1[..., 0]) * (b1[..., 3] - b1[..., 1])
+    a2 = (b2[..., 2] - b2[..., 0]) * (b2[..., 3] - b2[..., 1])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return (inter / (a1 + a2 - inter)).astype(f)
+
+
+def detection_targets(proposals, gt_captions, gt_boxes, config, shuffle=None):
+    """DetectionTargetLayer for one image (:450-528): proposals [N,4] / gt_boxes [G,4] normalised, zero rows are
+    padding; gt_captions [G,T].  Positives: IoU >= 0.5 with some GT box (at most TRAIN_ROIS_PER_IMAGE *
+    ROI_POSITIVE_RATIO of them), negatives fill up to the 1/ratio proportion; a positive RoI takes the caption of its
+    best GT box, negatives and padding get zeros.  shuffle(idx) -> permuted idx (None keeps proposal order)."""
+    f = np.float32
+    p = np.asarray(proposals, f)
+    p = p[np.abs(p).sum(axis=1) > 0]
+    g = np.asarray(gt_boxes, f)
+    keep = np.abs(g).sum(axis=1) > 0
+    g, caps = g[keep], np.asarray(gt_captions)[keep]
+    iou = box_iou_f32(p, g)
+    best = iou.max(axis=1) if g.shape[0] else np.zeros(len(p), f)
+    mix = shuffle if shuffle is not None else (lambda a: a)
+    n_rois, ratio = config.TRAIN_ROIS_PER_IMAGE, config.ROI_POSITIVE_RATIO
+    pos = mix(np.nonzero(best >= 0.5)[0])[:int(n_rois * ratio)]
+    neg = mix(np.nonzero(best < 0.5)[0])[:int((1.0 / ratio) * len(pos)) - len(pos)]
+    rois = np.zeros((n_rois, 4), f)
+    out_caps = np.zeros((n_rois, caps.shape[1]), caps.dtype)
+    rois[:len(pos)] = p[pos]
+    rois[len(pos):len(pos) + len(neg)] = p[neg]
+    if len(pos):
+        out_caps[:len(pos)] = caps[iou[pos].argmax(axis=1)]
+    return rois, out_caps, len(pos), len(neg)
+
+
+def mold_image(images, config):
+    return utils.mold_image(images, config)
+
+
+def load_image_gt(dataset, config, image_id, augment=False, rng=np.random):
+    """image (resized + padded), image_meta, gt_captions [G,T], gt_boxes [G,4] (dense_model.py:953-984).
+    As in the reference the boxes are handed on exactly as the dataset stores them: they are NOT rescaled or padded
+    with the image, and the horizontal flip mirrors only the image (quirk kept so that the same dataset yields the
+    same training inputs)."""
+    image = dataset.load_image(image_id)
+    boxes, captions = dataset.load_captions_and_rois(image_id)
+    shape = image.shape
+    image, window, scale, padding = utils.resize_image(image, min_dim=config.IMAGE_MIN_DIM, max_dim=config.IMAGE_MAX_DIM,
+                                                       padding=config.IMAGE_PADDING)
+    if augment and rng.randint(0, 2):
+        image = image[:, ::-1]
+    return image, utils.compose_image_meta(image_id, shape, window), captions, boxes
+
+
+def data_generator(dataset, config, shuffle=True, augment=True, batch_size=1, rng=np.random):
+    """Infinite generator of ([images f32 molded, image_meta, rpn_match [B,A,1], rpn_bbox [B,256,4], gt_captions
+    [B,MAX_GT,T], gt_boxes [B,MAX_GT,4]], []) -- the six training inputs of the reference's generator (:1260-1403)."""
+    image_ids = np.copy(dataset.image_ids)
+    anchors = utils.generate_pyramid_anchors(config.RPN_ANCHOR_SCALES, config.RPN_ANCHOR_RATIOS, config.BACKBONE_SHAPES,
+                                             config.BACKBONE_STRIDES, config.RPN_ANCHOR_STRIDE)
+    b, index, errors = 0, -1, 0
+    while True:
+        index = (index + 1) % len(image_ids)
+        if shuffle and index == 0:
+            rng.shuffle(image_ids)
+        image_id = image_ids[index]
+        try:
+            image, meta, caps, boxes = load_image_gt(dataset, config, image_id, augment, rng)
+            match, deltas = build_rpn_targets(image.shape, anchors, caps, boxes, config, rng)
+        except (GeneratorExit, KeyboardInterrupt):
+            raise
+        except Exception:
+            errors += 1
+            if errors > 5:
+                raise
+            continue
+        if boxes.shape[0] > config.MAX_GT_INSTANCES:
+            pick = rng.choice(np.arange(boxes.shape[0]), config.MAX_GT_INSTANCES, replace=False)
+            caps, boxes = caps[pick], boxes[pick]
+        if b == 0:
+            images = np.zeros((batch_size,) + image.shape, np.float32)
+            metas = np.zeros((batch_size,) + meta.shape, meta.dtype)
+            matches = np.zeros((batch_size, anchors.shape[0], 1), match.dtype)
+            bboxes = np.zeros((batch_size, config.RPN_TRAIN_ANCHORS_PER_IMAGE, 4), deltas.dtype)
+            gt_caps = np.zeros((batch_size, config.MAX_GT_INSTANCES, config.PADDING_SIZE), caps.dtype)
+            gt_boxes = np.zeros((batch_size, config.MAX_GT_INSTANCES, 4), boxes.dtype)
+        images[b] = mold_image(image.astype(np.float32), config)
+        metas[b], matches[b], bboxes[b] = meta, match[:, None], deltas
+        gt_caps[b, :caps.shape[0]], gt_boxes[b, :boxes.shape[0]] = caps, boxes
+        b += 1
+        if b >= batch_size:
+            yield [images, metas, matches, bboxes, gt_caps, gt_boxes], []
+            b = 0
+
+
+# ------------------------------------------------------------------------------------------------
+# the model
+# ------------------------------------------------------------------------------------------------
+
+class DenseImageCapRCNN(object):
+    LOSS_NAMES = ("rpn_class_loss", "rpn_bbox_loss", "imgcap_loss")
+    LAYER_REGEX = {
+        "no_backbone": r"(imgcap\_.*)|(rpn\_.*)|(fpn\_.*)|(mrcnn\_.*)",
+        "caption_only": r"imgcap\_.*",
+    }
+
+    def __init__(self, mode, config, model_dir, device=None, stage4_blocks=22, seed=0, lstm_units=512):
+        assert mode in ['training', 'inference']
+        if config.IMAGES_PER_GPU != 1:
+            raise ValueError("the joint model runs one image per GPU (train_dense_captions.py:27); scale out with ParallelModel")
+        h, w = config.IMAGE_SHAPE[:2]
+        if h % 64 or w % 64:
+            raise Exception("Image size must be dividable by 2 at least 6 times to avoid fractions when downscaling and up-scaling.")
+        self.mode, self.config, self.model_dir = mode, config, model_dir
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self.stage4_blocks, self.units = stage4_blocks, lstm_units
+        self.epoch = 0
+        self.A = len(config.RPN_ANCHOR_RATIOS)
+        if 6 * self.A > HEAD_PAD:
+            raise ValueError("at most 3 anchors per location")
+        self._rng = np.random.RandomState(seed)
+        self.optimizer = None
+        self.grad_sync = None
+        self._trainable_regex = self.LAYER_REGEX["no_backbone"]
+        self._build(seed)
+
+    # ---- construction -----------------------------------------------------------------------
+    def _build(self, seed):
+        cfg, dev = self.config, self.device
+        W = dict(synth.encoder_weights(seed, self.stage4_blocks))
+        W.update(synth.rpn_weights(seed + 4, self.A))
+        self._backbone = {k: v for k, v in W.items() if not k.startswith(("fpn_", "rpn_"))}
+        extra = []
+        for name, k, cin in FPN_CONVS:
+            extra.append((name + "/kernel", pack_conv_kernel(W[name + "/kernel"]), True))
+            extra.append((name + "/bias", W[name + "/bias"], True))
+        extra.append(("rpn_conv_shared/kernel", pack_conv_kernel(W["rpn_conv_shared/kernel"]), True))
+        extra.append(("rpn_conv_shared/bias", W["rpn_conv_shared/bias"], True))
+        hk, hb = fuse_rpn_head(W, HEAD_PAD)
+        extra.append(("rpn_head/kernel", pack_conv_kernel(hk), True))
+        extra.append(("rpn_head/bias", hb, True))
+        self.caption_model = CaptionModelV1([cfg.POOL_SIZE, cfg.POOL_SIZE, 256], cfg, self.units, 'training', dev, seed,
+                                            extra_params=extra)
+        self.store = self.caption_model.store
+        self._plan = None
+        self._reg_coef = None
+        self._bufs = {}
+
+    def _buf(self, key, shape, dtype=torch.float32, zero=False):
+        b = self._bufs.get(key)
+        if b is None or tuple(b.shape) != tuple(shape) or b.dtype != dtype:
+            b = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            self._bufs[key] = b
+        return b
+
+    def plan(self):
+        if self._plan is None:
+            cfg, w = self.config, self.store.w
+            ext = {name: (w[name + "/kernel"], None, w[name + "/bias"]) for name, _, _ in FPN_CONVS}
+            ext["rpn_conv_shared"] = (w["rpn_conv_shared/kernel"], None, w["rpn_conv_shared/bias"])
+            ext["rpn_head"] = (w["rpn_head/kernel"], None, w["rpn_head/bias"])
+            count = cfg.POST_NMS_ROIS_TRAINING if self.mode == "training" else cfg.POST_NMS_ROIS_INFERENCE
+            rpn = dict(scales=cfg.RPN_ANCHOR_SCALES, ratios=cfg.RPN_ANCHOR_RATIOS, strides=cfg.BACKBONE_STRIDES,
+                       anchor_stride=cfg.RPN_ANCHOR_STRIDE, bbox_std=[float(v) for v in cfg.RPN_BBOX_STD_DEV],
+                       nms_threshold=cfg.RPN_NMS_THRESHOLD, proposal_count=count, head_channels=HEAD_PAD)
+            h, wd = [int(v) for v in cfg.IMAGE_SHAPE[:2]]
+            # the FPN/RPN weights change every step: the plan reads them in place from the parameter bucket
+            self._plan = EncoderPlan(self._backbone, 1, h, wd, self.device, self.stage4_blocks, cfg.MEAN_PIXEL, rpn=rpn, external=ext)
+        return self._plan
+
+    # ---- weights ----------------------------------------------------------------------------
+    def _unpacked(self, name, packed):
+        k = dict((n, kk) for n, kk, _ in FPN_CONVS).get(name, 3 if name == "rpn_conv_shared" else 1)
+        cout = packed.shape[0]
+        return np.ascontiguousarray(packed.reshape(cout, k, k, -1).transpose(1, 2, 3, 0))
+
+    def get_weights_dict(self):
+        """'<layer>/<weight>' -> ndarray with the reference's Keras layer names and HWIO kernels."""
+        out = dict(self._backbone)
+        for k, v in self.store.to_numpy().items():
+            layer, wname = k.split("/")
+            if layer == "rpn_head":
+                a2, a6 = 2 * self.A, 6 * self.A
+                if wname == "kernel":
+                    hwio = self._unpacked(layer, v)
+                    out["rpn_class_raw/kernel"], out["rpn_bbox_pred/kernel"] = hwio[..., :a2], hwio[..., a2:a6]
+                else:
+                    out["rpn_class_raw/bias"], out["rpn_bbox_pred/bias"] = v[:a2], v[a2:a6]
+            elif wname == "kernel" and layer.startswith(("fpn_", "rpn_")):
+                out[k] = self._unpacked(layer, v)
+            else:
+                out[k] = v
+        return out
+
+    def set_weights(self, weights):
+        """Assign any subset of the model's weights (reference names, HWIO kernels)."""
+        W = dict(weights)
+        st = self.store
+        if any(k.startswith(("rpn_class_raw/", "rpn_bbox_pred/")) for k in W):
+            cur = self.get_weights_dict()
+            full = {k: W.get(k, cur[k]) for k in ("rpn_class_raw/kernel", "rpn_class_raw/bias", "rpn_bbox_pred/kernel", "rpn_bbox_pred/bias")}
+            hk, hb = fuse_rpn_head(full, HEAD_PAD)
+            st.assign("rpn_head/kernel", pack_conv_kernel(hk))
+            st.assign("rpn_head/bias", hb)
+        backbone_changed = False
+        for k, v in W.items():
+            layer = k.split("/")[0]
+            if layer in ("rpn_class_raw", "rpn_bbox_pred"):
+                continue
+            if k in st.w:
+                packed = k.endswith("/kernel") and layer.startswith(("fpn_", "rpn_"))
+                st.assign(k, pack_conv_kernel(np.asarray(v, np.float32)) if packed else v)
+            elif k in self._backbone:
+                self._backbone[k] = np.asarray(v, np.float32)
+                backbone_changed = True
+        if backbone_changed:
+            self._plan = None
+
+    def load_weights(self, filepath, by_name=False, exclude=None):
+        loaded = load_weight_file(filepath)
+        known = set(self.get_weights_dict())
+        pick = {}
+        for k, v in loaded.items():
+            if exclude and k.split("/")[0] in exclude:
+                continue
+            if k not in known:
+                if by_name:
+                    continue
+                raise KeyError("weight %s is not part of this model" % k)
+            pick[k] = v
+        self.set_weights(pick)
+
+    def save_weights(self, path):
+        np.savez(path, **self.get_weights_dict())
+
+    def _weights_changed(self):
+        pass
+
+    @property
+    def trainable_weights(self):
+        rx = re.compile(self._trainable_regex)
+        return [k for k in self.store.trainable_names if rx.fullmatch(k.split("/")[0])]
+
+    def set_trainable(self, layer_regex, keras_model=None, indent=0, verbose=1):
+        """Only the regexes that leave the backbone frozen are available (the reference trains "no_backbone",
+        train_dense_captions.py:199-203); a frozen subset is realised by masking its gradient."""
+        rx = re.compile(layer_regex)
+        if any(rx.fullmatch(s.name) for s in resnet_fpn_convs(self.stage4_blocks) if not s.name.startswith("fpn_")):
+            raise NotImplementedError("training ResNet stages is not on this path: use layers='no_backbone'")
+        self._trainable_regex = layer_regex
+        self._reg_coef = None
+
+    # ---- compile ----------------------------------------------------------------------------
+    def compile(self, learning_rate):
+        """Adam(lr, clipnorm=0.5, amsgrad=True); losses = the three graph losses + L2(WEIGHT_DECAY)(w)/size(w) over the
+        trainable non-BN weights (:1694-1730)."""
+        self.optimizer = Adam(lr=learning_rate, clipnorm=0.5, amsgrad=True)
+        self.caption_model.optimizer = self.optimizer
+
+    def _masks(self):
+        """Per-element L2 coefficient over the flat bucket, and a 0/1 gradient mask when set_trainable() froze a
+        subset (None when everything in the bucket trains)."""
+        if self._reg_coef is None:
+            st = self.store
+            rx = re.compile(self._trainable_regex)
+            coef = np.zeros(st.flat.numel(), np.float32)
+            mask = np.zeros(st.flat.numel(), np.float32)
+            base = st.flat.data_ptr()
+            a2, a6 = 2 * self.A, 6 * self.A
+            wd = float(self.config.WEIGHT_DECAY)
+            frozen = False
+            for name in st.trainable_names:
+                t = st.w[name]
+                off, n = (t.data_ptr() - base) // 4, t.numel()
+                layer, wname = name.split("/")
+                if layer == "rpn_head":                               # two Keras layers fused into one padded tensor
+                    per = n // HEAD_PAD                                # elements per output channel (512 or 1)
+                    for sub, c0, c1 in (("rpn_class_raw", 0, a2), ("rpn_bbox_pred", a2, a6)):
+                        if rx.fullmatch(sub):
+                            mask[off + c0 * per:off + c1 * per] = 1.0
+                            coef[off + c0 * per:off + c1 * per] = wd / ((c1 - c0) * per)
+                        else:
+                            frozen = True
+                elif rx.fullmatch(layer):
+                    mask[off:off + n] = 1.0
+                    if wname not in ("gamma", "beta"):
+                        coef[off:off + n] = wd / n
+                else:
+                    frozen = True
+            self._reg_coef = torch.tensor(coef, device=self.device)
+            self._train_mask = torch.tensor(mask, device=self.device) if frozen else None
+        return self._reg_coef, self._train_mask
+
+    # ---- one training step ------------------------------------------------------------------
+    def _images_u8(self, images):
+        a = np.asarray(images)
+        if a.dtype == np.uint8:
+            return a
+        # the generator yields molded float images (image - MEAN_PIXEL); the GPU molds from the uint8 original
+        return np.clip(np.rint(a.astype(np.float64) + np.asarray(self.config.MEAN_PIXEL, np.float64)), 0, 255).astype(np.uint8)
+
+    def _rpn_selection(self, rpn_match):
+        m = np.asarray(rpn_match).reshape(-1)
+        p = self.plan()
+        sizes = [h.shape[1] * h.shape[2] * self.A for h in p.rpn_heads]
+        if m.size != sum(sizes):
+            raise ValueError("rpn_match has %d anchors, the pyramid has %d" % (m.size, sum(sizes)))
+        idx = np.nonzero(m != 0)[0]
+        bounds = np.cumsum([0] + sizes)
+        level = np.searchsorted(bounds, idx, side="right") - 1
+        return level.astype(np.int32), (idx - bounds[level]).astype(np.int32), m[idx].astype(np.int32)
+
+    def forward_backward(self, inputs, shuffle="rng"):
+        """Losses and gradients of one image into the flat gradient bucket (no optimizer step).
+        Returns the device tensor [rpn_class_loss, rpn_bbox_loss, imgcap_loss, reg_loss]."""
+        images, _meta, rpn_match, rpn_bbox, gt_caps, gt_boxes = inputs[:6]
+        if len(images) != 1:
+            raise ValueError("one image per step and GPU (IMAGES_PER_GPU = 1)")
+        cfg, st, cm = self.config, self.store, self.caption_model
+        w, g = st.w, st.grad
+        dev = self.device
+        p = self.plan()
+        H, W = p.H, p.W
+        up = lambda a, dt=torch.float32: torch.tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+
+        # ---- forward: backbone + FPN + RPN (hipGraph), proposals, detection targets, RoIAlign, head + decoder
+        p.forward(torch.as_tensor(self._images_u8(images)))
+        proposals = p.proposals()
+        gt_norm = (np.asarray(gt_boxes[0], np.float32) / np.array([H, W, H, W], np.float32)).astype(np.float32)
+        mix = None if shuffle is None else (self._rng.permutation if shuffle == "rng" else shuffle)
+        rois, caps, npos, nneg = detection_targets(proposals[0].cpu().numpy(), gt_caps[0], gt_norm, cfg, mix)
+        self.last_targets = dict(rois=rois, caps=caps, npos=npos, nneg=nneg)
+        boxes = up(rois[None])
+        R = rois.shape[0]
+        feats = p.roi_features(boxes_norm=boxes, out=self._buf("feats", (1, R, cfg.POOL_SIZE, cfg.POOL_SIZE, 256)))
+        tg = caption_targets(caps)
+        live = (tg > 0).astype(np.float32)
+        count = float(live.sum())
+        loss_rows, _ = cm._forward_train(feats[0], caps, tg, want_grad=True, row_weights=live / max(count, 1.0), keras_sparse=True)
+        losses = self._buf("losses", (4,))
+        ops.mean(loss_rows, out=losses[2:3])                 # x rows below: the weights already carry 1/count
+
+        # ---- backward: decoder + head -> RoI features -> pyramid
+        dX = cm._backward(want_dx=True)
+        maps = list(p.P) + [p.P6]
+        dP = [self._buf("dP%d" % i, tuple(m.shape)) for i, m in enumerate(maps)]
+        for t in dP:
+            t.zero_()
+        ops.roi_align_pyramid_bwd(dP[:4], boxes, float(H * W), dX.view(1, R, cfg.POOL_SIZE, cfg.POOL_SIZE, 256), cfg.POOL_SIZE)
+
+        # ---- RPN losses and their gradients w.r.t. the fused head outputs
+        lvl, idx, mt = self._rpn_selection(rpn_match[0])
+        n_pos = int((mt == 1).sum())
+        dheads = [self._buf("dhead%d" % i, tuple(h.shape)) for i, h in enumerate(p.rpn_heads)]
+        for t in dheads:
+            t.zero_()
+        tdl = np.asarray(rpn_bbox[0], np.float32)
+        if n_pos > tdl.shape[0]:
+            raise ValueError("%d positive anchors but only %d target rows" % (n_pos, tdl.shape[0]))
+        ops.rpn_loss_grad(p.rpn_heads, dheads, up(lvl, torch.int32), up(idx, torch.int32), up(mt, torch.int32),
+                          up(tdl if tdl.size else np.zeros((1, 4), np.float32)), n_pos, losses[0:2], anchors_per_loc=self.A)
+
+        # ---- RPN backward (shared weights over the five levels: gradients accumulate)
+        wd_head = ops.conv_weight_dgrad_pack(w["rpn_head/kernel"], 1, 1, 512, out=self._buf("wd_head", (512, HEAD_PAD)))
+        wd_shared = ops.conv_weight_dgrad_pack(w["rpn_conv_shared/kernel"], 3, 3, 256, out=self._buf("wd_shared", (256, 9 * 512)))
+        for i, (pm, sh, dh) in enumerate(zip(maps, p.rpn_shared, dheads)):
+            _, h_, w_, _ = pm.shape
+            acc = i > 0
+            ops.conv2d_wgrad(sh, dh, 1, 1, 1, 0, 0, out=g["rpn_head/kernel"], accumulate=acc)
+            ops.colsum(dh.view(-1, HEAD_PAD), out=g["rpn_head/bias"], accumulate=acc)
+            dsh = ops.conv2d(dh, wd_head, 1, 1, 1, 0, 0, h_, w_, out=self._buf("dsh%d" % i, tuple(sh.shape)))
+            ops.relu_bwd(dsh.view(-1, 512), sh.view(-1, 512), dsh.view(-1, 512))
+            ops.conv2d_wgrad(pm, dsh, 3, 3, 1, 1, 1, out=g["rpn_conv_shared/kernel"], accumulate=acc)
+            ops.colsum(dsh.view(-1, 512), out=g["rpn_conv_shared/bias"], accumulate=acc)
+            ops.conv2d(dsh, wd_shared, 3, 3, 1, 1, 1, h_, w_, residual=dP[i], res_mode=1, out=dP[i])     # dP += dgrad
+        ops.scatter2_add(dP[4], dP[3])                       # P6 = MaxPooling2D(1, strides=2)(P5)
+
+        # ---- FPN backward
+        dpre = []
+        for i in range(4):
+            name = "fpn_p%d" % (i + 2)
+            wd = ops.conv_weight_dgrad_pack(w[name + "/kernel"], 3, 3, 256, out=self._buf("wd_" + name, (256, 9 * 256)))
+            _, h_, w_, _ = dP[i].shape
+            ops.conv2d_wgrad(p.pre[i], dP[i], 3, 3, 1, 1, 1, out=g[name + "/kernel"])
+            ops.colsum(dP[i].view(-1, 256), out=g[name + "/bias"])
+            dpre.append(ops.conv2d(dP[i], wd, 3, 3, 1, 1, 1, h_, w_, out=self._buf("dpre%d" % i, tuple(dP[i].shape))))
+        for i in range(3):                                   # pre[k] = upsample(pre[k+1]) + lateral(C_k)
+            ops.downsample2x_sum(dpre[i], out=dpre[i + 1], accumulate=True)
+        for i, cmap in enumerate(p.C):
+            name = "fpn_c%dp%d" % (i + 2, i + 2)
+            ops.conv2d_wgrad(cmap, dpre[i], 1, 1, 1, 0, 0, out=g[name + "/kernel"])
+            ops.colsum(dpre[i].view(-1, 256), out=g[name + "/bias"])
+
+        # ---- regulariser (+ frozen subset when set_trainable narrowed the set)
+        coef, mask = self._masks()
+        if mask is not None:
+            st.flat_grad.mul_(mask)
+        ops.l2_reg(st.flat, coef, st.flat_grad, loss=losses[3:4])
+        self._loss_scale = float(loss_rows.numel())
+        return losses
+
+    def _loss_list(self, losses):
+        v = losses.cpu().numpy().astype(np.float64)
+        out = dict(rpn_class_loss=v[0], rpn_bbox_loss=v[1], imgcap_loss=v[2] * self._loss_scale, reg_loss=v[3])
+        out["loss"] = out["rpn_class_loss"] + out["rpn_bbox_loss"] + out["imgcap_loss"] + out["reg_loss"]
+        return out
+
+    def train_on_batch(self, inputs, targets=None):
+        """One optimizer step; returns [loss, rpn_class_loss, rpn_bbox_loss, imgcap_loss] like the compiled Keras model
+        (metrics_names order, :1722-1730)."""
+        assert self.mode == "training", "Create model in training mode."
+        if self.optimizer is None:
+            raise RuntimeError("compile(learning_rate) first")
+        losses = self.forward_backward(inputs)
+        scale = self.grad_sync(self.store.flat_grad) if self.grad_sync is not None else 1.0
+        self.optimizer.apply(self.store, grad_scale=scale)
+        self.last_losses = d = self._loss_list(losses)
+        return [d["loss"], d["rpn_class_loss"], d["rpn_bbox_loss"], d["imgcap_loss"]]
+
+    def test_on_batch(self, inputs, targets=None):
+        self.last_losses = d = self._loss_list(self.forward_backward(inputs))
+        return [d["loss"], d["rpn_class_loss"], d["rpn_bbox_loss"], d["imgcap_loss"]]
+
+    # ---- training loop ----------------------------------------------------------------------
+    def train(self, train_dataset, val_dataset, learning_rate, epochs, layers):
+        """fit_generator over data_generator with a checkpoint per epoch (:1810-1888)."""
+        assert self.mode == "training", "Create model in training mode."
+        layers = self.LAYER_REGEX.get(layers, layers)
+        if layers in ("all", "3+", "4+", "5+"):
+            raise NotImplementedError("training ResNet stages is not on this path: use layers='no_backbone'")
+        cfg = self.config
+        train_generator = data_generator(train_dataset, cfg, shuffle=True, batch_size=cfg.BATCH_SIZE)
+        val_generator = data_generator(val_dataset, cfg, shuffle=True, batch_size=cfg.BATCH_SIZE, augment=False)
+        self.set_trainable(layers)
+        self.compile(learning_rate)
+        val_batch = next(val_generator)[0]
+        names = ("loss",) + self.LOSS_NAMES
+        history = []
+        for epoch in range(self.epoch, epochs):
+            sums = np.zeros(4)
+            for _ in range(cfg.STEPS_PER_EPOCH):
+                sums += np.asarray(self.train_on_batch(next(train_generator)[0]))
+            logs = {n: v / cfg.STEPS_PER_EPOCH for n, v in zip(names, sums)}
+            logs.update({"val_" + n: v for n, v in zip(names, self.test_on_batch(val_batch))})
+            history.append(logs)
+            print("Epoch %d/%d - " % (epoch + 1, epochs) + " - ".join("%s: %.4f" % kv for kv in sorted(logs.items())))
+            os.makedirs(self.model_dir, exist_ok=True)
+            self.save_weights(os.path.join(self.model_dir, "dense_image_cap_rcnn_%04d.npz" % (epoch + 1)))
+        self.epoch = max(self.epoch, epochs)
+        return history

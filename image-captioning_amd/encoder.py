@@ -19,11 +19,27 @@ from .layers import ConvSpec, resnet_fpn_convs
 from .packing import fold_bn, pack_conv_kernel, pack_stem_kernel
 
 
+def fuse_rpn_head(weights, channels=None):
+    """rpn_class_raw (2A channels) ++ rpn_bbox_pred (4A) as ONE 1x1 convolution, zero-padded to `channels` outputs."""
+    k = np.concatenate([weights["rpn_class_raw/kernel"], weights["rpn_bbox_pred/kernel"]], axis=3).astype(np.float32)
+    b = np.concatenate([weights["rpn_class_raw/bias"], weights["rpn_bbox_pred/bias"]]).astype(np.float32)
+    pad = (channels or k.shape[3]) - k.shape[3]
+    if pad < 0:
+        raise ValueError("rpn head needs %d channels, got %d" % (k.shape[3], channels))
+    if pad:
+        k = np.concatenate([k, np.zeros(k.shape[:3] + (pad,), np.float32)], axis=3)
+        b = np.concatenate([b, np.zeros(pad, np.float32)])
+    return k, b
+
+
 class EncoderPlan:
     def __init__(self, weights, batch, height, width, device, stage4_blocks=22,
-                 mean_pixel=(123.7, 116.8, 103.9), use_graph=True, rpn=None):
+                 mean_pixel=(123.7, 116.8, 103.9), use_graph=True, rpn=None, external=None):
         """rpn: None (GT-RoI variant: the RPN is never evaluated) or a dict with the config values the
-        proposal path needs: scales, ratios, strides, anchor_stride, bbox_std, nms_threshold, proposal_count."""
+        proposal path needs: scales, ratios, strides, anchor_stride, bbox_std, nms_threshold, proposal_count and
+        optionally head_channels (the fused class+bbox head padded to a multiple of 4 channels for the wgrad kernel).
+        external: {conv name: (packed kernel, scale or None, shift)} device tensors owned by the caller (the joint
+        model's trainable FPN/RPN weights live in its flat parameter bucket; the plan reads them in place)."""
         if height % 64 or width % 64:
             raise ValueError("Image size must be dividable by 2 at least 6 times (got %dx%d)" % (height, width))
         self.lib = _lib.load()
@@ -36,13 +52,15 @@ class EncoderPlan:
         self._warm = False
         self._specs = {s.name: s for s in resnet_fpn_convs(stage4_blocks)}
         self.rpn = rpn
+        self._external = dict(external or {})
         if rpn is not None:
             a = len(rpn["ratios"])
+            self.head_channels = hc = int(rpn.get("head_channels", 6 * a))
             self._specs["rpn_conv_shared"] = ConvSpec("rpn_conv_shared", None, 3, 256, 512, 1, "same")
-            self._specs["rpn_head"] = ConvSpec("rpn_head", None, 1, 512, 6 * a, 1, "valid")      # class_raw ++ bbox_pred
-            weights = dict(weights)
-            weights["rpn_head/kernel"] = np.concatenate([weights["rpn_class_raw/kernel"], weights["rpn_bbox_pred/kernel"]], axis=3)
-            weights["rpn_head/bias"] = np.concatenate([weights["rpn_class_raw/bias"], weights["rpn_bbox_pred/bias"]])
+            self._specs["rpn_head"] = ConvSpec("rpn_head", None, 1, 512, hc, 1, "valid")         # class_raw ++ bbox_pred (++ pad)
+            if "rpn_head" not in self._external:
+                weights = dict(weights)
+                weights["rpn_head/kernel"], weights["rpn_head/bias"] = fuse_rpn_head(weights, hc)
         self._w = {}
         self._upload(weights)
         self._build()
@@ -51,6 +69,9 @@ class EncoderPlan:
     def _upload(self, W):
         dev = self.device
         for s in self._specs.values():
+            if s.name in self._external:
+                self._w[s.name] = self._external[s.name]
+                continue
             k = np.asarray(W[s.name + "/kernel"], np.float32)
             if tuple(k.shape) != (s.k, s.k, s.cin, s.cout):
                 raise ValueError("%s/kernel has shape %s, expected %s" % (s.name, k.shape, (s.k, s.k, s.cin, s.cout)))
@@ -129,6 +150,7 @@ class EncoderPlan:
         C4 = stage(4, ["a"] + [chr(98 + i) for i in range(self.stage4_blocks)], 256, 1024, 2, C3)
         C5 = stage(5, "abc", 512, 2048, 2, C4)
         self.C = (C2, C3, C4, C5)
+        self.pre = None
         t5, t4 = self._buf(H // 32, W // 32, 256), self._buf(H // 16, W // 16, 256)
         t3, t2 = self._buf(H // 8, W // 8, 256), self._buf(H // 4, W // 4, 256)
         self._conv("fpn_c5p5", C5, t5, relu=False)
@@ -142,17 +164,20 @@ class EncoderPlan:
         self._conv("fpn_p4", t4, P4, relu=False)
         self._conv("fpn_p5", t5, P5, relu=False)
         self.P = (P2, P3, P4, P5)
+        self.pre = (t2, t3, t4, t5)                        # top-down sums: the inputs of fpn_p2..p5 (kept for the joint backward)
         if self.rpn is not None:
             from .utils import generate_pyramid_anchors
             P6 = self._buf(H // 64, W // 64, 256)
             self._ops.append(("sub2", P5, P6))
-            self.rpn_heads = []
+            self.P6 = P6
+            self.rpn_heads, self.rpn_shared = [], []
             for p in (P2, P3, P4, P5, P6):
                 sh = self._buf(p.shape[1], p.shape[2], 512)
-                hd = self._buf(p.shape[1], p.shape[2], 6 * len(self.rpn["ratios"]))
+                hd = self._buf(p.shape[1], p.shape[2], self.head_channels)
                 self._conv("rpn_conv_shared", p, sh)
                 self._conv("rpn_head", sh, hd, relu=False)
                 self.rpn_heads.append(hd)
+                self.rpn_shared.append(sh)
             shapes = [[-(-H // st), -(-W // st)] for st in self.rpn["strides"]]
             anchors = generate_pyramid_anchors(self.rpn["scales"], self.rpn["ratios"], shapes, self.rpn["strides"],
                                                self.rpn.get("anchor_stride", 1)).astype(np.float32)
@@ -241,7 +266,8 @@ class EncoderPlan:
             raise RuntimeError("this plan was built without the RPN")
         r = self.rpn
         return ops.rpn_proposals(self.rpn_heads, self.anchors, (self.H, self.W), r["proposal_count"], r["nms_threshold"],
-                                 r.get("bbox_std", (0.1, 0.1, 0.2, 0.2)), anchors_per_loc=len(r["ratios"]), debug=debug)
+                                 r.get("bbox_std", (0.1, 0.1, 0.2, 0.2)), anchors_per_loc=len(r["ratios"]), debug=debug,
+                                 head_stride=self.head_channels)
 
     def normalize_boxes(self, rois_px):
         """rois / [h,w,h,w] in float32, as modified_dense_model.py:1522-1527 (the molded image's size,

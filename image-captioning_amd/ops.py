@@ -7,7 +7,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (AmsgradDesc, BnReluDesc, ConvDesc, ProposalDesc, GemmDesc, LstmBwdDesc, LstmFwdDesc, RoiAlignDesc,
+from ._lib import (AmsgradDesc, BnReluDesc, ConvDesc, ProposalDesc, RpnLossDesc, GemmDesc, LstmBwdDesc, LstmFwdDesc, RoiAlignDesc,
                    SoftmaxCeDesc, check)
 
 
@@ -112,7 +112,7 @@ def conv2d(x, w_packed, kh, kw, stride, pad_t, pad_l, Ho, Wo, scale=None, shift=
     return out
 
 
-def conv2d_wgrad(x, dy, kh, kw, stride, pad_t, pad_l, out=None, split_k=0):
+def conv2d_wgrad(x, dy, kh, kw, stride, pad_t, pad_l, out=None, split_k=0, accumulate=False):
     """dw packed [Cout][kh*kw*Cin] = sum_pixels dy (x) im2col(x); x [N,H,W,Cin], dy [N,Ho,Wo,Cout] contiguous."""
     lib = _lib.load()
     _chk(x, name="x"), _chk(dy, name="dy")
@@ -126,6 +126,7 @@ def conv2d_wgrad(x, dy, kh, kw, stride, pad_t, pad_l, out=None, split_k=0):
     d.N, d.H, d.W, d.Cin = N, H, W, Cin
     d.Cout, d.kh, d.kw, d.stride, d.pad_t, d.pad_l, d.Ho, d.Wo = Cout, kh, kw, stride, pad_t, pad_l, Ho, Wo
     d.x, d.y, d.w, d.split_k = x.data_ptr(), dy.data_ptr(), _chk(out, name="dw").data_ptr(), int(split_k)
+    d.accumulate = int(accumulate)
     ws, wsb = WORKSPACE.get(lib.dc_conv2d_wgrad_workspace_bytes(C.byref(d)), x.device)
     check(lib.dc_conv2d_wgrad_f32(C.byref(d), _ptr(ws), wsb, _stream()), "dc_conv2d_wgrad_f32")
     return out
@@ -216,7 +217,7 @@ def subsample2(x, out=None):
 
 
 def rpn_proposals(heads, anchors, image_hw, proposal_count, nms_threshold, std_dev=(0.1, 0.1, 0.2, 0.2), pre_nms_limit=6000,
-                  anchors_per_loc=3, out=None, debug=False):
+                  anchors_per_loc=3, out=None, debug=False, head_stride=0):
     """heads: per-level fused RPN head outputs [B,H,W,A*6]; anchors [A_total,4] float32 device tensor.
     Returns proposals [B,count,4] (normalised, zero padded) and, with debug, (scores, order, keep)."""
     lib = _lib.load()
@@ -224,10 +225,11 @@ def rpn_proposals(heads, anchors, image_hw, proposal_count, nms_threshold, std_d
     d = ProposalDesc()
     d.B, d.levels, d.anchors_per_loc = B, len(heads), anchors_per_loc
     for i, h in enumerate(heads):
-        if not _chk(h, name="head").is_contiguous() or h.shape[-1] != anchors_per_loc * 6:
-            raise _lib.DcapError("rpn_proposals: heads must be contiguous [B,H,W,A*6]")
+        if not _chk(h, name="head").is_contiguous() or h.shape[-1] != (head_stride or anchors_per_loc * 6):
+            raise _lib.DcapError("rpn_proposals: heads must be contiguous [B,H,W,A*6] (or [B,H,W,head_stride])")
         d.heads[i] = h.data_ptr()
         d.Hs[i], d.Ws[i] = h.shape[1], h.shape[2]
+    d.head_stride = int(head_stride)
     d.anchors, d.A_total = _chk(anchors, name="anchors").data_ptr(), anchors.shape[0]
     for i in range(4):
         d.std_dev[i] = float(std_dev[i])
@@ -293,7 +295,8 @@ def lstm_seq_bwd(z, U_rec, mask, h_seq, c_seq, B, T, dh_seq=None, dh_last=None, 
     return dz, dU
 
 
-def softmax_ce(logits, targets=None, probs=None, loss_rows=None, dlogits=None, grad_scale=1.0):
+def softmax_ce(logits, targets=None, probs=None, loss_rows=None, dlogits=None, grad_scale=1.0, row_weights=None,
+               keras_sparse=False):
     lib = _lib.load()
     _chk(logits, name="logits")
     d = SoftmaxCeDesc()
@@ -307,6 +310,8 @@ def softmax_ce(logits, targets=None, probs=None, loss_rows=None, dlogits=None, g
     d.loss_rows = None if loss_rows is None else _chk(loss_rows, name="loss_rows").data_ptr()
     d.dlogits = None if dlogits is None else dlogits.data_ptr()
     d.grad_scale = float(grad_scale)
+    d.row_weights = None if row_weights is None else _chk(row_weights, name="row_weights").data_ptr()
+    d.keras_sparse = int(keras_sparse)
     check(lib.dc_softmax_ce_f32(C.byref(d), _stream()), "dc_softmax_ce_f32")
 
 
@@ -359,6 +364,54 @@ def bn_relu_bwd(acc, bias, gamma, beta, mean, var, dy, dacc, dgamma, dbeta, dbia
     d.dgamma, d.dbeta, d.dbias = (_chk(t, name="bn grad").data_ptr() for t in (dgamma, dbeta, dbias))
     check(lib.dc_bn_relu_bwd_f32(C.byref(d), _stream()), "dc_bn_relu_bwd_f32")
     return dacc
+
+
+def conv_weight_dgrad_pack(w_packed, kh, kw, cin, out=None):
+    """[Cout][kh*kw*Cin] -> [Cin][kh*kw*Cout] with the taps rotated: the weights that make conv2d() the data gradient."""
+    lib = _lib.load()
+    cout = w_packed.shape[0]
+    if out is None:
+        out = torch.empty((cin, kh * kw * cout), dtype=torch.float32, device=w_packed.device)
+    check(lib.dc_conv_weight_dgrad_pack_f32(_ptr(_chk(w_packed, name="w")), _ptr(out), cout, kh, kw, cin, _stream()),
+          "dc_conv_weight_dgrad_pack_f32")
+    return out
+
+
+def rpn_loss_grad(heads, dheads, sel_level, sel_index, sel_match, target_deltas, n_pos, losses, image=0, anchors_per_loc=3):
+    """RPN class + bbox losses of image `image` and their gradients scattered into the (pre-zeroed) dheads."""
+    lib = _lib.load()
+    d = RpnLossDesc()
+    d.levels, d.anchors_per_loc, d.head_stride = len(heads), anchors_per_loc, heads[0].shape[-1]
+    for i, (h, g) in enumerate(zip(heads, dheads)):
+        per = h.shape[1] * h.shape[2] * h.shape[3]
+        d.heads[i] = h.data_ptr() + 4 * per * image
+        d.dheads[i] = g.data_ptr() + 4 * per * image
+        d.Hs[i], d.Ws[i] = h.shape[1], h.shape[2]
+    d.n_sel, d.n_pos = sel_level.numel(), int(n_pos)
+    d.sel_level, d.sel_index, d.sel_match = (_chk(t, torch.int32, "sel").data_ptr() for t in (sel_level, sel_index, sel_match))
+    d.target_deltas = _chk(target_deltas, name="target_deltas").data_ptr()
+    d.losses = _chk(losses, name="losses").data_ptr()
+    check(lib.dc_rpn_loss_grad_f32(C.byref(d), _stream()), "dc_rpn_loss_grad_f32")
+
+
+def scatter2_add(coarse, fine):
+    lib = _lib.load()
+    N, Hc, Wc, Cc = coarse.shape
+    check(lib.dc_scatter2_add_f32(_ptr(_chk(coarse, name="coarse")), _ptr(_chk(fine, name="fine")), N, Hc, Wc, Cc, _stream()), "dc_scatter2_add_f32")
+    return fine
+
+
+def l2_reg(w, coef, grad=None, loss=None):
+    lib = _lib.load()
+    check(lib.dc_l2_reg_f32(_ptr(_chk(w, name="w")), _ptr(_chk(coef, name="coef")), None if grad is None else _ptr(grad), w.numel(),
+                            None if loss is None else _ptr(loss), _stream()), "dc_l2_reg_f32")
+    return loss
+
+
+def axpy(a, x, y):
+    lib = _lib.load()
+    check(lib.dc_axpy_f32(float(a), _ptr(_chk(x, name="x")), _ptr(_chk(y, name="y")), x.numel(), _stream()), "dc_axpy_f32")
+    return y
 
 
 def relu_bwd(dy, y, out):

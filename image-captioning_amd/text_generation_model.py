@@ -149,7 +149,9 @@ class CaptionModelV1(KerasLikeModel):
     D1 = 1024
     HEAD = (("mrcnn_class_conv1", "mrcnn_class_bn1"), ("mrcnn_class_conv2", "mrcnn_class_bn2"))
 
-    def __init__(self, features_input, config, units, mode, device=None, seed=0):
+    def __init__(self, features_input, config, units, mode, device=None, seed=0, extra_params=()):
+        """extra_params: (name, array, trainable) entries that share this model's flat parameter bucket (the joint
+        model's FPN/RPN weights: one optimizer launch and one gradient all-reduce cover everything)."""
         self.features_input, self.config, self.units, self.mode = list(features_input), config, units, mode
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.V, self.E, self.T = int(config.VOCABULARY_SIZE), int(config.EMBEDDING_SIZE), int(config.PADDING_SIZE)
@@ -163,6 +165,8 @@ class CaptionModelV1(KerasLikeModel):
         for k in sorted(W):
             frozen = k.startswith('imgcap_embedding') or 'moving_' in k
             st.add(k, W[k], not frozen)
+        for name, array, trainable in extra_params:
+            st.add(name, array, trainable)
         self.store = st.finalize()
         self.grad_sync = None
         self._bufs = {}
@@ -218,7 +222,9 @@ class CaptionModelV1(KerasLikeModel):
         up = lambda a, dt: torch.tensor(np.ascontiguousarray(a), dtype=dt, device=self.device)
         return up(ids.T.reshape(-1), torch.int32), up((ids != 0).T.reshape(-1), torch.uint8), B, T
 
-    def _forward_train(self, feat, caps, targets=None, want_probs=False, want_grad=False):
+    def _forward_train(self, feat, caps, targets=None, want_probs=False, want_grad=False, row_weights=None, keras_sparse=False):
+        """row_weights [B,T] + keras_sparse: the joint model's masked K.sparse_categorical_crossentropy
+        (dense_img_cap/dense_model.py:936-946); loss rows and dlogits are then weighted per row instead of 1/N."""
         ids_tm, mask, B, T = self._tables(caps)
         X = feat.reshape(B, -1)
         f = self._head_forward(X)
@@ -229,11 +235,17 @@ class CaptionModelV1(KerasLikeModel):
         if targets is not None:
             tg = torch.tensor(np.ascontiguousarray(np.asarray(targets, np.int32).T.reshape(-1)), device=self.device)
             loss_rows = self._buf('loss_rows', (N,))
-        ops.softmax_ce(logits, tg, probs, loss_rows, logits if want_grad else None, grad_scale=1.0 / N)
+        rw = None
+        if row_weights is not None:
+            rw = torch.tensor(np.ascontiguousarray(np.asarray(row_weights, np.float32).T.reshape(-1)), device=self.device)
+        ops.softmax_ce(logits, tg, probs, loss_rows, logits if want_grad else None, grad_scale=1.0 if rw is not None else 1.0 / N,
+                       row_weights=rw, keras_sparse=keras_sparse)
         self._ctx = (X, f, ids_tm, mask, B, T)
         return loss_rows, probs
 
-    def _backward(self):
+    def _backward(self, want_dx=False):
+        """Gradients of every trainable weight into the flat bucket; with want_dx also returns the gradient w.r.t.
+        the flattened RoI features [B, pool*pool*C] (the joint model backpropagates it through RoIAlign)."""
         w, g, u = self.store.w, self.store.grad, self.units
         X, f, ids_tm, mask, B, T = self._ctx
         bf = self._bufs
@@ -278,6 +290,9 @@ class CaptionModelV1(KerasLikeModel):
             ops.gemm(inputs[li], dacc, a_trans=True, out=gk.view(-1, gk.shape[-1]))
             if li == 1:
                 dy = ops.gemm(dacc, k.view(-1, k.shape[-1]), b_trans=True, out=self._buf('dhact0', (B, self.FEAT)))
+            elif want_dx:
+                return ops.gemm(dacc, k.view(-1, k.shape[-1]), b_trans=True, out=self._buf('dX', tuple(X.shape)))
+        return None
 
     def train_step(self, feat, caps, targets):
         if self.optimizer is None:

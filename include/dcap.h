@@ -91,6 +91,7 @@ typedef struct {
     const float* residual;  int res_mode;
     int relu;
     int split_k;
+    int accumulate;           /* wgrad only: dw += (a weight shared by several inputs, e.g. the RPN over P2..P6) */
 } dc_conv_desc;
 
 size_t dc_conv2d_workspace_bytes(const dc_conv_desc* d);
@@ -159,6 +160,7 @@ typedef struct {
     int B, levels, anchors_per_loc;
     const float* heads[5];
     int Hs[5], Ws[5];
+    int head_stride;          /* floats per cell in heads[] (0 = anchors_per_loc*6; > that when the head is padded) */
     const float* anchors;
     int A_total;
     float std_dev[4];
@@ -242,6 +244,9 @@ typedef struct {
     float* loss_rows;
     float* dlogits;
     float grad_scale;
+    const float* row_weights; /* optional [M]: loss_rows and dlogits rows are multiplied by it (0 drops a row) */
+    int keras_sparse;         /* 1: K.sparse_categorical_crossentropy on probabilities (dense_img_cap/dense_model.py:943-945):
+                                 q = clip(p,1e-7,1-1e-7); loss = -log q_t + log sum(q), gradient through clip and sum */
 } dc_softmax_ce_desc;
 
 int dc_softmax_ce_f32(const dc_softmax_ce_desc* d, void* stream);
@@ -277,6 +282,39 @@ typedef struct {
 
 int dc_bn_relu_fwd_f32(const dc_bn_relu_desc* d, void* stream);
 int dc_bn_relu_bwd_f32(const dc_bn_relu_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Joint-model helpers (dense_img_cap/dense_model.py).
+ * dc_conv_weight_dgrad_pack: packed forward weights [Cout][kh*kw*Cin] -> packed data-gradient weights
+ *   [Cin][kh*kw*Cout] (taps rotated 180 degrees), re-derived on the device after every optimizer step.
+ * dc_rpn_loss_grad: rpn_class_loss_graph + rpn_bbox_loss_graph (:877-933) for ONE image: `sel` lists the n_sel
+ *   non-neutral anchors as (level, cell*A + a) pairs with their match (+1/-1) in anchor order; target_deltas
+ *   [n_pos][4] in the order of the positive ones.  Writes d(loss)/d(head) into the (pre-zeroed) padded head
+ *   gradients dheads[l] [H,W,head_stride] of this image and losses[0..1] = (class, bbox).
+ * dc_scatter2_add: fine[n,2y,2x,c] += coarse[n,y,x,c]  (backward of P6 = MaxPooling2D(1, strides 2)(P5)).
+ * dc_axpy: y += a*x  (L2 regulariser gradient, compile() :1715-1718).
+ * ------------------------------------------------------------------------------------------------ */
+int dc_conv_weight_dgrad_pack_f32(const float* w, float* out, int Cout, int kh, int kw, int Cin, void* stream);
+typedef struct {
+    int levels, anchors_per_loc, head_stride;
+    const float* heads[5];
+    float*       dheads[5];
+    int Hs[5], Ws[5];
+    int n_sel, n_pos;
+    const int32_t* sel_level;     /* [n_sel] */
+    const int32_t* sel_index;     /* [n_sel] cell*A + a within the level */
+    const int32_t* sel_match;     /* [n_sel] +1 / -1 */
+    const float*   target_deltas; /* [n_pos][4] */
+    float* losses;                /* [2] */
+} dc_rpn_loss_desc;
+int dc_rpn_loss_grad_f32(const dc_rpn_loss_desc* d, void* stream);
+int dc_scatter2_add_f32(const float* coarse, float* fine, int N, int Hc, int Wc, int C, void* stream);
+/* keras.regularizers.l2(WEIGHT_DECAY)(w) / size(w) summed over the trainable non-BN weights
+ * (dense_img_cap/dense_model.py:1712-1718) over one flat bucket: coef[i] = WEIGHT_DECAY/size of i's tensor (0 where not
+ * regularised).  grad[i] += 2*coef[i]*w[i] (grad may be NULL); loss[0] = sum coef[i]*w[i]^2 (loss may be NULL). */
+int dc_l2_reg_f32(const float* w, const float* coef, float* grad, size_t n, float* loss, void* stream);
+
+int dc_axpy_f32(float a, const float* x, float* y, size_t n, void* stream);
 
 /* out = (y > 0) ? dy : 0 over [M][N] (row strides ld): backward of Activation('relu') given its output. */
 int dc_relu_bwd_f32(const float* dy, const float* y, float* out, int M, int N, int ld, void* stream);
