@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void rpn_loss_grad_kernel(dc_rpn_loss_desc d) 
     const float invn = 1.f / (float)d.n_sel;
     g[a * 2] = (p0 - (cls == 0 ? 1.f : 0.f)) * invn;
     g[a * 2 + 1] = (p1 - (cls == 1 ? 1.f : 0.f)) * invn;
-    atomicAdd(&d.losses[0], -logf(cls ? p1 : p0) * invn);
+    atomicAdd(&d.losses[0], (logf(e0 + e1) - ((cls ? l1 : l0) - mx)) * invn);      // log-sum-exp form: finite for any logits
     if (m == 1) {
         // rank of this positive among the positives = number of positives before it in sel (sel is in anchor order)
         int rank = 0;

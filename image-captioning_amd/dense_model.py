@@ -449,14 +449,14 @@ class DenseImageCapRCNN(object):
                           up(tdl if tdl.size else np.zeros((1, 4), np.float32)), n_pos, losses[0:2], anchors_per_loc=self.A)
 
         # ---- RPN backward (shared weights over the five levels: gradients accumulate)
-        wd_head = ops.conv_weight_dgrad_pack(w["rpn_head/kernel"], 1, 1, 512, out=self._buf("wd_head", (512, HEAD_PAD)))
         wd_shared = ops.conv_weight_dgrad_pack(w["rpn_conv_shared/kernel"], 3, 3, 256, out=self._buf("wd_shared", (256, 9 * 512)))
         for i, (pm, sh, dh) in enumerate(zip(maps, p.rpn_shared, dheads)):
             _, h_, w_, _ = pm.shape
             acc = i > 0
             ops.conv2d_wgrad(sh, dh, 1, 1, 1, 0, 0, out=g["rpn_head/kernel"], accumulate=acc)
             ops.colsum(dh.view(-1, HEAD_PAD), out=g["rpn_head/bias"], accumulate=acc)
-            dsh = ops.conv2d(dh, wd_head, 1, 1, 1, 0, 0, h_, w_, out=self._buf("dsh%d" % i, tuple(sh.shape)))
+            dsh = self._buf("dsh%d" % i, tuple(sh.shape))          # 1x1 head: its data gradient is a K = 20 GEMM on the packed weights
+            ops.gemm(dh.view(-1, HEAD_PAD), w["rpn_head/kernel"], out=dsh.view(-1, 512))
             ops.relu_bwd(dsh.view(-1, 512), sh.view(-1, 512), dsh.view(-1, 512))
             ops.conv2d_wgrad(pm, dsh, 3, 3, 1, 1, 1, out=g["rpn_conv_shared/kernel"], accumulate=acc)
             ops.colsum(dsh.view(-1, 512), out=g["rpn_conv_shared/bias"], accumulate=acc)

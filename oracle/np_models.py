@@ -427,9 +427,12 @@ def joint_trainable(Wt):
     return [k for k in Wt if k.startswith(JOINT_TRAINABLE_PREFIXES) and not k.startswith('imgcap_embedding') and 'moving_' not in k]
 
 
-def joint_loss_and_grads(Wt, image_u8, rpn_match, rpn_bbox_target, gt_captions, gt_boxes_px, cfg, shuffle=None, stage4_blocks=22):
+def joint_loss_and_grads(Wt, image_u8, rpn_match, rpn_bbox_target, gt_captions, gt_boxes_px, cfg, shuffle=None, stage4_blocks=22,
+                         targets_override=None):
     """One training step's losses and gradients for ONE image (IMAGES_PER_GPU = 1, train_dense_captions.py:27).
     cfg: dict(mean_pixel, scales, ratios, strides, proposal_count, nms, train_rois, positive_ratio, weight_decay, T).
+    targets_override = (rois [R,4] normalised, caps [R,T]) replaces the DetectionTargetLayer's sample (which carries no
+    gradient): parity tests hand in the sample the device drew, since near-tied proposal scores may order differently.
     Returns (losses dict, grads dict over joint_trainable(Wt), aux dict)."""
     x = O.mold_image(image_u8[None], cfg['mean_pixel'])
     _, H, W, _ = x.shape
@@ -455,6 +458,8 @@ def joint_loss_and_grads(Wt, image_u8, rpn_match, rpn_bbox_target, gt_captions, 
     proposals, _, _ = O.proposal_layer(probs[:, 1], bbox, anchors, (H, W), cfg['proposal_count'], cfg['nms'])
     gt_norm = (np.asarray(gt_boxes_px, np.float32) / np.array([H, W, H, W], np.float32)).astype(np.float32)
     rois, caps, npos, nneg = O.detection_targets(proposals, gt_captions, gt_norm, cfg['train_rois'], cfg['positive_ratio'], shuffle)
+    if targets_override is not None:
+        rois, caps = np.asarray(targets_override[0], np.float32), np.asarray(targets_override[1])
     maps = [P[2], P[3], P[4], P[5]]
     feats = O.pyramid_roi_align(rois[None], maps, (H, W, 3), 7)[0]
     cap_probs, cache = v1_training_forward(Wt, feats, caps.astype(np.float64))

@@ -24,7 +24,7 @@ def dev(a, dtype=torch.float32):
 
 
 def close(got, want, tol=2e-5):
-    got = got.detach().cpu().numpy().astype(np.float64)
+    got = (got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)).astype(np.float64)
     want = np.asarray(want, np.float64)
     assert got.shape == want.shape, (got.shape, want.shape)
     scale = max(1.0, float(np.abs(want).max()))
@@ -345,3 +345,119 @@ def test_downsample2x_sum_is_upsample_adjoint(ops):
     acc = dev(np.ones_like(want))
     ops.downsample2x_sum(dev(fine), out=acc, accumulate=True)
     close(acc, want + 1, 1e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+# joint-model (configs[4]) kernels
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("M,V", [(9, 24), (33, 1000), (6, 50001)])
+def test_masked_keras_sparse_ce(ops, M, V):
+    """imgcap_caption_loss_graph: K.sparse_categorical_crossentropy on a softmax row (clip + renormalise) times a
+    per-row weight; rows with weight 0 contribute nothing."""
+    rng = np.random.default_rng(V)
+    z = 3.0 * rng.standard_normal((M, V))
+    t = rng.integers(0, V, M)
+    z[0, t[0]] = -60.0
+    z[1, :] = -50.0
+    z[1, t[1]] = 50.0
+    w = rng.random(M)
+    w[2] = 0.0
+    p = O.softmax(z)
+    want_loss, want_d = O.sparse_cce_keras_with_grad(t, p, w)
+    ld = (V + 3) // 4 * 4
+    zd = torch.zeros(M, ld, device="cuda")
+    zd[:, :V] = dev(z)
+    dl = torch.empty_like(zd)
+    loss = torch.empty(M, device="cuda")
+    ops.softmax_ce(zd[:, :V], dev(t, torch.int32), None, loss, dl[:, :V], grad_scale=1.0, row_weights=dev(w), keras_sparse=True)
+    close(loss, want_loss, 2e-5)
+    close(dl[:, :V], want_d, 2e-5)
+    assert float(dl[2, :V].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("S", [64, 256])
+def test_rpn_losses_and_head_gradients(ops, S):
+    rng = np.random.default_rng(S)
+    A, stride = 3, 20
+    shapes = [(S // s, S // s) for s in (4, 8, 16, 32, 64)]
+    heads = [rng.standard_normal((1, h, w, stride)) for h, w in shapes]
+    n_anchor = sum(h * w * A for h, w in shapes)
+    match = np.zeros(n_anchor, np.int32)
+    pick = rng.choice(n_anchor, 90, replace=False)
+    match[pick] = np.where(rng.random(90) < 0.4, 1, -1)
+    match[n_anchor - 1], match[0] = 1, -1                              # first and last anchor take part
+    n_pos = int((match == 1).sum())
+    target = 1.5 * rng.standard_normal((128, 4))
+    logits = np.concatenate([h[0, :, :, :2 * A].reshape(-1, 2) for h in heads])
+    bbox = np.concatenate([h[0, :, :, 2 * A:6 * A].reshape(-1, 4) for h in heads])
+    l_cls, d_cls = O.rpn_class_loss(match, logits)
+    l_box, d_box = O.rpn_bbox_loss(target, match, bbox)
+    sizes = np.array([0] + [h * w * A for h, w in shapes]).cumsum()
+    idx = np.nonzero(match)[0]
+    lvl = np.searchsorted(sizes, idx, side="right") - 1
+    dh = [torch.zeros(h.shape, device="cuda") for h in heads]
+    losses = torch.empty(2, device="cuda")
+    ops.rpn_loss_grad([dev(h) for h in heads], dh, dev(lvl, torch.int32), dev(idx - sizes[lvl], torch.int32),
+                      dev(match[idx], torch.int32), dev(target), n_pos, losses)
+    close(losses, np.array([l_cls, l_box]), 1e-5)
+    for i, (h, w) in enumerate(shapes):
+        n = h * w * A
+        got = dh[i].cpu().numpy()[0]
+        close(got[:, :, :2 * A].reshape(-1, 2), d_cls[sizes[i]:sizes[i] + n], 1e-5)
+        close(got[:, :, 2 * A:6 * A].reshape(-1, 4), d_box[sizes[i]:sizes[i] + n], 1e-5)
+        assert np.all(got[:, :, 6 * A:] == 0)
+
+
+def test_dgrad_weight_pack_scatter_l2(ops):
+    from image_captioning_amd.packing import pack_conv_kernel, pack_conv_kernel_dgrad
+    rng = np.random.default_rng(11)
+    for k, cin, cout in ((3, 64, 128), (1, 512, 20)):
+        w = rng.standard_normal((k, k, cin, cout)).astype(np.float32)
+        got = ops.conv_weight_dgrad_pack(dev(pack_conv_kernel(w)), k, k, cin).cpu().numpy()
+        assert np.array_equal(got, pack_conv_kernel_dgrad(w))
+    coarse, fine = rng.standard_normal((2, 3, 5, 8)), rng.standard_normal((2, 6, 10, 8))
+    want = fine.copy()
+    want[:, ::2, ::2, :] += coarse
+    close(ops.scatter2_add(dev(coarse), dev(fine)), want, 1e-6)
+    n = 5000
+    wv, coef, g = rng.standard_normal(n), rng.random(n) * (rng.random(n) < 0.7), rng.standard_normal(n)
+    gd, loss = dev(g), torch.empty(1, device="cuda")
+    ops.l2_reg(dev(wv), dev(coef), gd, loss)
+    close(gd, g + 2 * coef * wv, 1e-6)
+    close(loss, np.array([(coef * wv * wv).sum()]), 1e-5)
+
+
+@pytest.mark.parametrize("case", [(1, 2, 2, 64, 20, 1), (1, 4, 4, 256, 512, 3), (1, 16, 16, 512, 20, 1), (1, 8, 8, 2048, 256, 1)])
+def test_wgrad_small_levels_and_accumulation(ops, case):
+    """Pixel counts that are not a multiple of the K-tile (P5/P6 of small images), the padded 20-channel RPN head, and
+    accumulation over pyramid levels."""
+    from image_captioning_amd.packing import pack_conv_kernel
+    N, H, W, Cin, Cout, k = case
+    rng = np.random.default_rng(sum(case))
+    x, dy = rng.standard_normal((N, H, W, Cin)), rng.standard_normal((N, H, W, Cout))
+    w = np.zeros((k, k, Cin, Cout))
+    _, dw, _ = O.conv2d_nhwc_backward(x, w, dy, 1, 'same' if k == 3 else 'valid')
+    pad = (k - 1) // 2
+    base = rng.standard_normal(pack_conv_kernel(dw).shape)
+    out = dev(base)
+    ops.conv2d_wgrad(dev(x), dev(dy), k, k, 1, pad, pad, out=out, accumulate=True)
+    close(out, base + pack_conv_kernel(dw), 3e-5)
+    ops.conv2d_wgrad(dev(x), dev(dy), k, k, 1, pad, pad, out=out)
+    close(out, pack_conv_kernel(dw), 3e-5)
+    if Cout == 20:                                                     # data gradient through the padded head: a K = 20 GEMM
+        wk = rng.standard_normal((1, 1, Cin, Cout))                    # on the packed forward weights [Cout][Cin] as they are
+        dx, _, _ = O.conv2d_nhwc_backward(x, wk, dy, 1, 'valid')
+        close(ops.gemm(dev(dy.reshape(-1, Cout)), dev(pack_conv_kernel(wk))), dx.reshape(-1, Cin), 3e-5)
+
+
+def test_conv_residual_in_place(ops):
+    """dP += dgrad: the residual operand may alias the output."""
+    from image_captioning_amd.packing import pack_conv_kernel
+    rng = np.random.default_rng(12)
+    x, w = rng.standard_normal((1, 16, 16, 512)), rng.standard_normal((3, 3, 512, 256)) / 60
+    acc = rng.standard_normal((1, 16, 16, 256))
+    want = acc + O.conv2d_nhwc(x, w, None, 1, 'same')
+    out = dev(acc)
+    ops.conv2d(dev(x), dev(pack_conv_kernel(w)), 3, 3, 1, 1, 1, 16, 16, residual=out, res_mode=1, out=out)
+    close(out, want, 3e-5)

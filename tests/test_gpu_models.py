@@ -232,3 +232,122 @@ def test_image_level_features_with_rpn_proposals(gpu):
     assert len(a & b) >= 0.9 * len(b), "only %d of %d proposals agree" % (len(a & b), len(b))
     want = M.image_level_features(feats[0])
     assert np.abs(vec - want).max() < 2e-2 * np.abs(want).max()
+
+
+# ---------------------------------------------------------------------------------------------
+# joint model (configs[4]): dense_img_cap/dense_model.py
+# ---------------------------------------------------------------------------------------------
+
+def make_joint(S=128, V=24, T=5, blocks=1):
+    from image_captioning_amd import synth
+    from image_captioning_amd.config import Config
+    from image_captioning_amd.dense_model import DenseImageCapRCNN
+
+    class Cfg(Config):
+        NAME = "joint"
+        IMAGES_PER_GPU = 1
+        IMAGE_MIN_DIM = S
+        IMAGE_MAX_DIM = S
+        POST_NMS_ROIS_TRAINING = 60
+        TRAIN_ROIS_PER_IMAGE = 12
+        PADDING_SIZE = T
+        VOCABULARY_SIZE = V
+        EMBEDDING_SIZE = 300
+    cfg = Cfg()
+    Wt = dict(synth.encoder_weights(0, blocks), **synth.rpn_weights(4))
+    Wt['rpn_conv_shared/kernel'] = Wt['rpn_conv_shared/kernel'] * np.float32(0.05)
+    Wt['rpn_bbox_pred/kernel'] = Wt['rpn_bbox_pred/kernel'] * np.float32(0.3)
+    Wt.update(synth.head_weights(1))
+    Wt['mrcnn_class_conv1/kernel'] = Wt['mrcnn_class_conv1/kernel'] * np.float32(0.05)   # random FPN maps are O(10): keep the
+    Wt.update(synth.v1_weights(2, V))                                                    # vocabulary softmax out of saturation
+    Wt['imgcap_embedding_layer/embeddings'] = synth.embedding_matrix(3, V)
+    cfg.EMBEDDING_WEIGHTS = Wt['imgcap_embedding_layer/embeddings']
+    model = DenseImageCapRCNN("training", cfg, "logs", stage4_blocks=blocks)
+    model.set_weights(Wt)
+    return model, cfg, Wt
+
+
+def joint_inputs(S, V, T, seed=8):
+    from image_captioning_amd import synth
+    rng = np.random.default_rng(seed)
+    img = synth.images(7, 1, S, S)
+    gt_boxes = np.zeros((1, 6, 4), np.float32)
+    gt_boxes[0, :3] = np.array([[10, 12, 70, 90], [40, 30, 120, 128], [0, 0, 50, 40]], np.float32) * (S / 128.0)
+    gt_caps = np.zeros((1, 6, T), np.int32)
+    gt_caps[0, :3] = synth.captions_v1(9, 3, T, V, lmin=1, lmax=3)
+    n_anchor = sum((S // s) ** 2 for s in (4, 8, 16, 32, 64)) * 3
+    match = np.zeros((1, n_anchor, 1), np.int32)
+    match[0, rng.choice(n_anchor, 40, replace=False), 0] = np.where(rng.random(40) < 0.4, 1, -1)
+    tdelta = rng.standard_normal((1, 64, 4))
+    return [img, np.zeros((1, 12)), match, tdelta, gt_caps, gt_boxes]
+
+
+def joint_oracle(Wt, cfg, inputs, targets, blocks):
+    img, _, match, tdelta, gt_caps, gt_boxes = inputs
+    oc = dict(mean_pixel=MEAN, scales=cfg.RPN_ANCHOR_SCALES, ratios=cfg.RPN_ANCHOR_RATIOS, strides=cfg.BACKBONE_STRIDES,
+              proposal_count=cfg.POST_NMS_ROIS_TRAINING, nms=cfg.RPN_NMS_THRESHOLD, train_rois=cfg.TRAIN_ROIS_PER_IMAGE,
+              positive_ratio=cfg.ROI_POSITIVE_RATIO, weight_decay=cfg.WEIGHT_DECAY, T=cfg.PADDING_SIZE)
+    return M.joint_loss_and_grads(Wt, img[0], match[0, :, 0], tdelta[0], gt_caps[0], gt_boxes[0], oc, stage4_blocks=blocks,
+                                  targets_override=targets)
+
+
+def joint_grads_as_reference(model):
+    """The flat gradient bucket re-expressed with the reference's layer names and HWIO kernels."""
+    st = model.store
+    saved = st.flat.clone()
+    st.flat.copy_(st.flat_grad)
+    try:
+        out = model.get_weights_dict()
+    finally:
+        st.flat.copy_(saved)
+    return out
+
+
+def test_joint_model_step_matches_oracle(gpu):
+    """One image through FPN + RPN + proposals + detection targets + RoIAlign + head + Model-3 decoder: the four loss
+    terms and the gradient of every trainable weight against the oracle's hand-written backward (which
+    tests/test_oracle_vs_torch.py ties to torch autograd), given the RoI sample the device drew."""
+    S, V, T, blocks = 128, 24, 5, 1
+    model, cfg, Wt = make_joint(S, V, T, blocks)
+    inputs = joint_inputs(S, V, T)
+    for rep in range(2):                                   # eager plan, then captured graph
+        losses = model._loss_list(model.forward_backward(inputs, shuffle=None))
+    tg = model.last_targets
+    assert tg['npos'] > 0, "no positive RoI: the caption loss is not exercised"
+    want, G, aux = joint_oracle(Wt, cfg, inputs, (tg['rois'], tg['caps']), blocks)
+    # the device's own proposals reproduce the oracle's sample unless near-tied scores swapped
+    agree = sum(1 for r in tg['rois'] if np.abs(aux['proposals'] - r).sum(1).min() < 1e-5)
+    assert agree >= 0.8 * (tg['npos'] + tg['nneg'])
+    for k in ('imgcap_loss', 'rpn_class_loss', 'rpn_bbox_loss', 'reg_loss', 'loss'):
+        assert abs(losses[k] - want[k]) < 1e-4 * max(1.0, abs(want[k])), (k, losses[k], want[k])
+    got = joint_grads_as_reference(model)
+    for k in M.joint_trainable(Wt):
+        assert rel_err(got[k], G[k]) < 2e-4, (k, rel_err(got[k], G[k]))
+
+
+def test_joint_model_training_reduces_loss_and_round_trips_weights(gpu, tmp_path):
+    S, V, T, blocks = 128, 24, 5, 1
+    model, cfg, Wt = make_joint(S, V, T, blocks)
+    back = model.get_weights_dict()
+    for k, v in Wt.items():
+        assert np.array_equal(back[k], np.asarray(v, np.float32)), k
+    inputs = joint_inputs(S, V, T)
+    model.compile(3e-5)
+    first = model.train_on_batch(inputs)
+    assert len(first) == 4 and abs(first[0] - (first[1] + first[2] + first[3] + model.last_losses['reg_loss'])) < 1e-5
+    for _ in range(12):
+        last = model.train_on_batch(inputs)
+    assert np.isfinite(last).all() and last[1] + last[2] < first[1] + first[2]       # the RPN targets are fixed: its losses fall
+    path = str(tmp_path / "joint.npz")
+    model.save_weights(path)
+    other, _, _ = make_joint(S, V, T, blocks)
+    other.load_weights(path, by_name=True)
+    a, b = model.get_weights_dict(), other.get_weights_dict()
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    # caption_only freezes FPN/RPN/head: their weights stay put, the decoder moves
+    other.set_trainable(other.LAYER_REGEX["caption_only"])
+    other.compile(1e-3)
+    other.train_on_batch(inputs)
+    c = other.get_weights_dict()
+    assert np.array_equal(b['fpn_p3/kernel'], c['fpn_p3/kernel']) and np.array_equal(b['mrcnn_class_conv1/kernel'], c['mrcnn_class_conv1/kernel'])
+    assert not np.array_equal(b['imgcap_lstm_d2/kernel'], c['imgcap_lstm_d2/kernel'])
