@@ -82,16 +82,50 @@ extern "C" int dc_debug_stamps(unsigned long long* out, int reset) {
 extern "C" int dc_version(void) { return 1; }
 extern "C" const char* dc_last_error(void) { return g_err; }
 
+// K not a multiple of the 32-deep K-tile (vocabulary 50 000, T*B = 3000 caption rows, 300-d embeddings): the bulk runs on
+// the unchecked fast loaders and the last K % 32 columns are accumulated by one launch of the range-checked kernel.
+// Only for additive epilogues (bias / residual / accumulate), which commute with the split.
+static bool gemm_split_tail(const dc_gemm_desc* d, dc_gemm_desc* bulk, dc_gemm_desc* tail) {
+    if ((d->K & 31) == 0 || d->K < 128 || d->relu || d->scale) return false;
+    const int K0 = d->K & ~31;
+    *bulk = *d;
+    bulk->K = K0;
+    if (!gemm_is_fast(bulk)) return false;
+    *tail = *d;
+    tail->K = d->K - K0;
+    if (d->a_gather && d->a_trans) tail->a_gather = d->a_gather + K0;
+    else tail->A = d->A + (d->a_trans ? (size_t)K0 * d->lda : (size_t)K0);
+    tail->B = d->B + (d->b_trans ? (size_t)K0 : (size_t)K0 * d->ldb);
+    tail->scale = tail->shift = tail->residual = nullptr;
+    tail->res_rows = 0;
+    tail->accumulate = 1;
+    tail->split_k = 1;
+    return true;
+}
+
 extern "C" size_t dc_gemm_workspace_bytes(const dc_gemm_desc* d) {
     if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+    dc_gemm_desc bulk, tail;
+    if (gemm_split_tail(d, &bulk, &tail)) d = &bulk;
     const TileChoice t = choose_tile(d->M, d->N, d->K, d->split_k, gemm_is_fast(d));
     return t.split > 1 ? (size_t)t.split * d->M * d->N * sizeof(float) : 0;
 }
+
+static int gemm_run(const dc_gemm_desc* d, void* workspace, size_t workspace_bytes, hipStream_t s);
 
 extern "C" int dc_gemm_f32(const dc_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = gemm_validate(d);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    dc_gemm_desc bulk, tail;
+    if (gemm_split_tail(d, &bulk, &tail)) {
+        rc = gemm_run(&bulk, workspace, workspace_bytes, s);
+        return rc ? rc : gemm_run(&tail, workspace, workspace_bytes, s);
+    }
+    return gemm_run(d, workspace, workspace_bytes, s);
+}
+
+static int gemm_run(const dc_gemm_desc* d, void* workspace, size_t workspace_bytes, hipStream_t s) {
     const bool fast = gemm_is_fast(d);
     const TileChoice t = choose_tile(d->M, d->N, d->K, d->split_k, fast);
     Epilogue ep{d->C, d->ldc, d->scale, d->shift, d->residual, d->ldr, d->residual ? (d->res_rows > 0 ? 3 : 1) : 0, d->res_rows, 0, d->relu, d->accumulate, 0};

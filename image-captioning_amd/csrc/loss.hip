@@ -143,20 +143,59 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
     }
 }
 
-// out[n] (+)= sum_m x[m][n]; block = 64 columns x 4 row lanes, rows summed in a fixed order.
+// out[n] (+)= sum_m x[m][n].  A block is CL column lanes x (256/CL) row lanes (CL = power of two <= 64, chosen from N so
+// that narrow matrices such as the 20-channel RPN head still use every lane), VEC floats per lane; gridDim.y row chunks.
+// One chunk: written straight to out.  Several chunks (tall activations / gradients): every chunk writes its partial row
+// into the caller's workspace [chunks][N] and colsum_finish_kernel adds them in chunk order -- the result does not depend
+// on scheduling (no atomics), which keeps training runs bit-reproducible.
+template <int VEC>
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int M, int N, int ld, float* __restrict__ out,
-                                                     int accumulate) {
-    __shared__ float red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-    float s = 0.f;
-    if (c < N)
-        for (int m = rl; m < M; m += 4) s += x[(long)m * ld + c];
-    red[rl][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (rl == 0 && c < N) {
-        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        out[c] = accumulate ? out[c] + v : v;
+                                                     int accumulate, int cl_log2, int rows_per_chunk, float* __restrict__ partial) {
+    __shared__ float red[256 * VEC];
+    const int CL = 1 << cl_log2, RL = 256 >> cl_log2;
+    const int cl = threadIdx.x & (CL - 1), rl = threadIdx.x >> cl_log2;
+    const int c = (blockIdx.x * CL + cl) * VEC;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    float s[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) s[v] = 0.f;
+    if (c < N) {
+#pragma unroll 4
+        for (int m = r0 + rl; m < r1; m += RL) {
+            if constexpr (VEC == 4) {
+                const float4 q = *reinterpret_cast<const float4*>(x + (long)m * ld + c);
+                s[0] += q.x; s[1] += q.y; s[2] += q.z; s[3] += q.w;
+            } else {
+                s[0] += x[(long)m * ld + c];
+            }
+        }
     }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) red[(rl * CL + cl) * VEC + v] = s[v];
+    __syncthreads();
+    for (int h = RL >> 1; h > 0; h >>= 1) {
+        if (rl < h) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) red[(rl * CL + cl) * VEC + v] += red[((rl + h) * CL + cl) * VEC + v];
+        }
+        __syncthreads();
+    }
+    if (rl == 0 && c < N) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            if (gridDim.y > 1) partial[(long)blockIdx.y * N + c + v] = red[cl * VEC + v];
+            else out[c + v] = accumulate ? out[c + v] + red[cl * VEC + v] : red[cl * VEC + v];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, int chunks, int N, float* __restrict__ out,
+                                                            int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    float s = accumulate ? out[c] : 0.f;
+    for (int k = 0; k < chunks; ++k) s += partial[(long)k * N + c];
+    out[c] = s;
 }
 
 // one wave per row, float4 per lane
@@ -366,10 +405,48 @@ extern "C" int dc_fold_time_f32(const float* x, int T, int B, int N, int ld, flo
     return check_launch("fold_time_kernel");
 }
 
-extern "C" int dc_colsum_f32(const float* x, int M, int N, int ld, float* out, int accumulate, void* stream) {
+struct ColsumPlan { bool vec; int cl_log2, col_tiles, chunks, rows_per_chunk; };
+static ColsumPlan colsum_plan(const float* x, int M, int N, int ld) {
+    ColsumPlan p;
+    p.vec = (N & 3) == 0 && (ld & 3) == 0 && aligned16(x);
+    const int lanes = p.vec ? N / 4 : N;
+    p.cl_log2 = 0;
+    while ((1 << p.cl_log2) < lanes && p.cl_log2 < 6) ++p.cl_log2;
+    const int CL = 1 << p.cl_log2, RL = 256 >> p.cl_log2;
+    p.col_tiles = (lanes + CL - 1) / CL;
+    // enough blocks to cover the chip a few times over, each summing at least 4 rows per row lane
+    p.chunks = std::max(1, std::min((kNumCU * 4) / p.col_tiles, M / (RL * 4)));
+    p.rows_per_chunk = (M + p.chunks - 1) / p.chunks;
+    p.chunks = (M + p.rows_per_chunk - 1) / p.rows_per_chunk;
+    return p;
+}
+
+extern "C" size_t dc_colsum_workspace_bytes(int M, int N, int ld) {
+    if (M <= 0 || N <= 0) return 0;
+    const ColsumPlan p = colsum_plan(nullptr, M, N, ld);
+    return p.chunks > 1 ? (size_t)p.chunks * N * sizeof(float) : 0;
+}
+
+extern "C" int dc_colsum_f32(const float* x, int M, int N, int ld, float* out, int accumulate, void* workspace, size_t workspace_bytes,
+                             void* stream) {
     DC_REQUIRE(x && out && M > 0 && N > 0 && ld >= N, DC_EINVAL, "dc_colsum: bad arguments");
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), x, M, N, ld, out, accumulate);
-    return check_launch("colsum_kernel");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ColsumPlan p = colsum_plan(x, M, N, ld);
+    if (p.chunks > 1 && (!workspace || workspace_bytes < (size_t)p.chunks * N * sizeof(float))) {
+        p.chunks = 1;                                     // no scratch: one block column walks all rows (slow, still exact)
+        p.rows_per_chunk = M;
+    }
+    float* partial = static_cast<float*>(workspace);
+    if (p.vec)
+        hipLaunchKernelGGL(colsum_kernel<4>, dim3(p.col_tiles, p.chunks), dim3(256), 0, s, x, M, N, ld, out, accumulate, p.cl_log2,
+                           p.rows_per_chunk, partial);
+    else
+        hipLaunchKernelGGL(colsum_kernel<1>, dim3(p.col_tiles, p.chunks), dim3(256), 0, s, x, M, N, ld, out, accumulate, p.cl_log2,
+                           p.rows_per_chunk, partial);
+    int rc = check_launch("colsum_kernel");
+    if (rc || p.chunks == 1) return rc;
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, s, partial, p.chunks, N, out, accumulate);
+    return check_launch("colsum_finish_kernel");
 }
 
 extern "C" int dc_sumsq_f32(const float* x, size_t n, float* out, int accumulate, void* stream) {

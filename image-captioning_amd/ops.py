@@ -437,7 +437,8 @@ def colsum(x, out=None, accumulate=False):
     _chk(x, name="x")
     if out is None:
         out = torch.empty((x.shape[1],), dtype=torch.float32, device=x.device)
-    check(lib.dc_colsum_f32(_ptr(x), x.shape[0], x.shape[1], x.stride(0), _ptr(out), int(accumulate), _stream()), "dc_colsum_f32")
+    ws, wsb = WORKSPACE.get(lib.dc_colsum_workspace_bytes(x.shape[0], x.shape[1], x.stride(0)), x.device)
+    check(lib.dc_colsum_f32(_ptr(x), x.shape[0], x.shape[1], x.stride(0), _ptr(out), int(accumulate), _ptr(ws), wsb, _stream()), "dc_colsum_f32")
     return out
 
 

@@ -323,8 +323,12 @@ int dc_relu_bwd_f32(const float* dy, const float* y, float* out, int M, int N, i
  * over timesteps -- RepeatVector(feature), text_generation_model.py:146). */
 int dc_fold_time_f32(const float* x, int T, int B, int N, int ld, float* out, int ld_out, void* stream);
 
-/* out[n] (+)= sum_m x[m][n]  -- bias gradients. */
-int dc_colsum_f32(const float* x, int M, int N, int ld, float* out, int accumulate, void* stream);
+/* out[n] (+)= sum_m x[m][n]  -- bias gradients (K.sum over batch/time inside the Dense/Conv backward of Keras).
+ * Tall matrices are summed in row chunks through `workspace` (dc_colsum_workspace_bytes) and combined in a fixed
+ * order: bit-reproducible.  Without workspace the kernel falls back to one chunk. */
+size_t dc_colsum_workspace_bytes(int M, int N, int ld);
+int dc_colsum_f32(const float* x, int M, int N, int ld, float* out, int accumulate, void* workspace, size_t workspace_bytes,
+                  void* stream);
 
 /* out[0] (+)= sum(x^2) -- global-norm clipping (Adam(clipnorm=0.5), dense_img_cap/dense_model.py:1699). */
 int dc_sumsq_f32(const float* x, size_t n, float* out, int accumulate, void* stream);

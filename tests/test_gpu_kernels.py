@@ -461,3 +461,41 @@ def test_conv_residual_in_place(ops):
     out = dev(acc)
     ops.conv2d(dev(x), dev(pack_conv_kernel(w)), 3, 3, 1, 1, 1, 16, 16, residual=out, res_mode=1, out=out)
     close(out, want, 3e-5)
+
+
+@pytest.mark.parametrize("M,N", [(5000, 20), (65536, 256), (3000, 1003), (7, 4), (300, 50000), (4097, 512)])
+def test_colsum_shapes(ops, M, N):
+    """Bias gradients: narrow RPN head, tall conv gradients (row chunks + atomics), odd widths, the vocabulary bias."""
+    rng = np.random.default_rng(M + N)
+    x = rng.standard_normal((M, N)).astype(np.float32)
+    want = x.astype(np.float64).sum(0)
+    close(ops.colsum(dev(x)), want, 2e-6 * np.sqrt(M))
+    acc = dev(np.full(N, 2.0))
+    ops.colsum(dev(x), out=acc, accumulate=True)
+    close(acc, want + 2, 2e-6 * np.sqrt(M))
+
+
+@pytest.mark.parametrize("ta,tb,M,N,K", [(1, 0, 1024, 520, 3000), (0, 1, 300, 1024, 5008), (0, 0, 200, 2048, 300), (1, 1, 64, 64, 200)])
+def test_gemm_k_tail_split(ops, ta, tb, M, N, K):
+    """K % 32 != 0: bulk on the fast loaders + one range-checked tail launch, with bias / residual / accumulate and split-K."""
+    rng = np.random.default_rng(K)
+    A, B = rng.standard_normal((M, K)), rng.standard_normal((K, N)) / np.sqrt(K)
+    sh, R, C0 = rng.standard_normal(N), rng.standard_normal((M, N)), rng.standard_normal((M, N))
+    a = dev(A.T if ta else A)
+    b = dev(B.T if tb else B)
+    for split in (0, 3):
+        out = dev(C0)
+        ops.gemm(a, b, out=out, a_trans=bool(ta), b_trans=bool(tb), shift=dev(sh), residual=dev(R), accumulate=True, split_k=split)
+        close(out, A @ B + sh + R + C0)
+    close(ops.gemm(a, b, a_trans=bool(ta), b_trans=bool(tb)), A @ B)
+
+
+def test_gemm_k_tail_split_with_gather(ops):
+    rng = np.random.default_rng(9)
+    V, E, N, rows = 400, 300, 256, 200
+    table, W = rng.standard_normal((V, E)), rng.standard_normal((E, N))
+    ids = rng.integers(0, V, rows)
+    close(ops.gemm(dev(table), dev(W), gather=dev(ids, torch.int32), shift=dev(np.ones(N))), table[ids] @ W + 1.0)   # K = 300
+    dz = rng.standard_normal((rows, N))
+    got = ops.gemm(dev(table), dev(dz), a_trans=True, gather=dev(ids, torch.int32))                                    # K = 200 rows
+    close(got, table[ids].T @ dz, 5e-5)
