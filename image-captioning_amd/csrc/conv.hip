@@ -148,8 +148,10 @@ static int wgrad_validate(const dc_conv_desc* d) {
 
 static TileChoice wgrad_tile(const dc_conv_desc* d) {
     const int M = d->Cout, N = d->kh * d->kw * d->Cin, K = d->N * d->Ho * d->Wo;
-    TileChoice t = choose_tile(M, N, K, d->split_k, false);         // 64x64 tiles: a column tile stays inside one tap
-    return t;
+    // a column tile must stay inside one (ky,kx) tap: 128-wide tiles need Cin % 128 == 0; the range-checked A loader
+    // (pixel count not a multiple of 32) exists for 64x64 only
+    const bool big = d->Cin % 128 == 0 && d->Cout >= 128 && K % 32 == 0;
+    return choose_tile(M, N, K, d->split_k, big);
 }
 
 extern "C" size_t dc_conv2d_wgrad_workspace_bytes(const dc_conv_desc* d) {
@@ -168,8 +170,12 @@ extern "C" int dc_conv2d_wgrad_f32(const dc_conv_desc* d, void* workspace, size_
                 (unsigned)((size_t)d->N * d->H * d->W * d->Cin * sizeof(float))};
     if (K % 32 == 0) {
         DenseMCT<true> al{d->y, d->Cout, M, nullptr};               // A^T: dy is [pixels][Cout]
-        return launch_igemm<64, 64, DenseMCT<true>, Im2colMC>(al, bl, ep, M, N, K, t.split, workspace, workspace_bytes,
-                                                             static_cast<hipStream_t>(stream));
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        if (t.bm == 128 && t.bn == 128)
+            return launch_igemm<128, 128, DenseMCT<true>, Im2colMC>(al, bl, ep, M, N, K, t.split, workspace, workspace_bytes, s);
+        if (t.bm == 128 && t.bn == 64)
+            return launch_igemm<128, 64, DenseMCT<true>, Im2colMC>(al, bl, ep, M, N, K, t.split, workspace, workspace_bytes, s);
+        return launch_igemm<64, 64, DenseMCT<true>, Im2colMC>(al, bl, ep, M, N, K, t.split, workspace, workspace_bytes, s);
     }
     DenseMCT<false> al{d->y, d->Cout, M, nullptr};                  // pixel count not a multiple of the K-tile (tiny pyramid levels)
     return launch_igemm<64, 64, DenseMCT<false>, Im2colMC>(al, bl, ep, M, N, K, t.split, workspace, workspace_bytes,

@@ -16,6 +16,7 @@
 // MFMA j of an 8-wide K chunk contracts k = {j, 4+j} (lane half h takes k = 4h+j) on BOTH operands,
 // so the permuted K order is consistent.
 #pragma once
+#include <math.h>
 #include "dcap_internal.h"
 #include <stdlib.h>
 
@@ -704,21 +705,50 @@ int launch_igemm(const AL& al, const BL& bl, const Epilogue& ep, int M, int N, i
 struct TileChoice {
     int bm, bn, split;
 };
+// Tile / split-K choice.  Grids that fill the chip twice over keep the largest tile that does so; smaller ones run 64x64
+// tiles with split-K (the rule the encoder's layer table was tuned with).  Tall-K problems that under-fill the chip
+// (K >= 8192: weight gradients over pixels, the vocabulary GEMMs) are priced with a small model: waves of blocks over the
+// CUs (2 resident blocks per CU -> half-wave granularity) x K-tiles per slice x time per K-tile, where bigger tiles run
+// the MFMA pipe more efficiently (measured: ~0.70 / 0.58 / 0.45 of peak for 128x128 / 128x64 / 64x64), plus the split-K
+// slab traffic.  DCAP_TILE=64|12864|128 forces a tile (experiments only).
 inline TileChoice choose_tile(int M, int N, int K, int user_split, bool allow_128 = true) {
     auto nb = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     TileChoice t{64, 64, 1};
-    static int force = -1;       // experiment knob: DCAP_TILE=64|12864|128
+    static int force = -1;
     if (force < 0) { const char* e = getenv("DCAP_TILE"); force = e ? atoi(e) : 0; }
+    const int ktiles = (K + BK - 1) / BK;
+    bool priced = false;
     if (force == 64 || !allow_128) t = {64, 64, 1};
     else if (force == 12864) t = {128, 64, 1};
     else if (force == 128) t = {128, 128, 1};
     else if (N >= 128 && nb(128, 128) >= 2 * kNumCU) t = {128, 128, 1};
     else if (nb(128, 64) >= 2 * kNumCU) t = {128, 64, 1};
+    else if (user_split <= 0 && N >= 64 && ktiles >= 256) priced = true;
+    if (priced) {
+        const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+        const double eff[3] = {0.70, 0.58, 0.45};
+        const double cu_flops = 157.3e12 / kNumCU;
+        double best = 1e30;
+        for (int c = 0; c < 3; ++c) {
+            const int bm = cand[c][0], bn = cand[c][1];
+            if (bn > 64 && N < 128) continue;
+            const double blocks = nb(bm, bn);
+            const double t_tile = 2.0 * bm * bn * BK / (cu_flops * eff[c]);
+            for (int sp = 1; sp <= 32; sp = sp < 4 ? sp + 1 : sp + sp / 2) {
+                if (sp > 1 && ktiles / sp < 4) break;               // keep >= 4 K-tiles (128 deep) per slice
+                const double w = blocks * sp / kNumCU;
+                const double waves = w <= 1.0 ? 1.0 : ceil(w * 2.0) / 2.0;
+                double cost = waves * ((ktiles + sp - 1) / sp) * t_tile + 4e-6;
+                if (sp > 1) cost += (double)M * N * 4.0 * (sp + 1) / 4e12 + 3e-6;
+                if (cost < best) { best = cost; t = {bm, bn, sp}; }
+            }
+        }
+        return t;
+    }
     if (user_split > 0) {
         t.split = user_split;
     } else {
         const int blocks = nb(t.bm, t.bn);
-        const int ktiles = (K + BK - 1) / BK;
         if (blocks < kNumCU && ktiles >= 8) {
             int s = (2 * kNumCU + blocks - 1) / blocks;
             if (s > ktiles / 4) s = ktiles / 4;      // keep >= 4 K-tiles (128 deep) per slice

@@ -415,7 +415,7 @@ static ColsumPlan colsum_plan(const float* x, int M, int N, int ld) {
     const int CL = 1 << p.cl_log2, RL = 256 >> p.cl_log2;
     p.col_tiles = (lanes + CL - 1) / CL;
     // enough blocks to cover the chip a few times over, each summing at least 4 rows per row lane
-    p.chunks = std::max(1, std::min((kNumCU * 4) / p.col_tiles, M / (RL * 4)));
+    p.chunks = std::max(1, std::min(std::min((kNumCU * 4) / p.col_tiles, M / (RL * 4)), 128));   // <= 128 partial rows to combine
     p.rows_per_chunk = (M + p.chunks - 1) / p.chunks;
     p.chunks = (M + p.rows_per_chunk - 1) / p.rows_per_chunk;
     return p;
