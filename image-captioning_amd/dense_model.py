@@ -125,6 +125,57 @@ def mold_image(images, config):
     return utils.mold_image(images, config)
 
 
+def non_max_suppression(boxes, scores, threshold):
+    """Greedy NMS on (y1,x1,y2,x2) boxes, best score first (utils.non_max_suppression of the reference); returns the
+    kept indices in score order."""
+    boxes = np.asarray(boxes, np.float64)
+    if boxes.shape[0] == 0:
+        return np.zeros(0, np.int32)
+    area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+    order = np.argsort(scores)[::-1]
+    keep = []
+    while order.size:
+        i = order[0]
+        keep.append(i)
+        rest = order[1:]
+        ih = np.maximum(np.minimum(boxes[i, 2], boxes[rest, 2]) - np.maximum(boxes[i, 0], boxes[rest, 0]), 0)
+        iw = np.maximum(np.minimum(boxes[i, 3], boxes[rest, 3]) - np.maximum(boxes[i, 1], boxes[rest, 1]), 0)
+        inter = ih * iw
+        with np.errstate(divide="ignore", invalid="ignore"):
+            iou = inter / (area[i] + area[rest] - inter)
+        order = rest[~(iou > threshold)]
+    return np.asarray(keep, np.int32)
+
+
+def clip_to_window(window, boxes):
+    boxes = np.array(boxes, np.float64)
+    boxes[:, [0, 2]] = np.clip(boxes[:, [0, 2]], window[0], window[2])
+    boxes[:, [1, 3]] = np.clip(boxes[:, [1, 3]], window[1], window[3])
+    return boxes
+
+
+def refine_generations(rois, word_scores, window, config):
+    """GenerationMatchLayer for one image (:593-630): caption score = sum over positions of log(max word probability)
+    (word_scores [N,T] holds those maxima); boxes to pixels of the molded image, clipped to the window, rounded;
+    NMS(DETECTION_NMS_THRESHOLD) on the clipped boxes by caption score; the best DETECTION_MAX_INSTANCES survive.
+    (The reference then indexes `keep` by its own leading values, which raises for most inputs; the evident intent --
+    the leading entries of `keep` -- is what runs here.)  Returns (int32 boxes [K,4], kept indices [K])."""
+    with np.errstate(divide="ignore"):
+        scores = np.log(np.asarray(word_scores, np.float64)).sum(axis=1)
+    h, w = config.IMAGE_SHAPE[:2]
+    boxes = clip_to_window(window, np.asarray(rois, np.float64) * np.array([h, w, h, w], np.float64))
+    keep = non_max_suppression(boxes, scores, config.DETECTION_NMS_THRESHOLD)[:config.DETECTION_MAX_INSTANCES]
+    return np.rint(boxes[keep]).astype(np.int32), keep
+
+
+def unmold_generations(boxes, image_shape, window):
+    """Boxes of the molded image -> the original image's pixels (:1925-1962); returns (boxes, mask of non-empty ones)."""
+    scale = min(image_shape[0] / (window[2] - window[0]), image_shape[1] / (window[3] - window[1]))
+    shift = np.array([window[0], window[1], window[0], window[1]])
+    out = ((np.asarray(boxes) - shift) * scale).astype(np.int32)
+    return out, (out[:, 2] - out[:, 0]) * (out[:, 3] - out[:, 1]) > 0
+
+
 def load_image_gt(dataset, config, image_id, augment=False, rng=np.random):
     """image (resized + padded), image_meta, gt_captions [G,T], gt_boxes [G,4] (dense_model.py:953-984).
     As in the reference the boxes are handed on exactly as the dataset stores them: they are NOT rescaled or padded
@@ -321,6 +372,20 @@ class DenseImageCapRCNN(object):
     def save_weights(self, path):
         np.savez(path, **self.get_weights_dict())
 
+    def find_last(self):
+        """(model_dir, newest checkpoint written by train()) or (model_dir, None) -- dense_model.py:1631-1654."""
+        if not os.path.isdir(self.model_dir):
+            return None, None
+        names = sorted(f for f in os.listdir(self.model_dir) if f.startswith("dense_image_cap_rcnn_") and f.endswith(".npz"))
+        return self.model_dir, (os.path.join(self.model_dir, names[-1]) if names else None)
+
+    def summary(self):
+        rows = ["%-40s %-24s %s" % (k, tuple(v.shape), "trainable" if k in self.store.grad else "frozen")
+                for k, v in sorted(self.store.w.items())]
+        rows.append("backbone (frozen, BN folded): %d tensors" % len(self._backbone))
+        rows.append("trainable parameters: %d" % self.store.n_train)
+        return "\n".join(rows)
+
     def _weights_changed(self):
         pass
 
@@ -508,6 +573,39 @@ class DenseImageCapRCNN(object):
     def test_on_batch(self, inputs, targets=None):
         self.last_losses = d = self._loss_list(self.forward_backward(inputs))
         return [d["loss"], d["rpn_class_loss"], d["rpn_bbox_loss"], d["imgcap_loss"]]
+
+    # ---- inference -------------------------------------------------------------------------
+    def mold_inputs(self, images):
+        molded, metas, windows = [], [], []
+        for image in images:
+            m, window, scale, padding = utils.resize_image(image, min_dim=self.config.IMAGE_MIN_DIM, max_dim=self.config.IMAGE_MAX_DIM,
+                                                           padding=self.config.IMAGE_PADDING)
+            molded.append(m)                                # mean subtraction happens on the GPU
+            metas.append(utils.compose_image_meta(0, image.shape, window))
+            windows.append(window)
+        return np.stack(molded), np.stack(metas), np.stack(windows)
+
+    def generate_captions(self, images, verbose=0, return_probabilities=True):
+        """The inference graph (:1602-1622) + generate_captions (:1964-2003): RPN proposals (POST_NMS_ROIS_INFERENCE) ->
+        RoI features -> greedy ROICaptionInferenceLayer -> GenerationMatchLayer -> boxes in the original image.
+        Returns [{'rois': int32 [K,4], 'captions': f32 [K,T,V] word probabilities, 'ids': int32 [K,T]}]; with
+        return_probabilities=False the [K,T,V] tensor (3 GB at 1000 RoIs x 15 x 50 000) stays on the GPU and is dropped."""
+        assert self.mode == "inference", "Create model in inference mode."
+        assert len(images) == self.config.BATCH_SIZE, "len(images) must be equal to BATCH_SIZE"
+        molded, metas, windows = self.mold_inputs(images)
+        p = self.plan()
+        p.forward(torch.as_tensor(molded))
+        proposals = p.proposals()
+        self.last_proposals = proposals
+        feats = p.roi_features(boxes_norm=proposals)
+        probs, ids, word_scores = self.caption_model.generate(feats[0], return_probabilities=return_probabilities)
+        boxes, keep = refine_generations(proposals[0].cpu().numpy(), word_scores, windows[0], self.config)
+        final, ok = unmold_generations(boxes, images[0].shape, windows[0])
+        keep = keep[ok]
+        out = {"rois": final[ok], "ids": ids[keep]}
+        if return_probabilities:
+            out["captions"] = probs[keep]
+        return [out]
 
     # ---- training loop ----------------------------------------------------------------------
     def train(self, train_dataset, val_dataset, learning_rate, epochs, layers):

@@ -91,11 +91,14 @@ class ParallelModel(object):
     def shard_inputs(self, inputs):
         return [shard(x, self.rank, self.gpu_count) for x in inputs]
 
-    def train_on_batch(self, inputs, targets):
-        """Global batch in, split like tf.split; returns the mean over towers of the tower losses."""
-        loss = self.inner_model.train_on_batch(self.shard_inputs(inputs), shard(targets, self.rank, self.gpu_count))
+    def train_on_batch(self, inputs, targets=None):
+        """Global batch in, split like tf.split; returns the mean over towers of the tower losses (a scalar, or the
+        joint model's [loss, rpn_class_loss, rpn_bbox_loss, imgcap_loss] list)."""
+        mine = None if targets is None or len(targets) == 0 else shard(targets, self.rank, self.gpu_count)
+        loss = self.inner_model.train_on_batch(self.shard_inputs(inputs), mine)
         if self.gpu_count > 1:
-            t = torch.tensor([loss], dtype=torch.float64, device=self.inner_model.device)
+            t = torch.tensor(loss if isinstance(loss, (list, tuple)) else [loss], dtype=torch.float64, device=self.inner_model.device)
             dist.all_reduce(t)
-            loss = float(t.item()) / self.gpu_count
+            vals = (t / self.gpu_count).tolist()
+            loss = vals if isinstance(loss, (list, tuple)) else vals[0]
         return loss

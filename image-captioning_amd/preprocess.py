@@ -12,6 +12,33 @@ def word_tokenize(text):
     return _TOKEN.findall(text)
 
 
+def load_embeddings(file_name):
+    """GloVe text file -> {word: float vector} (dense_img_cap/preprocess.py:30-40); keys lower-cased."""
+    table = {}
+    with open(file_name, 'r', encoding='utf-8') as doc:
+        for line in doc:
+            parts = line.rstrip('\n').lower().split(' ')
+            if len(parts) > 1:
+                table[parts[0]] = np.array(parts[1:], dtype=np.float64)
+    return table
+
+
+def tokenize_corpus(data_file, train, embeddings, min_count=15):
+    """Vocabulary of the training regions (dense_img_cap/preprocess.py:43-56): tokens seen at least 15 times that have an
+    embedding and are not punctuation."""
+    import json
+    from collections import Counter
+    from string import punctuation
+    train = set(train)
+    counts = Counter()
+    with open(data_file, 'r', encoding='utf-8') as doc:
+        for image in json.load(doc):
+            if image['id'] in train:
+                for region in image['regions']:
+                    counts.update(word_tokenize(region['phrase'].lower()))
+    return {w for w, n in counts.items() if n >= min_count and w in embeddings and w not in punctuation}
+
+
 def load_corpus(tokens, embeddings, embeddings_dim):
     """ids: 0 <unk>/pad (zero row), 1 <start>, 2 <end> (uniform(-0.5,0.5) rows), then the tokens."""
     id_to_word = {0: '<unk>', 1: '<start>', 2: '<end>'}

@@ -339,24 +339,34 @@ class CaptionModelV1(KerasLikeModel):
         loss_rows, _ = self._forward_train(self._dev_feat(feat), caps, self._target_ids(targets))
         return float(ops.mean(loss_rows).item())
 
-    def generate(self, feat):
+    def generate(self, feat, return_probabilities=None):
         """ROICaptionInferenceLayer (:192-232): start token 1; step j feeds [prev..., 0...] through the word
-        model and appends float(argmax).  Returns (probs [B,T,V], ids [B,T])."""
+        model and appends float(argmax).  Returns (probs [B,T,V], ids [B,T]); with return_probabilities given (the joint
+        model) returns (probs or None, ids, word_scores [B,T] = the probability of each chosen word)."""
         feat = self._dev_feat(feat)
         B, T = feat.shape[0], self.T
         f = self._head_forward(feat.reshape(B, -1))
         prefix = np.zeros((B, T), np.float32)
         prefix[:, 0] = 1
-        rows, ids = [], np.zeros((B, T), np.int32)
+        want_probs = return_probabilities is None or return_probabilities
+        rows, ids, best = [], np.zeros((B, T), np.int32), np.zeros((B, T), np.float32)
+        rng = torch.arange(B, device=self.device)
         for j in range(T):
             ids_tm, mask, _, _ = self._tables(prefix)
             logits = self._word_model(f, ids_tm, mask, B, T)
             last = logits[(T - 1) * B:]                        # LSTM-2's last (carried) state = state after step j
             probs = self._buf('gprobs', (B, (self.V + 3) // 4 * 4))[:, :self.V]
             ops.softmax_ce(last, None, probs, None, None)
-            nxt = ops.argmax_rows(probs).cpu().numpy()
-            rows.append(probs.cpu().numpy())
+            nxt_d = ops.argmax_rows(probs)
+            nxt = nxt_d.cpu().numpy()
+            if want_probs:
+                rows.append(probs.cpu().numpy())
+            if return_probabilities is not None:
+                best[:, j] = probs[rng, nxt_d.long()].cpu().numpy()
             ids[:, j] = nxt
             if j + 1 < T:
                 prefix[:, j + 1] = nxt
-        return np.stack(rows, axis=1), ids
+        all_probs = np.stack(rows, axis=1) if want_probs else None
+        if return_probabilities is None:
+            return all_probs, ids
+        return all_probs, ids, best

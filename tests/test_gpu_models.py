@@ -351,3 +351,39 @@ def test_joint_model_training_reduces_loss_and_round_trips_weights(gpu, tmp_path
     c = other.get_weights_dict()
     assert np.array_equal(b['fpn_p3/kernel'], c['fpn_p3/kernel']) and np.array_equal(b['mrcnn_class_conv1/kernel'], c['mrcnn_class_conv1/kernel'])
     assert not np.array_equal(b['imgcap_lstm_d2/kernel'], c['imgcap_lstm_d2/kernel'])
+
+
+def test_joint_model_inference_captions(gpu):
+    """Inference graph of the joint model: proposals -> RoI features -> greedy decoder -> GenerationMatchLayer.  The decoded
+    ids of the surviving boxes against the oracle's greedy decoder run on the oracle's features of the same proposals."""
+    from image_captioning_amd import synth
+    from image_captioning_amd.dense_model import DenseImageCapRCNN
+    S, V, T, blocks = 128, 24, 5, 1
+    _, cfg, Wt = make_joint(S, V, T, blocks)
+    cfg.POST_NMS_ROIS_INFERENCE = 40
+    cfg.DETECTION_MAX_INSTANCES = 10
+    model = DenseImageCapRCNN("inference", cfg, "logs", stage4_blocks=blocks)
+    model.set_weights(Wt)
+    img = synth.images(7, 1, S, S)
+    res = model.generate_captions([img[0]])[0]
+    K = res["rois"].shape[0]
+    assert 0 < K <= 10 and res["captions"].shape == (K, T, V) and res["ids"].shape == (K, T)
+    assert np.all(res["rois"][:, 2] > res["rois"][:, 0]) and res["rois"].min() >= 0 and res["rois"].max() <= S
+    np.testing.assert_allclose(res["captions"].sum(-1), 1.0, atol=1e-5)
+    assert np.array_equal(res["captions"].argmax(-1), res["ids"])
+    props = model.last_proposals.cpu().numpy()
+    x = O.mold_image(img, MEAN)
+    _, C2, C3, C4, C5 = M.resnet_graph(x, Wt, blocks)
+    maps = M.fpn_graph(C2, C3, C4, C5, Wt)[:4]
+    feats = O.pyramid_roi_align(props, list(maps), (S, S, 3), 7)[0]
+    want_probs, want_ids = M.v1_greedy_decode(Wt, feats, T)
+    # match the survivors back to their proposals through the decoded probabilities
+    hits = 0
+    for k in range(K):
+        d = np.abs(want_probs - res["captions"][k][None]).reshape(len(want_probs), -1).max(1)
+        j = int(d.argmin())
+        assert d[j] < 1e-3
+        hits += int(np.array_equal(want_ids[j], res["ids"][k]))
+    assert hits == K
+    light = model.generate_captions([img[0]], return_probabilities=False)[0]
+    assert "captions" not in light and np.array_equal(light["ids"], res["ids"]) and np.array_equal(light["rois"], res["rois"])

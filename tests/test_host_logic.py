@@ -244,3 +244,56 @@ def test_joint_data_generator_layout():
     from image_captioning_amd.dense_model import DenseImageCapRCNN
     u8 = DenseImageCapRCNN._images_u8(type("M", (), {"config": cfg})(), inputs[0])
     assert u8.dtype == np.uint8 and np.allclose(u8.astype(np.float32) - cfg.MEAN_PIXEL, inputs[0], atol=1e-4)
+
+
+def test_train_dense_captions_dataset_and_vocabulary(tmp_path):
+    import json
+    from image_captioning_amd import preprocess
+    from image_captioning_amd.train_dense_captions import DenseCapConfig, VisualGenomeDataset, load_vocabulary
+    glove = tmp_path / "glove.txt"
+    words = ["a", "red", "car", "dog", "on", "grass", "rare"]
+    glove.write_text("\n".join("%s %s" % (w, " ".join("%.3f" % (0.01 * (i + j)) for j in range(300))) for i, w in enumerate(words)))
+    regions = [{"id": 1, "regions": [{"phrase": "A red car.", "x": 5, "y": 6, "width": 30, "height": 20},
+                                     {"phrase": "!!!", "x": 0, "y": 0, "width": 4, "height": 4},
+                                     {"phrase": "a dog on grass " * 8, "x": 1, "y": 2, "width": 3, "height": 4}] * 15},
+               {"id": 2, "regions": [{"phrase": "rare", "x": 0, "y": 0, "width": 9, "height": 9}]}]
+    data = tmp_path / "regions.json"
+    data.write_text(json.dumps(regions))
+    meta = tmp_path / "meta.json"
+    meta.write_text(json.dumps([{"image_id": 1, "width": 64, "height": 48}, {"image_id": 2, "width": 10, "height": 10}]))
+    emb = preprocess.load_embeddings(str(glove))
+    assert set(emb) == set(words) and emb["car"].shape == (300,)
+    vocab = preprocess.tokenize_corpus(str(data), [1], emb)
+    assert vocab == {"a", "red", "car", "dog", "on", "grass"}            # 'rare' is not in the training split, '.' is punctuation
+    id_to_word, word_to_id, matrix = load_vocabulary(str(tmp_path / "cache"), str(glove), str(data), [1])
+    assert matrix.shape[0] % 4 == 0 and matrix.shape[0] == len(id_to_word) and word_to_id["<start>"] == 1
+    again = load_vocabulary(str(tmp_path / "cache"), str(glove), str(data), [1])                   # cached pickles
+    assert again[1] == word_to_id and np.array_equal(again[2], matrix)
+    cfg = DenseCapConfig(len(id_to_word), matrix)
+    assert cfg.BATCH_SIZE == 1 and cfg.EMBEDDING_SIZE == 300 and cfg.PADDING_SIZE == 15
+    ds = VisualGenomeDataset(word_to_id, cfg.PADDING_SIZE)
+    ds.load_visual_genome(str(tmp_path), [1], str(meta), str(data))
+    ds.prepare()
+    rois, caps = ds.load_captions_and_rois(0)
+    assert rois.shape == (30, 4) and caps.shape == (30, 15) and caps.dtype == np.float32           # the '!!!' regions encode to nothing
+    assert list(rois[0]) == [6, 5, 26, 35]
+    assert caps[0, 0] == 1 and caps[0, 4] == 2 and not caps[0, 5:].any()                          # <start> a red car <end>
+    assert caps[1, 0] == 1 and caps[1, 14] == 2 and np.all(caps[1, 1:14] > 2)                      # truncated to T-2 words
+
+
+def test_refine_and_unmold_generations():
+    from image_captioning_amd.dense_model import non_max_suppression, refine_generations, unmold_generations
+    cfg = _joint_cfg()
+    cfg.DETECTION_MAX_INSTANCES = 2
+    rois = np.array([[0.1, 0.1, 0.5, 0.5], [0.12, 0.1, 0.5, 0.52], [0.6, 0.6, 0.9, 1.2], [0.0, 0.0, 0.05, 0.05], [0.3, 0.5, 0.8, 0.9]])
+    word = np.array([[0.9, 0.9], [0.95, 0.95], [0.5, 0.5], [0.2, 0.9], [0.7, 0.7]])
+    keep = non_max_suppression(rois, np.log(word).sum(1), 0.3)
+    assert list(keep) == [1, 4, 2, 3]                                   # box 0 is suppressed by the better-scored box 1
+    window = (0, 16, 128, 112)
+    boxes, kept = refine_generations(rois, word, window, cfg)
+    assert list(kept) == [1, 4] and boxes.dtype == np.int32
+    assert list(boxes[0]) == [15, 16, 64, 67] and list(boxes[1]) == [38, 64, 102, 112]   # pixels, clipped to the window, rounded
+    final, ok = unmold_generations(boxes, (256, 192, 3), window)
+    assert list(final[0]) == [30, 0, 128, 102] and ok.all()
+    degenerate, ok = unmold_generations(np.array([[5, 16, 5, 40]]), (256, 192, 3), window)
+    assert not ok.any()
