@@ -590,7 +590,26 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(AL al, BL bl, Epilogue ep
     // ---- epilogue: transpose the accumulators through LDS so every lane owns 4 consecutive columns:
     // 16-byte residual loads / output stores in full 256-512 B row segments instead of 4-byte accesses
     // (the store tail of a wide 1x1 conv is issue-bound, not bandwidth-bound, with the raw MFMA layout).
+    // Residual / accumulate operands are fetched a group of rows ahead of the stores: C and res may alias as far as the
+    // compiler knows, so a load written after a store is never hoisted above it, and a short-K 1x1 conv (K = 256:
+    // 8 K-tiles) otherwise spends as long waiting on 16 dependent round trips as it spent on its MFMAs.
     constexpr int LDC = BN + 4;
+    constexpr int CPR = BN / 4, RPP = 256 / CPR;         // float4 columns per row, rows per pass
+    constexpr int PASSES = BM / RPP, G = PASSES < 8 ? PASSES : 8;
+    const int c4 = tid % CPR, rp = tid / CPR;
+    const int col = n0 + 4 * c4;
+    const bool full = !partial && ep.vec4 && col + 3 < N;
+    const bool pre_res = full && ep.res_mode != 0, pre_acc = full && ep.accumulate;
+    f4 qres[G], qacc[G];
+    auto prefetch = [&](int p0) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int row = min(m0 + (p0 + g) * RPP + rp, M - 1);      // clamped: rows past M are never stored
+            if (pre_res) qres[g] = *reinterpret_cast<const f4*>(ep.res_row(row) + col);
+            if (pre_acc) qacc[g] = *reinterpret_cast<const f4*>(ep.C + (long)row * ep.ldc + col);
+        }
+    };
+    prefetch(0);                                         // in flight while the tile goes through LDS
     float* Cs = smem;                       // all waves are past the loop's final barrier: LDS is free
     {
         const int i = lane & 31, h = lane >> 5;
@@ -603,14 +622,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(AL al, BL bl, Epilogue ep
                     Cs[(wm + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDC + wn + tn * 32 + i] = acc[tm][tn][r];
     }
     __syncthreads();
-    constexpr int CPR = BN / 4, RPP = 256 / CPR;         // float4 columns per row, rows per pass
-    const int c4 = tid % CPR, rp = tid / CPR;
-    const int col = n0 + 4 * c4;
     if (col >= N) return;
     if (partial) {
         float* prow = partial + (long)blockIdx.z * M * N;
 #pragma unroll 4
-        for (int p = 0; p < BM / RPP; ++p) {
+        for (int p = 0; p < PASSES; ++p) {
             const int lr = p * RPP + rp, row = m0 + lr;
             if (row >= M) break;
             const float4 v = *reinterpret_cast<const float4*>(&Cs[lr * LDC + 4 * c4]);
@@ -626,38 +642,38 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(AL al, BL bl, Epilogue ep
         }
         return;
     }
-    const bool full = ep.vec4 && col + 3 < N;
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (full) {
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ep.scale) sc = *reinterpret_cast<const float4*>(ep.scale + col);
         if (ep.shift) sh = *reinterpret_cast<const float4*>(ep.shift + col);
+#pragma unroll
+        for (int p0 = 0; p0 < PASSES; p0 += G) {
+            if (p0 > 0) prefetch(p0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int lr = (p0 + g) * RPP + rp, row = m0 + lr;
+                float4 v = *reinterpret_cast<const float4*>(&Cs[lr * LDC + 4 * c4]);
+                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                if (pre_res) { v.x += qres[g][0]; v.y += qres[g][1]; v.z += qres[g][2]; v.w += qres[g][3]; }
+                if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (pre_acc) { v.x += qacc[g][0]; v.y += qacc[g][1]; v.z += qacc[g][2]; v.w += qacc[g][3]; }
+                if (row < M) *reinterpret_cast<float4*>(ep.C + (long)row * ep.ldc + col) = v;
+            }
+        }
+        return;
     }
 #pragma unroll 4
-    for (int p = 0; p < BM / RPP; ++p) {
+    for (int p = 0; p < PASSES; ++p) {
         const int lr = p * RPP + rp, row = m0 + lr;
         if (row >= M) break;
-        float4 v = *reinterpret_cast<const float4*>(&Cs[lr * LDC + 4 * c4]);
+        const float4 v = *reinterpret_cast<const float4*>(&Cs[lr * LDC + 4 * c4]);
         float* crow = ep.C + (long)row * ep.ldc;
         const float* rr = ep.res_row(row);
-        if (full) {
-            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-            if (rr) {
-                const float4 q = *reinterpret_cast<const float4*>(rr + col);
-                v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-            }
-            if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (ep.accumulate) {
-                const float4 q = *reinterpret_cast<const float4*>(crow + col);
-                v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-            }
-            *reinterpret_cast<float4*>(crow + col) = v;
-        } else {
 #define DC_TAIL(j, e)                                                                                       \
     if (col + j < N)                                                                                        \
         crow[col + j] = ep.finish(e, ep.scale ? ep.scale[col + j] : 1.f, ep.shift ? ep.shift[col + j] : 0.f, rr, crow, col + j);
-            DC_TAIL(0, v.x) DC_TAIL(1, v.y) DC_TAIL(2, v.z) DC_TAIL(3, v.w)
+        DC_TAIL(0, v.x) DC_TAIL(1, v.y) DC_TAIL(2, v.z) DC_TAIL(3, v.w)
 #undef DC_TAIL
-        }
     }
 }
 
