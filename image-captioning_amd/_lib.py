@@ -32,7 +32,10 @@ class ConvDesc(C.Structure):
                 ("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p),
                 ("scale", C.c_void_p), ("shift", C.c_void_p),
                 ("residual", C.c_void_p), ("res_mode", C.c_int),
-                ("relu", C.c_int), ("split_k", C.c_int), ("accumulate", C.c_int)]
+                ("relu", C.c_int), ("split_k", C.c_int), ("accumulate", C.c_int), ("math", C.c_int)]
+
+
+MATH_F32, MATH_BF16X3 = 0, 1
 
 
 class RoiAlignDesc(C.Structure):
@@ -148,10 +151,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("DCAP_LIB", LIB_PATH)          # DCAP_LIB: an experiment build of the same library (tools/build_variant.sh)
+    if not os.path.exists(path):
         raise DcapError("%s is missing: build it with `python __graft_entry__.py` "
-                        "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+                        "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res

@@ -34,6 +34,30 @@ static int conv_validate(const dc_conv_desc* d, bool& stem) {
     return DC_OK;
 }
 
+// Tile choice of the split-bf16 main loop: its K-tile is ~3x shorter than the fp32 one, so barriers and the split cost
+// weigh more on small tiles -- always the widest tile the output allows, and split-K to put two blocks on every CU.
+static TileChoice conv_tile_bs(int M, int N, int K, int user_split) {
+    auto nb = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+    TileChoice t{64, 64, 1};
+    if (M >= 128 && N >= 128) t = {128, 128, 1};
+    else if (M >= 128 && N >= 64) t = {128, 64, 1};
+    if (t.bn == 128 && nb(128, 128) < 2 * kNumCU && nb(128, 64) >= 2 * kNumCU) t = {128, 64, 1};   // fills the chip without slabs
+    const int ktiles = (K + BK - 1) / BK;
+    const int blocks = ((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
+    if (user_split > 0) {
+        t.split = user_split;
+    } else if (blocks < 2 * kNumCU && ktiles >= 8) {
+        int s = (2 * kNumCU + blocks - 1) / blocks;
+        s = std::min(s, std::min(ktiles / 4, 16));
+        t.split = std::max(s, 1);
+    }
+    return t;
+}
+
+static inline TileChoice conv_tile(const dc_conv_desc* d, int M, int N, int K) {
+    return d->math == DC_MATH_BF16X3 ? conv_tile_bs(M, N, K, d->split_k) : choose_tile(M, N, K, d->split_k);
+}
+
 static inline void conv_dims(const dc_conv_desc* d, bool stem, int& M, int& N, int& K) {
     M = d->N * d->Ho * d->Wo;
     N = d->Cout;
@@ -42,12 +66,12 @@ static inline void conv_dims(const dc_conv_desc* d, bool stem, int& M, int& N, i
 
 using WeightKC = DenseKCT<true>;   // packed weights: K = kh*kw*Cin is a multiple of 32, rows 16-byte aligned
 
-template <class AL>
-static int conv_dispatch(const AL& al, const WeightKC& bl, const Epilogue& ep, int M, int N, int K, const TileChoice& t, void* ws,
+template <class AL, class BL>
+static int conv_dispatch(const AL& al, const BL& bl, const Epilogue& ep, int M, int N, int K, const TileChoice& t, void* ws,
                          size_t wsb, hipStream_t s) {
-    if (t.bm == 128 && t.bn == 128) return launch_igemm<128, 128, AL, WeightKC>(al, bl, ep, M, N, K, t.split, ws, wsb, s);
-    if (t.bm == 128 && t.bn == 64) return launch_igemm<128, 64, AL, WeightKC>(al, bl, ep, M, N, K, t.split, ws, wsb, s);
-    return launch_igemm<64, 64, AL, WeightKC>(al, bl, ep, M, N, K, t.split, ws, wsb, s);
+    if (t.bm == 128 && t.bn == 128) return launch_igemm<128, 128, AL, BL>(al, bl, ep, M, N, K, t.split, ws, wsb, s);
+    if (t.bm == 128 && t.bn == 64) return launch_igemm<128, 64, AL, BL>(al, bl, ep, M, N, K, t.split, ws, wsb, s);
+    return launch_igemm<64, 64, AL, BL>(al, bl, ep, M, N, K, t.split, ws, wsb, s);
 }
 
 // ---- maxpool 3x3 / stride 2 / TF SAME (pad only where the window leaves the image; padded cells never win)
@@ -95,7 +119,7 @@ extern "C" size_t dc_conv2d_workspace_bytes(const dc_conv_desc* d) {
     if (conv_validate(d, stem)) return 0;
     int M, N, K;
     conv_dims(d, stem, M, N, K);
-    const TileChoice t = choose_tile(M, N, K, d->split_k);
+    const TileChoice t = conv_tile(d, M, N, K);
     return t.split > 1 ? (size_t)t.split * M * N * sizeof(float) : 0;
 }
 
@@ -105,7 +129,7 @@ extern "C" int dc_conv2d_tile_config(const dc_conv_desc* d, int* bm, int* bn, in
     if (rc) return rc;
     int M, N, K;
     conv_dims(d, stem, M, N, K);
-    const TileChoice t = choose_tile(M, N, K, d->split_k);
+    const TileChoice t = conv_tile(d, M, N, K);
     if (bm) *bm = t.bm;
     if (bn) *bn = t.bn;
     if (split_k) *split_k = t.split;
@@ -119,16 +143,19 @@ extern "C" int dc_conv2d_nhwc_f32(const dc_conv_desc* d, void* workspace, size_t
     hipStream_t s = static_cast<hipStream_t>(stream);
     int M, N, K;
     conv_dims(d, stem, M, N, K);
-    const TileChoice t = choose_tile(M, N, K, d->split_k);
+    const TileChoice t = conv_tile(d, M, N, K);
     Epilogue ep{d->y, d->Cout, d->scale, d->shift, d->residual, d->Cout, d->res_mode, d->Ho, d->Wo, d->relu, 0, 0};
     ep.vec4 = (d->Cout & 3) == 0 && aligned16(d->y) && (!d->residual || aligned16(d->residual)) && (!d->scale || aligned16(d->scale)) &&
               (!d->shift || aligned16(d->shift));
-    WeightKC bl{d->w, K, N, nullptr};
+    DC_REQUIRE(d->math == DC_MATH_F32 || d->math == DC_MATH_BF16X3, DC_EINVAL, "dc_conv2d: unknown math mode %d", d->math);
+    if (d->math == DC_MATH_BF16X3) return conv2d_bf16x3(d, stem, ep, M, N, K, t.bm, t.bn, t.split, workspace, workspace_bytes, s);
     if (stem) {
+        WeightKC bl{d->w, K, N, nullptr};
         StemKC al{d->x, d->H, d->W, d->Ho, d->Wo, M, (unsigned)((size_t)d->N * d->H * d->W * 4 * sizeof(float))};
         return conv_dispatch(al, bl, ep, M, N, K, t, workspace, workspace_bytes, s);
     }
-    Im2colKC al{d->x, d->H, d->W, d->Cin, d->Ho, d->Wo, d->stride, d->pad_t, d->pad_l, d->kw, d->Cin / 32, M,
+    ConvWeightKC bl{d->w, K, N, d->kh * d->kw, d->Cin};
+    Im2colKC al{d->x, d->H, d->W, d->Cin, d->Ho, d->Wo, d->stride, d->pad_t, d->pad_l, d->kw, d->kh * d->kw, M,
                 (unsigned)((size_t)d->N * d->H * d->W * d->Cin * sizeof(float))};
     return conv_dispatch(al, bl, ep, M, N, K, t, workspace, workspace_bytes, s);
 }

@@ -135,6 +135,44 @@ struct DenseKCT {
 };
 using DenseKC = DenseKCT<false>;
 
+// Packed conv weights [Cout][taps*Cin] walked in Im2colKC's chunk-major K order: K-tile t -> tap t % taps, channels
+// 32*(t / taps).  Host-checked like the FAST dense loader (Cin % 32 == 0, aligned rows, < 4 GiB).
+struct ConvWeightKC {
+    static constexpr bool KC = true;
+    __device__ __forceinline__ int kclamp(int k0, int) const { return k0; }     // tiles past the end re-read in-range data
+    const float* p;
+    long ld;
+    int rows, taps, Cin;
+    template <int BT>
+    struct State {
+        unsigned boff[BT / 32];
+        int tap, koff;              // block-uniform position of the NEXT K-tile (incremental, like Im2colKC)
+    };
+    template <int BT>
+    __device__ __forceinline__ void init(State<BT>& s, int row0, int tid) const {
+        const int rr = tid >> 3;
+        s.tap = -1;
+#pragma unroll
+        for (int i = 0; i < BT / 32; ++i) s.boff[i] = (unsigned)(((long)min(row0 + rr + 32 * i, rows - 1) * ld + 4 * (tid & 7)) * 4);
+    }
+    template <int BT>
+    __device__ __forceinline__ void load(State<BT>& s, f4 (&r)[BT / 32], int k0, int, int) const {
+        if (s.tap < 0) {                                  // first tile of this block: one division
+            const int t = k0 >> 5, chunk = t / taps;
+            s.tap = t - chunk * taps;
+            s.koff = s.tap * Cin + chunk * 32;
+        }
+        const float* kb = p + min(s.koff, (int)ld - BK);   // block-uniform; clamped for the loads issued past the last tile
+#pragma unroll
+        for (int i = 0; i < BT / 32; ++i) r[i] = ldg_f4(kb, s.boff[i]);
+        if (++s.tap == taps) { s.tap = 0; s.koff += 32 - (taps - 1) * Cin; } else { s.koff += Cin; }
+    }
+    template <int BT>
+    __device__ __forceinline__ void store(const State<BT>&, float* S, f4 (&r)[BT / 32], int tid) const {
+        store_kc<BT>(S, r, tid);
+    }
+};
+
 // K x cols, cols contiguous (K-major operand); optional gather of the K rows.
 template <bool FAST>
 struct DenseMCT {
@@ -191,6 +229,9 @@ using DenseMC = DenseMCT<false>;
 
 // NHWC activations viewed as the im2col matrix [N*Ho*Wo][kh*kw*Cin] (cin fastest), Cin % 32 == 0:
 // one K-tile of 32 lies inside one (ky,kx) tap, so a row's 128 B are contiguous in memory.
+// K is VISITED chunk-major: K-tile t covers channels 32*(t / taps) .. +31 of tap t % taps (ConvWeightKC walks the packed
+// weights in the same order).  The kh*kw taps of one 32-channel chunk touch the same few cache lines per pixel, so a 3x3
+// conv re-reads its inputs from L1/L2 instead of streaming them nine times from the Infinity Cache.
 // Per thread and staged row: the byte offset of the output-aligned pixel (always inside the image) and a
 // bit mask of the taps that fall inside the image; per K-tile: one uniform tap offset.  Out-of-image
 // taps re-load the aligned pixel (valid memory) and are zeroed at store() time, after the MFMAs.
@@ -198,7 +239,7 @@ struct Im2colKC {
     static constexpr bool KC = true;
     __device__ __forceinline__ int kclamp(int k0, int) const { return k0; }     // range-checked buffer loads
     const float* x;
-    int H, W, Cin, Ho, Wo, stride, pad_t, pad_l, kw, cin_tiles, M;
+    int H, W, Cin, Ho, Wo, stride, pad_t, pad_l, kw, taps, M;
     unsigned x_bytes;               // size of the activation tensor (buffer range for the zero-filling loads)
     template <int BT>
     struct State {
@@ -232,8 +273,8 @@ struct Im2colKC {
     template <int BT>
     __device__ __forceinline__ void load(State<BT>& s, f4 (&r)[BT / 32], int k0, int kend, int tid) const {
         if (s.ky < 0) {                                   // first tile of this block (split-K start): one division
-            const int kt = k0 >> 5, tap = kt / cin_tiles;
-            s.c = (kt - tap * cin_tiles) * 32;
+            const int kt = k0 >> 5, chunk = kt / taps, tap = kt - chunk * taps;
+            s.c = chunk * 32;
             s.ky = tap / kw;
             s.kx = tap - s.ky * kw;
         }
@@ -245,10 +286,9 @@ struct Im2colKC {
             const bool in = ((s.mask[i] >> tap) & 1ull) != 0;
             r[i] = buf_f4(s.rsrc, in ? s.boff[i] + (unsigned)ubytes : kOobOffset);     // out of image -> hardware zero
         }
-        s.c += 32;
-        if (s.c == Cin) {
-            s.c = 0;
-            if (++s.kx == kw) { s.kx = 0; ++s.ky; }
+        if (++s.kx == kw) {                               // next tap of this channel chunk; then the next chunk
+            s.kx = 0;
+            if ((s.ky + 1) * kw == taps) { s.ky = 0; s.c += 32; } else { ++s.ky; }
         }
     }
     template <int BT>
@@ -484,6 +524,104 @@ constexpr size_t igemm_lds_bytes() {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Tile epilogue shared by the f32 and the split-bf16 main loops.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__device__ __forceinline__ void store_tile(f32x16 (&acc)[BM / 64][BN / 64], float* smem, const Epilogue& ep, float* __restrict__ partial,
+                                           int M, int N, int m0, int n0, int wm, int wn) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // ---- epilogue: transpose the accumulators through LDS so every lane owns 4 consecutive columns:
+    // 16-byte residual loads / output stores in full 256-512 B row segments instead of 4-byte accesses
+    // (the store tail of a wide 1x1 conv is issue-bound, not bandwidth-bound, with the raw MFMA layout).
+    // Residual / accumulate operands are fetched a group of rows ahead of the stores: C and res may alias as far as the
+    // compiler knows, so a load written after a store is never hoisted above it, and a short-K 1x1 conv (K = 256:
+    // 8 K-tiles) otherwise spends as long waiting on 16 dependent round trips as it spent on its MFMAs.
+    constexpr int LDC = BN + 4;
+    constexpr int CPR = BN / 4, RPP = 256 / CPR;         // float4 columns per row, rows per pass
+    constexpr int PASSES = BM / RPP, G = PASSES < 8 ? PASSES : 8;
+    const int c4 = tid % CPR, rp = tid / CPR;
+    const int col = n0 + 4 * c4;
+    const bool full = !partial && ep.vec4 && col + 3 < N;
+    const bool pre_res = full && ep.res_mode != 0, pre_acc = full && ep.accumulate;
+    f4 qres[G], qacc[G];
+    auto prefetch = [&](int p0) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int row = min(m0 + (p0 + g) * RPP + rp, M - 1);      // clamped: rows past M are never stored
+            if (pre_res) qres[g] = *reinterpret_cast<const f4*>(ep.res_row(row) + col);
+            if (pre_acc) qacc[g] = *reinterpret_cast<const f4*>(ep.C + (long)row * ep.ldc + col);
+        }
+    };
+    prefetch(0);                                         // in flight while the tile goes through LDS
+    float* Cs = smem;                       // all waves are past the loop's final barrier: LDS is free
+    {
+        const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Cs[(wm + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDC + wn + tn * 32 + i] = acc[tm][tn][r];
+    }
+    __syncthreads();
+    if (col >= N) return;
+    if (partial) {
+        float* prow = partial + (long)blockIdx.z * M * N;
+#pragma unroll 4
+        for (int p = 0; p < PASSES; ++p) {
+            const int lr = p * RPP + rp, row = m0 + lr;
+            if (row >= M) break;
+            const float4 v = *reinterpret_cast<const float4*>(&Cs[lr * LDC + 4 * c4]);
+            float* o = prow + (long)row * N + col;
+            if ((N & 3) == 0) {
+                *reinterpret_cast<float4*>(o) = v;
+            } else {
+                o[0] = v.x;
+                if (col + 1 < N) o[1] = v.y;
+                if (col + 2 < N) o[2] = v.z;
+                if (col + 3 < N) o[3] = v.w;
+            }
+        }
+        return;
+    }
+    if (full) {
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ep.scale) sc = *reinterpret_cast<const float4*>(ep.scale + col);
+        if (ep.shift) sh = *reinterpret_cast<const float4*>(ep.shift + col);
+#pragma unroll
+        for (int p0 = 0; p0 < PASSES; p0 += G) {
+            if (p0 > 0) prefetch(p0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int lr = (p0 + g) * RPP + rp, row = m0 + lr;
+                float4 v = *reinterpret_cast<const float4*>(&Cs[lr * LDC + 4 * c4]);
+                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                if (pre_res) { v.x += qres[g][0]; v.y += qres[g][1]; v.z += qres[g][2]; v.w += qres[g][3]; }
+                if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (pre_acc) { v.x += qacc[g][0]; v.y += qacc[g][1]; v.z += qacc[g][2]; v.w += qacc[g][3]; }
+                if (row < M) *reinterpret_cast<float4*>(ep.C + (long)row * ep.ldc + col) = v;
+            }
+        }
+        return;
+    }
+#pragma unroll 4
+    for (int p = 0; p < PASSES; ++p) {
+        const int lr = p * RPP + rp, row = m0 + lr;
+        if (row >= M) break;
+        const float4 v = *reinterpret_cast<const float4*>(&Cs[lr * LDC + 4 * c4]);
+        float* crow = ep.C + (long)row * ep.ldc;
+        const float* rr = ep.res_row(row);
+#define DC_TAIL(j, e)                                                                                       \
+    if (col + j < N)                                                                                        \
+        crow[col + j] = ep.finish(e, ep.scale ? ep.scale[col + j] : 1.f, ep.shift ? ep.shift[col + j] : 0.f, rr, crow, col + j);
+        DC_TAIL(0, v.x) DC_TAIL(1, v.y) DC_TAIL(2, v.z) DC_TAIL(3, v.w)
+#undef DC_TAIL
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The kernel.  grid.x = tiles_m*tiles_n (XCD-remapped so consecutive tiles along N, which share the
 // A panel, run on one XCD), grid.z = split-K slices.  With split-K the raw partial sums go to the
 // slab  partial[z][M][N]  and splitk_reduce_kernel applies the epilogue.
@@ -587,97 +725,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(AL al, BL bl, Epilogue ep
     }
 #endif
 
-    // ---- epilogue: transpose the accumulators through LDS so every lane owns 4 consecutive columns:
-    // 16-byte residual loads / output stores in full 256-512 B row segments instead of 4-byte accesses
-    // (the store tail of a wide 1x1 conv is issue-bound, not bandwidth-bound, with the raw MFMA layout).
-    // Residual / accumulate operands are fetched a group of rows ahead of the stores: C and res may alias as far as the
-    // compiler knows, so a load written after a store is never hoisted above it, and a short-K 1x1 conv (K = 256:
-    // 8 K-tiles) otherwise spends as long waiting on 16 dependent round trips as it spent on its MFMAs.
-    constexpr int LDC = BN + 4;
-    constexpr int CPR = BN / 4, RPP = 256 / CPR;         // float4 columns per row, rows per pass
-    constexpr int PASSES = BM / RPP, G = PASSES < 8 ? PASSES : 8;
-    const int c4 = tid % CPR, rp = tid / CPR;
-    const int col = n0 + 4 * c4;
-    const bool full = !partial && ep.vec4 && col + 3 < N;
-    const bool pre_res = full && ep.res_mode != 0, pre_acc = full && ep.accumulate;
-    f4 qres[G], qacc[G];
-    auto prefetch = [&](int p0) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int row = min(m0 + (p0 + g) * RPP + rp, M - 1);      // clamped: rows past M are never stored
-            if (pre_res) qres[g] = *reinterpret_cast<const f4*>(ep.res_row(row) + col);
-            if (pre_acc) qacc[g] = *reinterpret_cast<const f4*>(ep.C + (long)row * ep.ldc + col);
-        }
-    };
-    prefetch(0);                                         // in flight while the tile goes through LDS
-    float* Cs = smem;                       // all waves are past the loop's final barrier: LDS is free
-    {
-        const int i = lane & 31, h = lane >> 5;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    Cs[(wm + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDC + wn + tn * 32 + i] = acc[tm][tn][r];
-    }
-    __syncthreads();
-    if (col >= N) return;
-    if (partial) {
-        float* prow = partial + (long)blockIdx.z * M * N;
-#pragma unroll 4
-        for (int p = 0; p < PASSES; ++p) {
-            const int lr = p * RPP + rp, row = m0 + lr;
-            if (row >= M) break;
-            const float4 v = *reinterpret_cast<const float4*>(&Cs[lr * LDC + 4 * c4]);
-            float* o = prow + (long)row * N + col;
-            if ((N & 3) == 0) {
-                *reinterpret_cast<float4*>(o) = v;
-            } else {
-                o[0] = v.x;
-                if (col + 1 < N) o[1] = v.y;
-                if (col + 2 < N) o[2] = v.z;
-                if (col + 3 < N) o[3] = v.w;
-            }
-        }
-        return;
-    }
-    if (full) {
-        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ep.scale) sc = *reinterpret_cast<const float4*>(ep.scale + col);
-        if (ep.shift) sh = *reinterpret_cast<const float4*>(ep.shift + col);
-#pragma unroll
-        for (int p0 = 0; p0 < PASSES; p0 += G) {
-            if (p0 > 0) prefetch(p0);
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const int lr = (p0 + g) * RPP + rp, row = m0 + lr;
-                float4 v = *reinterpret_cast<const float4*>(&Cs[lr * LDC + 4 * c4]);
-                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-                if (pre_res) { v.x += qres[g][0]; v.y += qres[g][1]; v.z += qres[g][2]; v.w += qres[g][3]; }
-                if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                if (pre_acc) { v.x += qacc[g][0]; v.y += qacc[g][1]; v.z += qacc[g][2]; v.w += qacc[g][3]; }
-                if (row < M) *reinterpret_cast<float4*>(ep.C + (long)row * ep.ldc + col) = v;
-            }
-        }
-        return;
-    }
-#pragma unroll 4
-    for (int p = 0; p < PASSES; ++p) {
-        const int lr = p * RPP + rp, row = m0 + lr;
-        if (row >= M) break;
-        const float4 v = *reinterpret_cast<const float4*>(&Cs[lr * LDC + 4 * c4]);
-        float* crow = ep.C + (long)row * ep.ldc;
-        const float* rr = ep.res_row(row);
-#define DC_TAIL(j, e)                                                                                       \
-    if (col + j < N)                                                                                        \
-        crow[col + j] = ep.finish(e, ep.scale ? ep.scale[col + j] : 1.f, ep.shift ? ep.shift[col + j] : 0.f, rr, crow, col + j);
-        DC_TAIL(0, v.x) DC_TAIL(1, v.y) DC_TAIL(2, v.z) DC_TAIL(3, v.w)
-#undef DC_TAIL
-    }
+    store_tile<BM, BN>(acc, smem, ep, partial, M, N, m0, n0, wm, wn);
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int splits, int M, int N, Epilogue ep);
+
+// conv forward on the split-bf16 main loop (conv_bs.hip)
+int conv2d_bf16x3(const dc_conv_desc* d, bool stem, const Epilogue& ep, int M, int N, int K, int bm, int bn, int split, void* workspace,
+                  size_t workspace_bytes, hipStream_t s);
 
 // Host-side launch helper (defined in igemm_launch.hip).
 template <int BM, int BN, class AL, class BL>

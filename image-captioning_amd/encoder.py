@@ -19,6 +19,18 @@ from .layers import ConvSpec, resnet_fpn_convs
 from .packing import fold_bn, pack_conv_kernel, pack_stem_kernel
 
 
+DEFAULT_CONV_MATH = "f32"
+
+
+def conv_math_mode(math=None):
+    import os
+    name = math if math is not None else os.environ.get("DCAP_CONV_MATH", DEFAULT_CONV_MATH)
+    try:
+        return {"f32": _lib.MATH_F32, "bf16x3": _lib.MATH_BF16X3}[name]
+    except KeyError:
+        raise ValueError("conv math must be 'f32' or 'bf16x3', got %r" % (name,))
+
+
 def fuse_rpn_head(weights, channels=None):
     """rpn_class_raw (2A channels) ++ rpn_bbox_pred (4A) as ONE 1x1 convolution, zero-padded to `channels` outputs."""
     k = np.concatenate([weights["rpn_class_raw/kernel"], weights["rpn_bbox_pred/kernel"]], axis=3).astype(np.float32)
@@ -34,7 +46,7 @@ def fuse_rpn_head(weights, channels=None):
 
 class EncoderPlan:
     def __init__(self, weights, batch, height, width, device, stage4_blocks=22,
-                 mean_pixel=(123.7, 116.8, 103.9), use_graph=True, rpn=None, external=None):
+                 mean_pixel=(123.7, 116.8, 103.9), use_graph=True, rpn=None, external=None, math=None):
         """rpn: None (GT-RoI variant: the RPN is never evaluated) or a dict with the config values the
         proposal path needs: scales, ratios, strides, anchor_stride, bbox_std, nms_threshold, proposal_count and
         optionally head_channels (the fused class+bbox head padded to a multiple of 4 channels for the wgrad kernel).
@@ -43,6 +55,9 @@ class EncoderPlan:
         if height % 64 or width % 64:
             raise ValueError("Image size must be dividable by 2 at least 6 times (got %dx%d)" % (height, width))
         self.lib = _lib.load()
+        # conv arithmetic: 'f32' (fp32 MFMA products) or 'bf16x3' (three-piece bf16 split, six matrix-pipe products, fp32
+        # accumulate); DCAP_CONV_MATH overrides the default for experiments
+        self.math = conv_math_mode(math)
         self.B, self.H, self.W = batch, height, width
         self.device = torch.device(device)
         self.mean_pixel = [float(v) for v in mean_pixel]
@@ -111,7 +126,7 @@ class EncoderPlan:
         d.scale = None if sc is None else sc.data_ptr()
         d.shift = sh.data_ptr()
         d.residual = None if residual is None else residual.data_ptr()
-        d.res_mode, d.relu, d.split_k = res_mode, int(relu), 0
+        d.res_mode, d.relu, d.split_k, d.math = res_mode, int(relu), 0, self.math
         self._ws_bytes = max(self._ws_bytes, self.lib.dc_conv2d_workspace_bytes(C.byref(d)))
         self._ops.append(("conv", d, name))
         self.flops += 2.0 * N * Ho * Wo * Cout * s.k * s.k * s.cin

@@ -89,7 +89,7 @@ def gemm(A, B, out=None, a_trans=False, b_trans=False, gather=None, scale=None, 
 
 
 def conv2d(x, w_packed, kh, kw, stride, pad_t, pad_l, Ho, Wo, scale=None, shift=None, residual=None,
-           res_mode=0, relu=False, out=None, split_k=0):
+           res_mode=0, relu=False, out=None, split_k=0, math=0):
     """NHWC conv forward with fused epilogue; see dc_conv2d_nhwc_f32.  x [N,H,W,Cin] contiguous."""
     lib = _lib.load()
     _chk(x, name="x"), _chk(w_packed, name="w")
@@ -106,7 +106,7 @@ def conv2d(x, w_packed, kh, kw, stride, pad_t, pad_l, Ho, Wo, scale=None, shift=
     d.scale = None if scale is None else scale.data_ptr()
     d.shift = None if shift is None else shift.data_ptr()
     d.residual = None if residual is None else _chk(residual, name="residual").data_ptr()
-    d.res_mode, d.relu, d.split_k = int(res_mode), int(relu), int(split_k)
+    d.res_mode, d.relu, d.split_k, d.math = int(res_mode), int(relu), int(split_k), int(math)
     ws, wsb = WORKSPACE.get(lib.dc_conv2d_workspace_bytes(C.byref(d)), x.device)
     check(lib.dc_conv2d_nhwc_f32(C.byref(d), _ptr(ws), wsb, _stream()), "dc_conv2d_nhwc_f32")
     return out

@@ -79,6 +79,8 @@ int    dc_gemm_f32(const dc_gemm_desc* d, void* workspace, size_t workspace_byte
  * Cin must be a multiple of 32, except the stem: Cin==4 (RGBX), kh==kw==7, stride 2, with w packed
  * as [Cout][7][8][4] (kx==7 and c==3 entries zero).
  * ------------------------------------------------------------------------------------------------ */
+#define DC_MATH_F32 0
+#define DC_MATH_BF16X3 1
 typedef struct {
     int N, H, W, Cin;
     int Cout, kh, kw, stride, pad_t, pad_l;
@@ -92,6 +94,9 @@ typedef struct {
     int relu;
     int split_k;
     int accumulate;           /* wgrad only: dw += (a weight shared by several inputs, e.g. the RPN over P2..P6) */
+    int math;                 /* forward only: DC_MATH_F32 = fp32 MFMA (exact fp32 products), DC_MATH_BF16X3 = every operand
+                                 element split into three bf16 pieces, six bf16 MFMA products, fp32 accumulate (fp32-grade
+                                 accuracy on the bf16 matrix pipe; csrc/igemm_bf16s.h) */
 } dc_conv_desc;
 
 size_t dc_conv2d_workspace_bytes(const dc_conv_desc* d);

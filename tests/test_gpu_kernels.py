@@ -104,8 +104,11 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("math", [0, 1], ids=["f32", "bf16x3"])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv2d_matches_oracle(ops, case):
+def test_conv2d_matches_oracle(ops, case, math):
+    """math 0: fp32 MFMA products; math 1: operands split into three bf16 pieces, six matrix-pipe products -- held to the
+    SAME 2e-5 tolerance against the float64 oracle."""
     from image_captioning_amd.packing import pack_conv_kernel
     N, H, W, Cin, Cout, k, stride, padding, res_mode, relu = case
     rng = np.random.default_rng(sum(int(v) * (i + 1) for i, v in enumerate(case) if not isinstance(v, str)))
@@ -125,12 +128,31 @@ def test_conv2d_matches_oracle(ops, case):
         y = np.maximum(y, 0)
     pt, pl = (O.same_pad(H, k, stride)[0], O.same_pad(W, k, stride)[0]) if padding == 'same' else (0, 0)
     got = ops.conv2d(dev(x), dev(pack_conv_kernel(w)), k, k, stride, pt, pl, Ho, Wo, dev(sc), dev(sh),
-                     None if res is None else dev(res), res_mode, relu)
+                     None if res is None else dev(res), res_mode, relu, math=math)
     close(got, y)
 
 
+def test_conv2d_bf16x3_error_is_fp32_grade(ops):
+    """The split-bf16 path against the exact-fp32 path on a long reduction (3x3x512): both err against float64 by a few
+    1e-7 relative to the output scale; a two-piece split (1e-5) or a dropped product would fail this by orders of magnitude.
+    Includes operands spanning 12 orders of magnitude and exact powers of two."""
+    from image_captioning_amd.packing import pack_conv_kernel
+    rng = np.random.default_rng(99)
+    x = rng.standard_normal((1, 16, 16, 512)) * np.exp(rng.uniform(-14, 14, (1, 16, 16, 512)))
+    x[0, 0, 0, :8] = [1.0, 2.0, 0.5, 1 + 2.0 ** -23, 3.0, 65536.0, 2.0 ** -20, 0.0]
+    w = rng.standard_normal((3, 3, 512, 128)) / np.sqrt(9 * 512)
+    want = O.conv2d_nhwc(x.astype(np.float32), w.astype(np.float32), None, 1, 'same')
+    scale = np.abs(want).max()
+    errs = []
+    for math in (0, 1):
+        got = ops.conv2d(dev(x), dev(pack_conv_kernel(w)), 3, 3, 1, 1, 1, 16, 16, math=math).cpu().numpy().astype(np.float64)
+        errs.append(np.abs(got - want).max() / scale)
+    assert errs[0] < 5e-6 and errs[1] < 5e-6 and errs[1] < 4 * errs[0] + 2e-7, errs
+
+
+@pytest.mark.parametrize("math", [0, 1], ids=["f32", "bf16x3"])
 @pytest.mark.parametrize("N,H,W", [(1, 32, 32), (2, 64, 96)])
-def test_stem_mold_maxpool(ops, N, H, W):
+def test_stem_mold_maxpool(ops, N, H, W, math):
     from image_captioning_amd.packing import pack_stem_kernel
     rng = np.random.default_rng(H)
     img = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)
@@ -142,7 +164,7 @@ def test_stem_mold_maxpool(ops, N, H, W):
     close(rgbx[..., :3], x, 1e-6)
     assert float(rgbx[..., 3].abs().max()) == 0.0
     y = np.maximum(O.conv2d_nhwc(x, w, None, 2, (3, 3, 3, 3)) * sc + sh, 0)
-    got = ops.conv2d(rgbx, dev(pack_stem_kernel(w)), 7, 7, 2, 3, 3, H // 2, W // 2, dev(sc), dev(sh), None, 0, True)
+    got = ops.conv2d(rgbx, dev(pack_stem_kernel(w)), 7, 7, 2, 3, 3, H // 2, W // 2, dev(sc), dev(sh), None, 0, True, math=math)
     close(got, y)
     close(ops.maxpool3x3s2_same(got), O.maxpool3x3s2_same(got.cpu().numpy().astype(np.float64)), 1e-7)
 
