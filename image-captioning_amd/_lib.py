@@ -32,7 +32,7 @@ class ConvDesc(C.Structure):
                 ("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p),
                 ("scale", C.c_void_p), ("shift", C.c_void_p),
                 ("residual", C.c_void_p), ("res_mode", C.c_int),
-                ("relu", C.c_int), ("split_k", C.c_int), ("accumulate", C.c_int), ("math", C.c_int)]
+                ("relu", C.c_int), ("split_k", C.c_int), ("accumulate", C.c_int), ("math", C.c_int), ("w_split", C.c_void_p)]
 
 
 MATH_F32, MATH_BF16X3 = 0, 1
@@ -103,6 +103,7 @@ SYMBOLS = {
     "dc_last_error": (C.c_char_p, []),
     "dc_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
     "dc_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dc_split_bf16x3_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_conv2d_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "dc_conv2d_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_conv2d_tile_config": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -77,6 +77,7 @@ class EncoderPlan:
                 weights = dict(weights)
                 weights["rpn_head/kernel"], weights["rpn_head/bias"] = fuse_rpn_head(weights, hc)
         self._w = {}
+        self._wsplit = {}
         self._upload(weights)
         self._build()
 
@@ -127,6 +128,11 @@ class EncoderPlan:
         d.shift = sh.data_ptr()
         d.residual = None if residual is None else residual.data_ptr()
         d.res_mode, d.relu, d.split_k, d.math = res_mode, int(relu), 0, self.math
+        if self.math == _lib.MATH_BF16X3 and name != "conv1" and name not in self._external:
+            # frozen weights: the three-piece bf16 split is paid once here instead of in every K-tile
+            if name not in self._wsplit:
+                self._wsplit[name] = ops.split_bf16x3(wp)
+            d.w_split = self._wsplit[name].data_ptr()
         self._ws_bytes = max(self._ws_bytes, self.lib.dc_conv2d_workspace_bytes(C.byref(d)))
         self._ops.append(("conv", d, name))
         self.flops += 2.0 * N * Ho * Wo * Cout * s.k * s.k * s.cin

@@ -89,7 +89,7 @@ def gemm(A, B, out=None, a_trans=False, b_trans=False, gather=None, scale=None, 
 
 
 def conv2d(x, w_packed, kh, kw, stride, pad_t, pad_l, Ho, Wo, scale=None, shift=None, residual=None,
-           res_mode=0, relu=False, out=None, split_k=0, math=0):
+           res_mode=0, relu=False, out=None, split_k=0, math=0, w_split=None):
     """NHWC conv forward with fused epilogue; see dc_conv2d_nhwc_f32.  x [N,H,W,Cin] contiguous."""
     lib = _lib.load()
     _chk(x, name="x"), _chk(w_packed, name="w")
@@ -107,8 +107,21 @@ def conv2d(x, w_packed, kh, kw, stride, pad_t, pad_l, Ho, Wo, scale=None, shift=
     d.shift = None if shift is None else shift.data_ptr()
     d.residual = None if residual is None else _chk(residual, name="residual").data_ptr()
     d.res_mode, d.relu, d.split_k, d.math = int(res_mode), int(relu), int(split_k), int(math)
+    d.w_split = None if w_split is None else _chk(w_split, torch.int16, "w_split").data_ptr()
     ws, wsb = WORKSPACE.get(lib.dc_conv2d_workspace_bytes(C.byref(d)), x.device)
     check(lib.dc_conv2d_nhwc_f32(C.byref(d), _ptr(ws), wsb, _stream()), "dc_conv2d_nhwc_f32")
+    return out
+
+
+def split_bf16x3(x, out=None):
+    """fp32 tensor -> int16 tensor [3, *x.shape] of bf16 bit patterns with x = p0 + p1 + p2 (pre-split conv weights)."""
+    lib = _lib.load()
+    _chk(x, name="x")
+    if not x.is_contiguous():
+        raise _lib.DcapError("split_bf16x3: x must be contiguous")
+    if out is None:
+        out = torch.empty((3,) + tuple(x.shape), dtype=torch.int16, device=x.device)
+    check(lib.dc_split_bf16x3_f32(_ptr(x), _ptr(out), x.numel(), _stream()), "dc_split_bf16x3_f32")
     return out
 
 

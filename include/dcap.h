@@ -97,8 +97,12 @@ typedef struct {
     int math;                 /* forward only: DC_MATH_F32 = fp32 MFMA (exact fp32 products), DC_MATH_BF16X3 = every operand
                                  element split into three bf16 pieces, six bf16 MFMA products, fp32 accumulate (fp32-grade
                                  accuracy on the bf16 matrix pipe; csrc/igemm_bf16s.h) */
+    const uint16_t* w_split;  /* optional with DC_MATH_BF16X3: the weights already split by dc_split_bf16x3_f32 into three bf16
+                                 planes [3][Cout][kh*kw*Cin] (same packing as w); NULL = split on the fly from w */
 } dc_conv_desc;
 
+/* x = p0 + p1 + p2 with bf16 pieces rounded to nearest even: out[0..n) = p0, out[n..2n) = p1, out[2n..3n) = p2. */
+int dc_split_bf16x3_f32(const float* x, uint16_t* out, size_t n, void* stream);
 size_t dc_conv2d_workspace_bytes(const dc_conv_desc* d);
 int    dc_conv2d_nhwc_f32(const dc_conv_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -104,7 +104,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("math", [0, 1], ids=["f32", "bf16x3"])
+@pytest.mark.parametrize("math", [0, 1, 2], ids=["f32", "bf16x3", "bf16x3-presplit"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d_matches_oracle(ops, case, math):
     """math 0: fp32 MFMA products; math 1: operands split into three bf16 pieces, six matrix-pipe products -- held to the
@@ -127,9 +127,23 @@ def test_conv2d_matches_oracle(ops, case, math):
     if relu:
         y = np.maximum(y, 0)
     pt, pl = (O.same_pad(H, k, stride)[0], O.same_pad(W, k, stride)[0]) if padding == 'same' else (0, 0)
-    got = ops.conv2d(dev(x), dev(pack_conv_kernel(w)), k, k, stride, pt, pl, Ho, Wo, dev(sc), dev(sh),
-                     None if res is None else dev(res), res_mode, relu, math=math)
+    wp = dev(pack_conv_kernel(w))
+    got = ops.conv2d(dev(x), wp, k, k, stride, pt, pl, Ho, Wo, dev(sc), dev(sh),
+                     None if res is None else dev(res), res_mode, relu, math=min(math, 1),
+                     w_split=ops.split_bf16x3(wp) if math == 2 else None)
     close(got, y)
+
+
+def test_split_bf16x3_pieces(ops):
+    """x = p0 + p1 + p2 to within 2^-25 |x|, every piece a bf16 (low 16 bits of its fp32 pattern zero)."""
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal(4097) * np.exp(rng.uniform(-20, 20, 4097))).astype(np.float32)
+    x[:4] = [0.0, 1.0, -2.5, 2.0 ** -120]
+    planes = ops.split_bf16x3(dev(x)).cpu().numpy().view(np.uint16).astype(np.uint32)
+    pieces = (planes << 16).view(np.float32).astype(np.float64)
+    err = np.abs(pieces.sum(0) - x.astype(np.float64))
+    assert np.all(err <= np.abs(x.astype(np.float64)) * 2.0 ** -24 + 1e-44)
+    assert np.all(np.abs(pieces[1]) <= np.abs(pieces[0]) * 2.0 ** -7 + 1e-44)
 
 
 def test_conv2d_bf16x3_error_is_fp32_grade(ops):

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--filter", default="")
     ap.add_argument("--math", type=int, default=0, help="0 = fp32 MFMA, 1 = split-bf16 (6 products)")
+    ap.add_argument("--presplit", action="store_true", help="math 1: weights pre-split into bf16 planes")
     args = ap.parse_args()
     dev = torch.device("cuda")
     B = args.batch
@@ -58,7 +59,8 @@ def main():
             res = torch.randn(B, Ho // 2, Ho // 2, Cout, device=dev)
         y = torch.empty(B, Ho, Ho, Cout, device=dev)
         pad = (k - 1) // 2
-        run = lambda: ops.conv2d(x, w, k, k, stride, pad, pad, Ho, Ho, sc, sh, res, res_mode, bool(relu), out=y, math=args.math)
+        wsp = ops.split_bf16x3(w) if (args.presplit and args.math == 1) else None
+        run = lambda: ops.conv2d(x, w, k, k, stride, pad, pad, Ho, Ho, sc, sh, res, res_mode, bool(relu), out=y, math=args.math, w_split=wsp)
         for _ in range(3):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
