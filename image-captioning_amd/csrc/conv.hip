@@ -149,12 +149,11 @@ extern "C" int dc_conv2d_nhwc_f32(const dc_conv_desc* d, void* workspace, size_t
               (!d->shift || aligned16(d->shift));
     DC_REQUIRE(d->math == DC_MATH_F32 || d->math == DC_MATH_BF16X3, DC_EINVAL, "dc_conv2d: unknown math mode %d", d->math);
     if (d->math == DC_MATH_BF16X3) return conv2d_bf16x3(d, stem, ep, M, N, K, t.bm, t.bn, t.split, workspace, workspace_bytes, s);
+    WeightKC bl{d->w, K, N, nullptr};
     if (stem) {
-        WeightKC bl{d->w, K, N, nullptr};
         StemKC al{d->x, d->H, d->W, d->Ho, d->Wo, M, (unsigned)((size_t)d->N * d->H * d->W * 4 * sizeof(float))};
         return conv_dispatch(al, bl, ep, M, N, K, t, workspace, workspace_bytes, s);
     }
-    ConvWeightKC bl{d->w, K, N, d->kh * d->kw, d->Cin};
     Im2colKC al{d->x, d->H, d->W, d->Cin, d->Ho, d->Wo, d->stride, d->pad_t, d->pad_l, d->kw, d->kh * d->kw, M,
                 (unsigned)((size_t)d->N * d->H * d->W * d->Cin * sizeof(float))};
     return conv_dispatch(al, bl, ep, M, N, K, t, workspace, workspace_bytes, s);

@@ -51,14 +51,14 @@ int conv2d_bf16x3(const dc_conv_desc* d, bool stem, const Epilogue& ep, int M, i
     if (d->w_split && !stem && bs_version() == 2) {
         DC_REQUIRE(aligned16(d->w_split), DC_EALIGN, "dc_conv2d: w_split must be 16-byte aligned");
         SplitWeightKC bl{d->w_split, K, N, d->kh * d->kw, d->Cin};
-        Im2colKC al{d->x, d->H, d->W, d->Cin, d->Ho, d->Wo, d->stride, d->pad_t, d->pad_l, d->kw, d->kh * d->kw, M,
+        Im2colKCcm al{d->x, d->H, d->W, d->Cin, d->Ho, d->Wo, d->stride, d->pad_t, d->pad_l, d->kw, d->kh * d->kw, M,
                     (unsigned)((size_t)d->N * d->H * d->W * d->Cin * sizeof(float))};
-        if (bm == 128 && bn == 128) return launch_igemm_bs2<128, 128, Im2colKC, SplitWeightKC>(al, bl, ep, M, N, K, split, workspace, workspace_bytes, s);
-        if (bm == 128 && bn == 64) return launch_igemm_bs2<128, 64, Im2colKC, SplitWeightKC>(al, bl, ep, M, N, K, split, workspace, workspace_bytes, s);
-        return launch_igemm_bs2<64, 64, Im2colKC, SplitWeightKC>(al, bl, ep, M, N, K, split, workspace, workspace_bytes, s);
+        if (bm == 128 && bn == 128) return launch_igemm_bs2<128, 128, Im2colKCcm, SplitWeightKC>(al, bl, ep, M, N, K, split, workspace, workspace_bytes, s);
+        if (bm == 128 && bn == 64) return launch_igemm_bs2<128, 64, Im2colKCcm, SplitWeightKC>(al, bl, ep, M, N, K, split, workspace, workspace_bytes, s);
+        return launch_igemm_bs2<64, 64, Im2colKCcm, SplitWeightKC>(al, bl, ep, M, N, K, split, workspace, workspace_bytes, s);
     }
     ConvWeightKC bl{d->w, K, N, d->kh * d->kw, d->Cin};
-    Im2colKC al{d->x, d->H, d->W, d->Cin, d->Ho, d->Wo, d->stride, d->pad_t, d->pad_l, d->kw, d->kh * d->kw, M,
+    Im2colKCcm al{d->x, d->H, d->W, d->Cin, d->Ho, d->Wo, d->stride, d->pad_t, d->pad_l, d->kw, d->kh * d->kw, M,
                 (unsigned)((size_t)d->N * d->H * d->W * d->Cin * sizeof(float))};
     return dispatch_bs(al, bl, ep, M, N, K, bm, bn, split, workspace, workspace_bytes, s);
 }

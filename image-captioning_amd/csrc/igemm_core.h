@@ -229,13 +229,16 @@ using DenseMC = DenseMCT<false>;
 
 // NHWC activations viewed as the im2col matrix [N*Ho*Wo][kh*kw*Cin] (cin fastest), Cin % 32 == 0:
 // one K-tile of 32 lies inside one (ky,kx) tap, so a row's 128 B are contiguous in memory.
-// K is VISITED chunk-major: K-tile t covers channels 32*(t / taps) .. +31 of tap t % taps (ConvWeightKC walks the packed
-// weights in the same order).  The kh*kw taps of one 32-channel chunk touch the same few cache lines per pixel, so a 3x3
-// conv re-reads its inputs from L1/L2 instead of streaming them nine times from the Infinity Cache.
+// CM = false: K is visited in storage order (tap-major, the packed weights read linearly by DenseKCT).
+// CM = true: chunk-major -- K-tile t covers channels 32*(t / taps) .. +31 of tap t % taps (ConvWeightKC walks the packed
+// weights in the same order): the kh*kw taps of one 32-channel chunk touch the same few cache lines per pixel.  Worth ~3 %
+// on the split-bf16 main loop, whose K-tile is 3x shorter; on the fp32 loop the extra per-tile scalar work costs more
+// than the locality gains (64x64 tiles: -4 %), so it stays on storage order.
 // Per thread and staged row: the byte offset of the output-aligned pixel (always inside the image) and a
 // bit mask of the taps that fall inside the image; per K-tile: one uniform tap offset.  Out-of-image
 // taps re-load the aligned pixel (valid memory) and are zeroed at store() time, after the MFMAs.
-struct Im2colKC {
+template <bool CM>
+struct Im2colKCT {
     static constexpr bool KC = true;
     __device__ __forceinline__ int kclamp(int k0, int) const { return k0; }     // range-checked buffer loads
     const float* x;
@@ -273,8 +276,17 @@ struct Im2colKC {
     template <int BT>
     __device__ __forceinline__ void load(State<BT>& s, f4 (&r)[BT / 32], int k0, int kend, int tid) const {
         if (s.ky < 0) {                                   // first tile of this block (split-K start): one division
-            const int kt = k0 >> 5, chunk = kt / taps, tap = kt - chunk * taps;
-            s.c = chunk * 32;
+            const int kt = k0 >> 5;
+            int tap;
+            if constexpr (CM) {
+                const int chunk = kt / taps;
+                tap = kt - chunk * taps;
+                s.c = chunk * 32;
+            } else {
+                const int cin_tiles = Cin >> 5;
+                tap = kt / cin_tiles;
+                s.c = (kt - tap * cin_tiles) * 32;
+            }
             s.ky = tap / kw;
             s.kx = tap - s.ky * kw;
         }
@@ -286,9 +298,17 @@ struct Im2colKC {
             const bool in = ((s.mask[i] >> tap) & 1ull) != 0;
             r[i] = buf_f4(s.rsrc, in ? s.boff[i] + (unsigned)ubytes : kOobOffset);     // out of image -> hardware zero
         }
-        if (++s.kx == kw) {                               // next tap of this channel chunk; then the next chunk
-            s.kx = 0;
-            if ((s.ky + 1) * kw == taps) { s.ky = 0; s.c += 32; } else { ++s.ky; }
+        if constexpr (CM) {
+            if (++s.kx == kw) {                           // next tap of this channel chunk; then the next chunk
+                s.kx = 0;
+                if ((s.ky + 1) * kw == taps) { s.ky = 0; s.c += 32; } else { ++s.ky; }
+            }
+        } else {
+            s.c += 32;
+            if (s.c == Cin) {
+                s.c = 0;
+                if (++s.kx == kw) { s.kx = 0; ++s.ky; }
+            }
         }
     }
     template <int BT>
@@ -296,6 +316,9 @@ struct Im2colKC {
         store_kc<BT>(S, r, tid);
     }
 };
+
+using Im2colKC = Im2colKCT<false>;
+using Im2colKCcm = Im2colKCT<true>;
 
 // wgrad's B operand: the im2col matrix K-major.  K rows = output pixels (all images), columns
 // n = tap*Cin + ci; a column tile of BT lies inside one tap (Cin % BT == 0), so a K row is a contiguous run of

@@ -55,7 +55,7 @@ def load_weight_file(filepath):
 
 
 class DenseImageCapRCNN(object):
-    def __init__(self, mode, config, model_dir, use_generated_rois=False, device=None, stage4_blocks=22):
+    def __init__(self, mode, config, model_dir, use_generated_rois=False, device=None, stage4_blocks=22, conv_math=None):
         assert mode in ['training', 'inference']
         if mode == 'training':
             raise NotImplementedError("the joint training graph (dense_img_cap/dense_model.py) is a SURVEY 8(f) 'next' row")
@@ -64,6 +64,7 @@ class DenseImageCapRCNN(object):
         self.model_dir = model_dir
         self.use_generated_rois = use_generated_rois
         self.stage4_blocks = stage4_blocks
+        self.conv_math = conv_math          # None: encoder.DEFAULT_CONV_MATH / DCAP_CONV_MATH; 'f32' | 'bf16x3'
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self._weights = None
         self._plans = {}
@@ -113,7 +114,7 @@ class DenseImageCapRCNN(object):
             if self._weights is None:
                 raise RuntimeError("load_weights()/set_weights() must be called before inference")
             self._plans[key] = EncoderPlan(self._weights, batch, h, w, self.device, self.stage4_blocks,
-                                           self.config.MEAN_PIXEL, rpn=self._rpn_config())
+                                           self.config.MEAN_PIXEL, rpn=self._rpn_config(), math=self.conv_math)
         return self._plans[key]
 
     def extract_features(self, images_u8, rois_px=None):
