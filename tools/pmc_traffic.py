@@ -1,0 +1,42 @@
+"""Merge two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; --output-format csv) into per-kernel HBM bytes per launch.
+gfx950 correction (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE counts 128-byte requests as 64 B -> doubled;
+WRITE_SIZE as read; both in KB of 1024 B.
+Usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json>"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def load(d, counter):
+    acc = defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != counter:
+                continue
+            k = r["Kernel_Name"][:90]
+            acc[k][0] += 1
+            acc[k][1] += float(r["Counter_Value"])
+    return acc
+
+
+def main():
+    fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in fetch:
+        n, f = fetch[k]
+        nw, w = write.get(k, [0, 0.0])
+        if n == 0:
+            continue
+        fk, wk = f / n, (w / nw if nw else 0.0)
+        out[k] = {"launches": n, "fetch_KB_raw": fk, "write_KB": wk, "hbm_bytes_per_launch_corrected": (2.0 * fk + wk) * 1024.0,
+                  "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); WRITE_SIZE as read; KB = 1024 B"}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch_corrected"] * kv[1]["launches"])[:12]:
+        print("%8.1f MB/launch x %4d  %s" % (v["hbm_bytes_per_launch_corrected"] / 1e6, v["launches"], k[:70]))
+
+
+if __name__ == "__main__":
+    main()
