@@ -35,7 +35,7 @@ class ConvDesc(C.Structure):
                 ("relu", C.c_int), ("split_k", C.c_int), ("accumulate", C.c_int), ("math", C.c_int), ("w_split", C.c_void_p)]
 
 
-MATH_F32, MATH_BF16X3 = 0, 1
+MATH_F32, MATH_BF16X3, MATH_BF16X2 = 0, 1, 2
 
 
 class RoiAlignDesc(C.Structure):

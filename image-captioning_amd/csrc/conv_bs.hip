@@ -17,7 +17,12 @@ static int bs_version() {
 
 template <class AL, class BL>
 static int dispatch_bs(const AL& al, const BL& bl, const Epilogue& ep, int M, int N, int K, int bm, int bn, int split, void* ws,
-                       size_t wsb, hipStream_t s) {
+                       size_t wsb, hipStream_t s, int pieces) {
+    if (pieces == 2) {
+        if (bm == 128 && bn == 128) return launch_igemm_bs<128, 128, AL, BL, 2>(al, bl, ep, M, N, K, split, ws, wsb, s);
+        if (bm == 128 && bn == 64) return launch_igemm_bs<128, 64, AL, BL, 2>(al, bl, ep, M, N, K, split, ws, wsb, s);
+        return launch_igemm_bs<64, 64, AL, BL, 2>(al, bl, ep, M, N, K, split, ws, wsb, s);
+    }
     if (bs_version() == 1) {
         if (bm == 128 && bn == 128) return launch_igemm_bs<128, 128, AL, BL>(al, bl, ep, M, N, K, split, ws, wsb, s);
         if (bm == 128 && bn == 64) return launch_igemm_bs<128, 64, AL, BL>(al, bl, ep, M, N, K, split, ws, wsb, s);
@@ -43,12 +48,13 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
 
 int conv2d_bf16x3(const dc_conv_desc* d, bool stem, const Epilogue& ep, int M, int N, int K, int bm, int bn, int split, void* workspace,
                   size_t workspace_bytes, hipStream_t s) {
+    const int pieces = d->math == DC_MATH_BF16X2 ? 2 : 3;
     if (stem) {
         WeightKCb bl{d->w, K, N, nullptr};
         StemKC al{d->x, d->H, d->W, d->Ho, d->Wo, M, (unsigned)((size_t)d->N * d->H * d->W * 4 * sizeof(float))};
-        return dispatch_bs(al, bl, ep, M, N, K, bm, bn, split, workspace, workspace_bytes, s);
+        return dispatch_bs(al, bl, ep, M, N, K, bm, bn, split, workspace, workspace_bytes, s, pieces);
     }
-    if (d->w_split && !stem && bs_version() == 2) {
+    if (d->w_split && !stem && bs_version() == 2 && pieces == 3) {
         DC_REQUIRE(aligned16(d->w_split), DC_EALIGN, "dc_conv2d: w_split must be 16-byte aligned");
         SplitWeightKC bl{d->w_split, K, N, d->kh * d->kw, d->Cin};
         Im2colKCcm al{d->x, d->H, d->W, d->Cin, d->Ho, d->Wo, d->stride, d->pad_t, d->pad_l, d->kw, d->kh * d->kw, M,
@@ -60,7 +66,7 @@ int conv2d_bf16x3(const dc_conv_desc* d, bool stem, const Epilogue& ep, int M, i
     ConvWeightKC bl{d->w, K, N, d->kh * d->kw, d->Cin};
     Im2colKCcm al{d->x, d->H, d->W, d->Cin, d->Ho, d->Wo, d->stride, d->pad_t, d->pad_l, d->kw, d->kh * d->kw, M,
                 (unsigned)((size_t)d->N * d->H * d->W * d->Cin * sizeof(float))};
-    return dispatch_bs(al, bl, ep, M, N, K, bm, bn, split, workspace, workspace_bytes, s);
+    return dispatch_bs(al, bl, ep, M, N, K, bm, bn, split, workspace, workspace_bytes, s, pieces);
 }
 
 }  // namespace dcap

@@ -52,7 +52,7 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& p0, unsig
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // registers (thread = row tid>>3 (+32 i), k quad tid&7) -> three bf16 planes [plane][BT rows][LDB]
-template <int BT, int NR>
+template <int BT, int NR, int NP = 3>
 __device__ __forceinline__ void store_split_kc(__bf16* S, const f4 (&r)[NR], int tid) {
     static_assert(NR == BT / 32, "one f4 per 32 staged rows");
     const int q = tid & 7, rr = tid >> 3;
@@ -64,7 +64,7 @@ __device__ __forceinline__ void store_split_kc(__bf16* S, const f4 (&r)[NR], int
         __bf16* d = S + (rr + 32 * i) * LDB + 4 * q;
         *reinterpret_cast<u32x2*>(d) = u32x2{a0, b0};
         *reinterpret_cast<u32x2*>(d + BT * LDB) = u32x2{a1, b1};
-        *reinterpret_cast<u32x2*>(d + 2 * BT * LDB) = u32x2{a2, b2};
+        if constexpr (NP == 3) *reinterpret_cast<u32x2*>(d + 2 * BT * LDB) = u32x2{a2, b2};      // NP == 2: the third piece is dead code
     }
 }
 
@@ -126,21 +126,23 @@ __device__ __forceinline__ void stage_store(const L& l, const ST& st, __bf16* S,
     else store_split_kc<BT>(S, r, tid);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NP = 3>
 constexpr size_t igemm_bs_lds_bytes() {
-    constexpr size_t stage = (size_t)3 * (BM + BN) * LDB * sizeof(__bf16);
+    constexpr size_t stage = (size_t)NP * (BM + BN) * LDB * sizeof(__bf16);
     constexpr size_t cimage = (size_t)BM * (BN + 4) * sizeof(float);
     return stage > cimage ? stage : cimage;
 }
 
-template <int BM, int BN, class AL, class BL>
+// NP = 3: six products (fp32-grade).  NP = 2: pieces p0, p1 only (x = p0 + p1 to 2^-17 |x|) and the three products
+// a0*b0 + a0*b1 + a1*b0 -- a 16-bit-mantissa product (2^-16 relative, 32x finer than TF32) at half the MFMAs.
+template <int BM, int BN, class AL, class BL, int NP = 3>
 __global__ __launch_bounds__(256, 2) void igemm_bs_kernel(AL al, BL bl, Epilogue ep, int M, int N, int K, int klen,
                                                        float* __restrict__ partial) {
     static_assert(AL::KC && BL::KC, "split-bf16 main loop: both operands K-contiguous");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TM = BM / 64, TN = BN / 64;
     __bf16* As = reinterpret_cast<__bf16*>(smem);
-    __bf16* Bs = As + 3 * BM * LDB;
+    __bf16* Bs = As + NP * BM * LDB;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_n = (N + BN - 1) / BN;
@@ -180,8 +182,8 @@ __global__ __launch_bounds__(256, 2) void igemm_bs_kernel(AL al, BL bl, Epilogue
 
     auto phase = [&](int kt, f4 (&qa)[BM / 32], f4 (&qb)[BN / 32]) {
         // registers (tile kt) -> bf16 planes in LDS; every wave is past the previous tile's fragment reads (barrier below)
-        store_split_kc<BM>(As, qa, tid);
-        store_split_kc<BN>(Bs, qb, tid);
+        store_split_kc<BM, BM / 32, NP>(As, qa, tid);
+        store_split_kc<BN, BN / 32, NP>(Bs, qb, tid);
         __syncthreads();
         // refill the drained registers with tile kt+2: unconditional (clamped / range-checked)
 #ifndef DCAP_EXP_NOLOAD
@@ -194,9 +196,9 @@ __global__ __launch_bounds__(256, 2) void igemm_bs_kernel(AL al, BL bl, Epilogue
 #ifndef DCAP_EXP_NOFRAG
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
-            bf16x8 a[TM][3], b[TN][3];
+            bf16x8 a[TM][NP], b[TN][NP];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
+            for (int p = 0; p < NP; ++p) {
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) a[tm][p] = *reinterpret_cast<const bf16x8*>(afrag + (p * BM + tm * 32) * LDB + 16 * s);
 #pragma unroll
@@ -212,9 +214,11 @@ __global__ __launch_bounds__(256, 2) void igemm_bs_kernel(AL al, BL bl, Epilogue
                     acc[tm][tn] = c;
                     continue;
 #endif
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[tn][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][2], c, 0, 0, 0);
+                    if constexpr (NP == 3) {
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][2], b[tn][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][2], c, 0, 0, 0);
+                    }
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][0], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][1], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][0], c, 0, 0, 0);
@@ -246,12 +250,25 @@ constexpr size_t igemm_bs2_lds_bytes() {
     return stages > cimage ? stages : cimage;
 }
 
+// NCW consumer waves (4: one per SIMD; 8: two per SIMD, so one wave's fragment-read / barrier latency hides under the
+// other's MFMAs) + 4 producer waves.  A consumer wave owns TM x TN 32x32 accumulator blocks.
+template <int BM, int BN>
+struct bs2_shape {
+    static constexpr int NCW = (BM * BN > 64 * 64) ? 8 : 4;
+    static constexpr int BLOCKS = (BM / 32) * (BN / 32);                 // 32x32 blocks in the tile
+    static constexpr int PER = BLOCKS / NCW;                             // per consumer wave
+    static constexpr int TN = 1, TM = PER;                               // a wave's blocks are stacked along M
+    static constexpr int WC = BN / 32, WR = BM / (32 * TM);              // wave grid
+    static constexpr int THREADS = (NCW + 4) * 64;
+};
+
 template <int BM, int BN, class AL, class BL>
-__global__ __launch_bounds__(512, (BM * BN <= 64 * 64) ? 2 : 1) void igemm_bs2_kernel(AL al, BL bl, Epilogue ep, int M, int N, int K, int klen,
+__global__ __launch_bounds__((bs2_shape<BM, BN>::THREADS), 1) void igemm_bs2_kernel(AL al, BL bl, Epilogue ep, int M, int N, int K, int klen,
                                                                                  float* __restrict__ partial) {
     static_assert(AL::KC && BL::KC, "split-bf16 main loop: both operands K-contiguous");
+    using SH = bs2_shape<BM, BN>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int TM = SH::TM, TN = SH::TN, NCW = SH::NCW;
     constexpr int STAGE = 3 * (BM + BN) * LDB;                 // bf16 elements per stage
     __bf16* S0 = reinterpret_cast<__bf16*>(smem);
 
@@ -263,9 +280,9 @@ __global__ __launch_bounds__(512, (BM * BN <= 64 * 64) ? 2 : 1) void igemm_bs2_k
     const int kend = min(K, kbeg + klen);
     const int nkt = (kend - kbeg + BK - 1) / BK;
 
-    if (wave >= 4) {
+    if (wave >= NCW) {
         // ------------------------------------------------------------------ producer waves
-        const int ptid = tid - 256;
+        const int ptid = tid - NCW * 64;
         typename AL::template State<BM> sa;
         typename BL::template State<BN> sb;
         al.template init<BM>(sa, m0, ptid);
@@ -310,7 +327,7 @@ __global__ __launch_bounds__(512, (BM * BN <= 64 * 64) ? 2 : 1) void igemm_bs2_k
     }
     // ---------------------------------------------------------------------- consumer waves
     const int lane = tid & 63;
-    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+    const int wm = (wave / SH::WC) * (32 * TM), wn = (wave % SH::WC) * (32 * TN);
     const int li = lane & 31, lh = lane >> 5;
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -357,7 +374,7 @@ __global__ __launch_bounds__(512, (BM * BN <= 64 * 64) ? 2 : 1) void igemm_bs2_k
 #endif
         __syncthreads();                                     // tile kt consumed; tile kt+1 staged
     }
-    store_tile<BM, BN>(acc, smem, ep, partial, M, N, m0, n0, wm, wn);
+    store_tile<BM, BN, TM, TN, NCW * 64>(acc, smem, ep, partial, M, N, m0, n0, wm, wn);
 }
 
 template <int BM, int BN, class AL, class BL>
@@ -384,7 +401,7 @@ int launch_igemm_bs2(const AL& al, const BL& bl, const Epilogue& ep, int M, int 
         attr_set = true;
     }
     dim3 grid(tiles, 1, split_k);
-    hipLaunchKernelGGL((igemm_bs2_kernel<BM, BN, AL, BL>), grid, dim3(512), lds, stream, al, bl, ep, M, N, K, klen, partial);
+    hipLaunchKernelGGL((igemm_bs2_kernel<BM, BN, AL, BL>), grid, dim3(bs2_shape<BM, BN>::THREADS), lds, stream, al, bl, ep, M, N, K, klen, partial);
     int rc = check_launch("igemm_bs2_kernel");
     if (rc) return rc;
     if (split_k > 1) {
@@ -396,7 +413,7 @@ int launch_igemm_bs2(const AL& al, const BL& bl, const Epilogue& ep, int M, int 
     return rc;
 }
 
-template <int BM, int BN, class AL, class BL>
+template <int BM, int BN, class AL, class BL, int NP = 3>
 int launch_igemm_bs(const AL& al, const BL& bl, const Epilogue& ep, int M, int N, int K, int split_k, void* workspace,
                     size_t workspace_bytes, hipStream_t stream) {
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
@@ -412,15 +429,15 @@ int launch_igemm_bs(const AL& al, const BL& bl, const Epilogue& ep, int M, int N
                    "igemm split-K needs %zu workspace bytes, got %zu", need, workspace_bytes);
         partial = static_cast<float*>(workspace);
     }
-    constexpr size_t lds = igemm_bs_lds_bytes<BM, BN>();
+    constexpr size_t lds = igemm_bs_lds_bytes<BM, BN, NP>();
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bs_kernel<BM, BN, AL, BL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bs_kernel<BM, BN, AL, BL, NP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     dim3 grid(tiles, 1, split_k);
-    hipLaunchKernelGGL((igemm_bs_kernel<BM, BN, AL, BL>), grid, dim3(256), lds, stream, al, bl, ep, M, N, K, klen, partial);
+    hipLaunchKernelGGL((igemm_bs_kernel<BM, BN, AL, BL, NP>), grid, dim3(256), lds, stream, al, bl, ep, M, N, K, klen, partial);
     int rc = check_launch("igemm_bs_kernel");
     if (rc) return rc;
     if (split_k > 1) {

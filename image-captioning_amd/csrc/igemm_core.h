@@ -549,10 +549,10 @@ constexpr size_t igemm_lds_bytes() {
 // ------------------------------------------------------------------------------------------------
 // Tile epilogue shared by the f32 and the split-bf16 main loops.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN>
-__device__ __forceinline__ void store_tile(f32x16 (&acc)[BM / 64][BN / 64], float* smem, const Epilogue& ep, float* __restrict__ partial,
+// TM x TN = 32x32 accumulator blocks per wave (wave origin wm, wn inside the tile); NT = threads taking part (waves 0..NT/64-1).
+template <int BM, int BN, int TM = BM / 64, int TN = BN / 64, int NT = 256>
+__device__ __forceinline__ void store_tile(f32x16 (&acc)[TM][TN], float* smem, const Epilogue& ep, float* __restrict__ partial,
                                            int M, int N, int m0, int n0, int wm, int wn) {
-    constexpr int TM = BM / 64, TN = BN / 64;
     const int tid = threadIdx.x, lane = tid & 63;
     // ---- epilogue: transpose the accumulators through LDS so every lane owns 4 consecutive columns:
     // 16-byte residual loads / output stores in full 256-512 B row segments instead of 4-byte accesses
@@ -561,7 +561,7 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[BM / 64][BN / 64], floa
     // compiler knows, so a load written after a store is never hoisted above it, and a short-K 1x1 conv (K = 256:
     // 8 K-tiles) otherwise spends as long waiting on 16 dependent round trips as it spent on its MFMAs.
     constexpr int LDC = BN + 4;
-    constexpr int CPR = BN / 4, RPP = 256 / CPR;         // float4 columns per row, rows per pass
+    constexpr int CPR = BN / 4, RPP = NT / CPR;          // float4 columns per row, rows per pass
     constexpr int PASSES = BM / RPP, G = PASSES < 8 ? PASSES : 8;
     const int c4 = tid % CPR, rp = tid / CPR;
     const int col = n0 + 4 * c4;

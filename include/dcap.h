@@ -81,6 +81,7 @@ int    dc_gemm_f32(const dc_gemm_desc* d, void* workspace, size_t workspace_byte
  * ------------------------------------------------------------------------------------------------ */
 #define DC_MATH_F32 0
 #define DC_MATH_BF16X3 1
+#define DC_MATH_BF16X2 2
 typedef struct {
     int N, H, W, Cin;
     int Cout, kh, kw, stride, pad_t, pad_l;
@@ -96,7 +97,8 @@ typedef struct {
     int accumulate;           /* wgrad only: dw += (a weight shared by several inputs, e.g. the RPN over P2..P6) */
     int math;                 /* forward only: DC_MATH_F32 = fp32 MFMA (exact fp32 products), DC_MATH_BF16X3 = every operand
                                  element split into three bf16 pieces, six bf16 MFMA products, fp32 accumulate (fp32-grade
-                                 accuracy on the bf16 matrix pipe; csrc/igemm_bf16s.h) */
+                                 accuracy on the bf16 matrix pipe; csrc/igemm_bf16s.h); DC_MATH_BF16X2 = two pieces, three
+                                 products: a 16-bit-mantissa product (2^-16 relative; TF32 is 2^-11) at half the MFMAs */
     const uint16_t* w_split;  /* optional with DC_MATH_BF16X3: the weights already split by dc_split_bf16x3_f32 into three bf16
                                  planes [3][Cout][kh*kw*Cin] (same packing as w); NULL = split on the fly from w */
 } dc_conv_desc;

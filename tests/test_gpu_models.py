@@ -387,3 +387,31 @@ def test_joint_model_inference_captions(gpu):
     assert hits == K
     light = model.generate_captions([img[0]], return_probabilities=False)[0]
     assert "captions" not in light and np.array_equal(light["ids"], res["ids"]) and np.array_equal(light["rois"], res["rois"])
+
+
+@pytest.mark.parametrize("math,tol", [("f32", 2e-4), ("bf16x3", 2e-4), ("bf16x2", 1e-3)])
+def test_encoder_conv_math_modes(gpu, math, tol):
+    """The three conv arithmetic modes through the whole ResNet+FPN+RoIAlign stack against the float64 oracle: exact fp32
+    products and the 3-piece bf16 split are held to 2e-4 of the feature scale, the 2-piece split (2^-16 products) to the
+    1e-3 north-star tolerance (measured ~1e-5: see DESIGN.md)."""
+    from image_captioning_amd import synth
+    from image_captioning_amd.config import Config
+    from image_captioning_amd.modified_dense_model import DenseImageCapRCNN
+
+    class Cfg(Config):
+        IMAGES_PER_GPU = 1
+        IMAGE_MIN_DIM = 256
+        IMAGE_MAX_DIM = 256
+    Wt = synth.encoder_weights(0, stage4_blocks=3)
+    img = synth.images(5, 1, 256, 256)
+    rois = synth.rois(6, 1, 16, 256, 256, lo=16, hi=256)
+    want = M.encoder_features(img, rois, Wt, MEAN, stage4_blocks=3)
+    model = DenseImageCapRCNN("inference", Cfg(), "logs", stage4_blocks=3, conv_math=math)
+    model.set_weights(Wt)
+    got = model.extract_features(img, rois).cpu().numpy()
+    err = rel_err(got, want)
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/math_mode_errors.txt", "a") as f:
+        f.write("%s %.3e\n" % (math, err))
+    assert err < tol, (math, err)

@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--filter", default="")
-    ap.add_argument("--math", type=int, default=0, help="0 = fp32 MFMA, 1 = split-bf16 (6 products)")
+    ap.add_argument("--math", type=int, default=0, help="0 = fp32 MFMA, 1 = split-bf16 (3 pieces, 6 products), 2 = 2 pieces, 3 products")
     ap.add_argument("--presplit", action="store_true", help="math 1: weights pre-split into bf16 planes")
     args = ap.parse_args()
     dev = torch.device("cuda")
