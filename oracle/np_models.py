@@ -3,7 +3,8 @@ oracle/np_models.py -- CPU restatement (NumPy float64) of the reference's model 
 ResNet-101 + FPN + PyramidROIAlign encoder, RoI head, caption decoders v2 (inject / merge) and v1
 (par-inject, T teacher-forced prefixes), their losses, gradients, Keras AMSGrad and greedy decode.
 
-*** TEST INFRASTRUCTURE, NOT PRODUCT CODE.  PARITY UNPINNED (see np_oracle.py header). ***
+*** TEST INFRASTRUCTURE, NOT PRODUCT CODE.  PARITY UNPINNED for the model graphs in this file (the Keras/TF arithmetic
+cannot run here); the host-side geometry they call is pinned -- see the np_oracle.py header. ***
 
 Weights are a dict keyed '<keras layer name>/<weight name>' with Keras shapes
 (kernel HWIO / [in,out], LSTM gate blocks i,f,c,o).

@@ -6,13 +6,18 @@ dense-captioning hot path of frosinastojanovska/image-captioning.
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
 The product path (image-captioning_amd/) never imports it and fails loudly without its HIP library.
 
-*** PARITY UNPINNED. ***
-The reference's arithmetic lives in Keras 2.1.x / TensorFlow 1.x (un-vendored, un-pinned, not
-installable here: no network, Python 3.10).  The reference repo ships no tests, golden vectors or
-fixtures for this path.  This file restates the documented semantics of
-those libraries at the reference's call sites (cited per function, paths relative to
-/root/reference).  It is checked against analytic known-answer tests and an independent torch
-restatement (oracle/torch_ref.py), not against outputs of the reference itself.
+*** PARITY: host-side geometry PINNED by outputs of the reference's own code; layer arithmetic UNPINNED. ***
+Pinned (tests/golden/make_reference_vectors.py runs the reference's pure-NumPy functions and its config module in this
+container and stores inputs + outputs in tests/golden/reference_host_vectors.npz; tests/test_golden_reference.py): anchor
+generation, IoU, NMS, box-delta application / refinement, mold_image -- for this file -- plus, for the product's host
+mirrors, Config, the Dataset class, resize/pad, image meta, build_rpn_targets, load_image_gt, the joint and v1
+data generators and the vocabulary helpers.
+Unpinned: the reference's layer arithmetic lives in Keras 2.1.x / TensorFlow 1.x (un-vendored, un-pinned, not
+installable here: no network, Python 3.10), and the reference repo ships no tests, golden vectors or fixtures for it
+(SURVEY.md section 4, 8c).  For conv / BN / pooling / crop_and_resize / LSTM / softmax-CE / losses / Adam this file
+restates the documented semantics of those libraries at the reference's call sites (cited per function, paths relative to
+/root/reference); that part is checked against analytic known-answer tests and an independent torch restatement
+(oracle/torch_ref.py), not against outputs of the reference itself.
 
 Everything is float64 unless a function says otherwise (box-coordinate arithmetic follows TF's
 float32 kernels so that index decisions -- pyramid level, out-of-range bins -- are bit-faithful).

@@ -1,0 +1,251 @@
+"""Golden vectors produced by RUNNING THE REFERENCE'S OWN CODE in this container (not a restatement).
+
+The reference's Keras/TensorFlow graph code cannot run here (tensorflow / keras / skimage / nltk are not installed and there
+is no network), but its host-side geometry is plain NumPy.  This script
+  * imports  dense_img_cap/config.py  as a module (it only needs numpy), and
+  * takes the pure-NumPy FUNCTIONS it needs out of  dense_img_cap/utils.py  and  dense_img_cap/dense_model.py  by parsing
+    those files with `ast` at run time and compiling just these function definitions into a namespace that holds `np`,
+    `math` and `random` -- the modules' top-level `import tensorflow / keras / skimage` lines are never executed, no
+    stand-in for a missing library is written, and no reference source text is stored in this repository;
+then calls them on seeded inputs and stores inputs + outputs in  tests/golden/reference_host_vectors.npz .
+
+tests/test_golden_reference.py checks the oracle (oracle/np_oracle.py) and the product's host code against these
+vectors.  What this pins: Config's derived attributes, anchor generation, IoU, NMS, box-delta application / refinement,
+image meta, mold/unmold, RPN target building (incl. its use of np.random), clip_to_window, unmold_generations, the Dataset
+base class, resize_image's padding/window logic (scale == 1: scipy.misc.imresize no longer exists), load_image_gt and the
+joint model's data_generator (all six input arrays), the v1 create_roi_info / data_generator batch layout (features come
+from a seeded table standing in for the Keras feature model, which is the generator's INPUT, not code under test) and the
+vocabulary helpers load_corpus / encode_word / encode_word_v2 / decode_word / decode_caption.
+What stays unpinned: every Keras/TF layer's arithmetic (conv, BN, LSTM, crop_and_resize, losses, optimizer).
+
+Run:  python tests/golden/make_reference_vectors.py        (needs /root/reference; the GPU box never runs this)
+"""
+import ast
+import importlib.util
+import math
+import os
+import random
+import types
+
+import numpy as np
+
+REF = "/root/reference/dense_img_cap"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_host_vectors.npz")
+
+
+def functions_from(path, names, extra_globals=None):
+    """Compile the named top-level (or class-level) function definitions of a reference file, and nothing else."""
+    with open(path, "r", encoding="utf-8") as f:
+        tree = ast.parse(f.read(), filename=path)
+    ns = {"np": np, "math": math, "random": random}
+    ns.update(extra_globals or {})
+    found = {}
+    for node in ast.walk(tree):
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef)) and node.name in names and node.name not in found:
+            mod = ast.Module(body=[node], type_ignores=[])
+            exec(compile(mod, path, "exec"), ns)
+            found[node.name] = ns[node.name]
+    missing = set(names) - set(found)
+    if missing:
+        raise RuntimeError("not found in %s: %s" % (path, sorted(missing)))
+    return types.SimpleNamespace(**found)
+
+
+def main():
+    spec = importlib.util.spec_from_file_location("ref_config", os.path.join(REF, "config.py"))
+    ref_config = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_config)
+    U = functions_from(os.path.join(REF, "utils.py"),
+                       ["compute_iou", "compute_overlaps", "non_max_suppression", "apply_box_deltas", "box_refinement",
+                        "generate_anchors", "generate_pyramid_anchors", "trim_zeros"])
+    D = functions_from(os.path.join(REF, "dense_model.py"),
+                       ["compose_image_meta", "parse_image_meta", "mold_image", "unmold_image", "build_rpn_targets",
+                        "clip_to_window", "unmold_generations"], extra_globals={"utils": U})
+    out = {}
+
+    # ---- Config: class defaults and the attributes __init__ derives
+    class Cfg(ref_config.Config):
+        NAME = "golden"
+        IMAGES_PER_GPU = 3
+        GPU_COUNT = 2
+        IMAGE_MAX_DIM = 512
+        IMAGE_MIN_DIM = 384
+    c = Cfg()
+    base = ref_config.Config
+    for k in ("BACKBONE_STRIDES", "RPN_ANCHOR_SCALES", "RPN_ANCHOR_RATIOS", "RPN_ANCHOR_STRIDE", "RPN_NMS_THRESHOLD",
+              "RPN_TRAIN_ANCHORS_PER_IMAGE", "POST_NMS_ROIS_TRAINING", "POST_NMS_ROIS_INFERENCE", "IMAGE_MIN_DIM", "IMAGE_MAX_DIM",
+              "MEAN_PIXEL", "TRAIN_ROIS_PER_IMAGE", "ROI_POSITIVE_RATIO", "POOL_SIZE", "MAX_GT_INSTANCES", "RPN_BBOX_STD_DEV",
+              "BBOX_STD_DEV", "DETECTION_MAX_INSTANCES", "DETECTION_NMS_THRESHOLD", "LEARNING_RATE", "LEARNING_MOMENTUM",
+              "WEIGHT_DECAY", "STEPS_PER_EPOCH", "VALIDATION_STEPS", "GPU_COUNT", "IMAGES_PER_GPU"):
+        out["config_default/" + k] = np.asarray(getattr(base, k), dtype=np.float64)
+    out["config_derived/BATCH_SIZE"] = np.asarray(c.BATCH_SIZE)
+    out["config_derived/IMAGE_SHAPE"] = np.asarray(c.IMAGE_SHAPE)
+    out["config_derived/BACKBONE_SHAPES"] = np.asarray(c.BACKBONE_SHAPES)
+
+    # ---- anchors
+    for S in (256, 1024):
+        shapes = np.array([[int(math.ceil(S / s)), int(math.ceil(S / s))] for s in base.BACKBONE_STRIDES])
+        a = U.generate_pyramid_anchors(base.RPN_ANCHOR_SCALES, base.RPN_ANCHOR_RATIOS, shapes, base.BACKBONE_STRIDES, 1)
+        if S == 256:
+            out["anchors256"] = a
+        else:
+            out["anchors1024/count"] = np.asarray(a.shape[0])
+            out["anchors1024/head"], out["anchors1024/tail"] = a[:64], a[-64:]
+            out["anchors1024/every4099"] = a[::4099]
+            out["anchors1024/colsum"] = a.sum(axis=0)
+    out["anchors_single"] = U.generate_anchors([32, 64], [0.5, 1, 2], [3, 5], 16, 2)
+
+    # ---- IoU / NMS / box deltas
+    rng = np.random.RandomState(0)
+
+    def boxes(n, lo=0, hi=200):
+        y, x = rng.uniform(lo, hi, n), rng.uniform(lo, hi, n)
+        return np.stack([y, x, y + rng.uniform(4, 90, n), x + rng.uniform(4, 90, n)], axis=1)
+    b1, b2 = boxes(60), boxes(7)
+    b1[10] = b2[3]                                           # an exact match
+    out["iou/b1"], out["iou/b2"], out["iou/out"] = b1, b2, U.compute_overlaps(b1, b2)
+    nb = boxes(120)
+    nb[40:80] = nb[:40] + rng.normal(0, 3, (40, 4))          # heavy overlaps
+    ns = rng.uniform(0, 1, 120)
+    ns[5] = ns[6]                                            # a tie
+    out["nms/boxes"], out["nms/scores"] = nb, ns
+    for t in (0.3, 0.5, 0.7):
+        out["nms/keep_%02d" % int(t * 10)] = U.non_max_suppression(nb.copy(), ns.copy(), t)
+    ib = np.round(boxes(30)).astype(np.int32)
+    out["nms/int_boxes"], out["nms/int_keep"] = ib, U.non_max_suppression(ib, ns[:30].copy(), 0.5)
+    d = rng.normal(0, 0.4, (60, 4))
+    out["deltas/in"], out["deltas/applied"] = d, U.apply_box_deltas(b1.copy(), d)
+    g = b1 + rng.normal(0, 6, b1.shape)
+    g[:, 2:] = np.maximum(g[:, 2:], g[:, :2] + 2)
+    out["refine/gt"], out["refine/out"] = g, U.box_refinement(b1.copy(), g)
+    tz = np.round(boxes(9)).astype(np.int32)
+    tz[[2, 5, 8]] = 0
+    out["trim/in"], out["trim/out"] = tz, U.trim_zeros(tz)
+
+    # ---- image meta / mold
+    win = (0, 16, 384, 496)
+    meta = D.compose_image_meta(17, (480, 640, 3), win)
+    out["meta/one"] = meta
+    mid, mshape, mwin = D.parse_image_meta(np.stack([meta, D.compose_image_meta(3, (100, 50, 3), (1, 2, 3, 4))]))
+    out["meta/id"], out["meta/shape"], out["meta/window"] = mid, mshape, mwin
+    img = rng.randint(0, 256, (5, 7, 3)).astype(np.uint8)
+    molded = D.mold_image(img, base)
+    out["mold/img"], out["mold/out"], out["mold/back"] = img, molded, D.unmold_image(molded, base)
+
+    # ---- RPN targets (consumes np.random exactly as the reference does)
+    class TCfg(ref_config.Config):
+        NAME = "t"
+        RPN_TRAIN_ANCHORS_PER_IMAGE = 64
+    tcfg = TCfg()
+    gt = np.array([[10, 12, 70, 90], [40, 30, 120, 128], [0, 0, 50, 40], [100, 100, 250, 240], [5, 150, 60, 250]], np.int32)
+    for seed in (0, 1):
+        np.random.seed(100 + seed)
+        match, bbox = D.build_rpn_targets((256, 256, 3), out["anchors256"], None, gt, tcfg)
+        out["rpn_targets/match_%d" % seed], out["rpn_targets/bbox_%d" % seed] = match, bbox
+    out["rpn_targets/gt"] = gt
+
+    # ---- inference-side box handling
+    w2 = np.array([0, 16, 128, 112])
+    rb = boxes(12, -20, 140)
+    out["clip/window"], out["clip/in"], out["clip/out"] = w2, rb, D.clip_to_window(w2, rb.copy())
+    gen = np.concatenate([np.rint(out["clip/out"]), rng.uniform(0, 1, (12, 6))], axis=1)
+    gen[4, :4] = [5, 20, 5, 60]                              # zero area: dropped
+    ub, uc = D.unmold_generations(None, gen.copy(), (256, 192, 3), w2)
+    out["unmold/in"], out["unmold/boxes"], out["unmold/captions"] = gen, ub, uc
+
+    # ---- Dataset base class, resize_image (scale == 1), load_image_gt, the joint data_generator
+    import logging
+    U2 = functions_from(os.path.join(REF, "utils.py"),
+                        ["Dataset", "resize_image", "compute_iou", "compute_overlaps", "generate_anchors", "generate_pyramid_anchors"])
+    D2 = functions_from(os.path.join(REF, "dense_model.py"),
+                        ["compose_image_meta", "mold_image", "build_rpn_targets", "load_image_gt", "data_generator"],
+                        extra_globals={"utils": U2, "logging": logging})
+
+    class GCfg(ref_config.Config):
+        NAME = "gen"
+        IMAGES_PER_GPU = 1
+        IMAGE_MIN_DIM = 96
+        IMAGE_MAX_DIM = 128
+        RPN_TRAIN_ANCHORS_PER_IMAGE = 32
+        MAX_GT_INSTANCES = 4
+        PADDING_SIZE = 6
+    gcfg = GCfg()
+
+    def toy_image(i):
+        return np.random.RandomState(1000 + i).randint(0, 256, (96 if i % 2 == 0 else 128, 128, 3)).astype(np.uint8)
+
+    def toy_regions(i):
+        r = np.random.RandomState(2000 + i)
+        n = 6 if i == 0 else 2
+        y, x = r.randint(0, 60, n), r.randint(0, 60, n)
+        bx = np.stack([y, x, y + r.randint(8, 60, n), x + r.randint(8, 60, n)], axis=1)
+        return bx, r.randint(1, 9, (n, 6)).astype(np.float32)
+
+    class Toy(U2.Dataset):
+        def load_image(self, image_id):
+            return toy_image(image_id)
+
+        def load_captions_and_rois(self, image_id):
+            return toy_regions(image_id)
+    ds = Toy()
+    for i in range(3):
+        ds.add_image("toy", image_id=i, path="img%d" % i, width=128, height=96)
+    ds.prepare()
+    out["dataset/image_ids"] = np.asarray(ds.image_ids)
+    out["dataset/num_images"] = np.asarray(ds.num_images)
+    img0, win0, sc0, pad0 = U2.resize_image(toy_image(0), min_dim=96, max_dim=128, padding=True)
+    out["resize/image"], out["resize/window"], out["resize/scale"], out["resize/padding"] = img0, np.asarray(win0), np.asarray(sc0), np.asarray(pad0)
+    np.random.seed(7)
+    random.seed(7)
+    gen = D2.data_generator(ds, gcfg, shuffle=False, augment=False, batch_size=1)
+    for b in range(3):
+        inputs, outputs = next(gen)
+        assert outputs == []
+        for j, name in enumerate(("images", "image_meta", "rpn_match", "rpn_bbox", "gt_captions", "gt_boxes")):
+            out["joint_gen/%d/%s" % (b, name)] = inputs[j]
+
+    # ---- v1 generator (dense_img_cap_separate_models/text_generation_model.py): batch layout and one-hot targets
+    SEP = "/root/reference/dense_img_cap_separate_models"
+    table = {i: np.random.RandomState(3000 + i).standard_normal((4, 2, 2, 3)).astype(np.float32) for i in range(3)}
+    V1 = functions_from(os.path.join(SEP, "text_generation_model.py"), ["create_roi_info", "data_generator"],
+                        extra_globals={"generate_features": lambda dataset, image_id, model: table[image_id]})
+
+    class ToyV1:
+        _image_ids = np.arange(3)
+
+        def load_captions_and_rois(self, image_id):
+            r = np.random.RandomState(4000 + image_id)
+            caps = np.zeros((2 + image_id, 5), np.float32)
+            for k in range(caps.shape[0]):
+                n = r.randint(1, 4)
+                caps[k, 0], caps[k, 1:1 + n], caps[k, 1 + n] = 1, r.randint(3, 11, n), 2
+            return None, caps
+    dv1 = ToyV1()
+    dv1.rois = V1.create_roi_info(dv1)
+    out["v1_gen/roi_count"] = np.asarray(len(dv1.rois))
+    out["v1_gen/roi_image_ids"] = np.asarray([r[0] for r in dv1.rois])
+    vcfg = types.SimpleNamespace(VOCABULARY_SIZE=12)
+    g1 = V1.data_generator(dv1, None, vcfg, 4)
+    for b in range(3):
+        (feat, words), onehot = next(g1)
+        out["v1_gen/%d/features" % b], out["v1_gen/%d/words" % b], out["v1_gen/%d/onehot" % b] = feat, words, onehot
+
+    # ---- vocabulary helpers
+    P = functions_from(os.path.join(SEP, "preprocess.py"), ["load_corpus", "encode_word", "encode_word_v2", "decode_word", "decode_caption"])
+    emb = {w: np.random.RandomState(50 + i).standard_normal(8) for i, w in enumerate(["a", "red", "car", "dog"])}
+    np.random.seed(11)
+    w2i, i2w, mat = P.load_corpus(["a", "red", "car", "dog"], emb, 8)
+    out["vocab/matrix"] = mat
+    out["vocab/ids"] = np.asarray([w2i[w] for w in ["a", "red", "car", "dog"]])
+    out["vocab/specials"] = np.asarray([w2i[k] for k in sorted(k for k in w2i if k.startswith("<"))])
+    out["vocab/special_names"] = np.asarray(sorted(k for k in w2i if k.startswith("<")))
+    out["vocab/encode_known_unknown"] = np.asarray([P.encode_word("car", w2i), P.encode_word("zebra", w2i)])
+    onehots = np.eye(len(i2w))[[w2i["red"], w2i["dog"]]]
+    out["vocab/decode_caption"] = np.asarray(P.decode_caption(onehots, i2w))
+
+    np.savez_compressed(OUT, **out)
+    print("wrote %s: %d arrays, %.1f KB" % (OUT, len(out), os.path.getsize(OUT) / 1024))
+
+
+if __name__ == "__main__":
+    main()
