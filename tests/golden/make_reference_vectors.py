@@ -230,6 +230,14 @@ def main():
         (feat, words), onehot = next(g1)
         out["v1_gen/%d/features" % b], out["v1_gen/%d/words" % b], out["v1_gen/%d/onehot" % b] = feat, words, onehot
 
+    # ---- mold_inputs of the RoI feature extractor (dense_img_cap_separate_models/modified_dense_model.py)
+    US = functions_from(os.path.join(SEP, "utils.py"), ["resize_image"])
+    MD = functions_from(os.path.join(SEP, "modified_dense_model.py"), ["mold_inputs", "mold_image", "compose_image_meta"],
+                        extra_globals={"utils": US})
+    holder = types.SimpleNamespace(config=gcfg)
+    molded, metas, windows = MD.mold_inputs(holder, [toy_image(0), toy_image(1)])
+    out["mold_inputs/molded"], out["mold_inputs/metas"], out["mold_inputs/windows"] = molded, metas, windows
+
     # ---- vocabulary helpers
     P = functions_from(os.path.join(SEP, "preprocess.py"), ["load_corpus", "encode_word", "encode_word_v2", "decode_word", "decode_caption"])
     emb = {w: np.random.RandomState(50 + i).standard_normal(8) for i, w in enumerate(["a", "red", "car", "dog"])}

@@ -226,3 +226,21 @@ def test_vocabulary_helpers_match_reference():
     np.testing.assert_array_equal([P.encode_word("car", w2i), P.encode_word("zebra", w2i)], G["vocab/encode_known_unknown"])
     onehots = np.eye(len(i2w))[[w2i["red"], w2i["dog"]]]
     assert P.decode_caption(onehots, i2w) == str(G["vocab/decode_caption"])
+
+
+def test_mold_inputs_matches_reference():
+    """The mirror keeps the images uint8 (the mean is subtracted on the GPU): reference molded == mirror - MEAN_PIXEL."""
+    from image_captioning_amd.config import Config
+    from image_captioning_amd.modified_dense_model import DenseImageCapRCNN
+
+    class GCfg(Config):
+        NAME = "gen"
+        IMAGES_PER_GPU = 1
+        IMAGE_MIN_DIM = 96
+        IMAGE_MAX_DIM = 128
+    holder = type("H", (), {"config": GCfg()})()
+    molded, metas, windows = DenseImageCapRCNN.mold_inputs(holder, [_toy_image(0), _toy_image(1)])
+    assert molded.dtype == np.uint8
+    np.testing.assert_allclose(molded.astype(np.float32) - GCfg.MEAN_PIXEL, G["mold_inputs/molded"], atol=0)
+    np.testing.assert_array_equal(metas, G["mold_inputs/metas"])
+    np.testing.assert_array_equal(windows, G["mold_inputs/windows"])
