@@ -1,0 +1,35 @@
+#!/bin/bash
+# ON THE GPU BOX: rocprofv3 evidence for RoIAlign's HBM rate: kernel durations (kernel trace) + FETCH_SIZE / WRITE_SIZE (separate PMC
+# passes) of tools/roialign_bench.py -> gpurun_out/roialign_profile.txt
+set -e
+root=$PWD; out=$PWD/gpurun_out/roialign_prof; mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+python3 $root/tools/roialign_bench.py > $out/events.txt 2>&1
+rocprofv3 --kernel-trace --stats -d $out/trace -o ra -- python3 $root/tools/roialign_bench.py > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/f -- python3 $root/tools/roialign_bench.py > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/w -- python3 $root/tools/roialign_bench.py > /dev/null 2>&1
+python3 - "$out" <<'PY'
+import csv, glob, os, sqlite3, sys
+out = sys.argv[1]
+def pmc(d, name):
+    vals = []
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "roi_align_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name:
+                vals.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+    return [v for _, v in sorted(vals)]
+fetch, write = pmc(os.path.join(out, "f"), "FETCH_SIZE"), pmc(os.path.join(out, "w"), "WRITE_SIZE")
+db = sqlite3.connect(os.path.join(out, "trace", "ra_results.db"))
+durs = [r[0] for r in db.execute("select (end - start) from kernels where name like '%roi_align_kernel%' order by start")]
+n = len(durs) // 3
+with open(os.path.join(os.path.dirname(out), "roialign_profile.txt"), "w") as f:
+    f.write(open(os.path.join(out, "events.txt")).read())
+    f.write("\nrocprofv3: per configuration (53 launches each): mean kernel duration, HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE (KB), achieved HBM rate\n")
+    for i, label in enumerate(("B=2 R=32", "B=16 R=32", "B=16 R=128")):
+        d = sum(durs[i * n:(i + 1) * n]) / n / 1e3
+        fb = sum(fetch[i * n:(i + 1) * n]) / n * 2 * 1024
+        wb = sum(write[i * n:(i + 1) * n]) / n * 1024
+        f.write("%-11s %7.2f us   fetch %8.2f MB  write %7.2f MB   %6.2f TB/s HBM\n" % (label, d, fb / 1e6, wb / 1e6, (fb + wb) / d / 1e6))
+print(open(os.path.join(os.path.dirname(out), "roialign_profile.txt")).read())
+PY
+rm -rf $out
