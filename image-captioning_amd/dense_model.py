@@ -243,7 +243,7 @@ class DenseImageCapRCNN(object):
         "caption_only": r"imgcap\_.*",
     }
 
-    def __init__(self, mode, config, model_dir, device=None, stage4_blocks=22, seed=0, lstm_units=512):
+    def __init__(self, mode, config, model_dir, device=None, stage4_blocks=22, seed=0, lstm_units=512, conv_math=None):
         assert mode in ['training', 'inference']
         if config.IMAGES_PER_GPU != 1:
             raise ValueError("the joint model runs one image per GPU (train_dense_captions.py:27); scale out with ParallelModel")
@@ -253,6 +253,7 @@ class DenseImageCapRCNN(object):
         self.mode, self.config, self.model_dir = mode, config, model_dir
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.stage4_blocks, self.units = stage4_blocks, lstm_units
+        self.conv_math = conv_math          # None -> encoder default / DCAP_CONV_MATH; forward convs and data gradients
         self.epoch = 0
         self.A = len(config.RPN_ANCHOR_RATIOS)
         if 6 * self.A > HEAD_PAD:
@@ -304,7 +305,8 @@ class DenseImageCapRCNN(object):
                        nms_threshold=cfg.RPN_NMS_THRESHOLD, proposal_count=count, head_channels=HEAD_PAD)
             h, wd = [int(v) for v in cfg.IMAGE_SHAPE[:2]]
             # the FPN/RPN weights change every step: the plan reads them in place from the parameter bucket
-            self._plan = EncoderPlan(self._backbone, 1, h, wd, self.device, self.stage4_blocks, cfg.MEAN_PIXEL, rpn=rpn, external=ext)
+            self._plan = EncoderPlan(self._backbone, 1, h, wd, self.device, self.stage4_blocks, cfg.MEAN_PIXEL, rpn=rpn, external=ext,
+                                     math=self.conv_math)
         return self._plan
 
     # ---- weights ----------------------------------------------------------------------------
@@ -525,7 +527,7 @@ class DenseImageCapRCNN(object):
             ops.relu_bwd(dsh.view(-1, 512), sh.view(-1, 512), dsh.view(-1, 512))
             ops.conv2d_wgrad(pm, dsh, 3, 3, 1, 1, 1, out=g["rpn_conv_shared/kernel"], accumulate=acc)
             ops.colsum(dsh.view(-1, 512), out=g["rpn_conv_shared/bias"], accumulate=acc)
-            ops.conv2d(dsh, wd_shared, 3, 3, 1, 1, 1, h_, w_, residual=dP[i], res_mode=1, out=dP[i])     # dP += dgrad
+            ops.conv2d(dsh, wd_shared, 3, 3, 1, 1, 1, h_, w_, residual=dP[i], res_mode=1, out=dP[i], math=p.math)     # dP += dgrad
         ops.scatter2_add(dP[4], dP[3])                       # P6 = MaxPooling2D(1, strides=2)(P5)
 
         # ---- FPN backward
@@ -536,7 +538,7 @@ class DenseImageCapRCNN(object):
             _, h_, w_, _ = dP[i].shape
             ops.conv2d_wgrad(p.pre[i], dP[i], 3, 3, 1, 1, 1, out=g[name + "/kernel"])
             ops.colsum(dP[i].view(-1, 256), out=g[name + "/bias"])
-            dpre.append(ops.conv2d(dP[i], wd, 3, 3, 1, 1, 1, h_, w_, out=self._buf("dpre%d" % i, tuple(dP[i].shape))))
+            dpre.append(ops.conv2d(dP[i], wd, 3, 3, 1, 1, 1, h_, w_, out=self._buf("dpre%d" % i, tuple(dP[i].shape)), math=p.math))
         for i in range(3):                                   # pre[k] = upsample(pre[k+1]) + lateral(C_k)
             ops.downsample2x_sum(dpre[i], out=dpre[i + 1], accumulate=True)
         for i, cmap in enumerate(p.C):

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--vocab", type=int, default=50000)
     ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--conv-math", default=None, help="f32 | bf16x3 | bf16x2 (forward convs and data gradients)")
     a = ap.parse_args()
     S, V, T = a.size, a.vocab, 15
 
@@ -34,7 +35,7 @@ def main():
         EMBEDDING_SIZE = 300
     cfg = Cfg()
     cfg.EMBEDDING_WEIGHTS = synth.embedding_matrix(3, V)
-    model = DenseImageCapRCNN("training", cfg, "logs")
+    model = DenseImageCapRCNN("training", cfg, "logs", conv_math=a.conv_math)
     # random FPN maps are O(10): keep the RPN / head activations in a trained network's range
     w = model.get_weights_dict()
     model.set_weights({"rpn_conv_shared/kernel": w["rpn_conv_shared/kernel"] * np.float32(0.02),
