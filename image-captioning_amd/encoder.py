@@ -275,7 +275,9 @@ class EncoderPlan:
             self._warm = True
         else:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread-local capture: the RCCL watchdog thread of a multi-GPU run polls events while this thread captures;
+            # under the default (global) mode that would invalidate the capture
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self._run_ops()
             self._graph = g
             g.replay()
