@@ -401,7 +401,8 @@ def rpn_loss_grad(heads, dheads, sel_level, sel_index, sel_match, target_deltas,
         d.dheads[i] = g.data_ptr() + 4 * per * image
         d.Hs[i], d.Ws[i] = h.shape[1], h.shape[2]
     d.n_sel, d.n_pos = sel_level.numel(), int(n_pos)
-    d.sel_level, d.sel_index, d.sel_match = (_chk(t, torch.int32, "sel").data_ptr() for t in (sel_level, sel_index, sel_match))
+    if d.n_sel:                                         # no selected anchor (all neutral): the kernel only zeroes the losses
+        d.sel_level, d.sel_index, d.sel_match = (_chk(t, torch.int32, "sel").data_ptr() for t in (sel_level, sel_index, sel_match))
     d.target_deltas = _chk(target_deltas, name="target_deltas").data_ptr()
     d.losses = _chk(losses, name="losses").data_ptr()
     check(lib.dc_rpn_loss_grad_f32(C.byref(d), _stream()), "dc_rpn_loss_grad_f32")

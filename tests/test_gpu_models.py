@@ -415,3 +415,27 @@ def test_encoder_conv_math_modes(gpu, math, tol):
     with open("gpurun_out/math_mode_errors.txt", "a") as f:
         f.write("%s %.3e\n" % (math, err))
     assert err < tol, (math, err)
+
+
+def test_joint_model_degenerate_batches(gpu):
+    """No positive RoI (no GT box overlaps a proposal), no RPN anchors selected: the caption and RPN losses are exactly 0,
+    the gradient is the L2 regulariser's alone, nothing is NaN, and an optimizer step still works."""
+    S, V, T, blocks = 128, 24, 5, 1
+    model, cfg, Wt = make_joint(S, V, T, blocks)
+    inputs = joint_inputs(S, V, T)
+    inputs[2] = np.zeros_like(inputs[2])                       # every anchor neutral
+    inputs[5] = np.zeros_like(inputs[5])
+    inputs[5][0, 0] = [0, 0, 1, 1]                             # a 1-pixel GT box: IoU < 0.5 with every proposal
+    losses = model._loss_list(model.forward_backward(inputs, shuffle=None))
+    assert model.last_targets['npos'] == 0 and model.last_targets['nneg'] == 0
+    assert losses['imgcap_loss'] == 0.0 and losses['rpn_class_loss'] == 0.0 and losses['rpn_bbox_loss'] == 0.0
+    assert losses['reg_loss'] > 0 and np.isfinite(losses['loss'])
+    got = joint_grads_as_reference(model)
+    wd = cfg.WEIGHT_DECAY
+    for k in ('fpn_p2/kernel', 'rpn_class_raw/kernel', 'imgcap_lstm_d2/kernel', 'mrcnn_class_conv1/bias'):
+        want = 2.0 * wd * np.asarray(Wt[k], np.float64) / np.asarray(Wt[k]).size
+        assert rel_err(got[k], want) < 1e-5, k
+    assert float(np.abs(got['mrcnn_class_bn1/gamma']).max()) == 0.0          # BN gamma/beta are not regularised
+    model.compile(1e-4)
+    out = model.train_on_batch(inputs)
+    assert np.isfinite(out).all()
