@@ -75,6 +75,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f4 buf_f4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
     return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0));
 }
+// per-lane offset (VGPR, range-checked) + block-uniform offset (SGPR): no VALU between the address and the load
+__device__ __forceinline__ f4 buf_f4s(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off, unsigned uniform_off) {
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off, (int)uniform_off, 0));
+}
 constexpr unsigned kOobOffset = 0x80000000u;     // beyond any tensor the host admits (< 2 GiB)
 
 __device__ __forceinline__ f4 ldg_f4(const float* base, unsigned byte_off) {
@@ -95,10 +99,12 @@ struct DenseKCT {
     struct State {
         const float* base[FAST ? 1 : BT / 32];
         unsigned boff[FAST ? BT / 32 : 1];
+        __amdgpu_buffer_rsrc_t rsrc;        // FAST: lane offset in a VGPR, K offset in an SGPR -> no address VALU per K-tile
     };
     template <int BT>
     __device__ __forceinline__ void init(State<BT>& s, int row0, int tid) const {
         const int rr = tid >> 3;
+        if constexpr (FAST) s.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)0xFFFFFFF0u, 0x00020000);
 #pragma unroll
         for (int i = 0; i < BT / 32; ++i) {
             int row = row0 + rr + 32 * i;
@@ -117,9 +123,8 @@ struct DenseKCT {
     template <int BT>
     __device__ __forceinline__ void load(State<BT>& s, f4 (&r)[BT / 32], int k0, int kend, int tid) const {
         if constexpr (FAST) {
-            const float* kb = p + k0;                         // block-uniform
 #pragma unroll
-            for (int i = 0; i < BT / 32; ++i) r[i] = ldg_f4(kb, s.boff[i]);
+            for (int i = 0; i < BT / 32; ++i) r[i] = buf_f4s(s.rsrc, s.boff[i], (unsigned)k0 * 4u);      // k0 block-uniform
         } else {
             const int k = k0 + 4 * (tid & 7);
 #pragma unroll
@@ -249,13 +254,25 @@ struct Im2colKCT {
         __amdgpu_buffer_rsrc_t rsrc;
         unsigned boff[BT / 32];     // ((n*H + oy*stride)*W + ox*stride)*Cin*4 + 16*(tid&7): the output-aligned pixel
         unsigned long long mask[BT / 32];     // bit (ky*kw + kx): that tap of this output pixel lies inside the image
+        unsigned sel[BT / 32];      // storage order only: boff or the out-of-range offset, for the CURRENT tap
         int ky, kx, c;              // block-uniform position of the NEXT K-tile (incremental, no division)
+        int fresh;                  // sel[] must be recomputed (first tile of the block / of a tap)
     };
     template <int BT>
     __device__ __forceinline__ void init(State<BT>& s, int row0, int tid) const {
         const int rr = tid >> 3;
-        s.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)x_bytes, 0x00020000);
+        if constexpr (CM) {
+            s.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)x_bytes, 0x00020000);
+        } else {
+            // Storage order: the tap offset and the channel offset are block-uniform and travel in the load's SGPR offset,
+            // which must be non-negative: the descriptor's base is moved back by the largest negative tap offset.  Only
+            // in-image taps are ever issued with an in-range lane offset (the others carry kOobOffset), so no byte in
+            // front of the tensor is touched.
+            const long bias = ((long)pad_t * W + pad_l) * Cin;
+            s.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) - bias, 0, (int)(x_bytes + bias * 4), 0x00020000);
+        }
         s.ky = -1;
+        s.fresh = 1;
 #pragma unroll
         for (int i = 0; i < BT / 32; ++i) {
             const int m = min(row0 + rr + 32 * i, M - 1);          // rows past M feed nothing that is stored
@@ -291,12 +308,26 @@ struct Im2colKCT {
             s.kx = tap - s.ky * kw;
         }
         const int ky = s.ky, kx = s.kx;
-        const int ubytes = (((ky - pad_t) * W + (kx - pad_l)) * Cin + s.c) * 4;      // block-uniform, may be negative
         const int tap = ky * kw + kx;                                                  // block-uniform
+        if constexpr (CM) {
+            const int ubytes = (((ky - pad_t) * W + (kx - pad_l)) * Cin + s.c) * 4;  // block-uniform, may be negative
 #pragma unroll
-        for (int i = 0; i < BT / 32; ++i) {
-            const bool in = ((s.mask[i] >> tap) & 1ull) != 0;
-            r[i] = buf_f4(s.rsrc, in ? s.boff[i] + (unsigned)ubytes : kOobOffset);     // out of image -> hardware zero
+            for (int i = 0; i < BT / 32; ++i) {
+                const bool in = ((s.mask[i] >> tap) & 1ull) != 0;
+                r[i] = buf_f4(s.rsrc, in ? s.boff[i] + (unsigned)ubytes : kOobOffset); // out of image -> hardware zero
+            }
+        } else {
+            // f32 MFMAs run on the VALU lanes: a co-resident wave's address arithmetic cannot issue while another wave's
+            // MFMA burst holds the SIMD, so its loads would go out only after the burst (stamps: the "issue loads" phase
+            // was as long as the MFMA phase).  Per K-tile this path is VALU-free: the per-lane select happens once per tap.
+            if (s.fresh) {
+                s.fresh = 0;
+#pragma unroll
+                for (int i = 0; i < BT / 32; ++i) s.sel[i] = ((s.mask[i] >> tap) & 1ull) ? s.boff[i] : kOobOffset;
+            }
+            const unsigned soff = (unsigned)(((ky * W + kx) * Cin + s.c) * 4);         // block-uniform, >= 0 (SGPR)
+#pragma unroll
+            for (int i = 0; i < BT / 32; ++i) r[i] = buf_f4s(s.rsrc, s.sel[i], soff);
         }
         if constexpr (CM) {
             if (++s.kx == kw) {                           // next tap of this channel chunk; then the next chunk
@@ -307,6 +338,7 @@ struct Im2colKCT {
             s.c += 32;
             if (s.c == Cin) {
                 s.c = 0;
+                s.fresh = 1;
                 if (++s.kx == kw) { s.kx = 0; ++s.ky; }
             }
         }

@@ -10,11 +10,11 @@ cp -r $ROOT/image-captioning_amd/csrc $D/image-captioning_amd/csrc
 cp -r $ROOT/image_captioning_amd $D/
 cp $ROOT/include/dcap.h $D/include/
 cd $D/image-captioning_amd/csrc
-for f in gemm gemm_tn conv lstm loss roialign; do
+for f in gemm gemm_tn conv conv_bs lstm loss roialign proposal; do
   hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fgpu-rdc -DDCAP_STAMPS -c $f.hip -o $f.o 2>/dev/null &
 done
 wait
-hipcc --offload-arch=gfx950 -fgpu-rdc -shared -fPIC -o libdcap_hip.so gemm.o gemm_tn.o conv.o lstm.o loss.o roialign.o
+hipcc --offload-arch=gfx950 -fgpu-rdc -shared -fPIC -o libdcap_hip.so gemm.o gemm_tn.o conv.o conv_bs.o lstm.o loss.o roialign.o proposal.o
 cd $D
 python - "$@" <<'PY'
 import ctypes as C, sys, torch, numpy as np
