@@ -736,9 +736,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(AL al, BL bl, Epilogue ep
     // coissue.hip: every extra VALU adds its full ~4 cycles per 64-cycle MFMA), so the loop keeps the
     // per-tile VALU count minimal (32-bit offsets, uniform bases, hardware zero-fill) and only memory
     // latency is left to hide behind the co-resident block's burst.
-    for (int kt = 0; kt < nkt; kt += KT) {
-        float* cur = smem + ((kt / KT) & 1) * (KT * STAGE);
-        float* nxt = smem + (((kt / KT) & 1) ^ 1) * (KT * STAGE);
+    // One pipeline step on compile-time LDS stages: fragment and store addresses become a constant VGPR plus an immediate
+    // offset (a run-time stage index costs an address add per ds instruction -- VALU, i.e. MFMA time on this pipe).
+    auto step = [&](int kt, float* cur, float* nxt) {
 #ifdef DCAP_STAMPS
         unsigned long long t0, t1, t2, t3, t4, t5;
 #endif
@@ -772,6 +772,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(AL al, BL bl, Epilogue ep
 #ifdef DCAP_STAMPS
         st[0] += t1 - t0; st[1] += t2 - t1; st[2] += t3 - t2; st[3] += t4 - t3; st[4] += t5 - t4; st[5] += KT;
 #endif
+    };
+    float* const stage0 = smem;
+    float* const stage1 = smem + KT * STAGE;
+    for (int kt = 0; kt < nkt; kt += 2 * KT) {
+        step(kt, stage0, stage1);
+        if (kt + KT < nkt) step(kt + KT, stage1, stage0);
     }
 #ifdef DCAP_STAMPS
     if (lane == 0 && blockIdx.x < 4096) {
