@@ -191,12 +191,14 @@ struct DenseMCT {
     struct State {
         int col;
         unsigned boff[BT / 32];
+        __amdgpu_buffer_rsrc_t rsrc;        // FAST: see DenseKCT
     };
     template <int BT>
     __device__ __forceinline__ void init(State<BT>& s, int col0, int tid) const {
         constexpr int QPR = BT / 4, RPP = 256 / QPR;
         s.col = col0 + 4 * (tid % QPR);
         if constexpr (FAST) {
+            s.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)0xFFFFFFF0u, 0x00020000);
             s.col = min(s.col, cols - 4);
 #pragma unroll
             for (int i = 0; i < BT / 32; ++i) s.boff[i] = (unsigned)((((long)(tid / QPR) + RPP * i) * ld + s.col) * 4);
@@ -208,9 +210,9 @@ struct DenseMCT {
         const int kr = tid / QPR;
         if constexpr (FAST) {
             if (gather == nullptr) {
-                const float* kb = p + (long)k0 * ld;          // block-uniform
+                const unsigned soff = (unsigned)((long)k0 * ld * 4);          // block-uniform, < 4 GiB (host-checked span)
 #pragma unroll
-                for (int i = 0; i < BT / 32; ++i) r[i] = ldg_f4(kb, s.boff[i]);
+                for (int i = 0; i < BT / 32; ++i) r[i] = buf_f4s(s.rsrc, s.boff[i], soff);
                 return;
             }
         }
