@@ -69,7 +69,7 @@ __global__ void lstm_gate_bwd_kernel(const float* __restrict__ z_t, const float*
 
 // ------------------------------------------------------------------------------------------------
 // Fused forward timestep (U % 32 == 0): z_t = zx_t + h_{t-1} * U_rec, gates, cell update, mask carry in ONE
-// launch.  Block = 32 batch rows x 8 units (= 32 columns: 4 gates x 8 units), 4 waves that split K = U
+// launch.  Block = 64 batch rows x 8 units (= 32 columns: 4 gates x 8 units), 4 waves that split K = U
 // four ways; every wave streams its K range straight from global/L2 into MFMA fragments (one 16-byte load
 // of h per 4 MFMAs, one dword of U_rec per MFMA, prefetched 4 chunks ahead; SGPR-advanced bases: no
 // per-chunk VALU), the four partial 32x32 tiles meet in LDS and the 256 threads finish the gate math.
@@ -78,73 +78,104 @@ __global__ void lstm_gate_bwd_kernel(const float* __restrict__ z_t, const float*
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef float f4_t __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void lstm_step_fused_kernel(float* __restrict__ z_t, const float* __restrict__ U_rec,
-                                                              const float* __restrict__ h_prev, const float* __restrict__ c_prev,
-                                                              const uint8_t* __restrict__ mask_t, float* __restrict__ h_t,
-                                                              float* __restrict__ c_t, int B, int U) {
-    __shared__ float part[4][32][33];
+// ------------------------------------------------------------------------------------------------
+// The weights: the first version of this kernel read U_rec in place: a block's 32 columns are 4 gate segments of 8 floats,
+// i.e. 32 useful bytes per 128-byte line, and every weight was fetched once per 32-row block -- 128 MB through L2 per
+// timestep at U = 1024, B = 64 (41-60 us: L2-bandwidth-bound).  Now dc_lstm_seq_fwd_f32 first repacks U_rec (once per
+// call, 4U^2 floats into the workspace) so that a block's 32 columns are ONE contiguous 128-byte line per k row
+// (Upk[k][u/8][gate][u%8]), and a block covers 64 batch rows (two MFMA row blocks share every weight fragment).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_pack_urec_kernel(const float* __restrict__ U_rec, float* __restrict__ Upk, int U) {
+    const long total = (long)U * 4 * U;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int within = (int)(idx & 31), g = within >> 3, j = within & 7;
+        const long blk = idx >> 5;
+        const int ub = (int)(blk % (U / 8));
+        const long k = blk / (U / 8);
+        Upk[idx] = U_rec[k * (4L * U) + (long)g * U + ub * 8 + j];
+    }
+}
+
+__global__ __launch_bounds__(256) void lstm_step_fused2_kernel(float* __restrict__ z_t, const float* __restrict__ Upk,
+                                                               const float* __restrict__ h_prev, const float* __restrict__ c_prev,
+                                                               const uint8_t* __restrict__ mask_t, float* __restrict__ h_t,
+                                                               float* __restrict__ c_t, int B, int U) {
+    __shared__ float part[4][64][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int u0 = blockIdx.x * 8, r0 = blockIdx.y * 32;
+    const int ub = blockIdx.x, u0 = ub * 8, r0 = blockIdx.y * 64;
     const int i = lane & 31, h = lane >> 5;
     const int kq = U / 4, kbeg = wave * kq;
-    f32x16_t acc;
+    f32x16_t acc0, acc1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    // A: h_prev[row][k], lane (row i, half h) takes k = 8c + 4h .. +3 ; B: U_rec[k][col], col i -> gate i>>3, unit u0 + (i&7)
-    const int arow = min(r0 + i, B - 1);
-    const float* ap = h_prev + (long)arow * U + kbeg + 4 * h;
-    const float* bp = U_rec + (long)(kbeg + 4 * h) * (4 * U) + (i >> 3) * U + u0 + (i & 7);
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const float* ap0 = h_prev + (long)min(r0 + i, B - 1) * U + kbeg + 4 * h;
+    const float* ap1 = h_prev + (long)min(r0 + 32 + i, B - 1) * U + kbeg + 4 * h;
+    const long kstride = (long)(U / 8) * 32;                                  // floats between consecutive k rows of Upk
+    const float* bp = Upk + (long)(kbeg + 4 * h) * kstride + (long)ub * 32 + i;
     constexpr int PF = 4;
     const int nch = kq / 8;
-    f4_t a[PF];
+    f4_t a0[PF], a1[PF];
     float b[PF][4];
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
         const int c = min(p, nch - 1);
-        a[p] = *reinterpret_cast<const f4_t*>(ap + 8 * c);
+        a0[p] = *reinterpret_cast<const f4_t*>(ap0 + 8 * c);
+        a1[p] = *reinterpret_cast<const f4_t*>(ap1 + 8 * c);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[p][j] = bp[(long)(8 * c + j) * (4 * U)];
+        for (int j = 0; j < 4; ++j) b[p][j] = bp[(long)(8 * c + j) * kstride];
     }
     for (int c0 = 0; c0 < nch; c0 += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
-            const f4_t av = a[p];
+            const f4_t x0 = a0[p], x1 = a1[p];
             const float b0 = b[p][0], b1 = b[p][1], b2 = b[p][2], b3 = b[p][3];
             const int cn = min(c0 + p + PF, nch - 1);                 // prefetch (clamped: extra loads are discarded)
-            a[p] = *reinterpret_cast<const f4_t*>(ap + 8 * cn);
+            a0[p] = *reinterpret_cast<const f4_t*>(ap0 + 8 * cn);
+            a1[p] = *reinterpret_cast<const f4_t*>(ap1 + 8 * cn);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[p][j] = bp[(long)(8 * cn + j) * (4 * U)];
+            for (int j = 0; j < 4; ++j) b[p][j] = bp[(long)(8 * cn + j) * kstride];
             if (c0 + p < nch) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b2, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b3, acc, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.x, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.x, b0, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, b1, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.y, b1, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.z, b2, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.z, b2, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.w, b3, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.w, b3, acc1, 0, 0, 0);
             }
         }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * h][i] = acc[r];
-    __syncthreads();
-    // gate math: thread -> (row tid>>3, unit tid&7)
-    const int row = tid >> 3, uu = tid & 7;
-    const int brow = r0 + row;
-    if (brow >= B) return;
-    float zg[4];
-    float* zrow = z_t + (long)brow * 4 * U + u0 + uu;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int col = g * 8 + uu;
-        zg[g] = zrow[(long)g * U] + ((part[0][row][col] + part[1][row][col]) + (part[2][row][col] + part[3][row][col]));
-        zrow[(long)g * U] = zg[g];
+    for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+        part[wave][rr][i] = acc0[r];
+        part[wave][32 + rr][i] = acc1[r];
     }
-    const long o = (long)brow * U + u0 + uu;
-    const float ig = hard_sigmoid(zg[0]), fg = hard_sigmoid(zg[1]), gg = tanhf(zg[2]), og = hard_sigmoid(zg[3]);
-    const float hp = h_prev[o], cp = c_prev[o];
-    const float cn = fg * cp + ig * gg;
-    const float hn = og * tanhf(cn);
-    const bool m = mask_t ? (mask_t[brow] != 0) : true;
-    h_t[o] = m ? hn : hp;
-    c_t[o] = m ? cn : cp;
+    __syncthreads();
+    // gate math: 64 rows x 8 units = 512 items, two per thread
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = (tid >> 3) + 32 * q, uu = tid & 7;
+        const int brow = r0 + row;
+        if (brow >= B) continue;
+        float zg[4];
+        float* zrow = z_t + (long)brow * 4 * U + u0 + uu;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = g * 8 + uu;
+            zg[g] = zrow[(long)g * U] + ((part[0][row][col] + part[1][row][col]) + (part[2][row][col] + part[3][row][col]));
+            zrow[(long)g * U] = zg[g];
+        }
+        const long o = (long)brow * U + u0 + uu;
+        const float ig = hard_sigmoid(zg[0]), fg = hard_sigmoid(zg[1]), gg = tanhf(zg[2]), og = hard_sigmoid(zg[3]);
+        const float hp = h_prev[o], cp = c_prev[o];
+        const float cn = fg * cp + ig * gg;
+        const float hn = og * tanhf(cn);
+        const bool m = mask_t ? (mask_t[brow] != 0) : true;
+        h_t[o] = m ? hn : hp;
+        c_t[o] = m ? cn : cp;
+    }
 }
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -192,7 +223,9 @@ extern "C" size_t dc_lstm_seq_workspace_bytes(int B, int T, int U) {
         dc_gemm_desc c = dU_desc(B, T, U, nullptr, nullptr, nullptr, 0);
         g = std::max(g, dc_gemm_workspace_bytes(&c));
     }
-    return align_up(g) + 2 * align_up((size_t)B * U * sizeof(float));
+    const size_t bwd = align_up(g) + 2 * align_up((size_t)B * U * sizeof(float));
+    const size_t fwd = align_up(g) + ((U & 31) == 0 ? align_up((size_t)4 * U * U * sizeof(float)) : 0);     // + the repacked U_rec
+    return std::max(fwd, bwd);
 }
 
 extern "C" int dc_lstm_seq_fwd_f32(const dc_lstm_fwd_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
@@ -202,14 +235,24 @@ extern "C" int dc_lstm_seq_fwd_f32(const dc_lstm_fwd_desc* d, void* workspace, s
                DC_EWORKSPACE, "dc_lstm_seq_fwd: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int B = d->B, U = d->U, n = B * U, blocks = (n + 255) / 256;
+    const bool fused = (U & 31) == 0 && d->T > 1;
+    float* Upk = nullptr;
+    if (fused) {                                   // line-contiguous copy of the recurrent weights at the END of the workspace
+        const size_t pack_bytes = align_up((size_t)4 * U * U * sizeof(float));
+        Upk = reinterpret_cast<float*>(static_cast<char*>(workspace) + (workspace_bytes - pack_bytes) / 256 * 256);
+        const long total = (long)4 * U * U;
+        hipLaunchKernelGGL(lstm_pack_urec_kernel, dim3((int)std::min<long>((total + 255) / 256, (long)kNumCU * 8)), dim3(256), 0, s, d->U_rec, Upk, U);
+        int rc = check_launch("lstm_pack_urec_kernel");
+        if (rc) return rc;
+    }
     for (int t = 0; t < d->T; ++t) {
         float* z_t = d->z + (long)t * B * 4 * U;
         const float* hp = t ? d->h_seq + (long)(t - 1) * n : nullptr;
         const float* cp = t ? d->c_seq + (long)(t - 1) * n : nullptr;
-        if (t && (U & 31) == 0) {
-            hipLaunchKernelGGL(lstm_step_fused_kernel, dim3(U / 8, (B + 31) / 32), dim3(256), 0, s, z_t, d->U_rec, hp, cp,
+        if (t && fused) {
+            hipLaunchKernelGGL(lstm_step_fused2_kernel, dim3(U / 8, (B + 63) / 64), dim3(256), 0, s, z_t, Upk, hp, cp,
                                d->mask ? d->mask + (long)t * B : nullptr, d->h_seq + (long)t * n, d->c_seq + (long)t * n, B, U);
-            int rc = check_launch("lstm_step_fused_kernel");
+            int rc = check_launch("lstm_step_fused2_kernel");
             if (rc) return rc;
             continue;
         }
