@@ -117,6 +117,73 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const float4* __restrict__
     }
 }
 
+// Greedy scan, one wave per image, 64 candidates per round (k <= 8192).  The removed-set lives in registers (lane l owns
+// words l and l+64).  A round loads each candidate's suppression bits WITHIN the round (one word per lane), resolves the
+// round serially on scalar values (ctz over the alive bits + readlane: no memory in the dependent chain), then ORs the
+// kept candidates' full rows into the removed-set eight rows at a time (independent loads in flight).  The first version
+// walked the candidates one by one with a barrier and a dependent global row load per kept box: 1.4 ms for 6000 -> 2000.
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, l), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(64) void nms_scan_wave_kernel(const float4* __restrict__ boxes, const unsigned long long* __restrict__ mask, int k,
+                                                           int words, int count, float4* __restrict__ proposals, int* __restrict__ keep_out) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const unsigned long long* M = mask + (long)b * k * words;
+    unsigned long long rem0 = 0, rem1 = 0;
+    int kept = 0;
+    auto self_bits = [&](int c) -> unsigned long long {
+        const int i = c * 64 + lane;
+        return (c < words && i < k) ? M[(long)i * words + c] : 0ull;
+    };
+    unsigned long long self = self_bits(0);
+    for (int c = 0; c < words && kept < count; ++c) {
+        const unsigned long long self_next = self_bits(c + 1);                 // independent of the scan state: prefetch
+        const unsigned long long remc = readlane64(c < 64 ? rem0 : rem1, c & 63);
+        const int left = k - c * 64;
+        unsigned long long alive = ~remc;
+        if (left < 64) alive &= (1ull << left) - 1ull;
+        unsigned long long keepmask = 0;
+        int room = count - kept;
+        while (alive != 0 && room > 0) {                                       // uniform
+            const int j = __builtin_ctzll(alive);
+            keepmask |= 1ull << j;
+            --room;
+            alive &= ~(1ull << j);
+            alive &= ~readlane64(self, j);
+        }
+        if ((keepmask >> lane) & 1ull) {
+            const int slot = kept + __builtin_popcountll(keepmask & ((1ull << lane) - 1ull));
+            proposals[(long)b * count + slot] = boxes[(long)b * k + c * 64 + lane];
+            if (keep_out) keep_out[(long)b * count + slot] = c * 64 + lane;
+        }
+        kept += __builtin_popcountll(keepmask);
+        unsigned long long km = keepmask;
+        while (km != 0) {                                                      // uniform; 8 rows (16 loads per lane) in flight
+            unsigned long long v0[8], v1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                v0[u] = 0; v1[u] = 0;
+                if (km != 0) {
+                    const int j = __builtin_ctzll(km);
+                    km &= km - 1ull;
+                    const unsigned long long* row = M + (long)(c * 64 + j) * words;
+                    if (lane < words) v0[u] = row[lane];
+                    if (lane + 64 < words) v1[u] = row[lane + 64];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { rem0 |= v0[u]; rem1 |= v1[u]; }
+        }
+        self = self_next;
+    }
+    for (int r = kept + lane; r < count; r += 64) {
+        proposals[(long)b * count + r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (keep_out) keep_out[(long)b * count + r] = -1;
+    }
+}
+
 __global__ void subsample2_kernel(const float4* __restrict__ x, float4* __restrict__ y, int N, int H, int W, int C4) {
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     const long total = (long)N * Ho * Wo * C4;
@@ -252,8 +319,12 @@ extern "C" int dc_proposals_f32(const dc_proposal_desc* d, void* workspace, size
     }
     hipLaunchKernelGGL(decode_kernel, dim3((d->B * k + 255) / 256), dim3(256), 0, s, *d, vals, deltas, boxes, k);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words, d->B), dim3(64), 0, s, boxes, mask, k, words, d->nms_threshold);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(d->B), dim3(64), (size_t)words * 8, s, boxes, mask, k, words, d->proposal_count,
-                       reinterpret_cast<float4*>(d->proposals), d->keep_out);
+    if (words <= 128)
+        hipLaunchKernelGGL(nms_scan_wave_kernel, dim3(d->B), dim3(64), 0, s, boxes, mask, k, words, d->proposal_count,
+                           reinterpret_cast<float4*>(d->proposals), d->keep_out);
+    else
+        hipLaunchKernelGGL(nms_scan_kernel, dim3(d->B), dim3(64), (size_t)words * 8, s, boxes, mask, k, words, d->proposal_count,
+                           reinterpret_cast<float4*>(d->proposals), d->keep_out);
     rc = check_launch("proposal kernels");
     if (rc) return rc;
     if (d->scores_out) {
