@@ -189,13 +189,23 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     }
 }
 
+// partial [chunks][N] -> out[N]: a block is 16 columns x 16 chunk lanes (lane q adds chunks q, q+16, ... in order), then a fixed
+// LDS tree over the 16 lanes: a column's result never depends on scheduling, and the chain of dependent loads is chunks/16 long.
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, int chunks, int N, float* __restrict__ out,
                                                             int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= N) return;
-    float s = accumulate ? out[c] : 0.f;
-    for (int k = 0; k < chunks; ++k) s += partial[(long)k * N + c];
-    out[c] = s;
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    float s = 0.f;
+    if (c < N)
+        for (int k = q; k < chunks; k += 16) s += partial[(long)k * N + c];
+    red[q][cl] = s;
+    __syncthreads();
+    for (int h = 8; h > 0; h >>= 1) {
+        if (q < h) red[q][cl] += red[q + h][cl];
+        __syncthreads();
+    }
+    if (q == 0 && c < N) out[c] = accumulate ? out[c] + red[0][cl] : red[0][cl];
 }
 
 // one wave per row, float4 per lane
@@ -445,7 +455,7 @@ extern "C" int dc_colsum_f32(const float* x, int M, int N, int ld, float* out, i
                            p.rows_per_chunk, partial);
     int rc = check_launch("colsum_kernel");
     if (rc || p.chunks == 1) return rc;
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, s, partial, p.chunks, N, out, accumulate);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 15) / 16), dim3(256), 0, s, partial, p.chunks, N, out, accumulate);
     return check_launch("colsum_finish_kernel");
 }
 
