@@ -14,21 +14,10 @@ MODEL_DIR = os.path.join(ROOT_DIR, "logs")
 MODEL_PATH = os.path.join(ROOT_DIR, "rcnn_coco.npz")      # the reference's rcnn_coco.h5, converted
 
 
-class DenseCapConfig(Config):
-    NAME = "dense image captioning"
-    GPU_COUNT = 1
-    IMAGES_PER_GPU = 3
-    STEPS_PER_EPOCH = 500
-    VALIDATION_STEPS = 50
-    EMBEDDING_SIZE = 100
-    PADDING_SIZE = 5
-    REDUCE_EMBEDDINGS = True
-
-
-class InferenceConfig(DenseCapConfig):
-    GPU_COUNT = 1
-    IMAGES_PER_GPU = 1
-
+# DenseCapConfig / InferenceConfig of the reference script (:22-54): batch of one image at inference
+DenseCapConfig = type("DenseCapConfig", (Config,), dict(NAME="dense image captioning", GPU_COUNT=1, IMAGES_PER_GPU=3, STEPS_PER_EPOCH=500,
+                                                     VALIDATION_STEPS=50, EMBEDDING_SIZE=100, PADDING_SIZE=5, REDUCE_EMBEDDINGS=True))
+InferenceConfig = type("InferenceConfig", (DenseCapConfig,), dict(GPU_COUNT=1, IMAGES_PER_GPU=1))
 
 config = InferenceConfig()
 
@@ -45,11 +34,10 @@ def load_model(weights=None, model_path=None, **kw):
 
 
 def generate_features(dataset, image_id, model):
-    image = dataset.load_image(image_id)
-    rois, _ = dataset.load_captions_and_rois(image_id)
-    rois = np.expand_dims(rois, axis=0)
-    results = model.generate_captions([image], rois, verbose=0)
-    return results[0]['features']
+    """[N,7,7,256] features of the image's ground-truth regions (one batch of one image)."""
+    boxes = dataset.load_captions_and_rois(image_id)[0]
+    out = model.generate_captions([dataset.load_image(image_id)], boxes[np.newaxis], verbose=0)
+    return out[0]['features']
 
 
 def generate_image_level_features(dataset, image_id, model):

@@ -13,21 +13,9 @@ MODEL_DIR = os.path.join(ROOT_DIR, "logs")
 MODEL_PATH = os.path.join(ROOT_DIR, "img_cap_dense.npz")      # the reference's img_cap_dense.h5, converted
 
 
-class DenseCapConfig(Config):
-    NAME = "dense image captioning"
-    GPU_COUNT = 1
-    IMAGES_PER_GPU = 3
-    STEPS_PER_EPOCH = 500
-    VALIDATION_STEPS = 50
-    EMBEDDING_SIZE = 100
-    PADDING_SIZE = 5
-    REDUCE_EMBEDDINGS = True
-
-
-class InferenceConfig(DenseCapConfig):
-    GPU_COUNT = 1
-    IMAGES_PER_GPU = 1
-
+DenseCapConfig = type("DenseCapConfig", (Config,), dict(NAME="dense image captioning", GPU_COUNT=1, IMAGES_PER_GPU=3, STEPS_PER_EPOCH=500,
+                                                     VALIDATION_STEPS=50, EMBEDDING_SIZE=100, PADDING_SIZE=5, REDUCE_EMBEDDINGS=True))
+InferenceConfig = type("InferenceConfig", (DenseCapConfig,), dict(GPU_COUNT=1, IMAGES_PER_GPU=1))
 
 config = InferenceConfig()
 
