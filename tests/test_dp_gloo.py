@@ -72,3 +72,51 @@ def test_parallel_model_requires_one_process_per_gpu():
         grad_sync = None
     with pytest.raises(ValueError, match="one process per GPU"):
         ParallelModel(Dummy(), 8)
+
+
+def _worker_parallel_model(rank, world, port, out_dir):
+    """ParallelModel around a model that mimics the joint model's surface: flat parameter bucket, loss LIST, no targets."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from image_captioning_amd.parallel_model import ParallelModel, init_process_group_from_env
+    init_process_group_from_env(backend="gloo")
+
+    class Store:
+        def __init__(self):
+            self.flat = torch.full((8,), float(rank + 1))             # rank-dependent: broadcast must make them equal
+            self.flat_grad = torch.zeros(8)
+            self.frozen_names = ["emb"]
+            self.w = {"emb": torch.full((3,), float(10 * (rank + 1)))}
+
+    class Toy:
+        device = torch.device("cpu")
+
+        def __init__(self):
+            self.store, self.grad_sync, self.changed = Store(), None, 0
+
+        def _weights_changed(self):
+            self.changed += 1
+
+        def train_on_batch(self, inputs, targets=None):
+            assert targets is None
+            x = inputs[0]                                             # this rank's shard of the global batch
+            self.store.flat_grad[:] = float(x.sum())
+            scale = self.grad_sync(self.store.flat_grad)
+            self.store.flat -= 0.5 * scale * self.store.flat_grad
+            return [float(x.sum()), float(x.min()), float(x.max()), 1.0]
+    pm = ParallelModel(Toy(), world)
+    assert torch.all(pm.store.flat == 1.0) and torch.all(pm.store.w["emb"] == 10.0) and pm.inner_model.changed == 1
+    batch = np.arange(8, dtype=np.float64).reshape(4, 2)             # rank 0 gets rows 0-1, rank 1 rows 2-3
+    losses = pm.train_on_batch([batch], [])
+    want = [(1 + 5 + 9 + 13) / 2.0, (0 + 4) / 2.0, (3 + 7) / 2.0, 1.0]      # mean over towers of each entry
+    np.save(os.path.join(out_dir, "pm_%d.npy" % rank), np.array(list(losses) + pm.store.flat.tolist()))
+    assert np.allclose(losses, [14.0, 2.0, 5.0, 1.0]) and np.allclose(want, [14.0, 2.0, 5.0, 1.0])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_parallel_model_broadcast_loss_list_and_mean_gradient(tmp_path):
+    world = 2
+    mp.spawn(_worker_parallel_model, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a, b = np.load(tmp_path / "pm_0.npy"), np.load(tmp_path / "pm_1.npy")
+    np.testing.assert_allclose(a, b)                                   # same losses and same weights on both ranks
+    np.testing.assert_allclose(a[4:], 1.0 - 0.5 * (6.0 + 22.0) / 2.0)  # update used the MEAN over towers of the gradients
