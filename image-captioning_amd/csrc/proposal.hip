@@ -206,6 +206,7 @@ __global__ __launch_bounds__(256) void rpn_loss_grad_kernel(dc_rpn_loss_desc d) 
     const int l = d.sel_level[i], idx = d.sel_index[i], m = d.sel_match[i];
     const int A = d.anchors_per_loc;
     const int cell = idx / A, a = idx - cell * A;
+    if (l < 0 || l >= d.levels || idx < 0 || cell >= d.Hs[l] * d.Ws[l]) return;      // a malformed selection must not write out of bounds
     const float* h = d.heads[l] + (long)cell * d.head_stride;
     float* g = d.dheads[l] + (long)cell * d.head_stride;
     const float l0 = h[a * 2], l1 = h[a * 2 + 1];

@@ -8,8 +8,6 @@ generators call; the RPN is not evaluated) and use_generated_rois=True (RPN + Pr
 POST_NMS_ROIS_INFERENCE proposals, the feature_generation/ image-level path).  The joint training graph
 is a SURVEY.md section 8(f) "next" row and raises NotImplementedError.
 """
-import os
-
 import numpy as np
 import torch
 
