@@ -791,14 +791,109 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(AL al, BL bl, Epilogue ep
     store_tile<BM, BN>(acc, smem, ep, partial, M, N, m0, n0, wm, wn);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Producer / consumer variant for the 64x64 tile (the layers whose grids put only two blocks on a CU: ResNet stage 4/5 at
+// two images per GPU).  With the single-role kernel a wave that waits for its global loads cannot issue MFMAs, and at two
+// waves per SIMD that wait shows (stamps: 20-45 % of a K-tile in s_waitcnt vmcnt on these layers; a second register set
+// did not help).  Here waves 0-3 (one per SIMD) only read fragments and issue MFMAs, waves 4-7 only move data.  The data
+// movers need NO VALU per K-tile (buffer loads with SGPR offsets, ds_write with immediate offsets), so they do not take
+// fp32-lane cycles from the MFMAs; they keep four K-tiles of loads in flight and fill a four-stage LDS ring three tiles
+// ahead of the consumers.  One barrier per K-tile.  LDS 4 x 18 KB per block: two blocks per CU.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+constexpr int pc_stages() { return (BM * BN <= 64 * 64) ? 4 : 2; }      // ring depth = register sets: what fits two blocks per CU
+
+template <int BM, int BN, class AL, class BL>
+constexpr size_t igemm_pc_lds_bytes() {
+    constexpr size_t ring = (size_t)pc_stages<BM, BN>() * (lds_floats<BM, AL::KC>() + lds_floats<BN, BL::KC>()) * sizeof(float);
+    constexpr size_t cimage = (size_t)BM * (BN + 4) * sizeof(float);
+    return ring > cimage ? ring : cimage;
+}
+
+template <int BM, int BN, class AL, class BL>
+__global__ __launch_bounds__(512, 2) void igemm_pc_kernel(AL al, BL bl, Epilogue ep, int M, int N, int K, int klen,
+                                                       float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int TM = BM / 64, TN = BN / 64, NS = pc_stages<BM, BN>();
+    constexpr int A_FL = lds_floats<BM, AL::KC>(), B_FL = lds_floats<BN, BL::KC>(), STAGE = A_FL + B_FL;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int tiles_n = (N + BN - 1) / BN;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
+    const int kbeg = blockIdx.z * klen;
+    const int kend = min(K, kbeg + klen);
+    const int nkt = (kend - kbeg + BK - 1) / BK;
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ data movers
+        const int ptid = tid - 256;
+        typename AL::template State<BM> sa;
+        typename BL::template State<BN> sb;
+        al.template init<BM>(sa, m0, ptid);
+        bl.template init<BN>(sb, n0, ptid);
+        f4 ra[NS][BM / 32], rb[NS][BN / 32];              // register set j % NS holds tile j between its load and its LDS write
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int k0 = kbeg + j * BK;
+            al.template load<BM>(sa, ra[j], al.kclamp(k0, kend), kend, ptid);
+            bl.template load<BN>(sb, rb[j], bl.kclamp(k0, kend), kend, ptid);
+        }
+        // tile t: registers -> stage t % NS (compile-time `st`), then refill the set with tile t + NS
+        auto fill = [&](int t, float* st, f4 (&qa)[BM / 32], f4 (&qb)[BN / 32]) {
+            if (t < nkt) {
+                al.template store<BM>(sa, st, qa, ptid);
+                bl.template store<BN>(sb, st + A_FL, qb, ptid);
+            }
+            const int k0 = kbeg + (t + NS) * BK;
+            al.template load<BM>(sa, qa, al.kclamp(k0, kend), kend, ptid);
+            bl.template load<BN>(sb, qb, bl.kclamp(k0, kend), kend, ptid);
+        };
+#pragma unroll
+        for (int j = 0; j < NS - 1; ++j) fill(j, smem + j * STAGE, ra[j], rb[j]);          // tiles 0 .. NS-2 staged up front
+        __syncthreads();
+        for (int t0 = 0; t0 < nkt; t0 += NS) {
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                if (t0 + u < nkt) {                          // consumers are on tile t0+u; stage (u+NS-1) % NS was released at the last barrier
+                    fill(t0 + u + NS - 1, smem + ((u + NS - 1) % NS) * STAGE, ra[(u + NS - 1) % NS], rb[(u + NS - 1) % NS]);
+                    __syncthreads();
+                }
+            }
+        }
+        __syncthreads();                                     // the epilogue's barrier (store_tile)
+        return;
+    }
+    // ---------------------------------------------------------------------- MFMA waves
+    const int lane = tid & 63;
+    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+    __syncthreads();
+    for (int t0 = 0; t0 < nkt; t0 += NS) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            if (t0 + u < nkt) {
+                mma_tile<BM, BN, AL::KC, BL::KC>(smem + u * STAGE, smem + u * STAGE + A_FL, acc, wm, wn, lane);
+                __syncthreads();
+            }
+        }
+    }
+    store_tile<BM, BN>(acc, smem, ep, partial, M, N, m0, n0, wm, wn);
+}
+
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int splits, int M, int N, Epilogue ep);
 
 // conv forward on the split-bf16 main loop (conv_bs.hip)
 int conv2d_bf16x3(const dc_conv_desc* d, bool stem, const Epilogue& ep, int M, int N, int K, int bm, int bn, int split, void* workspace,
                   size_t workspace_bytes, hipStream_t s);
 
-// Host-side launch helper (defined in igemm_launch.hip).
-template <int BM, int BN, class AL, class BL>
+// Host-side launch helper.  PC = true selects the producer / consumer kernel (64x64 tiles).
+template <int BM, int BN, class AL, class BL, bool PC = false>
 int launch_igemm(const AL& al, const BL& bl, const Epilogue& ep, int M, int N, int K, int split_k, void* workspace,
                  size_t workspace_bytes, hipStream_t stream) {
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
@@ -814,15 +909,24 @@ int launch_igemm(const AL& al, const BL& bl, const Epilogue& ep, int M, int N, i
                    "igemm split-K needs %zu workspace bytes, got %zu", need, workspace_bytes);
         partial = static_cast<float*>(workspace);
     }
-    constexpr size_t lds = igemm_lds_bytes<BM, BN, AL, BL>();
+    constexpr size_t lds = PC ? igemm_pc_lds_bytes<BM, BN, AL, BL>() : igemm_lds_bytes<BM, BN, AL, BL>();
     static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, AL, BL>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
     dim3 grid(tiles, 1, split_k);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, AL, BL>), grid, dim3(256), lds, stream, al, bl, ep, M, N, K, klen, partial);
+    if constexpr (PC) {
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pc_kernel<BM, BN, AL, BL>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((igemm_pc_kernel<BM, BN, AL, BL>), grid, dim3(512), lds, stream, al, bl, ep, M, N, K, klen, partial);
+    } else {
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, AL, BL>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, AL, BL>), grid, dim3(256), lds, stream, al, bl, ep, M, N, K, klen, partial);
+    }
     int rc = check_launch("igemm_kernel");
     if (rc) return rc;
     if (split_k > 1) {
