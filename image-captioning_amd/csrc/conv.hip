@@ -208,7 +208,7 @@ extern "C" int dc_conv2d_wgrad_f32(const dc_conv_desc* d, void* workspace, size_
             return launch_igemm<128, 128, DenseMCT<true>, Im2colMC>(al, bl, ep, M, N, K, t.split, workspace, workspace_bytes, s);
         if (t.bm == 128 && t.bn == 64)
             return launch_igemm<128, 64, DenseMCT<true>, Im2colMC>(al, bl, ep, M, N, K, t.split, workspace, workspace_bytes, s);
-        return launch_igemm<64, 64, DenseMCT<true>, Im2colMC>(al, bl, ep, M, N, K, t.split, workspace, workspace_bytes, s);
+        return launch_igemm<64, 64, DenseMCT<true>, Im2colMC, true>(al, bl, ep, M, N, K, t.split, workspace, workspace_bytes, s);
     }
     DenseMCT<false> al{d->y, d->Cout, M, nullptr};                  // pixel count not a multiple of the K-tile (tiny pyramid levels)
     return launch_igemm<64, 64, DenseMCT<false>, Im2colMC>(al, bl, ep, M, N, K, t.split, workspace, workspace_bytes,

@@ -29,7 +29,7 @@ int gemm_dispatch(const AL& al, const BL& bl, const Epilogue& ep, const dc_gemm_
                   size_t wsb, hipStream_t s) {
     if (t.bm == 128 && t.bn == 128) return launch_igemm<128, 128, AL, BL>(al, bl, ep, d->M, d->N, d->K, t.split, ws, wsb, s);
     if (t.bm == 128 && t.bn == 64) return launch_igemm<128, 64, AL, BL>(al, bl, ep, d->M, d->N, d->K, t.split, ws, wsb, s);
-    return launch_igemm<64, 64, AL, BL>(al, bl, ep, d->M, d->N, d->K, t.split, ws, wsb, s);
+    return launch_igemm<64, 64, AL, BL, true>(al, bl, ep, d->M, d->N, d->K, t.split, ws, wsb, s);      // producer / consumer waves
 }
 
 // ragged shapes (K % 32 != 0, or a K-major operand whose row length is not a multiple of 4): guarded

@@ -9,7 +9,7 @@ static int dispatch(const AL& al, const BL& bl, const Epilogue& ep, const dc_gem
                     hipStream_t s) {
     if (t.bm == 128 && t.bn == 128) return launch_igemm<128, 128, AL, BL>(al, bl, ep, d->M, d->N, d->K, t.split, ws, wsb, s);
     if (t.bm == 128 && t.bn == 64) return launch_igemm<128, 64, AL, BL>(al, bl, ep, d->M, d->N, d->K, t.split, ws, wsb, s);
-    return launch_igemm<64, 64, AL, BL>(al, bl, ep, d->M, d->N, d->K, t.split, ws, wsb, s);
+    return launch_igemm<64, 64, AL, BL, true>(al, bl, ep, d->M, d->N, d->K, t.split, ws, wsb, s);      // producer / consumer waves
 }
 
 int gemm_fast_tn(const dc_gemm_desc* d, const Epilogue& ep, const TileChoice& t, void* ws, size_t wsb, hipStream_t s) {
