@@ -190,7 +190,8 @@ def main():
         groups = {}
         for name, fl, bm, bn, sk in table:
             kind = "StemKC" if name == "conv1" else "Im2colKCT<false>"
-            key = "igemm_kernel<%d, %d, dcap::%s, dcap::DenseKCT<true> >" % (bm, bn, kind)       # rocprof's spelling
+            kernel = "igemm_pc_kernel" if (bm, bn) == (64, 64) else "igemm_kernel"              # 64x64: producer/consumer waves
+            key = "%s<%d, %d, dcap::%s, dcap::DenseKCT<true> >" % (kernel, bm, bn, kind)         # rocprof's spelling
             g = groups.setdefault(key, {"flops": 0.0, "ms": 0.0, "launches": 0})
             g["flops"] += fl
             g["ms"] += times[name]
