@@ -69,9 +69,12 @@ using WeightKC = DenseKCT<true>;   // packed weights: K = kh*kw*Cin is a multipl
 template <class AL, class BL>
 static int conv_dispatch(const AL& al, const BL& bl, const Epilogue& ep, int M, int N, int K, const TileChoice& t, void* ws,
                          size_t wsb, hipStream_t s) {
-    if (t.bm == 128 && t.bn == 128) return launch_igemm<128, 128, AL, BL>(al, bl, ep, M, N, K, t.split, ws, wsb, s);
     static int pc = -1;              // experiment knob: DCAP_PC=0 runs the single-role kernels, 2 = producer/consumer on 128x64 too
     if (pc < 0) { const char* e = getenv("DCAP_PC"); pc = e ? atoi(e) : 1; }
+    if (t.bm == 128 && t.bn == 128) {
+        if (pc == 3) return launch_igemm<128, 128, AL, BL, true>(al, bl, ep, M, N, K, t.split, ws, wsb, s);
+        return launch_igemm<128, 128, AL, BL>(al, bl, ep, M, N, K, t.split, ws, wsb, s);
+    }
     if (t.bm == 128 && t.bn == 64) {
         if (pc == 2) return launch_igemm<128, 64, AL, BL, true>(al, bl, ep, M, N, K, t.split, ws, wsb, s);
         return launch_igemm<128, 64, AL, BL>(al, bl, ep, M, N, K, t.split, ws, wsb, s);

@@ -801,7 +801,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(AL al, BL bl, Epilogue ep
 // ahead of the consumers.  One barrier per K-tile.  LDS 4 x 18 KB per block: two blocks per CU.
 // ------------------------------------------------------------------------------------------------
 template <int BM, int BN>
-constexpr int pc_stages() { return (BM * BN <= 64 * 64) ? 4 : 2; }      // ring depth = register sets: what fits two blocks per CU
+constexpr int pc_stages() { return (BM * BN <= 64 * 64) ? 4 : (BM * BN >= 128 * 128 ? 3 : 2); }      // ring depth = register sets
 
 template <int BM, int BN, class AL, class BL>
 constexpr size_t igemm_pc_lds_bytes() {
@@ -811,7 +811,7 @@ constexpr size_t igemm_pc_lds_bytes() {
 }
 
 template <int BM, int BN, class AL, class BL>
-__global__ __launch_bounds__(512, 2) void igemm_pc_kernel(AL al, BL bl, Epilogue ep, int M, int N, int K, int klen,
+__global__ __launch_bounds__(512, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_pc_kernel(AL al, BL bl, Epilogue ep, int M, int N, int K, int klen,
                                                        float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TM = BM / 64, TN = BN / 64, NS = pc_stages<BM, BN>();
