@@ -535,3 +535,22 @@ def test_gemm_k_tail_split_with_gather(ops):
     dz = rng.standard_normal((rows, N))
     got = ops.gemm(dev(table), dev(dz), a_trans=True, gather=dev(ids, torch.int32))                                    # K = 200 rows
     close(got, table[ids].T @ dz, 5e-5)
+
+
+def test_degenerate_sizes_are_rejected_not_launched(ops):
+    """Empty operands (no RoIs, no rows, no columns) come back as DcapError from the C-ABI's validation -- never a zero-sized
+    grid or an out-of-bounds access."""
+    from image_captioning_amd._lib import DcapError
+    maps = [torch.zeros(1, 64 // s, 64 // s, 8, device="cuda") for s in (4, 8, 16, 32)]
+    with pytest.raises(DcapError):
+        ops.roi_align_pyramid(maps, torch.zeros(1, 0, 4, device="cuda"), 64 * 64, 7)
+    with pytest.raises(DcapError):
+        ops.gemm(torch.zeros(0, 32, device="cuda"), torch.zeros(32, 64, device="cuda"))
+    with pytest.raises(DcapError):
+        ops.softmax_ce(torch.zeros(0, 8, device="cuda"), torch.zeros(0, dtype=torch.int32, device="cuda"), None, torch.zeros(0, device="cuda"), None)
+    with pytest.raises(DcapError):
+        ops.colsum(torch.zeros(0, 16, device="cuda"))
+    with pytest.raises(DcapError):
+        ops.conv2d(torch.zeros(1, 8, 8, 48, device="cuda"), torch.zeros(32, 48, device="cuda"), 1, 1, 1, 0, 0, 8, 8)       # Cin % 32 != 0
+    with pytest.raises(DcapError):
+        ops.lstm_seq_fwd(torch.zeros(0, 16, device="cuda"), torch.zeros(4, 16, device="cuda"), None, 0, 1)
