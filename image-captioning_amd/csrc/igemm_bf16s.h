@@ -17,6 +17,8 @@
 // a CU and one block's split+store phase runs under the other's MFMAs); two K-tiles of staging registers keep every
 // global load in flight for two MFMA phases before it is drained.
 // Both operands must be K-contiguous (KC loaders): conv forward / data gradient and NT GEMMs.
+// DCAP_EXP_{NOSPLIT,NOMFMA,NOFRAG,NOLOAD} are ablation switches for tools/build_variant.sh (never defined in the product build):
+// they knock out one phase of the loop so that its share of the K-tile time can be read off a timing difference.
 #pragma once
 #include "igemm_core.h"
 
