@@ -439,3 +439,42 @@ def test_joint_model_degenerate_batches(gpu):
     model.compile(1e-4)
     out = model.train_on_batch(inputs)
     assert np.isfinite(out).all()
+
+
+def test_joint_model_train_loop_checkpoints_and_resumes(gpu, tmp_path):
+    """train(): data_generator -> train_on_batch x STEPS_PER_EPOCH -> validation -> checkpoint per epoch -> find_last /
+    load_weights resume (the flow of train_dense_captions.py:170-203 on a toy dataset)."""
+    from image_captioning_amd import utils
+    from image_captioning_amd.dense_model import DenseImageCapRCNN
+    S, V, T, blocks = 128, 24, 5, 1
+    _, cfg, Wt = make_joint(S, V, T, blocks)
+    cfg.STEPS_PER_EPOCH, cfg.MAX_GT_INSTANCES = 2, 6
+
+    class Toy(utils.Dataset):
+        def load_image(self, image_id):
+            return np.random.RandomState(image_id).randint(0, 255, (S, S, 3)).astype(np.uint8)
+
+        def load_captions_and_rois(self, image_id):
+            r = np.random.RandomState(100 + image_id)
+            y, x = r.randint(0, 60, 4), r.randint(0, 60, 4)
+            boxes = np.stack([y, x, y + r.randint(20, 60, 4), x + r.randint(20, 60, 4)], axis=1)
+            caps = np.zeros((4, T), np.float32)
+            caps[:, 0], caps[:, 1:3], caps[:, 3] = 1, r.randint(3, V, (4, 2)), 2
+            return boxes, caps
+    train, val = Toy(), Toy()
+    for ds, ids in ((train, range(3)), (val, range(3, 5))):
+        for i in ids:
+            ds.add_image("toy", image_id=i, path=None)
+        ds.prepare()
+    model = DenseImageCapRCNN("training", cfg, str(tmp_path / "logs"), stage4_blocks=blocks)
+    model.set_weights(Wt)
+    history = model.train(train, val, learning_rate=1e-5, epochs=2, layers="no_backbone")
+    assert len(history) == 2 and all(np.isfinite(v) for h in history for v in h.values())
+    assert set(history[0]) >= {"loss", "rpn_class_loss", "rpn_bbox_loss", "imgcap_loss", "val_loss"}
+    folder, last = model.find_last()
+    assert last.endswith("dense_image_cap_rcnn_0002.npz") and model.epoch == 2
+    resumed = DenseImageCapRCNN("training", cfg, folder, stage4_blocks=blocks)
+    resumed.load_weights(last, by_name=True)
+    a, b = model.get_weights_dict(), resumed.get_weights_dict()
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert not np.array_equal(a['fpn_p2/kernel'], np.asarray(Wt['fpn_p2/kernel'], np.float32))      # it did train
