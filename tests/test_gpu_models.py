@@ -478,3 +478,57 @@ def test_joint_model_train_loop_checkpoints_and_resumes(gpu, tmp_path):
     a, b = model.get_weights_dict(), resumed.get_weights_dict()
     assert all(np.array_equal(a[k], b[k]) for k in a)
     assert not np.array_equal(a['fpn_p2/kernel'], np.asarray(Wt['fpn_p2/kernel'], np.float32))      # it did train
+
+
+def test_v2_script_flow_end_to_end(gpu, tmp_path):
+    """The __main__ flow of text_generation_model_v2.py (:208-346) on a toy dataset: feature model -> load_sequences ->
+    data_generator -> build_model -> compile -> fit_generator with ModelCheckpoint + CSVLogger -> greedy decode."""
+    from image_captioning_amd import synth
+    from image_captioning_amd.config import Config
+    from image_captioning_amd.modified_dense_model import DenseImageCapRCNN
+    from image_captioning_amd.text_generation_model_v2 import (DenseCapConfig, VisualGenomeDataset, load_sequences, build_model,
+                                                               data_generator, Adam, ModelCheckpoint, CSVLogger)
+    S, V, T = 128, 40, 6
+
+    class FCfg(Config):
+        IMAGES_PER_GPU = 1
+        IMAGE_MIN_DIM = S
+        IMAGE_MAX_DIM = S
+    features_model = DenseImageCapRCNN("inference", FCfg(), "logs", stage4_blocks=1)
+    features_model.set_weights(synth.encoder_weights(0, 1))
+
+    class Toy(VisualGenomeDataset):
+        def load_image(self, image_id):
+            return np.random.RandomState(image_id).randint(0, 255, (S, S, 3)).astype(np.uint8)
+
+        def load_captions_and_rois(self, image_id):
+            r = np.random.RandomState(50 + image_id)
+            y, x = r.randint(0, 60, 3), r.randint(0, 60, 3)
+            rois = np.stack([y, x, y + r.randint(20, 60, 3), x + r.randint(20, 60, 3)], axis=1)
+            caps = [np.eye(V)[np.concatenate([r.randint(3, V, r.randint(2, 4)), [2]])] for _ in range(3)]      # one-hot words, <end> = 2
+            return rois, caps
+    ds = Toy({}, T)
+    for i in range(2):
+        ds.add_image("toy", image_id=i, path=None)
+    ds.prepare()
+    ds.add_sequences(load_sequences(ds))
+    assert len(ds.sequences) == sum(len(c) for i in range(2) for c in ds.load_captions_and_rois(i)[1])
+    cfg = DenseCapConfig(V, synth.embedding_matrix(3, V))
+    cfg.PADDING_SIZE = T
+    model = build_model((7, 7, 256), (T,), cfg, 256, True)
+    model.compile(optimizer=Adam(amsgrad=True), loss='categorical_crossentropy')
+    gen = data_generator(ds, features_model, cfg, 4)
+    val = next(data_generator(ds, features_model, cfg, 4))
+    ckpt, log = str(tmp_path / "model-{epoch:02d}-{val_loss:.2f}.h5"), str(tmp_path / "train.csv")
+    history = model.fit_generator(gen, epochs=3, steps_per_epoch=3, callbacks=[ModelCheckpoint(ckpt, verbose=0, save_weights_only=True, mode='min'),
+                                                                             CSVLogger(log)], validation_data=val, verbose=0)
+    assert len(history) == 3 and history[-1]["loss"] < history[0]["loss"]
+    saved = sorted(p.name for p in tmp_path.iterdir() if p.name.startswith("model-"))
+    assert len(saved) == 3 and saved[0].startswith("model-01-") and saved[0].endswith(".npz")
+    assert open(log).read().splitlines()[0] == "epoch,loss,val_loss"
+    other = build_model((7, 7, 256), (T,), cfg, 256, True, seed=5)
+    other.load_weights(str(tmp_path / saved[-1]), by_name=True)
+    feat = features_model.extract_features(np.stack([ds.load_image(0)]), ds.load_captions_and_rois(0)[0][None].astype(np.float32))[0]
+    a_ids, a_probs = model.greedy_decode(feat[0].cpu().numpy())
+    b_ids, b_probs = other.greedy_decode(feat[0].cpu().numpy())
+    assert np.array_equal(a_ids, b_ids) and np.array_equal(a_probs, b_probs) and len(a_ids) >= 1
