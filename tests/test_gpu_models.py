@@ -532,3 +532,63 @@ def test_v2_script_flow_end_to_end(gpu, tmp_path):
     a_ids, a_probs = model.greedy_decode(feat[0].cpu().numpy())
     b_ids, b_probs = other.greedy_decode(feat[0].cpu().numpy())
     assert np.array_equal(a_ids, b_ids) and np.array_equal(a_probs, b_probs) and len(a_ids) >= 1
+
+
+def test_v1_script_flow_end_to_end(gpu, tmp_path):
+    """The __main__ flow of text_generation_model.py (:375-470) on a toy dataset: feature model -> create_roi_info ->
+    data_generator -> build_lstm_model('training') -> fit_generator -> weights into the 'inference' model -> greedy captions."""
+    from image_captioning_amd import synth
+    from image_captioning_amd.config import Config
+    from image_captioning_amd.modified_dense_model import DenseImageCapRCNN
+    from image_captioning_amd.text_generation_model import (DenseCapConfig, VisualGenomeDataset, create_roi_info, build_lstm_model,
+                                                            data_generator, roi_caption_loss, Adam, ModelCheckpoint)
+    S, V, T, B = 128, 40, 6, 4
+
+    class FCfg(Config):
+        IMAGES_PER_GPU = 1
+        IMAGE_MIN_DIM = S
+        IMAGE_MAX_DIM = S
+    features_model = DenseImageCapRCNN("inference", FCfg(), "logs", stage4_blocks=1)
+    features_model.set_weights(synth.encoder_weights(0, 1))
+
+    class Toy(VisualGenomeDataset):
+        def load_image(self, image_id):
+            return np.random.RandomState(image_id).randint(0, 255, (S, S, 3)).astype(np.uint8)
+
+        def load_captions_and_rois(self, image_id):
+            r = np.random.RandomState(70 + image_id)
+            y, x = r.randint(0, 60, 3), r.randint(0, 60, 3)
+            rois = np.stack([y, x, y + r.randint(20, 60, 3), x + r.randint(20, 60, 3)], axis=1)
+            caps = np.zeros((3, T), np.float32)
+            for k in range(3):
+                n = r.randint(1, 4)
+                caps[k, 0], caps[k, 1:1 + n], caps[k, 1 + n] = 1, r.randint(3, V, n), 2
+            return rois, caps
+    ds = Toy({}, T)
+    for i in range(2):
+        ds.add_image("toy", image_id=i, path=None)
+    ds.prepare()
+    ds.add_rois(create_roi_info(ds))
+    assert len(ds.rois) == 6
+    cfg = DenseCapConfig(V, synth.embedding_matrix(3, V), B)
+    cfg.PADDING_SIZE = T
+    model = build_lstm_model([7, 7, 256], cfg, 512, 'training')
+    k1 = model.get_weights_dict()['mrcnn_class_conv1/kernel']
+    model.load_weights({'mrcnn_class_conv1/kernel': k1 * np.float32(0.05)})      # random FPN maps are O(10): keep the softmax out of
+    # the clipped (zero-gradient) regime; and a small step: Adam's first updates move all 12 544 inputs of a head unit by lr
+    # in the gradient's sign, which on these un-normalised random features kills every ReLU at the default lr
+    model.compile(optimizer=Adam(lr=2e-6, amsgrad=True), loss=roi_caption_loss)
+    gen = data_generator(ds, features_model, cfg, B)
+    val = next(data_generator(ds, features_model, cfg, B))
+    ckpt = str(tmp_path / "v1-{epoch:02d}.h5")
+    history = model.fit_generator(gen, epochs=4, steps_per_epoch=3, callbacks=[ModelCheckpoint(ckpt, save_weights_only=True)],
+                                  validation_data=val, verbose=0)
+    assert history[-1]["loss"] < history[0]["loss"] and np.isfinite(history[-1]["val_loss"]), history
+    infer = build_lstm_model([7, 7, 256], cfg, 512, 'inference', seed=9)
+    infer.load_weights(str(tmp_path / "v1-04.npz"), by_name=True)
+    (feat, words), _ = val
+    probs = infer.predict(feat)
+    assert probs.shape == (B, T, V)
+    np.testing.assert_allclose(probs.sum(-1), 1.0, atol=1e-5)
+    again, ids = infer.generate(feat)
+    assert np.array_equal(again, probs) and np.array_equal(ids, probs.argmax(-1))
