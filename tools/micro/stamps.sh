@@ -23,7 +23,8 @@ from image_captioning_amd import ops, _lib
 lib = _lib.load()
 lib.dc_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 shapes = [("res4_2b 3x3 256 b1", 1, 64, 256, 256, 3), ("res4_2b 3x3 256 b2", 2, 64, 256, 256, 3), ("res4_2b b4", 4, 64, 256, 256, 3),
-          ("fpn_p3 3x3 b2", 2, 128, 256, 256, 3), ("res4_2a 1x1 1024>256 b2", 2, 64, 1024, 256, 1)]
+          ("fpn_p3 3x3 b2", 2, 128, 256, 256, 3), ("res4_2a 1x1 1024>256 b2", 2, 64, 1024, 256, 1),
+          ("res4_2c 1x1 256>1024 b2", 2, 64, 256, 1024, 1), ("res3_2c 1x1 128>512 b2", 2, 128, 128, 512, 1)]
 for name, B, H, Cin, Cout, k in shapes:
     x = torch.randn(B, H, H, Cin, device='cuda'); w = torch.randn(Cout, k*k*Cin, device='cuda') * 0.02
     y = torch.empty(B, H, H, Cout, device='cuda')
