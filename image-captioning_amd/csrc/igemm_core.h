@@ -315,7 +315,7 @@ struct Im2colKCT {
             const int ubytes = (((ky - pad_t) * W + (kx - pad_l)) * Cin + s.c) * 4;  // block-uniform, may be negative
 #pragma unroll
             for (int i = 0; i < BT / 32; ++i) {
-                const bool in = ((s.mask[i] >> tap) & 1ull) != 0;
+                const bool in = tap < taps && ((s.mask[i] >> (tap & 63)) & 1ull) != 0;
                 r[i] = buf_f4(s.rsrc, in ? s.boff[i] + (unsigned)ubytes : kOobOffset); // out of image -> hardware zero
             }
         } else {
@@ -325,7 +325,8 @@ struct Im2colKCT {
             if (s.fresh) {
                 s.fresh = 0;
 #pragma unroll
-                for (int i = 0; i < BT / 32; ++i) s.sel[i] = ((s.mask[i] >> tap) & 1ull) ? s.boff[i] : kOobOffset;
+                for (int i = 0; i < BT / 32; ++i)       // tap >= taps: a tile issued past the end of K (never stored) must not address memory
+                    s.sel[i] = (tap < taps && ((s.mask[i] >> (tap & 63)) & 1ull)) ? s.boff[i] : kOobOffset;
             }
             const unsigned soff = (unsigned)(((ky * W + kx) * Cin + s.c) * 4);         // block-uniform, >= 0 (SGPR)
 #pragma unroll
