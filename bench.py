@@ -1,22 +1,28 @@
 #!/usr/bin/env python
 """bench.py -- captions/sec of one dense-captioning TRAIN STEP on synthetic Visual-Genome-shaped data.
 
-Workload (BASELINE.json configs[2], and configs[3] at --gpus 8): per GPU `images_per_gpu` (2) synthetic
+Default workload (BASELINE.json configs[2], and configs[3] at --gpus 8): per GPU `images_per_gpu` (2) synthetic
 1024x1024 images x 32 ground-truth RoIs x 15-token captions; one step =
   frozen ResNet-101 + FPN forward -> PyramidROIAlign -> frozen RoI head -> v2-inject caption decoder
-  (word-LSTM-1024, inject-LSTM-256, Dense-V softmax, V = 10 000) forward + backward -> [RCCL gradient
-  all-reduce] -> Keras AMSGrad update.
+  (word-LSTM-1024, inject-LSTM-256, fused Dense-V softmax / cross-entropy, V = 10 000) forward + backward -> [RCCL gradient
+  all-reduce, bucketed against the backward] -> Keras AMSGrad update.
 All arithmetic is fp32 (exact-f32 MFMA).  Inputs are resident in HBM before the timed region.
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py --config joint      BASELINE configs[4]: the joint model (bf16 decoder / head / vocabulary GEMMs), one
+                                      1024x1024 image per GPU and step, 2000 proposals -> 200 RoIs, V = 50 000
 
-Rank 0 prints ONE JSON line (see the driver contract) with two extra objects:
-  roofline     -- the dominant kernel (the conv implicit-GEMM instantiation with the largest time share):
-                  algorithmic FLOPs per launch / mean launch time (HIP events on the launch stream, taken
-                  in this process right after the timed steps) against the fp32 MFMA peak (157.3 TFLOP/s);
-  cpu_baseline -- the reference-as-written algorithm (oracle/torch_ref.py, float32, all host threads)
-                  timed on a bounded sample (N = 1 only).
+Rank 0 prints ONE JSON line (see the driver contract) with extra objects:
+  roofline      -- the dominant kernel (the conv implicit-GEMM instantiation with the largest time share): algorithmic FLOPs
+                   per launch / mean launch time against the fp32 MFMA peak (157.3 TFLOP/s).  The time is measured in this
+                   process with HIP events on the launch stream while a decoder step runs beside the encoder on its own
+                   stream, as in the timed pipeline -- the condition a rocprofv3 kernel trace of this command sees
+                   (profiles/r02_bench_kernel_stats.csv); `isolated` holds the same quantities with the chip to itself;
+  cpu_baseline  -- the reference-as-written algorithm (oracle/torch_ref.py, float32, all host threads) timed on a bounded
+                   sample of the same workload (N = 1 only);
+  other_configs -- BASELINE configs[2] proper (ONE image per step), configs[1] (v2-inject decoder on precomputed RoI
+                   features, batch 64) on the GPU, and the CPU companions of configs[0] / configs[1] (N = 1 only).
 """
 import argparse
 import json
@@ -32,7 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
-V2_INJECT_FWD_MF_PER_CAPTION = 310.3   # T=15, V=10k single pass
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
 def parse():
@@ -40,29 +46,56 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="e2e", choices=["e2e", "joint"], help="e2e = configs[2]/[3] (the headline); joint = configs[4]")
     ap.add_argument("--images-per-gpu", type=int, default=2)
     ap.add_argument("--rois", type=int, default=32)
     ap.add_argument("--tokens", type=int, default=15)
-    ap.add_argument("--vocab", type=int, default=10000)
+    ap.add_argument("--vocab", type=int, default=None, help="default 10000 (e2e) / 50000 (joint)")
     ap.add_argument("--image-size", type=int, default=1024)
     ap.add_argument("--stage4-blocks", type=int, default=22, help="22 = ResNet-101 (the benchmark config)")
     ap.add_argument("--no-pipeline", action="store_true", help="run encoder and decoder back to back on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-alt-math", action="store_true", help="skip the extra timing of the split-bf16 conv arithmetic")
-    ap.add_argument("--cpu-baseline-images", type=int, default=2)
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the configs[0]/[1]/[2]-proper companion legs")
+    ap.add_argument("--cpu-baseline-steps", type=int, default=5)
     ap.add_argument("--layer-table", default=None, help="write the per-layer conv timing table (TSV) to this path")
-    return ap.parse_args()
+    ap.add_argument("--joint-dtype", default="bf16", choices=["bf16", "f32"], help="joint leg: decoder/head/vocabulary arithmetic")
+    ap.add_argument("--joint-conv-math", default=None, help="joint leg: conv arithmetic (f32 | bf16x3 | bf16x2 | bf16)")
+    a = ap.parse_args()
+    if a.vocab is None:
+        a.vocab = 50000 if a.config == "joint" else 10000
+    return a
+
+
+def host_cores():
+    # the GPU box hands one GPU a share of 16 host cores; os.cpu_count() reports the whole machine
+    return max(1, min(len(os.sched_getaffinity(0)), 16))
+
+
+def _median_steps(fn, warm, steps, budget_s):
+    """`warm` untimed calls, then up to `steps` timed ones inside a wall-clock budget; returns (median seconds, n timed)."""
+    t_start = time.perf_counter()
+    for _ in range(warm):
+        fn()
+    times = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        fn()
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > budget_s:
+            break
+    return float(np.median(times)), len(times)
 
 
 def cpu_baseline(args):
     """Reference-as-written train step on the host (oracle/torch_ref.py), float32, all threads:
     batch-1 ResNet-101+FPN (+ the RPN convs the reference always evaluates) per image, RoIAlign, then
-    every (prefix -> next word) sample recomputing RoI head + word LSTM; Keras AMSGrad."""
+    every (prefix -> next word) sample recomputing RoI head + word LSTM; Keras AMSGrad.
+    BASELINE.md section 3 protocol: 2 warm-up steps, median of >= 5 timed steps (bounded to ~45 s)."""
     from oracle import torch_ref as TR
     from image_captioning_amd import synth
-    # the GPU box hands one GPU a share of 16 host cores; os.cpu_count() reports the whole machine
-    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+    cores = host_cores()
     torch.set_num_threads(cores)
     S, V, T, R = args.image_size, args.vocab, args.tokens, args.rois
     encW = TR.to_t(synth.encoder_weights(0, args.stage4_blocks), torch.float32)
@@ -77,26 +110,299 @@ def cpu_baseline(args):
     rois = synth.rois(98, 1, R, S, S)[0]
     caps = synth.captions_v2(97, R, T, V, full=True)
     state = {}
-    times = []
-    n_img = max(1, args.cpu_baseline_images)
-    t_start = time.perf_counter()
-    for i in range(1 + n_img):                    # first image is the warm-up
-        t0 = time.perf_counter()
-        TR.cpu_baseline_step(encW, decW, imgs[0], rois, caps, [123.7, 116.8, 103.9], T, V, state, args.stage4_blocks)
-        times.append(time.perf_counter() - t0)
-        if time.perf_counter() - t_start > 45.0:  # bounded sample: stop after ~45 s of CPU work
-            break
-    med = float(np.median(times[1:])) if len(times) > 1 else times[0]
-    n_img = max(1, len(times) - 1)
+    med, n = _median_steps(lambda: TR.cpu_baseline_step(encW, decW, imgs[0], rois, caps, [123.7, 116.8, 103.9], T, V, state,
+                                                        args.stage4_blocks), 2, max(1, args.cpu_baseline_steps), 45.0)
     return {"value": R / med, "unit": "captions/s", "cores": cores, "kind": "port",
-            "sample": "%d timed step(s) of 1 image x %d RoI x %d tok (median %.2f s/step) after 1 warm-up; "
-                      "reference-as-written algorithm incl. dead RPN convs, torch-CPU fp32" % (n_img, R, T, med)}
+            "sample": "median of %d timed train steps of 1 image x %d RoI x %d tok (%.2f s/step) after 2 warm-ups; "
+                      "reference-as-written algorithm incl. dead RPN convs, torch-CPU fp32" % (n, R, T, med)}
+
+
+def cpu_companions():
+    """CPU companions BASELINE.md section 3 promises: configs[0] (v1 decoder as written: T zero-padded prefixes x full 2-layer
+    LSTM, batch 8, V = 1000, T = 10 -- the reference's own CPU-runnable case) and configs[1] (v2-inject as written: batch of
+    64 (prefix -> next word) samples, each recomputing RoI head + 10-step word LSTM, V = 10 000): forward + backward
+    (autograd) + Keras AMSGrad, torch-CPU fp32, 2 warm-ups, median of 5."""
+    import math
+    from oracle import torch_ref as TR
+    from image_captioning_amd import synth
+    cores = host_cores()
+    torch.set_num_threads(cores)
+
+    def amsgrad(Wd, train, grads, st):
+        st['t'] = st.get('t', 0) + 1
+        lr_t = 1e-3 * math.sqrt(1 - 0.999 ** st['t']) / (1 - 0.9 ** st['t'])
+        with torch.no_grad():
+            for k, g in zip(train, grads):
+                m, v, vh = st.get(k, (torch.zeros_like(g),) * 3)
+                m, v = 0.9 * m + 0.1 * g, 0.999 * v + 0.001 * g * g
+                vh = torch.maximum(vh, v)
+                Wd[k] -= lr_t * m / (vh.sqrt() + 1e-7)
+                st[k] = (m, v, vh)
+
+    out = {}
+    rng = np.random.default_rng(5)
+    # configs[0]
+    V, T, B = 1000, 10, 8
+    W = dict(synth.head_weights(1), **synth.v1_weights(2, V))
+    W['imgcap_embedding_layer/embeddings'] = synth.embedding_matrix(3, V)
+    train = [k for k in W if not k.startswith('imgcap_embedding') and 'moving_' not in k]
+    Wd = TR.to_t(W, torch.float32, requires_grad=train)
+    feat = torch.tensor(rng.standard_normal((B, 7, 7, 256)).astype(np.float32))
+    caps = torch.tensor(synth.captions_v1(6, B, T, V))
+    st = {}
+
+    def step0():
+        loss = TR.v1_loss(Wd, feat, caps)
+        amsgrad(Wd, train, torch.autograd.grad(loss, [Wd[k] for k in train]), st)
+    med, n = _median_steps(step0, 2, 5, 20.0)
+    out["configs0_cpu"] = {"workload": "BASELINE configs[0]: text_generation_model.py decoder as written (T^2 prefix graph), RoI features "
+                                       "[8,7,7,256], V=1000, T=10, trainable head, train step", "value": B / med, "unit": "captions/s",
+                           "ms_per_step": 1e3 * med, "cores": cores, "kind": "port", "timed_steps": n}
+    # configs[1]
+    V, T, B = 10000, 10, 64
+    W = dict(synth.head_weights(1), **synth.v2_weights(2, V))
+    W['imgcap_embedding_layer/embeddings'] = synth.embedding_matrix(3, V)
+    train = [k for k in W if k.split('/')[0] in ('lstm_1', 'imgcap_lstm', 'imgcap_d1')]
+    Wd = TR.to_t(W, torch.float32, requires_grad=train)
+    feat = torch.tensor(rng.standard_normal((B, 7, 7, 256)).astype(np.float32))
+    words = torch.tensor(_prefix_batch(rng, B, T, V))
+    tgt = torch.tensor(rng.integers(3, V, B))
+    st = {}
+
+    def step1():
+        loss = TR.v2_loss(Wd, feat, words, tgt, True)
+        amsgrad(Wd, train, torch.autograd.grad(loss, [Wd[k] for k in train]), st)
+    med, n = _median_steps(step1, 2, 5, 20.0)
+    out["configs1_cpu"] = {"workload": "BASELINE configs[1]: text_generation_model_v2.py inject decoder as written, 64 (prefix -> next word) "
+                                       "samples on precomputed RoI features, V=10000, window 10, train step", "value": B / med,
+                           "unit": "samples/s", "ms_per_step": 1e3 * med, "cores": cores, "kind": "port", "timed_steps": n}
+    return out
+
+
+def _prefix_batch(rng, B, T, V):
+    """B pre-padded prefixes of random length 0..T (the reference's data_generator layout, _v2.py:183)."""
+    words = np.zeros((B, T), np.int64)
+    for b in range(B):
+        L = int(rng.integers(0, T + 1))
+        if L:
+            words[b, T - L:] = rng.integers(3, V, L)
+    return words
+
+
+def gpu_configs1(dev, steps=30):
+    """BASELINE configs[1] on the GPU: v2-inject decoder, as-written batch of 64 samples on precomputed RoI features."""
+    from image_captioning_amd import synth
+    from image_captioning_amd.text_generation_model_v2 import DenseCapConfig, build_model, Adam, SampleTables
+    V, T, B = 10000, 10, 64
+    cfg = DenseCapConfig(V, synth.embedding_matrix(3, V))
+    cfg.PADDING_SIZE = T
+    dec = build_model((7, 7, 256), (T,), cfg, 256, inject=True, device=dev, seed=0)
+    dec.compile(optimizer=Adam(amsgrad=True), loss="categorical_crossentropy")
+    rng = np.random.default_rng(5)
+    feat = torch.tensor(rng.standard_normal((B, 7, 7, 256)).astype(np.float32), device=dev)
+    tb = SampleTables.from_samples(_prefix_batch(rng, B, T, V), rng.integers(3, V, B), dev)
+    for _ in range(3):
+        dec.train_step(feat, tb)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = dec.train_step(feat, tb)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"workload": "BASELINE configs[1]: text_generation_model_v2.py inject decoder as written, 64 (prefix -> next word) samples on "
+                        "precomputed RoI features, V=10000, window 10, train step, fp32", "value": B / dt, "unit": "samples/s",
+            "ms_per_step": 1e3 * dt, "steps": steps, "final_loss": float(loss.item())}
+
+
+class E2E(object):
+    """The configs[2]/[3] train step: encoder plan + v2-inject decoder (+ ParallelModel), optionally pipelined on 2 streams."""
+
+    def __init__(self, args, dev, rank, world, B):
+        from image_captioning_amd import synth
+        from image_captioning_amd.config import Config
+        from image_captioning_amd.modified_dense_model import DenseImageCapRCNN
+        from image_captioning_amd.parallel_model import ParallelModel
+        from image_captioning_amd.pipeline import CaptionTrainPipeline
+        from image_captioning_amd.text_generation_model_v2 import DenseCapConfig, build_model, Adam, SampleTables
+        S, V, T, R = args.image_size, args.vocab, args.tokens, args.rois
+
+        class EncCfg(Config):
+            NAME = "bench"
+            IMAGES_PER_GPU = B
+            IMAGE_MIN_DIM = S
+            IMAGE_MAX_DIM = S
+
+        enc = DenseImageCapRCNN("inference", EncCfg(), "logs", device=dev, stage4_blocks=args.stage4_blocks)
+        enc.set_weights(synth.encoder_weights(0, args.stage4_blocks))
+        cfg = DenseCapConfig(V, synth.embedding_matrix(3, V))
+        cfg.PADDING_SIZE = T
+        dec = build_model((7, 7, 256), (T,), cfg, 256, inject=True, device=dev, seed=0)
+        dec.compile(optimizer=Adam(amsgrad=True), loss="categorical_crossentropy")
+        self.sync = None
+        if world > 1:
+            dec = ParallelModel(dec, world)
+            self.sync = dec.inner_model.grad_sync
+        seed = 1234 + rank
+        images = torch.tensor(synth.images(seed, B, S, S), device=dev)
+        rois = synth.rois(seed + 1, B, R, S, S)
+        caps = synth.captions_v2(seed + 2, B * R, T, V, full=True)
+        self.tables = SampleTables.from_captions(caps, dev)
+        self.plan = plan = enc.plan(B, S, S)
+        plan.images.copy_(images)
+        self.boxes = plan.normalize_boxes(rois)          # device-resident, normalised once
+        self.feat = torch.empty((B, R, 7, 7, 256), dtype=torch.float32, device=dev)
+        self.inner = dec.inner_model if world > 1 else dec
+        self.B, self.R = B, R
+        self.pipe = None if args.no_pipeline else CaptionTrainPipeline(plan, self.inner, R)
+
+    def step(self):
+        if self.pipe is not None:                     # encoder(i) overlaps decoder(i-1); flushed before the clock stops
+            return self.pipe.step(None, self.boxes, self.tables)
+        self.plan.forward(None)                       # images already resident in the plan's input buffer
+        self.plan.roi_features(boxes_norm=self.boxes, out=self.feat)
+        return self.inner.train_step(self.feat.view(self.B * self.R, 7, 7, 256), self.tables)
+
+    def flush(self):
+        return self.pipe.flush() if self.pipe is not None else None
+
+    def timed(self, warmup, steps, barrier):
+        for _ in range(max(warmup, 2)):               # >= 2: the second call captures the encoder hipGraph
+            loss = self.step()
+        self.flush()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = self.step()
+        last = self.flush()                           # every one of the K steps is complete inside the timed region
+        loss = last if last is not None else loss
+        barrier()
+        return time.perf_counter() - t0, loss
+
+    def roofline(self, args):
+        """Per-instantiation conv timing, in the pipeline's conditions and alone; the dominant kernel's roofline numbers."""
+        plan = self.plan
+        table = plan.conv_table()
+        beside = None
+        if self.pipe is not None:
+            s_dec, feat0 = self.pipe.s_dec, self.pipe.feat[0]
+
+            def beside():                              # one decoder train step on the decoder's stream, like the pipeline
+                with torch.cuda.stream(s_dec):
+                    self.inner.train_step(feat0.view(-1, 7, 7, 256), self.tables)
+        res = {}
+        for label, b in (("pipeline", beside), ("isolated", None)):
+            if label == "pipeline" and b is None:
+                continue
+            times = dict(plan.time_convs(reps=3, beside=b))
+            torch.cuda.synchronize()
+            groups = {}
+            for name, fl, bm, bn, sk in table:
+                kind = "StemKC" if name == "conv1" else "Im2colKCT<false>"
+                kernel = "igemm_pc_kernel" if (bm, bn) == (64, 64) else "igemm_kernel"              # 64x64: producer/consumer waves
+                key = "%s<%d, %d, dcap::%s, dcap::DenseKCT<true> >" % (kernel, bm, bn, kind)         # rocprof's spelling
+                g = groups.setdefault(key, {"flops": 0.0, "ms": 0.0, "launches": 0})
+                g["flops"] += fl
+                g["ms"] += times[name]
+                g["launches"] += 1
+            res[label] = (groups, times)
+        main = "pipeline" if "pipeline" in res else "isolated"
+        groups, times = res[main]
+        if args.layer_table:
+            with open(args.layer_table, "w") as f:
+                f.write("layer\tgflop\tbm\tbn\tsplit_k\tus_%s\ttflops_%s\tus_isolated\n" % (main, main))
+                iso = res["isolated"][1]
+                for name, fl, bm, bn, sk in table:
+                    f.write("%s\t%.3f\t%d\t%d\t%d\t%.1f\t%.1f\t%.1f\n" % (name, fl / 1e9, bm, bn, sk, 1e3 * times[name],
+                                                                          fl / (times[name] * 1e-3) / 1e12, 1e3 * iso[name]))
+        dom = max(groups, key=lambda k: groups[k]["ms"])
+        g = groups[dom]
+        achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
+        conv_ms = sum(v["ms"] for v in groups.values())
+        traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
+        for tname in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if traffic is None and os.path.exists(tpath):
+                for name, rec in json.load(open(tpath)).items():
+                    if name.startswith("void dcap::" + dom[:40]):
+                        traffic = rec["hbm_bytes_per_launch_corrected"]
+        out = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+               "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "measured": main + " (HIP events on the launch stream"
+               + (", one decoder train step running beside every encoder pass on the decoder stream)" if main == "pipeline" else ")"),
+               "launches_per_step": g["launches"], "gflop_per_launch": g["flops"] / g["launches"] / 1e9,
+               "avg_launch_us": 1e3 * g["ms"] / g["launches"],
+               "all_conv": {"gflop_per_step": plan.flops / 1e9, "ms_per_step": conv_ms, "tflops": plan.flops / (conv_ms * 1e-3) / 1e12},
+               "kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 4),
+                               "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in groups.items()}}
+        if main == "pipeline":
+            gi = res["isolated"][0][dom]
+            ai = gi["flops"] / (gi["ms"] * 1e-3) / 1e12
+            iso_ms = sum(v["ms"] for v in res["isolated"][0].values())
+            out["isolated"] = {"achieved": ai, "frac": ai / PEAK_F32_MFMA_TFLOPS, "avg_launch_us": 1e3 * gi["ms"] / gi["launches"],
+                               "all_conv_ms_per_step": iso_ms, "all_conv_tflops": plan.flops / (iso_ms * 1e-3) / 1e12}
+        return out
+
+
+def run_joint(args, dev, rank, world, barrier):
+    """BASELINE configs[4]: the joint model's train step (dense_img_cap/dense_model.py, train_dense_captions.py), one
+    1024x1024 image per GPU and step, 2000 proposals -> 200 RoIs (<= 66 positive), 15-token captions, V = 50 000;
+    decoder / RoI head / vocabulary layers in bf16 (fp32 master weights, fp32 accumulate)."""
+    from image_captioning_amd import synth, utils
+    from image_captioning_amd.config import Config
+    from image_captioning_amd.dense_model import DenseImageCapRCNN, build_rpn_targets
+    from image_captioning_amd.parallel_model import ParallelModel
+    S, V, T = args.image_size, args.vocab, args.tokens
+
+    class Cfg(Config):                                  # train_dense_captions.DenseCapConfig's values (:18-41) at the benchmark's size
+        NAME = "dense image captioning"
+        GPU_COUNT = 1
+        IMAGES_PER_GPU = 1
+        IMAGE_MIN_DIM = S
+        IMAGE_MAX_DIM = S
+        PADDING_SIZE = T
+        VOCABULARY_SIZE = V
+        EMBEDDING_SIZE = 300
+    cfg = Cfg()
+    cfg.EMBEDDING_WEIGHTS = synth.embedding_matrix(3, V)
+    model = DenseImageCapRCNN("training", cfg, "logs", device=dev, stage4_blocks=args.stage4_blocks, seed=0,
+                              conv_math=args.joint_conv_math, compute_dtype=args.joint_dtype)
+    # random FPN maps are O(10): keep the RPN / head activations in a trained network's range
+    w = model.get_weights_dict()
+    model.set_weights({"rpn_conv_shared/kernel": w["rpn_conv_shared/kernel"] * np.float32(0.02),
+                       "rpn_bbox_pred/kernel": w["rpn_bbox_pred/kernel"] * np.float32(0.3),
+                       "mrcnn_class_conv1/kernel": w["mrcnn_class_conv1/kernel"] * np.float32(0.05)})
+    model.compile(1e-5)
+    inner = model
+    if world > 1:
+        model = ParallelModel(model, world)
+    seed = 1234 + rank
+    rng = np.random.RandomState(seed)
+    img = synth.images(seed, 1, S, S)
+    n_gt = 40
+    y, x = rng.randint(0, S - 64, n_gt), rng.randint(0, S - 64, n_gt)
+    hh, ww = rng.randint(32, 400, n_gt), rng.randint(32, 400, n_gt)
+    boxes = np.stack([y, x, np.minimum(y + hh, S), np.minimum(x + ww, S)], axis=1).astype(np.int32)
+    caps = synth.captions_v1(seed + 2, n_gt, T, V, lmin=3, lmax=12).astype(np.int32)
+    anchors = utils.generate_pyramid_anchors(cfg.RPN_ANCHOR_SCALES, cfg.RPN_ANCHOR_RATIOS, cfg.BACKBONE_SHAPES, cfg.BACKBONE_STRIDES, 1)
+    match, deltas = build_rpn_targets(img[0].shape, anchors, caps, boxes, cfg, rng)
+    gt_caps = np.zeros((1, cfg.MAX_GT_INSTANCES, T), np.int32)
+    gt_boxes = np.zeros((1, cfg.MAX_GT_INSTANCES, 4), np.int32)
+    gt_caps[0, :n_gt], gt_boxes[0, :n_gt] = caps, boxes
+    inputs = [img, np.zeros((1, 12)), match[None, :, None], deltas[None], gt_caps, gt_boxes]
+    for _ in range(max(args.warmup, 2)):
+        out = inner.train_on_batch(inputs)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = inner.train_on_batch(inputs)              # per-rank image: every rank steps its own shard (weak scaling)
+    barrier()
+    dt = time.perf_counter() - t0
+    R = cfg.TRAIN_ROIS_PER_IMAGE
+    return dt, out, R, inner
 
 
 def main():
     args = parse()
-    from image_captioning_amd import synth
-    from image_captioning_amd.parallel_model import init_process_group_from_env, ParallelModel
+    from image_captioning_amd.parallel_model import init_process_group_from_env, GradAllReduce
     rank, world, local_rank = init_process_group_from_env()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
@@ -105,69 +411,47 @@ def main():
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
 
-    from image_captioning_amd.config import Config
-    from image_captioning_amd.modified_dense_model import DenseImageCapRCNN
-    from image_captioning_amd.text_generation_model_v2 import DenseCapConfig, build_model, Adam, SampleTables
-
-    S, V, T, R, B = args.image_size, args.vocab, args.tokens, args.rois, args.images_per_gpu
-
-    class EncCfg(Config):
-        NAME = "bench"
-        IMAGES_PER_GPU = B
-        IMAGE_MIN_DIM = S
-        IMAGE_MAX_DIM = S
-
-    enc = DenseImageCapRCNN("inference", EncCfg(), "logs", device=dev, stage4_blocks=args.stage4_blocks)
-    enc.set_weights(synth.encoder_weights(0, args.stage4_blocks))
-    cfg = DenseCapConfig(V, synth.embedding_matrix(3, V))
-    cfg.PADDING_SIZE = T
-    dec = build_model((7, 7, 256), (T,), cfg, 256, inject=True, device=dev, seed=0)
-    dec.compile(optimizer=Adam(amsgrad=True), loss="categorical_crossentropy")
-    if world > 1:
-        dec = ParallelModel(dec, world)
-
-    seed = 1234 + rank
-    images = torch.tensor(synth.images(seed, B, S, S), device=dev)
-    rois = synth.rois(seed + 1, B, R, S, S)
-    caps = synth.captions_v2(seed + 2, B * R, T, V, full=True)
-    tables = SampleTables.from_captions(caps, dev)
-    plan = enc.plan(B, S, S)
-    plan.images.copy_(images)
-    boxes = plan.normalize_boxes(rois)          # device-resident, normalised once
-    feat = torch.empty((B, R, 7, 7, 256), dtype=torch.float32, device=dev)
-    inner = dec.inner_model if world > 1 else dec
-
-    from image_captioning_amd.pipeline import CaptionTrainPipeline
-    pipe = None if args.no_pipeline else CaptionTrainPipeline(plan, inner, R)
-
-    def step():
-        if pipe is not None:                     # encoder(i) overlaps decoder(i-1); flushed before the clock stops
-            return pipe.step(None, boxes, tables)
-        plan.forward(None)                       # images already resident in the plan's input buffer
-        plan.roi_features(boxes_norm=boxes, out=feat)
-        return inner.train_step(feat.view(B * R, 7, 7, 256), tables)
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 2)):           # >= 2: the second call captures the encoder hipGraph
-        loss = step()
-    if pipe is not None:
-        pipe.flush()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    if pipe is not None:
-        loss = pipe.flush()                        # every one of the K steps is complete inside the timed region
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    def max_over_ranks(dt):
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            return float(tmax.item())
+        return dt
+
+    ranks_seen = GradAllReduce().check_ranks(dev)        # an actual all-reduce of ones: the ranks the backend connected
+    backend = dist.get_backend() if world > 1 else None
+    S, V, T, R, B = args.image_size, args.vocab, args.tokens, args.rois, args.images_per_gpu
+
+    if args.config == "joint":
+        dt, losses, rois_per_step, inner = run_joint(args, dev, rank, world, barrier)
+        dt = max_over_ranks(dt)
+        out = {
+            "metric": "captions/sec (train step) on 1024px joint model (2000 proposals -> 200 RoI x 15tok) synth",
+            "value": world * rois_per_step * args.steps / dt, "unit": "captions/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.joint_dtype == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4]: dense_img_cap joint model train step: frozen ResNet-101 + trainable FPN/RPN + "
+                                   "ProposalLayer(2000) + DetectionTargetLayer(200 RoIs) + RoIAlign + trainable RoI head + Model-3 decoder "
+                                   "+ 4 losses + Adam(amsgrad, clipnorm 0.5); %dx%d synth image, 1 image/GPU, V=%d, %d-token captions"
+                                   % (S, S, V, T), "images_per_gpu": 1, "rois_per_image": rois_per_step, "parallelism": "dp%d" % world,
+                       "decoder_dtype": args.joint_dtype, "conv_math": inner.conv_math_name, "losses": [float(v) for v in losses],
+                       "rccl_ranks": ranks_seen, "dist_backend": backend},
+        }
+        if rank == 0:
+            print(json.dumps(out))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    e2e = E2E(args, dev, rank, world, B)
+    dt, loss = e2e.timed(args.warmup, args.steps, barrier)
+    dt = max_over_ranks(dt)
     captions = world * B * R * args.steps
     final_loss = float(loss.item())
 
@@ -175,51 +459,19 @@ def main():
         "metric": "captions/sec (train step) on 1024px x 32RoI x 15tok synth",
         "value": captions / dt, "unit": "captions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if os.environ.get("DCAP_CONV_MATH", "f32") == "f32" else "f32 (conv operands as 3 bf16 pieces)", "data": "synthetic",
+        "dtype": "f32" if os.environ.get("DCAP_CONV_MATH", "f32") == "f32" else "f32 (conv operands as bf16 pieces)", "data": "synthetic",
         "config": {"workload": "BASELINE configs[2] (configs[3] at 8 GPUs): frozen ResNet-101+FPN fwd + PyramidROIAlign + "
                                "RoI head + v2-inject decoder fwd/bwd + AMSGrad, %dx%d synth images, %d RoI/img, %d-token captions, V=%d"
                                % (S, S, R, T, V),
                    "images_per_gpu": B, "global_batch_images": B * world, "captions_per_step": B * R * world,
                    "parallelism": "dp%d" % world, "stage4_blocks": args.stage4_blocks, "final_loss": final_loss,
-                   "pipeline": "encoder(i+1) || decoder(i), 2 HIP streams" if pipe is not None else "single stream"},
+                   "pipeline": "encoder(i+1) || decoder(i), 2 HIP streams" if e2e.pipe is not None else "single stream",
+                   "rccl_ranks": ranks_seen, "dist_backend": backend,
+                   "grad_allreduce": ("per layer group, asynchronous, issued as each group's backward is enqueued" if world > 1 else None)},
     }
 
     if rank == 0 and not args.no_roofline:
-        table = plan.conv_table()
-        times = dict(plan.time_convs(reps=3))
-        groups = {}
-        for name, fl, bm, bn, sk in table:
-            kind = "StemKC" if name == "conv1" else "Im2colKCT<false>"
-            kernel = "igemm_pc_kernel" if (bm, bn) == (64, 64) else "igemm_kernel"              # 64x64: producer/consumer waves
-            key = "%s<%d, %d, dcap::%s, dcap::DenseKCT<true> >" % (kernel, bm, bn, kind)         # rocprof's spelling
-            g = groups.setdefault(key, {"flops": 0.0, "ms": 0.0, "launches": 0})
-            g["flops"] += fl
-            g["ms"] += times[name]
-            g["launches"] += 1
-        if args.layer_table:
-            with open(args.layer_table, "w") as f:
-                f.write("layer\tgflop\tbm\tbn\tsplit_k\tus\ttflops\n")
-                for name, fl, bm, bn, sk in table:
-                    f.write("%s\t%.3f\t%d\t%d\t%d\t%.1f\t%.1f\n" % (name, fl / 1e9, bm, bn, sk, 1e3 * times[name],
-                                                                    fl / (times[name] * 1e-3) / 1e12))
-        dom = max(groups, key=lambda k: groups[k]["ms"])
-        g = groups[dom]
-        achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
-        conv_ms = sum(v["ms"] for v in groups.values())
-        traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath):
-            for name, rec in json.load(open(tpath)).items():
-                if name.startswith("void dcap::" + dom[:40]):
-                    traffic = rec["hbm_bytes_per_launch_corrected"]
-        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                           "launches_per_step": g["launches"], "gflop_per_launch": g["flops"] / g["launches"] / 1e9,
-                           "avg_launch_us": 1e3 * g["ms"] / g["launches"],
-                           "all_conv": {"gflop_per_step": plan.flops / 1e9, "ms_per_step": conv_ms,
-                                        "tflops": plan.flops / (conv_ms * 1e-3) / 1e12},
-                           "kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 4),
-                                           "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in groups.items()}}
+        out["roofline"] = e2e.roofline(args)
     if rank == 0 and world == 1 and not args.no_alt_math and os.environ.get("DCAP_CONV_MATH", "f32") == "f32":
         # Same workload with the encoder's convolutions on the bf16 matrix pipe (operands split into bf16 pieces on the fly,
         # fp32 accumulate; csrc/igemm_bf16s.h), each mode timed by a child process of this one after the headline run.
@@ -229,8 +481,8 @@ def main():
         labels = {"bf16x3": "3-piece bf16 split of both operands, 6 MFMA products, fp32 accumulate (fp32-grade: same test tolerances)",
                   "bf16x2": "2-piece bf16 split, 3 MFMA products, fp32 accumulate (2^-16 products; features within 1e-3 of the oracle)"}
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-alt-math",
-               "--no-cpu-baseline", "--images-per-gpu", str(B), "--rois", str(R), "--tokens", str(T), "--vocab", str(V),
-               "--image-size", str(S), "--stage4-blocks", str(args.stage4_blocks)] + (["--no-pipeline"] if args.no_pipeline else [])
+               "--no-cpu-baseline", "--no-other-configs", "--images-per-gpu", str(B), "--rois", str(R), "--tokens", str(T),
+               "--vocab", str(V), "--image-size", str(S), "--stage4-blocks", str(args.stage4_blocks)] + (["--no-pipeline"] if args.no_pipeline else [])
         out["alt_math"] = {}
         for mode, label in labels.items():
             try:
@@ -240,6 +492,26 @@ def main():
                                          "all_conv": alt.get("roofline", {}).get("all_conv")}
             except Exception as e:                             # the headline must not depend on the extra legs
                 out["alt_math"][mode] = {"error": repr(e)[:200]}
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        other = {}
+        try:
+            del e2e
+            torch.cuda.empty_cache()
+            one = E2E(args, dev, rank, world, 1)          # configs[2] proper: ONE image per step
+            dt1, _ = one.timed(2, 10, barrier)
+            other["configs2_one_image"] = {"workload": "BASELINE configs[2] as defined: 1 image x %d RoI per step, same model" % R,
+                                           "value": R * 10 / dt1, "unit": "captions/s", "ms_per_step": 1e3 * dt1 / 10, "steps": 10}
+            del one
+            torch.cuda.empty_cache()
+            other["configs1_gpu"] = gpu_configs1(dev)
+        except Exception as e:
+            other["error_gpu"] = repr(e)[:300]
+        if not args.no_cpu_baseline:
+            try:
+                other.update(cpu_companions())
+            except Exception as e:
+                other["error_cpu"] = repr(e)[:300]
+        out["other_configs"] = other
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:

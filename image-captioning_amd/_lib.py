@@ -135,7 +135,8 @@ SYMBOLS = {
     "dc_fold_time_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dc_colsum_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "dc_colsum_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "dc_sumsq_f32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
+    "dc_sumsq_workspace_bytes": (C.c_size_t, [C.c_size_t]),
+    "dc_sumsq_f32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_mean_f32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "dc_amsgrad_step_f32": (C.c_int, [C.POINTER(AmsgradDesc), C.c_void_p]),
 }

@@ -59,6 +59,9 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(dc_softmax_ce_desc d) {
     const int t = d.targets ? d.targets[row] : -1;
     float pt = 1.f;
     if (t >= 0 && t < V) pt = expf(z[t] - mx) * inv;
+    // dlogits may alias logits (dcap.h): every thread has read z[t] above; no wave may start overwriting the row before
+    // the slowest one has (the stores below are in place)
+    __syncthreads();
     const bool live = (pt >= 1e-7f) && (pt <= 1.f - 1e-7f);
     const float rw = d.row_weights ? d.row_weights[row] : 1.f;
     if (d.keras_sparse) {
@@ -282,12 +285,29 @@ __global__ __launch_bounds__(256) void axpy_kernel(float a, const float* __restr
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] += a * x[i];
 }
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
+// Global-norm clipping must give every data-parallel rank the SAME scale from the same (all-reduced) gradient, and a
+// single-GPU run the same bits twice: block partials go to the caller's workspace in block order and ONE block adds them
+// in a fixed tree -- no atomics, no dependence on scheduling.
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, size_t n, float* __restrict__ partial) {
     __shared__ float red[4];
     float s = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += x[i] * x[i];
+    const size_t n4 = n >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = x4[i];
+        s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += x[i] * x[i];
     s = block_reduce<false>(s, red);
-    if (threadIdx.x == 0) atomicAdd(out, s);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void sumsq_finish_kernel(const float* __restrict__ partial, int nparts, float* __restrict__ out, int accumulate) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += partial[i];
+    s = block_reduce<false>(s, red);
+    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + s : s;
 }
 
 // L2 weight regulariser of the joint model over the flat parameter bucket: coef[i] = WEIGHT_DECAY / size(tensor of i)
@@ -459,16 +479,23 @@ extern "C" int dc_colsum_f32(const float* x, int M, int N, int ld, float* out, i
     return check_launch("colsum_finish_kernel");
 }
 
-extern "C" int dc_sumsq_f32(const float* x, size_t n, float* out, int accumulate, void* stream) {
+static int sumsq_blocks(size_t n) { return (int)std::min<size_t>((n + 4095) / 4096, (size_t)kNumCU * 4); }
+
+extern "C" size_t dc_sumsq_workspace_bytes(size_t n) { return n ? (size_t)sumsq_blocks(n) * sizeof(float) : 0; }
+
+extern "C" int dc_sumsq_f32(const float* x, size_t n, float* out, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
     DC_REQUIRE(x && out && n > 0, DC_EINVAL, "dc_sumsq: bad arguments");
+    DC_REQUIRE(aligned16(x), DC_EALIGN, "dc_sumsq: x must be 16-byte aligned");
+    const int blocks = sumsq_blocks(n);
+    DC_REQUIRE(workspace && workspace_bytes >= (size_t)blocks * sizeof(float), DC_EWORKSPACE, "dc_sumsq: needs %zu workspace bytes",
+               (size_t)blocks * sizeof(float));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (!accumulate) {
-        hipError_t e = hipMemsetAsync(out, 0, sizeof(float), s);
-        DC_REQUIRE(e == hipSuccess, DC_ELAUNCH, "dc_sumsq: memset failed: %s", hipGetErrorString(e));
-    }
-    const int blocks = (int)std::min<size_t>((n + 1023) / 1024, (size_t)kNumCU * 4);
-    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, s, x, n, out);
-    return check_launch("sumsq_kernel");
+    float* partial = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, s, x, n, partial);
+    int rc = check_launch("sumsq_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, s, partial, blocks, out, accumulate);
+    return check_launch("sumsq_finish_kernel");
 }
 
 extern "C" int dc_l2_reg_f32(const float* w, const float* coef, float* grad, size_t n, float* loss, void* stream) {

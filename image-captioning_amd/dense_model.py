@@ -17,6 +17,7 @@ Trainable set = train(layers="no_backbone"): imgcap_*, rpn_*, fpn_*, mrcnn_* (de
 The detection-target sampling uses tf.random_shuffle in the reference (order is not reproducible there); here a seeded
 numpy permutation on the host, the only host round trip of the step (2000x4 floats down, 200x4 up).
 """
+import datetime
 import os
 import re
 
@@ -261,7 +262,11 @@ class DenseImageCapRCNN(object):
         self._rng = np.random.RandomState(seed)
         self.optimizer = None
         self.grad_sync = None
+        self.is_chief = True               # ParallelModel clears it on ranks > 0: one rank prints and writes checkpoints
+        self._outer = self                 # ParallelModel points it at the wrapper: train() then feeds GLOBAL batches through
+                                           # the wrapper's train_on_batch (tf.split over towers, losses averaged over towers)
         self._trainable_regex = self.LAYER_REGEX["no_backbone"]
+        self.set_log_dir()
         self._build(seed)
 
     # ---- construction -----------------------------------------------------------------------
@@ -370,16 +375,43 @@ class DenseImageCapRCNN(object):
                 raise KeyError("weight %s is not part of this model" % k)
             pick[k] = v
         self.set_weights(pick)
+        self.set_log_dir(filepath)          # like the reference (:1692): a checkpoint of train() carries its epoch
 
     def save_weights(self, path):
-        np.savez(path, **self.get_weights_dict())
+        """Atomic: written beside the target and renamed, so a reader (or a second rank) never sees a torn file."""
+        tmp = path + ".tmp.npz"
+        np.savez(tmp, **self.get_weights_dict())
+        os.replace(tmp, path)
+
+    def set_log_dir(self, model_path=None):
+        """Log directory and epoch counter (dense_model.py:1776-1798): <model_dir>/<name><YYYYMMDDTHHMM>/ with checkpoints
+        img_cap_<name>_<epoch:04d>.npz.  A model_path of that form resumes its directory and sets self.epoch to the
+        number of epochs that checkpoint has behind it (Keras numbers checkpoints from 1), i.e. train() continues with the next epoch.  (The reference's pattern
+        uses \\w+ for the name, which cannot match its own NAME "dense image captioning" -- its resume silently
+        restarts at epoch 0; names with spaces are accepted here.)"""
+        self.epoch = 0
+        now = datetime.datetime.now()
+        if model_path:
+            m = re.match(r".*/[\w ]+(\d{4})(\d{2})(\d{2})T(\d{2})(\d{2})/img\_cap\_[\w ]+?\_(\d{4})\.(?:npz|h5)$", str(model_path).replace(os.sep, "/"))
+            if m:
+                now = datetime.datetime(int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)))
+                self.epoch = int(m.group(6))
+        name = self.config.NAME.lower()
+        self.log_dir = os.path.join(self.model_dir, "{}{:%Y%m%dT%H%M}".format(name, now))
+        self.checkpoint_path = os.path.join(self.log_dir, "img_cap_{}_{{epoch:04d}}.npz".format(name))
 
     def find_last(self):
-        """(model_dir, newest checkpoint written by train()) or (model_dir, None) -- dense_model.py:1631-1654."""
+        """(log_dir of the last trained model, its newest checkpoint) -- dense_model.py:1631-1654: the last directory under
+        model_dir whose name starts with the config name, the last 'img_cap*' file in it."""
         if not os.path.isdir(self.model_dir):
             return None, None
-        names = sorted(f for f in os.listdir(self.model_dir) if f.startswith("dense_image_cap_rcnn_") and f.endswith(".npz"))
-        return self.model_dir, (os.path.join(self.model_dir, names[-1]) if names else None)
+        key = self.config.NAME.lower()
+        dirs = sorted(d for d in next(os.walk(self.model_dir))[1] if d.startswith(key))
+        if not dirs:
+            return None, None
+        dir_name = os.path.join(self.model_dir, dirs[-1])
+        cps = sorted(f for f in next(os.walk(dir_name))[2] if f.startswith("img_cap") and f.endswith((".npz", ".h5")))
+        return dir_name, (os.path.join(dir_name, cps[-1]) if cps else None)
 
     def summary(self):
         rows = ["%-40s %-24s %s" % (k, tuple(v.shape), "trainable" if k in self.store.grad else "frozen")
@@ -627,12 +659,16 @@ class DenseImageCapRCNN(object):
         for epoch in range(self.epoch, epochs):
             sums = np.zeros(4)
             for _ in range(cfg.STEPS_PER_EPOCH):
-                sums += np.asarray(self.train_on_batch(next(train_generator)[0]))
+                sums += np.asarray(self._outer.train_on_batch(next(train_generator)[0]))
             logs = {n: v / cfg.STEPS_PER_EPOCH for n, v in zip(names, sums)}
-            logs.update({"val_" + n: v for n, v in zip(names, self.test_on_batch(val_batch))})
+            # the reference validates on ONE fixed batch too: validation_data=next(val_generator) (:1878)
+            logs.update({"val_" + n: v for n, v in zip(names, self._outer.test_on_batch(val_batch))})
             history.append(logs)
-            print("Epoch %d/%d - " % (epoch + 1, epochs) + " - ".join("%s: %.4f" % kv for kv in sorted(logs.items())))
-            os.makedirs(self.model_dir, exist_ok=True)
-            self.save_weights(os.path.join(self.model_dir, "dense_image_cap_rcnn_%04d.npz" % (epoch + 1)))
+            if self.is_chief:
+                print("Epoch %d/%d - " % (epoch + 1, epochs) + " - ".join("%s: %.4f" % kv for kv in sorted(logs.items())))
+                os.makedirs(self.log_dir, exist_ok=True)
+                self.save_weights(self.checkpoint_path.format(epoch=epoch + 1))      # Keras ModelCheckpoint numbers epochs from 1
+            if self.grad_sync is not None:
+                self.grad_sync.barrier()                     # every rank sees the finished checkpoint before going on
         self.epoch = max(self.epoch, epochs)
         return history

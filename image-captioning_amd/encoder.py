@@ -237,9 +237,12 @@ class EncoderPlan:
             rows.append((op[2], 2.0 * d.N * d.Ho * d.Wo * d.Cout * s.k * s.k * s.cin, bm.value, bn.value, sk.value))
         return rows
 
-    def time_convs(self, reps=3):
+    def time_convs(self, reps=3, beside=None):
         """Eager replay with a HIP event pair around every conv launch on the launch stream; returns
-        [(layer, mean milliseconds)] (the roofline leg of bench.py)."""
+        [(layer, mean milliseconds)] (the roofline leg of bench.py).  beside: optional callable that enqueues the work
+        that shares the GPU with the encoder in the training pipeline (one decoder train step on the decoder's own
+        stream); it is called right before every timed replay, so the convolutions are timed IN the pipeline's
+        conditions -- what a rocprofv3 kernel trace of the whole bench sees -- instead of alone on the chip."""
         lib = self.lib
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         wsp, wsb = C.c_void_p(self._ws.data_ptr()), self._ws.numel()
@@ -247,6 +250,9 @@ class EncoderPlan:
         acc = [0.0] * len(convs)
         for _ in range(reps):
             self._run_ops()
+            torch.cuda.synchronize()
+            if beside is not None:
+                beside()
             evs = []
             for op in convs:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

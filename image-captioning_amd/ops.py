@@ -460,7 +460,8 @@ def sumsq(x, out=None, accumulate=False):
     lib = _lib.load()
     if out is None:
         out = torch.empty((1,), dtype=torch.float32, device=x.device)
-    check(lib.dc_sumsq_f32(_ptr(_chk(x, name="x")), x.numel(), _ptr(out), int(accumulate), _stream()), "dc_sumsq_f32")
+    ws, wsb = WORKSPACE.get(lib.dc_sumsq_workspace_bytes(x.numel()), x.device)
+    check(lib.dc_sumsq_f32(_ptr(_chk(x, name="x")), x.numel(), _ptr(out), int(accumulate), _ptr(ws), wsb, _stream()), "dc_sumsq_f32")
     return out
 
 

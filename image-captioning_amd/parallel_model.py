@@ -52,13 +52,47 @@ class GradAllReduce(object):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bucket_elems = max(1, bucket_bytes // 4)
 
+        self._pending = []              # (work handle, lo, hi) of the ranges already on the wire this step
+        self.ranks_seen = None          # world size RCCL reported after a real all-reduce (bench.py prints it)
+
+    def ready(self, flat_grad, lo, hi):
+        """A contiguous range [lo, hi) of the gradient bucket is final (its layer group's backward has been enqueued):
+        start its all-reduce now, asynchronously, so it travels over xGMI while the rest of the backward still runs
+        (bucketed against backward).  Ranges are cut into bucket_elems pieces."""
+        if self.world == 1 or hi <= lo:
+            return
+        for o in range(lo, hi, self.bucket_elems):
+            e = min(hi, o + self.bucket_elems)
+            self._pending.append((dist.all_reduce(flat_grad[o:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True), o, e))
+
     def __call__(self, flat_grad):
+        """Finish the step's exchange: reduce whatever ready() has not covered, wait for everything in flight (the
+        current stream then waits for the collectives), return the scale the optimizer applies (mean over towers)."""
         if self.world == 1:
             return 1.0
         n = flat_grad.numel()
-        for o in range(0, n, self.bucket_elems):
-            dist.all_reduce(flat_grad[o:min(n, o + self.bucket_elems)], op=dist.ReduceOp.SUM, group=self.group)
+        done = sorted((lo, hi) for _, lo, hi in self._pending)
+        pos = 0
+        for lo, hi in done + [(n, n)]:
+            if lo > pos:
+                self.ready(flat_grad, pos, lo)
+            pos = max(pos, hi)
+        for work, _, _ in self._pending:
+            work.wait()
+        self._pending = []
         return 1.0 / self.world
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier(group=self.group)
+
+    def check_ranks(self, device):
+        """An actual all-reduce of ones: the number of ranks the backend really connected."""
+        t = torch.ones(1, dtype=torch.float32, device=device)
+        if self.world > 1:
+            dist.all_reduce(t, group=self.group)
+        self.ranks_seen = int(round(float(t.item())))
+        return self.ranks_seen
 
 
 class ParallelModel(object):
@@ -75,6 +109,8 @@ class ParallelModel(object):
         self.gpu_count = gpu_count
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         keras_model.grad_sync = GradAllReduce()
+        keras_model.is_chief = self.rank == 0          # one rank prints and writes checkpoints (the others barrier)
+        keras_model._outer = self                      # the wrapped model's train() loop feeds global batches through this wrapper
         self.broadcast_weights()
 
     def broadcast_weights(self):
@@ -91,14 +127,20 @@ class ParallelModel(object):
     def shard_inputs(self, inputs):
         return [shard(x, self.rank, self.gpu_count) for x in inputs]
 
-    def train_on_batch(self, inputs, targets=None):
-        """Global batch in, split like tf.split; returns the mean over towers of the tower losses (a scalar, or the
-        joint model's [loss, rpn_class_loss, rpn_bbox_loss, imgcap_loss] list)."""
+    def _run(self, fn, inputs, targets):
         mine = None if targets is None or len(targets) == 0 else shard(targets, self.rank, self.gpu_count)
-        loss = self.inner_model.train_on_batch(self.shard_inputs(inputs), mine)
+        loss = fn(self.shard_inputs(inputs), mine)
         if self.gpu_count > 1:
             t = torch.tensor(loss if isinstance(loss, (list, tuple)) else [loss], dtype=torch.float64, device=self.inner_model.device)
             dist.all_reduce(t)
             vals = (t / self.gpu_count).tolist()
             loss = vals if isinstance(loss, (list, tuple)) else vals[0]
         return loss
+
+    def train_on_batch(self, inputs, targets=None):
+        """Global batch in, split like tf.split; returns the mean over towers of the tower losses (a scalar, or the
+        joint model's [loss, rpn_class_loss, rpn_bbox_loss, imgcap_loss] list)."""
+        return self._run(self.inner_model.train_on_batch, inputs, targets)
+
+    def test_on_batch(self, inputs, targets=None):
+        return self._run(self.inner_model.test_on_batch, inputs, targets)

@@ -341,8 +341,11 @@ size_t dc_colsum_workspace_bytes(int M, int N, int ld);
 int dc_colsum_f32(const float* x, int M, int N, int ld, float* out, int accumulate, void* workspace, size_t workspace_bytes,
                   void* stream);
 
-/* out[0] (+)= sum(x^2) -- global-norm clipping (Adam(clipnorm=0.5), dense_img_cap/dense_model.py:1699). */
-int dc_sumsq_f32(const float* x, size_t n, float* out, int accumulate, void* stream);
+/* out[0] (+)= sum(x^2) -- global-norm clipping (Adam(clipnorm=0.5), dense_img_cap/dense_model.py:1699).  Block partials go
+ * through `workspace` (dc_sumsq_workspace_bytes) and are combined in a fixed order: every data-parallel rank derives the
+ * same clip scale from the same all-reduced gradient, and a run is bit-reproducible. */
+size_t dc_sumsq_workspace_bytes(size_t n);
+int dc_sumsq_f32(const float* x, size_t n, float* out, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* mean of loss rows: out[0] = sum(x)/n. */
 int dc_mean_f32(const float* x, size_t n, float* out, void* stream);

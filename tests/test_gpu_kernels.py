@@ -255,6 +255,31 @@ def test_softmax_ce(ops, M, V):
     close(ops.mean(loss), np.array([O.categorical_crossentropy(t, p).mean()]), 1e-5)
 
 
+def test_softmax_ce_in_place_equals_out_of_place(ops):
+    """dlogits may alias logits (dcap.h): the in-place call must give the bits of the out-of-place one, every time
+    (a wave that finished its reductions early used to overwrite z[target] before a slower wave had read it)."""
+    rng = np.random.default_rng(77)
+    M, V = 960, 10000
+    z = dev(3.0 * rng.standard_normal((M, V)))
+    t = dev(rng.integers(0, V, M), torch.int32)
+    rw = dev(rng.uniform(0.0, 1.0, M))
+    for sparse in (False, True):
+        ref_dl, ref_loss = torch.empty_like(z), torch.empty(M, device="cuda")
+        ops.softmax_ce(z, t, None, ref_loss, ref_dl, grad_scale=1.0 / M, row_weights=rw, keras_sparse=sparse)
+        for _ in range(20):
+            zz, loss = z.clone(), torch.empty(M, device="cuda")
+            ops.softmax_ce(zz, t, None, loss, zz, grad_scale=1.0 / M, row_weights=rw, keras_sparse=sparse)
+            assert torch.equal(zz, ref_dl) and torch.equal(loss, ref_loss)
+
+
+def test_sumsq_is_bit_reproducible(ops):
+    x = dev(np.random.default_rng(3).standard_normal(10_000_019))
+    first = ops.sumsq(x).clone()
+    for _ in range(5):
+        assert torch.equal(ops.sumsq(x), first)
+    close(first, np.array([float((x.double() ** 2).sum())]), 1e-5)
+
+
 def test_argmax_lowest_index_wins_ties(ops):
     rng = np.random.default_rng(2)
     x = rng.standard_normal((33, 10000)).astype(np.float32)
@@ -371,6 +396,10 @@ def test_roi_align_backward_is_the_adjoint_of_forward(ops):
     lhs = float((fwd * g).sum())
     rhs = sum(float((d.cpu().numpy().astype(np.float64) * m).sum()) for d, m in zip(dm, maps))
     assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
+    # the scatter itself, element by element, against the oracle's NumPy loop (all four levels)
+    want = O.pyramid_roi_align_backward(O.normalize_boxes(rois, S, S), [m.shape for m in maps], (S, S), g)
+    for d, w in zip(dm, want):
+        close(d, w, 2e-5)
 
 
 def test_downsample2x_sum_is_upsample_adjoint(ops):

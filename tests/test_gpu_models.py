@@ -1,6 +1,8 @@
 """Model-level parity on the GPU (-m gpu): encoder, v2 decoders (as-written batches and the
 single-pass caption form), optimizer trajectory and greedy decode against the NumPy oracle.
 Tolerance per north_star: logits/probabilities within 1e-3 in fp32; token ids bit-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -472,123 +474,18 @@ def test_joint_model_train_loop_checkpoints_and_resumes(gpu, tmp_path):
     assert len(history) == 2 and all(np.isfinite(v) for h in history for v in h.values())
     assert set(history[0]) >= {"loss", "rpn_class_loss", "rpn_bbox_loss", "imgcap_loss", "val_loss"}
     folder, last = model.find_last()
-    assert last.endswith("dense_image_cap_rcnn_0002.npz") and model.epoch == 2
-    resumed = DenseImageCapRCNN("training", cfg, folder, stage4_blocks=blocks)
+    name = cfg.NAME.lower()
+    assert os.path.basename(last) == "img_cap_%s_0002.npz" % name and model.epoch == 2
+    assert os.path.basename(folder).startswith(name) and os.path.dirname(folder) == str(tmp_path / "logs")
+    resumed = DenseImageCapRCNN("training", cfg, str(tmp_path / "logs"), stage4_blocks=blocks)
+    assert resumed.epoch == 0
     resumed.load_weights(last, by_name=True)
+    assert resumed.epoch == 2 and resumed.log_dir == folder           # the checkpoint's name carries epoch and run directory
     a, b = model.get_weights_dict(), resumed.get_weights_dict()
     assert all(np.array_equal(a[k], b[k]) for k in a)
     assert not np.array_equal(a['fpn_p2/kernel'], np.asarray(Wt['fpn_p2/kernel'], np.float32))      # it did train
-
-
-def test_v2_script_flow_end_to_end(gpu, tmp_path):
-    """The __main__ flow of text_generation_model_v2.py (:208-346) on a toy dataset: feature model -> load_sequences ->
-    data_generator -> build_model -> compile -> fit_generator with ModelCheckpoint + CSVLogger -> greedy decode."""
-    from image_captioning_amd import synth
-    from image_captioning_amd.config import Config
-    from image_captioning_amd.modified_dense_model import DenseImageCapRCNN
-    from image_captioning_amd.text_generation_model_v2 import (DenseCapConfig, VisualGenomeDataset, load_sequences, build_model,
-                                                               data_generator, Adam, ModelCheckpoint, CSVLogger)
-    S, V, T = 128, 40, 6
-
-    class FCfg(Config):
-        IMAGES_PER_GPU = 1
-        IMAGE_MIN_DIM = S
-        IMAGE_MAX_DIM = S
-    features_model = DenseImageCapRCNN("inference", FCfg(), "logs", stage4_blocks=1)
-    features_model.set_weights(synth.encoder_weights(0, 1))
-
-    class Toy(VisualGenomeDataset):
-        def load_image(self, image_id):
-            return np.random.RandomState(image_id).randint(0, 255, (S, S, 3)).astype(np.uint8)
-
-        def load_captions_and_rois(self, image_id):
-            r = np.random.RandomState(50 + image_id)
-            y, x = r.randint(0, 60, 3), r.randint(0, 60, 3)
-            rois = np.stack([y, x, y + r.randint(20, 60, 3), x + r.randint(20, 60, 3)], axis=1)
-            caps = [np.eye(V)[np.concatenate([r.randint(3, V, r.randint(2, 4)), [2]])] for _ in range(3)]      # one-hot words, <end> = 2
-            return rois, caps
-    ds = Toy({}, T)
-    for i in range(2):
-        ds.add_image("toy", image_id=i, path=None)
-    ds.prepare()
-    ds.add_sequences(load_sequences(ds))
-    assert len(ds.sequences) == sum(len(c) for i in range(2) for c in ds.load_captions_and_rois(i)[1])
-    cfg = DenseCapConfig(V, synth.embedding_matrix(3, V))
-    cfg.PADDING_SIZE = T
-    model = build_model((7, 7, 256), (T,), cfg, 256, True)
-    model.compile(optimizer=Adam(amsgrad=True), loss='categorical_crossentropy')
-    gen = data_generator(ds, features_model, cfg, 4)
-    val = next(data_generator(ds, features_model, cfg, 4))
-    ckpt, log = str(tmp_path / "model-{epoch:02d}-{val_loss:.2f}.h5"), str(tmp_path / "train.csv")
-    history = model.fit_generator(gen, epochs=3, steps_per_epoch=3, callbacks=[ModelCheckpoint(ckpt, verbose=0, save_weights_only=True, mode='min'),
-                                                                             CSVLogger(log)], validation_data=val, verbose=0)
-    assert len(history) == 3 and history[-1]["loss"] < history[0]["loss"]
-    saved = sorted(p.name for p in tmp_path.iterdir() if p.name.startswith("model-"))
-    assert len(saved) == 3 and saved[0].startswith("model-01-") and saved[0].endswith(".npz")
-    assert open(log).read().splitlines()[0] == "epoch,loss,val_loss"
-    other = build_model((7, 7, 256), (T,), cfg, 256, True, seed=5)
-    other.load_weights(str(tmp_path / saved[-1]), by_name=True)
-    feat = features_model.extract_features(np.stack([ds.load_image(0)]), ds.load_captions_and_rois(0)[0][None].astype(np.float32))[0]
-    a_ids, a_probs = model.greedy_decode(feat[0].cpu().numpy())
-    b_ids, b_probs = other.greedy_decode(feat[0].cpu().numpy())
-    assert np.array_equal(a_ids, b_ids) and np.array_equal(a_probs, b_probs) and len(a_ids) >= 1
-
-
-def test_v1_script_flow_end_to_end(gpu, tmp_path):
-    """The __main__ flow of text_generation_model.py (:375-470) on a toy dataset: feature model -> create_roi_info ->
-    data_generator -> build_lstm_model('training') -> fit_generator -> weights into the 'inference' model -> greedy captions."""
-    from image_captioning_amd import synth
-    from image_captioning_amd.config import Config
-    from image_captioning_amd.modified_dense_model import DenseImageCapRCNN
-    from image_captioning_amd.text_generation_model import (DenseCapConfig, VisualGenomeDataset, create_roi_info, build_lstm_model,
-                                                            data_generator, roi_caption_loss, Adam, ModelCheckpoint)
-    S, V, T, B = 128, 40, 6, 4
-
-    class FCfg(Config):
-        IMAGES_PER_GPU = 1
-        IMAGE_MIN_DIM = S
-        IMAGE_MAX_DIM = S
-    features_model = DenseImageCapRCNN("inference", FCfg(), "logs", stage4_blocks=1)
-    features_model.set_weights(synth.encoder_weights(0, 1))
-
-    class Toy(VisualGenomeDataset):
-        def load_image(self, image_id):
-            return np.random.RandomState(image_id).randint(0, 255, (S, S, 3)).astype(np.uint8)
-
-        def load_captions_and_rois(self, image_id):
-            r = np.random.RandomState(70 + image_id)
-            y, x = r.randint(0, 60, 3), r.randint(0, 60, 3)
-            rois = np.stack([y, x, y + r.randint(20, 60, 3), x + r.randint(20, 60, 3)], axis=1)
-            caps = np.zeros((3, T), np.float32)
-            for k in range(3):
-                n = r.randint(1, 4)
-                caps[k, 0], caps[k, 1:1 + n], caps[k, 1 + n] = 1, r.randint(3, V, n), 2
-            return rois, caps
-    ds = Toy({}, T)
-    for i in range(2):
-        ds.add_image("toy", image_id=i, path=None)
-    ds.prepare()
-    ds.add_rois(create_roi_info(ds))
-    assert len(ds.rois) == 6
-    cfg = DenseCapConfig(V, synth.embedding_matrix(3, V), B)
-    cfg.PADDING_SIZE = T
-    model = build_lstm_model([7, 7, 256], cfg, 512, 'training')
-    k1 = model.get_weights_dict()['mrcnn_class_conv1/kernel']
-    model.load_weights({'mrcnn_class_conv1/kernel': k1 * np.float32(0.05)})      # random FPN maps are O(10): keep the softmax out of
-    # the clipped (zero-gradient) regime; and a small step: Adam's first updates move all 12 544 inputs of a head unit by lr
-    # in the gradient's sign, which on these un-normalised random features kills every ReLU at the default lr
-    model.compile(optimizer=Adam(lr=2e-6, amsgrad=True), loss=roi_caption_loss)
-    gen = data_generator(ds, features_model, cfg, B)
-    val = next(data_generator(ds, features_model, cfg, B))
-    ckpt = str(tmp_path / "v1-{epoch:02d}.h5")
-    history = model.fit_generator(gen, epochs=4, steps_per_epoch=3, callbacks=[ModelCheckpoint(ckpt, save_weights_only=True)],
-                                  validation_data=val, verbose=0)
-    assert history[-1]["loss"] < history[0]["loss"] and np.isfinite(history[-1]["val_loss"]), history
-    infer = build_lstm_model([7, 7, 256], cfg, 512, 'inference', seed=9)
-    infer.load_weights(str(tmp_path / "v1-04.npz"), by_name=True)
-    (feat, words), _ = val
-    probs = infer.predict(feat)
-    assert probs.shape == (B, T, V)
-    np.testing.assert_allclose(probs.sum(-1), 1.0, atol=1e-5)
-    again, ids = infer.generate(feat)
-    assert np.array_equal(again, probs) and np.array_equal(ids, probs.argmax(-1))
+    # train(epochs=3) after the resume runs exactly ONE more epoch (epoch index 2) and writes checkpoint 0003 only
+    before = set(os.listdir(folder))
+    more = resumed.train(train, val, learning_rate=1e-5, epochs=3, layers="no_backbone")
+    assert len(more) == 1 and resumed.epoch == 3
+    assert set(os.listdir(folder)) - before == {"img_cap_%s_0003.npz" % name}

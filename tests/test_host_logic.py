@@ -1,5 +1,7 @@
 """Host-side mirror of the reference interface (no GPU): Config values, datasets, sequence expansion,
 batch layouts of both data generators, sample tables, image molding, weight packing."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -297,3 +299,26 @@ def test_refine_and_unmold_generations():
     assert list(final[0]) == [30, 0, 128, 102] and ok.all()
     degenerate, ok = unmold_generations(np.array([[5, 16, 5, 40]]), (256, 192, 3), window)
     assert not ok.any()
+
+
+def test_joint_model_log_dir_and_epoch_from_checkpoint_name(tmp_path):
+    """set_log_dir / find_last follow dense_img_cap/dense_model.py:1631-1654, :1776-1798 (no GPU needed: unbound methods
+    on a stand-in object carrying config and model_dir)."""
+    import types
+    from image_captioning_amd.dense_model import DenseImageCapRCNN as J
+    cfg = types.SimpleNamespace(NAME="dense image captioning")
+    m = types.SimpleNamespace(config=cfg, model_dir=str(tmp_path))
+    J.set_log_dir(m)
+    assert m.epoch == 0 and os.path.dirname(m.log_dir) == str(tmp_path)
+    assert os.path.basename(m.log_dir).startswith("dense image captioning20")
+    run = tmp_path / "dense image captioning20260102T0304"
+    run.mkdir()
+    for e in (1, 2, 11):
+        (run / ("img_cap_dense image captioning_%04d.npz" % e)).write_bytes(b"")
+    (tmp_path / "other20260102T0304").mkdir()
+    assert J.find_last(m) == (str(run), str(run / "img_cap_dense image captioning_0011.npz"))
+    J.set_log_dir(m, str(run / "img_cap_dense image captioning_0011.npz"))
+    assert m.epoch == 11 and m.log_dir == str(run)
+    assert m.checkpoint_path.format(epoch=12) == str(run / "img_cap_dense image captioning_0012.npz")
+    J.set_log_dir(m, str(tmp_path / "mask_rcnn_coco.npz"))          # a foreign file: fresh run, epoch 0
+    assert m.epoch == 0 and m.log_dir != str(run)
