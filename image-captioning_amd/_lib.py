@@ -25,6 +25,18 @@ class GemmDesc(C.Structure):
                 ("relu", C.c_int), ("accumulate", C.c_int), ("split_k", C.c_int)]
 
 
+class GemmBf16Desc(C.Structure):
+    _fields_ = [("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("A", C.c_void_p), ("lda", C.c_int), ("a_trans", C.c_int),
+                ("a_gather", C.c_void_p), ("a_gather_rows", C.c_int),
+                ("B", C.c_void_p), ("ldb", C.c_int), ("b_trans", C.c_int),
+                ("C", C.c_void_p), ("ldc", C.c_int),
+                ("Cb", C.c_void_p), ("ldcb", C.c_int),
+                ("scale", C.c_void_p), ("shift", C.c_void_p),
+                ("residual", C.c_void_p), ("ldr", C.c_int), ("res_rows", C.c_int),
+                ("relu", C.c_int), ("accumulate", C.c_int), ("split_k", C.c_int)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int),
                 ("Cout", C.c_int), ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int),
@@ -103,6 +115,10 @@ SYMBOLS = {
     "dc_last_error": (C.c_char_p, []),
     "dc_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
     "dc_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dc_gemm_bf16_workspace_bytes": (C.c_size_t, [C.POINTER(GemmBf16Desc)]),
+    "dc_gemm_bf16": (C.c_int, [C.POINTER(GemmBf16Desc), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dc_cast_f32_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dc_cast_f32_bf16_2d": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dc_split_bf16x3_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_conv2d_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "dc_conv2d_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p]),

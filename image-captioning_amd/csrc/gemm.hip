@@ -21,7 +21,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int spli
     float v = 0.f;
     for (int s = 0; s < splits; ++s) v += partial[(long)s * total + idx];   // fixed order: reproducible
     const int row = (int)(idx / N), col = (int)(idx - (long)row * N);
-    ep.C[(long)row * ep.ldc + col] = ep.apply(v, row, col);
+    ep.put(row, col, ep.apply(v, row, col));
 }
 
 template <class AL, class BL>

@@ -1,0 +1,103 @@
+// gemm_bf16.hip -- dc_gemm_bf16: dense GEMM with bf16 operands in memory and fp32 accumulation on
+// v_mfma_f32_32x32x16_bf16 (bgemm_core.h), all three layouts of a training step (NN / NT / TN), the fused epilogue of
+// dc_gemm_f32 plus an optional bf16 copy of the output; and the fp32 -> bf16 cast that feeds it.
+#include "bgemm_core.h"
+#include <algorithm>
+
+namespace dcap {
+
+static int bgemm_validate(const dc_gemm_bf16_desc* d) {
+    DC_REQUIRE(d != nullptr, DC_EINVAL, "dc_gemm_bf16: null descriptor");
+    DC_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, DC_EINVAL, "dc_gemm_bf16: M,N,K must be positive (got %d,%d,%d)", d->M, d->N, d->K);
+    DC_REQUIRE(d->A && d->B && (d->C || d->Cb), DC_EINVAL, "dc_gemm_bf16: A, B and one of C / Cb must be non-null");
+    DC_REQUIRE(d->lda >= (d->a_trans ? d->M : d->K) && d->ldb >= (d->b_trans ? d->K : d->N), DC_EINVAL,
+               "dc_gemm_bf16: leading dimension smaller than the row length");
+    DC_REQUIRE((!d->C || d->ldc >= d->N) && (!d->Cb || d->ldcb >= d->N), DC_EINVAL, "dc_gemm_bf16: ldc / ldcb smaller than N");
+    DC_REQUIRE((d->K & 7) == 0 && (d->lda & 7) == 0 && (d->ldb & 7) == 0 && aligned16(d->A) && aligned16(d->B), DC_EALIGN,
+               "dc_gemm_bf16: K, lda, ldb must be multiples of 8 (16-byte chunks) and A, B 16-byte aligned");
+    DC_REQUIRE((!d->a_trans || ((d->M & 7) == 0)) && (d->b_trans || ((d->N & 7) == 0)), DC_EALIGN,
+               "dc_gemm_bf16: a K-major operand needs its row length (M for A^T, N for B) to be a multiple of 8");
+    DC_REQUIRE(!d->accumulate || d->C, DC_EINVAL, "dc_gemm_bf16: accumulate needs the fp32 output C");
+    DC_REQUIRE(!d->residual || d->ldr >= d->N, DC_EINVAL, "dc_gemm_bf16: ldr smaller than N");
+    const size_t lim = (size_t)0x7FFFFFF0u;              // 32-bit buffer offsets, with the out-of-range marker above every operand
+    const size_t a_span = (size_t)(d->a_trans ? d->K : d->M) * d->lda * 2, b_span = (size_t)(d->b_trans ? d->N : d->K) * d->ldb * 2;
+    DC_REQUIRE((d->a_gather || a_span < lim) && b_span < lim, DC_EINVAL, "dc_gemm_bf16: operands must span < 2 GiB");
+    DC_REQUIRE(!d->a_gather || d->a_gather_rows > 0, DC_EINVAL, "dc_gemm_bf16: a_gather needs a_gather_rows (rows of the gathered table)");
+    DC_REQUIRE(!d->a_gather || (size_t)d->a_gather_rows * d->lda * 2 < lim, DC_EINVAL, "dc_gemm_bf16: gathered table must span < 2 GiB");
+    return DC_OK;
+}
+
+static Epilogue bgemm_epilogue(const dc_gemm_bf16_desc* d) {
+    Epilogue ep{d->C, d->ldc, d->scale, d->shift, d->residual, d->ldr, d->residual ? (d->res_rows > 0 ? 3 : 1) : 0, d->res_rows, 0, d->relu,
+                d->accumulate, 0};
+    ep.Cb = d->Cb;
+    ep.ldcb = d->ldcb;
+    ep.vec4 = (d->N & 3) == 0 && (!d->C || ((d->ldc & 3) == 0 && aligned16(d->C))) && (!d->Cb || ((d->ldcb & 3) == 0 && (reinterpret_cast<uintptr_t>(d->Cb) & 7u) == 0)) &&
+              (!d->residual || ((d->ldr & 3) == 0 && aligned16(d->residual))) && (!d->scale || aligned16(d->scale)) && (!d->shift || aligned16(d->shift));
+    return ep;
+}
+
+static void bgemm_operands(const dc_gemm_bf16_desc* d, BOperand& a, BOperand& b) {
+    const size_t a_rows = d->a_gather ? (size_t)d->a_gather_rows : (size_t)(d->a_trans ? d->K : d->M);
+    a = BOperand{d->A, d->lda, d->M, d->a_gather, (unsigned)(a_rows * d->lda * 2)};
+    b = BOperand{d->B, d->ldb, d->N, nullptr, (unsigned)((size_t)(d->b_trans ? d->N : d->K) * d->ldb * 2)};
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ out, size_t n) {
+    typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        reinterpret_cast<us4*>(out)[i] = us4{Epilogue::bf16_bits(v.x), Epilogue::bf16_bits(v.y), Epilogue::bf16_bits(v.z), Epilogue::bf16_bits(v.w)};
+    }
+    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = Epilogue::bf16_bits(x[i]);
+}
+
+// rows x cols fp32 (row stride ld_in) -> bf16 (row stride ld_out), columns cols..cols_out-1 zero-filled (K padding)
+__global__ __launch_bounds__(256) void cast_bf16_2d_kernel(const float* __restrict__ x, long ld_in, unsigned short* __restrict__ out, long ld_out,
+                                                           int rows, int cols, int cols_out) {
+    const long total = (long)rows * cols_out;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int r = (int)(idx / cols_out), c = (int)(idx - (long)r * cols_out);
+        out[(long)r * ld_out + c] = c < cols ? Epilogue::bf16_bits(x[(long)r * ld_in + c]) : (unsigned short)0;
+    }
+}
+
+}  // namespace dcap
+
+using namespace dcap;
+
+extern "C" size_t dc_gemm_bf16_workspace_bytes(const dc_gemm_bf16_desc* d) {
+    if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+    const BSplit sp = bgemm_split(d->M, d->N, d->K, d->split_k);
+    return sp.split > 1 ? (size_t)sp.split * d->M * d->N * sizeof(float) : 0;
+}
+
+extern "C" int dc_gemm_bf16(const dc_gemm_bf16_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = bgemm_validate(d);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Epilogue ep = bgemm_epilogue(d);
+    BOperand a, b;
+    bgemm_operands(d, a, b);
+    if (!d->a_trans && !d->b_trans) return launch_bgemm<true, false>(a, b, ep, d->M, d->N, d->K, d->split_k, workspace, workspace_bytes, s);
+    if (!d->a_trans && d->b_trans) return launch_bgemm<true, true>(a, b, ep, d->M, d->N, d->K, d->split_k, workspace, workspace_bytes, s);
+    if (d->a_trans && !d->b_trans) return launch_bgemm<false, false>(a, b, ep, d->M, d->N, d->K, d->split_k, workspace, workspace_bytes, s);
+    return launch_bgemm<false, true>(a, b, ep, d->M, d->N, d->K, d->split_k, workspace, workspace_bytes, s);
+}
+
+extern "C" int dc_cast_f32_bf16(const float* x, uint16_t* out, size_t n, void* stream) {
+    DC_REQUIRE(x && out && n > 0, DC_EINVAL, "dc_cast_f32_bf16: bad arguments");
+    DC_REQUIRE(aligned16(x) && (reinterpret_cast<uintptr_t>(out) & 7u) == 0, DC_EALIGN, "dc_cast_f32_bf16: x 16-byte, out 8-byte aligned");
+    const int blocks = (int)std::min<size_t>((n / 4 + 255) / 256 + 1, (size_t)kNumCU * 8);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, out, n);
+    return check_launch("cast_bf16_kernel");
+}
+
+extern "C" int dc_cast_f32_bf16_2d(const float* x, int ld_in, uint16_t* out, int ld_out, int rows, int cols, int cols_out, void* stream) {
+    DC_REQUIRE(x && out && rows > 0 && cols > 0 && cols_out >= cols && ld_in >= cols && ld_out >= cols_out, DC_EINVAL, "dc_cast_f32_bf16_2d: bad arguments");
+    const long total = (long)rows * cols_out;
+    const int blocks = (int)std::min<long>((total + 255) / 256, (long)kNumCU * 8);
+    hipLaunchKernelGGL(cast_bf16_2d_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, (long)ld_in, out, (long)ld_out, rows, cols, cols_out);
+    return check_launch("cast_bf16_2d_kernel");
+}

@@ -476,6 +476,8 @@ struct Epilogue {
     int relu;
     int accumulate;
     int vec4;       // host-checked: C/res rows 16-byte aligned and N % 4 == 0 => 16-B epilogue accesses
+    unsigned short* Cb = nullptr;   // optional bf16 copy of the finished output (the next bf16 GEMM's operand); C may then be null
+    long ldcb = 0;
     // residual row pointer for output row `row` (nullptr when there is no residual)
     __device__ __forceinline__ const float* res_row(int row) const {
         if (res_mode == 1) return res + (long)row * ldr;
@@ -510,6 +512,12 @@ struct Epilogue {
         if (relu) v = fmaxf(v, 0.f);
         if (accumulate) v += C[(long)row * ldc + col];
         return v;
+    }
+    // round-to-nearest-even bf16 bits of a finite or non-finite float (the plain cast: v_cvt_pk_bf16_f32, NaN stays NaN)
+    static __device__ __forceinline__ unsigned short bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+    __device__ __forceinline__ void put(int row, int col, float v) const {
+        if (C) C[(long)row * ldc + col] = v;
+        if (Cb) Cb[(long)row * ldcb + col] = bf16_bits(v);
     }
 };
 
@@ -659,7 +667,14 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[TM][TN], float* smem, c
                 if (pre_res) { v.x += qres[g][0]; v.y += qres[g][1]; v.z += qres[g][2]; v.w += qres[g][3]; }
                 if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 if (pre_acc) { v.x += qacc[g][0]; v.y += qacc[g][1]; v.z += qacc[g][2]; v.w += qacc[g][3]; }
-                if (row < M) *reinterpret_cast<float4*>(ep.C + (long)row * ep.ldc + col) = v;
+                if (row < M) {
+                    if (ep.C) *reinterpret_cast<float4*>(ep.C + (long)row * ep.ldc + col) = v;
+                    if (ep.Cb) {
+                        typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+                        *reinterpret_cast<us4*>(ep.Cb + (long)row * ep.ldcb + col) =
+                            us4{Epilogue::bf16_bits(v.x), Epilogue::bf16_bits(v.y), Epilogue::bf16_bits(v.z), Epilogue::bf16_bits(v.w)};
+                    }
+                }
             }
         }
         return;
@@ -673,7 +688,7 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[TM][TN], float* smem, c
         const float* rr = ep.res_row(row);
 #define DC_TAIL(j, e)                                                                                       \
     if (col + j < N)                                                                                        \
-        crow[col + j] = ep.finish(e, ep.scale ? ep.scale[col + j] : 1.f, ep.shift ? ep.shift[col + j] : 0.f, rr, crow, col + j);
+        ep.put(row, col + j, ep.finish(e, ep.scale ? ep.scale[col + j] : 1.f, ep.shift ? ep.shift[col + j] : 0.f, rr, crow, col + j));
         DC_TAIL(0, v.x) DC_TAIL(1, v.y) DC_TAIL(2, v.z) DC_TAIL(3, v.w)
 #undef DC_TAIL
     }

@@ -7,7 +7,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (AmsgradDesc, BnReluDesc, ConvDesc, ProposalDesc, RpnLossDesc, GemmDesc, LstmBwdDesc, LstmFwdDesc, RoiAlignDesc,
+from ._lib import (AmsgradDesc, BnReluDesc, ConvDesc, GemmBf16Desc, ProposalDesc, RpnLossDesc, GemmDesc, LstmBwdDesc, LstmFwdDesc, RoiAlignDesc,
                    SoftmaxCeDesc, check)
 
 
@@ -86,6 +86,71 @@ def gemm(A, B, out=None, a_trans=False, b_trans=False, gather=None, scale=None, 
     ws, wsb = WORKSPACE.get(lib.dc_gemm_workspace_bytes(C.byref(d)), A.device)
     check(lib.dc_gemm_f32(C.byref(d), _ptr(ws), wsb, _stream()), "dc_gemm_f32")
     return out
+
+
+BF16 = torch.bfloat16
+
+
+def to_bf16(x, out=None, pad_cols=None):
+    """fp32 -> bf16 (round to nearest even) on the device.  pad_cols: for a 2-D x, the output's column count (>= x.shape[1],
+    extra columns zero) -- pads a contraction dimension to the multiple of 8 dc_gemm_bf16 wants."""
+    lib = _lib.load()
+    _chk(x, name="x")
+    if pad_cols is not None or (x.dim() == 2 and not x.is_contiguous()):
+        rows, cols = x.shape
+        co = cols if pad_cols is None else int(pad_cols)
+        if out is None:
+            out = torch.empty((rows, co), dtype=BF16, device=x.device)
+        check(lib.dc_cast_f32_bf16_2d(_ptr(x), x.stride(0), _ptr(out), out.stride(0), rows, cols, co, _stream()), "dc_cast_f32_bf16_2d")
+        return out
+    if not x.is_contiguous():
+        raise _lib.DcapError("to_bf16: x must be contiguous (or 2-D with unit column stride)")
+    if out is None:
+        out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    check(lib.dc_cast_f32_bf16(_ptr(x), _ptr(out), x.numel(), _stream()), "dc_cast_f32_bf16")
+    return out
+
+
+def gemm_bf16(A, B, out=None, out_bf16=None, a_trans=False, b_trans=False, gather=None, scale=None, shift=None,
+              residual=None, res_rows=0, relu=False, accumulate=False, split_k=0):
+    """op(A) @ op(B) with bf16 operands, fp32 accumulate (dc_gemm_bf16).  out: fp32 [M,N] result (allocated when neither
+    out nor out_bf16 is given); out_bf16: optional bf16 [M,N] copy of the result.  Returns out if present else out_bf16."""
+    lib = _lib.load()
+    _chk(A, BF16, "A"), _chk(B, BF16, "B")
+    if a_trans:
+        K, M = (gather.numel() if gather is not None else A.shape[0]), A.shape[1]
+    elif gather is not None:
+        M, K = gather.numel(), A.shape[1]
+    else:
+        M, K = A.shape
+    N = B.shape[0] if b_trans else B.shape[1]
+    kb = B.shape[1] if b_trans else B.shape[0]
+    if kb != K:
+        raise _lib.DcapError("gemm_bf16: inner dimensions differ (%d vs %d)" % (K, kb))
+    if out is None and out_bf16 is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    d = GemmBf16Desc()
+    d.M, d.N, d.K = M, N, K
+    d.A, d.lda, d.a_trans = A.data_ptr(), A.stride(0), int(a_trans)
+    if gather is not None:
+        d.a_gather, d.a_gather_rows = _chk(gather, torch.int32, "gather").data_ptr(), A.shape[0]
+    d.B, d.ldb, d.b_trans = B.data_ptr(), B.stride(0), int(b_trans)
+    for t, name, dt in ((out, "out", torch.float32), (out_bf16, "out_bf16", BF16)):
+        if t is not None and tuple(_chk(t, dt, name).shape) != (M, N):
+            raise _lib.DcapError("gemm_bf16: %s has shape %s, expected %s" % (name, tuple(t.shape), (M, N)))
+    if out is not None:
+        d.C, d.ldc = out.data_ptr(), out.stride(0)
+    if out_bf16 is not None:
+        d.Cb, d.ldcb = out_bf16.data_ptr(), out_bf16.stride(0)
+    d.scale = None if scale is None else _chk(scale, name="scale").data_ptr()
+    d.shift = None if shift is None else _chk(shift, name="shift").data_ptr()
+    if residual is not None:
+        _chk(residual, name="residual")
+        d.residual, d.ldr, d.res_rows = residual.data_ptr(), residual.stride(0), int(res_rows)
+    d.relu, d.accumulate, d.split_k = int(relu), int(accumulate), int(split_k)
+    ws, wsb = WORKSPACE.get(lib.dc_gemm_bf16_workspace_bytes(C.byref(d)), A.device)
+    check(lib.dc_gemm_bf16(C.byref(d), _ptr(ws), wsb, _stream()), "dc_gemm_bf16")
+    return out if out is not None else out_bf16
 
 
 def conv2d(x, w_packed, kh, kw, stride, pad_t, pad_l, Ho, Wo, scale=None, shift=None, residual=None,

@@ -69,6 +69,38 @@ size_t dc_gemm_workspace_bytes(const dc_gemm_desc* d);
 int    dc_gemm_f32(const dc_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * GEMM with bf16 operands (bit patterns in uint16_t), fp32 accumulate on the bf16 matrix pipe -- the arithmetic BASELINE
+ * configs[4] asks for (joint model in bf16: dense_img_cap/dense_model.py:738-817 RoI head + Model-3 decoder, :936-946
+ * vocabulary softmax).  Same operand conventions and epilogue as dc_gemm_f32; the result is written as fp32 (C), as bf16
+ * (Cb: the next bf16 GEMM's operand), or both.  K, lda, ldb multiples of 8; a K-major operand (a_trans = 1 / b_trans = 0)
+ * needs its row length (M / N) to be a multiple of 8.  a_gather (optional) indexes rows of a table of a_gather_rows rows:
+ * with a_trans = 0 tile row m is table row a_gather[m] (embedding lookup), with a_trans = 1 K row k is a_gather[k].
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int M, N, K;
+    const uint16_t* A;  int lda;  int a_trans;
+    const int32_t*  a_gather;  int a_gather_rows;
+    const uint16_t* B;  int ldb;  int b_trans;
+    float*          C;  int ldc;
+    uint16_t*       Cb; int ldcb;
+    const float*    scale;
+    const float*    shift;
+    const float*    residual;  int ldr;
+    int res_rows;
+    int relu;
+    int accumulate;
+    int split_k;
+} dc_gemm_bf16_desc;
+
+size_t dc_gemm_bf16_workspace_bytes(const dc_gemm_bf16_desc* d);
+int    dc_gemm_bf16(const dc_gemm_bf16_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+
+/* fp32 -> bf16 (round to nearest even): the bf16 shadow of weights / activations that feed dc_gemm_bf16.
+ * _2d: rows x cols with row strides, output columns cols..cols_out-1 zero-filled (pads K to a multiple of 8). */
+int dc_cast_f32_bf16(const float* x, uint16_t* out, size_t n, void* stream);
+int dc_cast_f32_bf16_2d(const float* x, int ld_in, uint16_t* out, int ld_out, int rows, int cols, int cols_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * conv2d NHWC forward as an implicit GEMM (LDS im2col tiles), fused frozen-BN / bias / residual /
  * ReLU epilogue.  Replaces KL.Conv2D + BatchNorm(training=False) + Add + Activation('relu'):
  *   feature_generation/dense_model.py:85-100 (identity_block), :120-139 (conv_block),

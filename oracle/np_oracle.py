@@ -650,3 +650,16 @@ def sparse_cce_keras_with_grad(target_ids, probs, weights):
     np.put_along_axis(g, idx[..., None], np.take_along_axis(g, idx[..., None], -1) - (ut / qt)[..., None], -1)
     dz = p * (g - (g * p).sum(-1, keepdims=True))
     return loss * w, dz * w[..., None]
+
+
+# ------------------------------------------------------------------ bf16 storage (BASELINE configs[4])
+
+def to_bf16(x):
+    """Round-to-nearest-even onto the bfloat16 grid (8 significant bits), returned as float64: the value a bf16 tensor
+    holds.  configs[4] stores weights / activations of the RoI head, the decoder and the vocabulary layers in bf16 and
+    accumulates in fp32; the oracle for those paths rounds the same operands and multiplies in float64."""
+    a = np.ascontiguousarray(np.asarray(x, np.float32))
+    u = a.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    out = (r & 0xFFFFFFFF).astype(np.uint32).view(np.float32).astype(np.float64)
+    return np.where(np.isfinite(a), out, a.astype(np.float64)).reshape(np.shape(x))

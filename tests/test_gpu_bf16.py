@@ -1,0 +1,121 @@
+"""bf16 kernels (BASELINE configs[4]: bf16 storage, fp32 accumulate) against the NumPy oracle on operands rounded to the
+same bf16 grid (-m gpu).  Products of bf16 values are exact in fp32, so the only difference to the float64 oracle is the
+fp32 accumulation order: tolerance 3e-5 of the output scale (K up to a few thousand); a bf16 OUTPUT is within one bf16
+ulp (2^-8 relative) of the rounded oracle value."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle as O
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from image_captioning_amd import ops as _ops, _lib
+    _lib.load()
+    return _ops
+
+
+def dev(a, dtype=torch.float32):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device="cuda")
+
+
+def close(got, want, tol=3e-5):
+    got = got.detach().float().cpu().numpy().astype(np.float64)
+    want = np.asarray(want, np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    scale = max(1.0, float(np.abs(want).max()))
+    err = float(np.abs(got - want).max()) / scale
+    assert err < tol, "max err %.3e (scaled) exceeds %.1e" % (err, tol)
+
+
+def test_cast_is_round_to_nearest_even(ops):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(10007) * 10.0 ** rng.integers(-20, 20, 10007), [0.0, -0.0, 1.0, 1.00390625, 1.01171875, 3.3895314e38]])
+    got = ops.to_bf16(dev(x)).float().cpu().numpy().astype(np.float64)
+    np.testing.assert_array_equal(got, O.to_bf16(x))
+    m = rng.standard_normal((5, 300))
+    padded = ops.to_bf16(dev(m), pad_cols=304).float().cpu().numpy()
+    np.testing.assert_array_equal(padded[:, :300], O.to_bf16(m))
+    assert padded.shape == (5, 304) and not padded[:, 300:].any()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 1024, 1024), (8, 1000, 512), (264, 136, 72), (960, 256, 2048), (1024, 2048, 3000)])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_bf16_layouts(ops, M, N, K, ta, tb):
+    """NN / NT / TN / TT incl. ragged edges (M, N not multiples of the 128 tile), K tails (K % 64 != 0) and automatic split-K."""
+    rng = np.random.default_rng(M * 7 + N * 3 + K + ta * 2 + tb)
+    A = rng.standard_normal((M, K))
+    B = rng.standard_normal((K, N))
+    a = ops.to_bf16(dev(A.T if ta else A))
+    b = ops.to_bf16(dev(B.T if tb else B))
+    close(ops.gemm_bf16(a, b, a_trans=bool(ta), b_trans=bool(tb)), O.to_bf16(A) @ O.to_bf16(B))
+
+
+@pytest.mark.parametrize("split", [0, 1, 3, 7])
+def test_gemm_bf16_epilogue_splitk_and_bf16_output(ops, split):
+    rng = np.random.default_rng(11 + split)
+    M, N, K = 200, 1024, 12544 // 4
+    A = rng.standard_normal((M, K))
+    B = rng.standard_normal((K, N)) / np.sqrt(K)
+    sc, sh = rng.uniform(0.5, 1.5, N), rng.standard_normal(N)
+    R = rng.standard_normal((M, N))
+    C0 = rng.standard_normal((M, N))
+    want = np.maximum((O.to_bf16(A) @ O.to_bf16(B)) * sc + sh + R, 0) + C0
+    out = dev(C0)
+    outb = torch.empty((M, N), dtype=BF, device="cuda")
+    ops.gemm_bf16(ops.to_bf16(dev(A)), ops.to_bf16(dev(B)), out=out, out_bf16=outb, scale=dev(sc), shift=dev(sh), residual=dev(R), relu=True,
+                  accumulate=True, split_k=split)
+    close(out, want)
+    got_b = outb.float().cpu().numpy().astype(np.float64)
+    assert np.abs(got_b - want).max() <= 2.0 ** -8 * np.abs(want).max() + 1e-6       # one bf16 ulp of the fp32 result
+    only_b = torch.empty((M, N), dtype=BF, device="cuda")                            # bf16-only output (no fp32 C)
+    ops.gemm_bf16(ops.to_bf16(dev(A)), ops.to_bf16(dev(B)), out_bf16=only_b, shift=dev(sh), split_k=split)
+    wb = O.to_bf16(A) @ O.to_bf16(B) + sh
+    assert np.abs(only_b.float().cpu().numpy() - wb).max() <= 2.0 ** -8 * np.abs(wb).max() + 1e-6
+
+
+def test_gemm_bf16_gather_rows_and_k(ops):
+    """a_gather: embedding lookup on the rows of A (forward) and on the K rows of A^T (the embedding-side weight gradient)."""
+    rng = np.random.default_rng(5)
+    V, E, Ep, N, U = 1000, 300, 304, 960, 512
+    table = rng.standard_normal((V, E))
+    ids = rng.integers(0, V, N)
+    W = rng.standard_normal((E, U))
+    tb = ops.to_bf16(dev(table), pad_cols=Ep)                         # K padded to a multiple of 8 with zeros
+    Wp = np.zeros((Ep, U))
+    Wp[:E] = W
+    close(ops.gemm_bf16(tb, ops.to_bf16(dev(Wp)), gather=dev(ids, torch.int32)), O.to_bf16(table)[ids] @ O.to_bf16(W))
+    dz = rng.standard_normal((N, U))
+    got = ops.gemm_bf16(tb, ops.to_bf16(dev(dz)), a_trans=True, gather=dev(ids, torch.int32))
+    want = np.zeros((Ep, U))
+    want[:E] = O.to_bf16(table)[ids].T @ O.to_bf16(dz)
+    close(got, want)
+
+
+def test_gemm_bf16_per_roi_residual_and_strided_views(ops):
+    rng = np.random.default_rng(6)
+    Bn, T, K, N = 24, 5, 512, 256
+    X = rng.standard_normal((T * Bn, K))
+    W = rng.standard_normal((K + 64, N + 8))
+    r = rng.standard_normal((Bn, N))
+    wb = ops.to_bf16(dev(W))
+    got = ops.gemm_bf16(ops.to_bf16(dev(X)), wb[64:, :N], residual=dev(r), res_rows=Bn)
+    close(got, O.to_bf16(X) @ O.to_bf16(W)[64:, :N] + np.tile(r, (T, 1)))
+
+
+def test_gemm_bf16_rejects_bad_arguments(ops):
+    from image_captioning_amd._lib import DcapError
+    a = torch.zeros((16, 60), dtype=BF, device="cuda")
+    b = torch.zeros((60, 16), dtype=BF, device="cuda")
+    with pytest.raises(DcapError):
+        ops.gemm_bf16(a, b)                                           # K % 8 != 0
+    with pytest.raises(DcapError):
+        ops.gemm_bf16(torch.zeros((16, 64), device="cuda"), torch.zeros((64, 16), dtype=BF, device="cuda"))     # fp32 operand
+    with pytest.raises(DcapError):
+        ops.gemm_bf16(torch.zeros((16, 64), dtype=BF, device="cuda"), torch.zeros((64, 12), dtype=BF, device="cuda"))   # N % 8 (K-major B)
