@@ -78,6 +78,14 @@ class SoftmaxCeDesc(C.Structure):
                 ("grad_scale", C.c_float), ("row_weights", C.c_void_p), ("keras_sparse", C.c_int)]
 
 
+class VocabCeDesc(C.Structure):
+    _fields_ = [("M", C.c_int), ("V", C.c_int), ("K", C.c_int), ("bf16", C.c_int),
+                ("X", C.c_void_p), ("ldx", C.c_int), ("W", C.c_void_p), ("ldw", C.c_int),
+                ("bias", C.c_void_p), ("targets", C.c_void_p), ("row_weights", C.c_void_p),
+                ("grad_scale", C.c_float), ("keras_sparse", C.c_int), ("loss_rows", C.c_void_p),
+                ("dlogits", C.c_void_p), ("lddl", C.c_int), ("dl_bf16", C.c_int), ("dbias", C.c_void_p)]
+
+
 class BnReluDesc(C.Structure):
     _fields_ = [("M", C.c_int), ("N", C.c_int), ("ld", C.c_int), ("acc", C.c_void_p),
                 ("bias", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p), ("var", C.c_void_p),
@@ -138,6 +146,8 @@ SYMBOLS = {
     "dc_lstm_seq_fwd_f32": (C.c_int, [C.POINTER(LstmFwdDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_lstm_seq_bwd_f32": (C.c_int, [C.POINTER(LstmBwdDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_softmax_ce_f32": (C.c_int, [C.POINTER(SoftmaxCeDesc), C.c_void_p]),
+    "dc_vocab_ce_workspace_bytes": (C.c_size_t, [C.POINTER(VocabCeDesc)]),
+    "dc_vocab_ce": (C.c_int, [C.POINTER(VocabCeDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_argmax_rows_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dc_gather_rows_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dc_bn_relu_fwd_f32": (C.c_int, [C.POINTER(BnReluDesc), C.c_void_p]),

@@ -699,27 +699,19 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[TM][TN], float* smem, c
 // A panel, run on one XCD), grid.z = split-K slices.  With split-K the raw partial sums go to the
 // slab  partial[z][M][N]  and splitk_reduce_kernel applies the epilogue.
 // ------------------------------------------------------------------------------------------------
+// The main loop as a device function (shared with the fused vocabulary softmax / cross-entropy kernels of vocab_ce.hip):
+// accumulates A[m0.., kbeg..kend) * B[kbeg..kend), n0..] into acc.
 template <int BM, int BN, class AL, class BL>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(AL al, BL bl, Epilogue ep, int M, int N, int K, int klen,
-                                                    float* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void igemm_mainloop(const AL& al, const BL& bl, float* smem, int m0, int n0, int kbeg, int kend,
+                                               f32x16 (&acc)[BM / 64][BN / 64], int wm, int wn) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int A_FL = lds_floats<BM, AL::KC>(), B_FL = lds_floats<BN, BL::KC>(), STAGE = A_FL + B_FL;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_n = (N + BN - 1) / BN;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
-    const int kbeg = blockIdx.z * klen;
-    const int kend = min(K, kbeg + klen);
-    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
-
+    const int tid = threadIdx.x, lane = tid & 63;
     typename AL::template State<BM> sa;
     typename BL::template State<BN> sb;
     al.template init<BM>(sa, m0, tid);
     bl.template init<BN>(sb, n0, tid);
 
-    f32x16 acc[TM][TN];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -804,6 +796,21 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(AL al, BL bl, Epilogue ep
     }
 #endif
 
+}
+
+template <int BM, int BN, class AL, class BL>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(AL al, BL bl, Epilogue ep, int M, int N, int K, int klen,
+                                                    float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6;
+    const int tiles_n = (N + BN - 1) / BN;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
+    const int kbeg = blockIdx.z * klen;
+    const int kend = min(K, kbeg + klen);
+    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+    f32x16 acc[BM / 64][BN / 64];
+    igemm_mainloop<BM, BN, AL, BL>(al, bl, smem, m0, n0, kbeg, kend, acc, wm, wn);
     store_tile<BM, BN>(acc, smem, ep, partial, M, N, m0, n0, wm, wn);
 }
 

@@ -1,0 +1,359 @@
+// vocab_ce.hip -- dc_vocab_ce: the vocabulary projection FUSED with softmax + Keras cross-entropy (forward and d/dlogits).
+//
+// Replaces  Dense(V, activation='softmax') + K.categorical_crossentropy / roi_caption_loss
+//   (dense_img_cap_separate_models/text_generation_model.py:153-154, :286-294; text_generation_model_v2.py:164, :267)
+// and the joint model's masked K.sparse_categorical_crossentropy (dense_img_cap/dense_model.py:936-946).
+//
+// The [rows, V] logits are never written: 600 MB of fp32 at 3000 caption rows x 50 000 words, read three times by an
+// unfused softmax.  Instead the GEMM main loop (fp32 MFMA: igemm_core.h; bf16: bgemm_core.h) runs once per PASS over
+// the 128 x 128 output tiles and each pass ends in a reduction epilogue on the tile while it sits in LDS:
+//   pass STATS  per row and column tile: max and sum of exp (online softmax partials), and the target's logit;
+//               a row kernel then combines the tiles: m, s, p_t, the loss row (categorical flavour) and the row's
+//               gradient scale;
+//   pass CLIP   (keras_sparse only) K.sparse_categorical_crossentropy clips the probabilities to [1e-7, 1-1e-7] and
+//               renormalises: S = sum clip(p), UP = sum of the unclipped p, per row and tile; a row kernel combines them
+//               into the loss row and the two row constants of the gradient;
+//   pass DL     recomputes the tile and writes d(loss)/d(logits) (fp32, or bf16 as the operand of the bf16 weight /
+//               data gradient GEMMs) plus per-tile column sums (the bias gradient, combined in a fixed order).
+// The recomputation costs one extra GEMM pass (two for keras_sparse); in exchange nothing of size rows x V is written
+// but the gradient itself.  All reductions are wavefront shuffles over the 32 lanes that share a row of the tile.
+#include "bgemm_core.h"
+#include <algorithm>
+
+namespace dcap {
+
+enum { CE_STATS = 0, CE_CLIP = 1, CE_DL = 2 };
+constexpr int CE_RI = 8;                 // floats of row info per row
+
+struct CeArgs {
+    int M, V, tiles_n;
+    const float* bias;                   // [V] or null
+    const int32_t* targets;              // [M]
+    float* stats;                        // [M][tiles_n][2]
+    float* zt;                           // [M]
+    const float* rowinfo;                // [M][CE_RI]: m, 1/s, gs, 1/S, c, tq  (see ce_rows_kernel)
+    float* dl_f32;
+    unsigned short* dl_bf16;
+    long lddl;
+    float* dbias_part;                   // [tiles_m][V] or null
+    int keras_sparse;
+};
+
+__device__ __forceinline__ float half_max(float v) {          // over the 32 lanes that share a tile row
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Epilogue of one 128 x 128 tile (accumulators in MFMA layout, wave origin wm, wn).
+template <int MODE>
+__device__ __forceinline__ void ce_epilogue(f32x16 (&acc)[2][2], float* Cs, const CeArgs& ce, int m0, int n0, int wm, int wn, int tile_m, int tile_n) {
+    constexpr int LDC = 128 + 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    {
+        const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Cs[(wm + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDC + wn + tn * 32 + i] = acc[tm][tn][r];
+    }
+    __syncthreads();
+    const int c4 = tid & 31, rp = tid >> 5;                    // 32 lanes x 4 columns per row, 8 rows per pass
+    const int col = n0 + 4 * c4;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ce.bias && col + 3 < ce.V) b4 = *reinterpret_cast<const float4*>(ce.bias + col);
+    else if (ce.bias) {
+        if (col < ce.V) b4.x = ce.bias[col];
+        if (col + 1 < ce.V) b4.y = ce.bias[col + 1];
+        if (col + 2 < ce.V) b4.z = ce.bias[col + 2];
+    }
+    const bool v0 = col < ce.V, v1 = col + 1 < ce.V, v2 = col + 2 < ce.V, v3 = col + 3 < ce.V;
+    float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f;          // DL: column sums over this thread's rows
+#pragma unroll 2
+    for (int p = 0; p < 16; ++p) {
+        const int lr = p * 8 + rp, row = m0 + lr;
+        const bool rv = row < ce.M;                            // uniform over the 32 lanes of the row
+        float4 z = *reinterpret_cast<const float4*>(&Cs[lr * LDC + 4 * c4]);
+        z.x += b4.x; z.y += b4.y; z.z += b4.z; z.w += b4.w;
+        const int t = rv ? ce.targets[row] : -1;
+        if constexpr (MODE == CE_STATS) {
+            float mx = fmaxf(fmaxf(v0 ? z.x : -INFINITY, v1 ? z.y : -INFINITY), fmaxf(v2 ? z.z : -INFINITY, v3 ? z.w : -INFINITY));
+            mx = half_max(mx);
+            float s = (v0 ? __expf(z.x - mx) : 0.f) + (v1 ? __expf(z.y - mx) : 0.f) + (v2 ? __expf(z.z - mx) : 0.f) + (v3 ? __expf(z.w - mx) : 0.f);
+            s = half_sum(s);
+            if (rv) {
+                if (c4 == 0) *reinterpret_cast<float2*>(ce.stats + ((long)row * ce.tiles_n + tile_n) * 2) = make_float2(mx, s);
+                if (t >= col && t < col + 4 && t < ce.V) ce.zt[row] = t == col ? z.x : (t == col + 1 ? z.y : (t == col + 2 ? z.z : z.w));
+            }
+        } else {
+            const float* ri = ce.rowinfo + (long)min(row, ce.M - 1) * CE_RI;
+            const float m = ri[0], inv_s = ri[1];
+            const float p0 = __expf(z.x - m) * inv_s, p1 = __expf(z.y - m) * inv_s, p2 = __expf(z.z - m) * inv_s, p3 = __expf(z.w - m) * inv_s;
+            auto unclipped = [](float q) { return q >= 1e-7f && q <= 1.f - 1e-7f; };
+            auto clip = [](float q) { return fminf(fmaxf(q, 1e-7f), 1.f - 1e-7f); };
+            if constexpr (MODE == CE_CLIP) {
+                float S = (v0 ? clip(p0) : 0.f) + (v1 ? clip(p1) : 0.f) + (v2 ? clip(p2) : 0.f) + (v3 ? clip(p3) : 0.f);
+                float U = ((v0 && unclipped(p0)) ? p0 : 0.f) + ((v1 && unclipped(p1)) ? p1 : 0.f) + ((v2 && unclipped(p2)) ? p2 : 0.f) +
+                          ((v3 && unclipped(p3)) ? p3 : 0.f);
+                S = half_sum(S);
+                U = half_sum(U);
+                if (rv && c4 == 0) *reinterpret_cast<float2*>(ce.stats + ((long)row * ce.tiles_n + tile_n) * 2) = make_float2(S, U);
+            } else {
+                const float gs = ri[2];
+                float g0, g1, g2, g3;
+                if (ce.keras_sparse) {
+                    const float invS = ri[3], c = ri[4], tq = ri[5];
+                    g0 = gs * p0 * ((unclipped(p0) ? invS : 0.f) - (t == col ? tq : 0.f) - c);
+                    g1 = gs * p1 * ((unclipped(p1) ? invS : 0.f) - (t == col + 1 ? tq : 0.f) - c);
+                    g2 = gs * p2 * ((unclipped(p2) ? invS : 0.f) - (t == col + 2 ? tq : 0.f) - c);
+                    g3 = gs * p3 * ((unclipped(p3) ? invS : 0.f) - (t == col + 3 ? tq : 0.f) - c);
+                } else {
+                    g0 = gs * (p0 - (t == col ? 1.f : 0.f));
+                    g1 = gs * (p1 - (t == col + 1 ? 1.f : 0.f));
+                    g2 = gs * (p2 - (t == col + 2 ? 1.f : 0.f));
+                    g3 = gs * (p3 - (t == col + 3 ? 1.f : 0.f));
+                }
+                if (rv) {
+                    cs0 += g0; cs1 += g1; cs2 += g2; cs3 += g3;
+                    if (ce.dl_f32) {
+                        float* o = ce.dl_f32 + (long)row * ce.lddl + col;
+                        if (v3) *reinterpret_cast<float4*>(o) = make_float4(g0, g1, g2, g3);
+                        else { if (v0) o[0] = g0; if (v1) o[1] = g1; if (v2) o[2] = g2; }
+                    } else {
+                        typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+                        unsigned short* o = ce.dl_bf16 + (long)row * ce.lddl + col;
+                        // columns V..lddl-1 of the gradient are zero-filled: they are the K padding of the bf16 GEMMs that read it
+                        const us4 q{Epilogue::bf16_bits(v0 ? g0 : 0.f), Epilogue::bf16_bits(v1 ? g1 : 0.f), Epilogue::bf16_bits(v2 ? g2 : 0.f),
+                                    Epilogue::bf16_bits(v3 ? g3 : 0.f)};
+                        if (col + 3 < ce.lddl) *reinterpret_cast<us4*>(o) = q;
+                        else { if (col < ce.lddl) o[0] = q[0]; if (col + 1 < ce.lddl) o[1] = q[1]; if (col + 2 < ce.lddl) o[2] = q[2]; }
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (MODE == CE_DL) {
+        if (ce.dbias_part) {                                   // column sums of the tile: 8 row lanes per column, fixed order
+            __syncthreads();                                   // every thread is done reading Cs
+            float* red = Cs;                                   // [8][128]
+            *reinterpret_cast<float4*>(&red[rp * 128 + 4 * c4]) = make_float4(cs0, cs1, cs2, cs3);
+            __syncthreads();
+            if (tid < 128 && n0 + tid < ce.V) {
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) s += red[q * 128 + tid];
+                ce.dbias_part[(long)tile_m * ce.V + n0 + tid] = s;
+            }
+        }
+    }
+}
+
+using CeA32 = DenseKCT<true>;
+using CeB32 = DenseMCT<true>;
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void vocab_ce_f32_kernel(CeA32 al, CeB32 bl, CeArgs ce, int K) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = lid / ce.tiles_n, tile_n = lid % ce.tiles_n;
+    const int m0 = tile_m * 128, n0 = tile_n * 128;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    f32x16 acc[2][2];
+    igemm_mainloop<128, 128, CeA32, CeB32>(al, bl, smem, m0, n0, 0, K, acc, wm, wn);
+    ce_epilogue<MODE>(acc, smem, ce, m0, n0, wm, wn, tile_m, tile_n);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void vocab_ce_bf16_kernel(BOperand a, BOperand b, CeArgs ce, int K) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = lid / ce.tiles_n, tile_n = lid % ce.tiles_n;
+    const int m0 = tile_m * 128, n0 = tile_n * 128;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    f32x16 acc[2][2];
+    bgemm_mainloop<true, false>(a, b, reinterpret_cast<char*>(smem), m0, n0, 0, K, acc, wm, wn);
+    ce_epilogue<MODE>(acc, smem, ce, m0, n0, wm, wn, tile_m, tile_n);
+}
+
+// One wave per row: combines the per-tile partials.
+//   phase 0 (after STATS): m = max m_j, s = sum s_j exp(m_j - m), p_t = exp(z_t - m)/s.
+//       categorical: loss = rw * -log(clip(p_t)); gs = grad_scale * rw when p_t is inside the clip range, else 0
+//       (K.categorical_crossentropy's clip has zero gradient outside; its renormalisation is the identity on a softmax row).
+//       keras_sparse: only m, 1/s, p_t are final; the CLIP pass follows.
+//   phase 1 (after CLIP, keras_sparse): S, UP -> q_t = clip(p_t); loss = rw * (-log q_t + log S);
+//       d/dz_k = gs * p_k * (u_k / S - [k == t] * tq - c),  tq = live / q_t,  c = UP / S - live * p_t / q_t,  gs = grad_scale * rw.
+__global__ __launch_bounds__(256) void ce_rows_kernel(int phase, int M, int tiles_n, const float* __restrict__ stats, const float* __restrict__ zt,
+                                                      const int32_t* __restrict__ targets, int V, const float* __restrict__ row_weights,
+                                                      float grad_scale, int keras_sparse, float* __restrict__ rowinfo,
+                                                      float* __restrict__ loss_rows) {
+    const int row = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float2* st = reinterpret_cast<const float2*>(stats) + (long)row * tiles_n;
+    float* ri = rowinfo + (long)row * CE_RI;
+    const float rw = row_weights ? row_weights[row] : 1.f;
+    const int t = targets[row];
+    if (phase == 0) {
+        float m = -INFINITY;
+        for (int j = lane; j < tiles_n; j += 64) m = fmaxf(m, st[j].x);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        float s = 0.f;
+        for (int j = lane; j < tiles_n; j += 64) { const float2 q = st[j]; s += q.y * __expf(q.x - m); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane != 0) return;
+        const float inv_s = 1.f / s;
+        const float pt = (t >= 0 && t < V) ? __expf(zt[row] - m) * inv_s : 1.f;
+        const bool live = pt >= 1e-7f && pt <= 1.f - 1e-7f;
+        ri[0] = m; ri[1] = inv_s; ri[6] = pt;
+        if (!keras_sparse) {
+            ri[2] = live ? grad_scale * rw : 0.f;
+            if (loss_rows) loss_rows[row] = rw * -logf(fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f));
+        }
+        return;
+    }
+    float S = 0.f, U = 0.f;
+    for (int j = lane; j < tiles_n; j += 64) { const float2 q = st[j]; S += q.x; U += q.y; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { S += __shfl_xor(S, o, 64); U += __shfl_xor(U, o, 64); }
+    if (lane != 0) return;
+    const float pt = ri[6];
+    const bool live = pt >= 1e-7f && pt <= 1.f - 1e-7f;
+    const float qt = fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f), invS = 1.f / S;
+    ri[2] = grad_scale * rw;
+    ri[3] = invS;
+    ri[4] = U * invS - (live ? pt / qt : 0.f);
+    ri[5] = live ? 1.f / qt : 0.f;
+    if (loss_rows) loss_rows[row] = rw * (-logf(qt) + logf(S));
+}
+
+// defined in loss.hip: partial [chunks][N] -> out[N] in a fixed order
+__global__ void colsum_finish_kernel(const float* __restrict__ partial, int chunks, int N, float* __restrict__ out, int accumulate);
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct CePlan {
+    int tiles_m, tiles_n;
+    size_t off_stats, off_zt, off_ri, off_db, total;
+};
+static CePlan ce_plan(const dc_vocab_ce_desc* d) {
+    CePlan p;
+    p.tiles_m = (d->M + 127) / 128;
+    p.tiles_n = (d->V + 127) / 128;
+    p.off_stats = 0;
+    p.off_zt = align256((size_t)d->M * p.tiles_n * 2 * sizeof(float));
+    p.off_ri = p.off_zt + align256((size_t)d->M * sizeof(float));
+    p.off_db = p.off_ri + align256((size_t)d->M * CE_RI * sizeof(float));
+    p.total = p.off_db + (d->dbias ? align256((size_t)p.tiles_m * d->V * sizeof(float)) : 0);
+    return p;
+}
+
+static int ce_validate(const dc_vocab_ce_desc* d) {
+    DC_REQUIRE(d != nullptr, DC_EINVAL, "dc_vocab_ce: null descriptor");
+    DC_REQUIRE(d->M > 0 && d->V > 0 && d->K > 0 && d->X && d->W && d->targets, DC_EINVAL, "dc_vocab_ce: bad arguments");
+    DC_REQUIRE(d->ldx >= d->K && d->ldw >= d->V, DC_EINVAL, "dc_vocab_ce: leading dimension smaller than the row length");
+    DC_REQUIRE(aligned16(d->X) && aligned16(d->W) && (!d->bias || aligned16(d->bias)), DC_EALIGN, "dc_vocab_ce: X, W, bias must be 16-byte aligned");
+    if (d->bf16) {
+        DC_REQUIRE((d->K & 7) == 0 && (d->ldx & 7) == 0 && (d->ldw & 7) == 0 && (d->V & 7) == 0, DC_EALIGN,
+                   "dc_vocab_ce (bf16): K, V, ldx, ldw must be multiples of 8");
+        DC_REQUIRE((size_t)d->M * d->ldx * 2 < (size_t)0x7FFFFFF0u && (size_t)d->K * d->ldw * 2 < (size_t)0x7FFFFFF0u, DC_EINVAL,
+                   "dc_vocab_ce (bf16): operands must span < 2 GiB");
+    } else {
+        DC_REQUIRE((d->K & 31) == 0 && (d->ldx & 3) == 0 && (d->ldw & 3) == 0 && (d->V & 3) == 0 && d->V >= 4, DC_EALIGN,
+                   "dc_vocab_ce (f32): K must be a multiple of 32 and V, ldx, ldw multiples of 4");
+        DC_REQUIRE((size_t)d->M * d->ldx * 4 < (size_t)0xFFFFFFF0u && (size_t)d->K * d->ldw * 4 < (size_t)0xFFFFFFF0u, DC_EINVAL,
+                   "dc_vocab_ce (f32): operands must span < 4 GiB");
+    }
+    if (d->dlogits) {
+        DC_REQUIRE(d->lddl >= d->V, DC_EINVAL, "dc_vocab_ce: lddl smaller than V");
+        DC_REQUIRE(d->dl_bf16 ? ((d->lddl & 3) == 0 && (reinterpret_cast<uintptr_t>(d->dlogits) & 7u) == 0) : ((d->lddl & 3) == 0 && aligned16(d->dlogits)),
+                   DC_EALIGN, "dc_vocab_ce: dlogits rows must be 16-byte (fp32) / 8-byte (bf16) aligned, lddl a multiple of 4");
+    }
+    DC_REQUIRE(!d->dbias || d->dlogits, DC_EINVAL, "dc_vocab_ce: dbias is a by-product of the dlogits pass");
+    return DC_OK;
+}
+
+template <int MODE>
+static int ce_launch(const dc_vocab_ce_desc* d, const CeArgs& ce, const CePlan& p, hipStream_t s) {
+    const int tiles = p.tiles_m * p.tiles_n;
+    if (d->bf16) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vocab_ce_bf16_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr = true;
+        }
+        BOperand a{static_cast<const unsigned short*>(d->X), d->ldx, d->M, nullptr, (unsigned)((size_t)d->M * d->ldx * 2)};
+        BOperand b{static_cast<const unsigned short*>(d->W), d->ldw, d->V, nullptr, (unsigned)((size_t)d->K * d->ldw * 2)};
+        hipLaunchKernelGGL((vocab_ce_bf16_kernel<MODE>), dim3(tiles), dim3(256), bgemm_lds_bytes(), s, a, b, ce, d->K);
+    } else {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vocab_ce_f32_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr = true;
+        }
+        CeA32 al{static_cast<const float*>(d->X), d->ldx, d->M, nullptr};
+        CeB32 bl{static_cast<const float*>(d->W), d->ldw, d->V, nullptr};
+        constexpr size_t lds = igemm_lds_bytes<128, 128, CeA32, CeB32>();
+        hipLaunchKernelGGL((vocab_ce_f32_kernel<MODE>), dim3(tiles), dim3(256), lds, s, al, bl, ce, d->K);
+    }
+    return check_launch("vocab_ce_kernel");
+}
+
+}  // namespace dcap
+
+using namespace dcap;
+
+extern "C" size_t dc_vocab_ce_workspace_bytes(const dc_vocab_ce_desc* d) {
+    if (!d || d->M <= 0 || d->V <= 0) return 0;
+    return ce_plan(d).total;
+}
+
+extern "C" int dc_vocab_ce(const dc_vocab_ce_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = ce_validate(d);
+    if (rc) return rc;
+    const CePlan p = ce_plan(d);
+    DC_REQUIRE(workspace && workspace_bytes >= p.total, DC_EWORKSPACE, "dc_vocab_ce: needs %zu workspace bytes, got %zu", p.total, workspace_bytes);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    CeArgs ce{};
+    ce.M = d->M; ce.V = d->V; ce.tiles_n = p.tiles_n;
+    ce.bias = d->bias; ce.targets = d->targets;
+    ce.stats = reinterpret_cast<float*>(ws + p.off_stats);
+    ce.zt = reinterpret_cast<float*>(ws + p.off_zt);
+    float* rowinfo = reinterpret_cast<float*>(ws + p.off_ri);
+    ce.rowinfo = rowinfo;
+    ce.keras_sparse = d->keras_sparse;
+    const int row_blocks = (d->M + 3) / 4;
+    rc = ce_launch<CE_STATS>(d, ce, p, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ce_rows_kernel, dim3(row_blocks), dim3(256), 0, s, 0, d->M, p.tiles_n, ce.stats, ce.zt, d->targets, d->V, d->row_weights,
+                       d->grad_scale, d->keras_sparse, rowinfo, d->loss_rows);
+    rc = check_launch("ce_rows_kernel");
+    if (rc) return rc;
+    if (d->keras_sparse) {
+        rc = ce_launch<CE_CLIP>(d, ce, p, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(ce_rows_kernel, dim3(row_blocks), dim3(256), 0, s, 1, d->M, p.tiles_n, ce.stats, ce.zt, d->targets, d->V, d->row_weights,
+                           d->grad_scale, d->keras_sparse, rowinfo, d->loss_rows);
+        rc = check_launch("ce_rows_kernel");
+        if (rc) return rc;
+    }
+    if (!d->dlogits) return DC_OK;
+    if (d->dl_bf16) ce.dl_bf16 = static_cast<unsigned short*>(d->dlogits);
+    else ce.dl_f32 = static_cast<float*>(d->dlogits);
+    ce.lddl = d->lddl;
+    ce.dbias_part = d->dbias ? reinterpret_cast<float*>(ws + p.off_db) : nullptr;
+    rc = ce_launch<CE_DL>(d, ce, p, s);
+    if (rc || !d->dbias) return rc;
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((d->V + 15) / 16), dim3(256), 0, s, ce.dbias_part, p.tiles_m, d->V, d->dbias, 0);
+    return check_launch("colsum_finish_kernel");
+}

@@ -7,7 +7,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (AmsgradDesc, BnReluDesc, ConvDesc, GemmBf16Desc, ProposalDesc, RpnLossDesc, GemmDesc, LstmBwdDesc, LstmFwdDesc, RoiAlignDesc,
+from ._lib import (AmsgradDesc, BnReluDesc, ConvDesc, GemmBf16Desc, VocabCeDesc, ProposalDesc, RpnLossDesc, GemmDesc, LstmBwdDesc, LstmFwdDesc, RoiAlignDesc,
                    SoftmaxCeDesc, check)
 
 
@@ -391,6 +391,41 @@ def softmax_ce(logits, targets=None, probs=None, loss_rows=None, dlogits=None, g
     d.row_weights = None if row_weights is None else _chk(row_weights, name="row_weights").data_ptr()
     d.keras_sparse = int(keras_sparse)
     check(lib.dc_softmax_ce_f32(C.byref(d), _stream()), "dc_softmax_ce_f32")
+
+
+def vocab_ce_supported(X, W):
+    """Shapes the fused vocabulary softmax / cross-entropy takes (otherwise: gemm + softmax_ce)."""
+    K, V = W.shape
+    if X.dtype == BF16:
+        return W.dtype == BF16 and K % 8 == 0 and V % 8 == 0 and X.stride(0) % 8 == 0 and W.stride(0) % 8 == 0
+    return K % 32 == 0 and V % 4 == 0 and V >= 4 and X.stride(0) % 4 == 0 and W.stride(0) % 4 == 0
+
+
+def vocab_ce(X, W, bias, targets, loss_rows=None, dlogits=None, dbias=None, grad_scale=1.0, row_weights=None, keras_sparse=False):
+    """Fused Dense(V) + softmax + Keras cross-entropy (dc_vocab_ce): X [M,K] and W [K,V] both float32 or both bf16; the
+    [M,V] logits are never materialised.  dlogits: float32 or bf16 [M, >=V] receives d(loss)/d(logits); dbias [V] its
+    column sums."""
+    lib = _lib.load()
+    bf = X.dtype == BF16
+    _chk(X, BF16 if bf else torch.float32, "X"), _chk(W, BF16 if bf else torch.float32, "W")
+    M, K = X.shape
+    if W.shape[0] != K:
+        raise _lib.DcapError("vocab_ce: inner dimensions differ (%d vs %d)" % (K, W.shape[0]))
+    d = VocabCeDesc()
+    d.M, d.V, d.K, d.bf16 = M, W.shape[1], K, int(bf)
+    d.X, d.ldx, d.W, d.ldw = X.data_ptr(), X.stride(0), W.data_ptr(), W.stride(0)
+    d.bias = None if bias is None else _chk(bias, name="bias").data_ptr()
+    d.targets = _chk(targets, torch.int32, "targets").data_ptr()
+    d.row_weights = None if row_weights is None else _chk(row_weights, name="row_weights").data_ptr()
+    d.grad_scale, d.keras_sparse = float(grad_scale), int(keras_sparse)
+    d.loss_rows = None if loss_rows is None else _chk(loss_rows, name="loss_rows").data_ptr()
+    if dlogits is not None:
+        if dlogits.dtype not in (torch.float32, BF16) or not dlogits.is_cuda or dlogits.stride(1) != 1 or dlogits.shape[0] != M:
+            raise _lib.DcapError("vocab_ce: dlogits must be a float32 or bf16 device matrix with M rows")
+        d.dlogits, d.lddl, d.dl_bf16 = dlogits.data_ptr(), dlogits.stride(0), int(dlogits.dtype == BF16)
+    d.dbias = None if dbias is None else _chk(dbias, name="dbias").data_ptr()
+    ws, wsb = WORKSPACE.get(lib.dc_vocab_ce_workspace_bytes(C.byref(d)), X.device)
+    check(lib.dc_vocab_ce(C.byref(d), _ptr(ws), wsb, _stream()), "dc_vocab_ce")
 
 
 def argmax_rows(x, out=None):

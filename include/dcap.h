@@ -294,6 +294,35 @@ typedef struct {
 
 int dc_softmax_ce_f32(const dc_softmax_ce_desc* d, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Vocabulary projection FUSED with softmax + cross-entropy: logits = X[M,K] * W[K,V] + bias are reduced tile by tile inside
+ * the GEMM and never written.  Replaces Dense(V, activation='softmax') + the losses above in training:
+ *   text_generation_model.py:153-154,286-294; text_generation_model_v2.py:164,267; dense_img_cap/dense_model.py:787-817,936-946.
+ *   bf16 = 0: X, W float32 (fp32 MFMA), K % 32 == 0, V % 4 == 0;  bf16 = 1: X, W bf16 bit patterns, K % 8 == 0, V % 8 == 0.
+ *   loss_rows [M] (optional), dlogits [M][lddl] (optional; float32, or bf16 when dl_bf16 -- then columns V..lddl-1 are written
+ *   as zeros so the matrix can feed dc_gemm_bf16 as an operand), dbias [V] (optional, needs dlogits): column sums of dlogits,
+ *   combined in a fixed order.  Semantics of loss / gradient / row_weights / keras_sparse exactly as dc_softmax_ce_f32.
+ * Cost model: one GEMM pass for the loss (two with keras_sparse) plus one for the gradient, against one pass plus four
+ * sweeps over a [M,V] float32 matrix unfused.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int M, V, K;
+    int bf16;
+    const void* X;  int ldx;
+    const void* W;  int ldw;
+    const float* bias;
+    const int32_t* targets;
+    const float* row_weights;
+    float grad_scale;
+    int keras_sparse;
+    float* loss_rows;
+    void* dlogits;  int lddl;  int dl_bf16;
+    float* dbias;
+} dc_vocab_ce_desc;
+
+size_t dc_vocab_ce_workspace_bytes(const dc_vocab_ce_desc* d);
+int    dc_vocab_ce(const dc_vocab_ce_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+
 /* tf.argmax over the last axis, lowest index wins ties (text_generation_model.py:222-225). */
 int dc_argmax_rows_f32(const float* x, int M, int V, int ld, int32_t* out, void* stream);
 

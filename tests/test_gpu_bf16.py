@@ -119,3 +119,83 @@ def test_gemm_bf16_rejects_bad_arguments(ops):
         ops.gemm_bf16(torch.zeros((16, 64), device="cuda"), torch.zeros((64, 16), dtype=BF, device="cuda"))     # fp32 operand
     with pytest.raises(DcapError):
         ops.gemm_bf16(torch.zeros((16, 64), dtype=BF, device="cuda"), torch.zeros((64, 12), dtype=BF, device="cuda"))   # N % 8 (K-major B)
+
+
+# ---------------------------------------------------------------------------------------------
+# fused vocabulary projection + softmax + cross-entropy (dc_vocab_ce), fp32 and bf16 operands
+# ---------------------------------------------------------------------------------------------
+
+def _ce_case(rng, M, V, K, bf16):
+    X = rng.standard_normal((M, K))
+    W = rng.standard_normal((K, V)) * (2.0 / np.sqrt(K))
+    b = rng.standard_normal(V)
+    t = rng.integers(0, V, M)
+    Xq, Wq = (O.to_bf16(X), O.to_bf16(W)) if bf16 else (X.astype(np.float32).astype(np.float64), W.astype(np.float32).astype(np.float64))
+    z = Xq @ Wq + b
+    return X, W, b, t, z
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("M,V,K", [(7, 1000, 256), (960, 10000, 256), (130, 1016, 2048), (64, 50000, 1024)])
+def test_vocab_ce_categorical(ops, bf16, M, V, K):
+    """Dense(V)+softmax+categorical CE fused: loss rows, d/dlogits and the bias gradient against the oracle applied to
+    the logits X@W+b (operands rounded to bf16 first in the bf16 case); clipped rows have zero gradient."""
+    rng = np.random.default_rng(V + K + M)
+    X, W, b, t, z = _ce_case(rng, M, V, K, bf16)
+    z[0] = X[0] @ W * 0 + b * 0                                        # row 0: uniform logits (loss = ln V)
+    X[0] = 0
+    b0 = b.copy()
+    Xd, Wd = dev(X), dev(W)
+    if bf16:
+        Xd, Wd = ops.to_bf16(Xd), ops.to_bf16(Wd)
+    z = (O.to_bf16(X) @ O.to_bf16(W) if bf16 else X.astype(np.float32).astype(np.float64) @ W.astype(np.float32).astype(np.float64)) + b0
+    p = O.softmax(z)
+    loss = torch.empty(M, device="cuda")
+    dl = torch.full((M, V), 7.0, device="cuda")
+    db = torch.empty(V, device="cuda")
+    assert ops.vocab_ce_supported(Xd, Wd)
+    ops.vocab_ce(Xd, Wd, dev(b0), dev(t, torch.int32), loss_rows=loss, dlogits=dl, dbias=db, grad_scale=1.0 / M)
+    want_d = O.softmax_ce_grad_logits(t, p, np.full(M, 1.0 / M))
+    close(loss, O.categorical_crossentropy(t, p), 2e-5)
+    close(dl * M, want_d * M, 2e-5)
+    close(db * M, want_d.sum(0) * M, 5e-5)
+    if bf16:                                                           # bf16 gradient output, K-padded with zeros
+        Vp = (V + 7) // 8 * 8
+        dlb = torch.full((M, Vp), 7.0, dtype=BF, device="cuda")
+        ops.vocab_ce(Xd, Wd, dev(b0), dev(t, torch.int32), dlogits=dlb, grad_scale=1.0)
+        got = dlb.float().cpu().numpy().astype(np.float64)
+        assert np.abs(got[:, :V] - want_d * M).max() <= 2.0 ** -8 * np.abs(want_d * M).max() + 1e-6 and not got[:, V:].any()
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("M,V,K", [(9, 24, 64), (33, 1000, 1024), (130, 50000, 1024)])
+def test_vocab_ce_masked_keras_sparse(ops, bf16, M, V, K):
+    """The joint model's imgcap_caption_loss_graph flavour: K.sparse_categorical_crossentropy (clip + renormalise) times a row
+    weight, incl. a clipped-low and a clipped-high target and a zero-weight row."""
+    rng = np.random.default_rng(V + K)
+    X, W, b, t, _ = _ce_case(rng, M, V, K, bf16)
+    b[t[0]] -= 80.0                                                    # (the bias is shared: every row sees it)
+    X[1] = 0
+    w = rng.random(M)
+    w[2] = 0.0
+    Xd, Wd = dev(X), dev(W)
+    if bf16:
+        Xd, Wd = ops.to_bf16(Xd), ops.to_bf16(Wd)
+    z = (O.to_bf16(X) @ O.to_bf16(W) if bf16 else X.astype(np.float32).astype(np.float64) @ W.astype(np.float32).astype(np.float64)) + b
+    p = O.softmax(z)
+    want_loss, want_d = O.sparse_cce_keras_with_grad(t, p, w)
+    Vp = (V + 3) // 4 * 4 if not bf16 else (V + 7) // 8 * 8
+    if V % (8 if bf16 else 4):
+        assert not ops.vocab_ce_supported(Xd, Wd)
+        return
+    loss = torch.empty(M, device="cuda")
+    dl = torch.empty((M, Vp), device="cuda")
+    db = torch.empty(V, device="cuda")
+    ops.vocab_ce(Xd, Wd, dev(b), dev(t, torch.int32), loss_rows=loss, dlogits=dl, dbias=db, grad_scale=1.0, row_weights=dev(w), keras_sparse=True)
+    close(loss, want_loss, 3e-5)
+    close(dl[:, :V], want_d, 3e-5)
+    close(db, want_d.sum(0), 1e-4)
+    assert float(dl[2, :V].abs().max()) == 0.0
+    only_loss = torch.empty(M, device="cuda")
+    ops.vocab_ce(Xd, Wd, dev(b), dev(t, torch.int32), loss_rows=only_loss, row_weights=dev(w), keras_sparse=True)      # forward only
+    assert torch.equal(only_loss, loss)
