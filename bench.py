@@ -61,7 +61,8 @@ def parse():
     ap.add_argument("--cpu-baseline-steps", type=int, default=5)
     ap.add_argument("--layer-table", default=None, help="write the per-layer conv timing table (TSV) to this path")
     ap.add_argument("--joint-dtype", default="bf16", choices=["bf16", "f32"], help="joint leg: decoder/head/vocabulary arithmetic")
-    ap.add_argument("--joint-conv-math", default=None, help="joint leg: conv arithmetic (f32 | bf16x3 | bf16x2 | bf16)")
+    ap.add_argument("--joint-conv-math", default=None, help="joint leg: conv arithmetic (f32 | bf16x3 | bf16x2 | bf16); default bf16 with "
+                    "--joint-dtype bf16 (forward convolutions and data gradients; weight gradients accumulate fp32 products)")
     a = ap.parse_args()
     if a.vocab is None:
         a.vocab = 50000 if a.config == "joint" else 10000
@@ -364,7 +365,7 @@ def run_joint(args, dev, rank, world, barrier):
     cfg = Cfg()
     cfg.EMBEDDING_WEIGHTS = synth.embedding_matrix(3, V)
     model = DenseImageCapRCNN("training", cfg, "logs", device=dev, stage4_blocks=args.stage4_blocks, seed=0,
-                              conv_math=args.joint_conv_math, compute_dtype=args.joint_dtype)
+                              conv_math=args.joint_conv_math or ("bf16" if args.joint_dtype == "bf16" else None), compute_dtype=args.joint_dtype)
     # random FPN maps are O(10): keep the RPN / head activations in a trained network's range
     w = model.get_weights_dict()
     model.set_weights({"rpn_conv_shared/kernel": w["rpn_conv_shared/kernel"] * np.float32(0.02),
@@ -377,10 +378,13 @@ def run_joint(args, dev, rank, world, barrier):
     seed = 1234 + rank
     rng = np.random.RandomState(seed)
     img = synth.images(seed, 1, S, S)
-    n_gt = 40
-    y, x = rng.randint(0, S - 64, n_gt), rng.randint(0, S - 64, n_gt)
-    hh, ww = rng.randint(32, 400, n_gt), rng.randint(32, 400, n_gt)
-    boxes = np.stack([y, x, np.minimum(y + hh, S), np.minimum(x + ww, S)], axis=1).astype(np.int32)
+    # ground truth = 40 of the (random-weight) RPN's own proposals, so that DetectionTargetLayer finds its 66 positive RoIs
+    plan = inner.plan()
+    plan.forward(torch.as_tensor(img))
+    props = plan.proposals()[0].cpu().numpy().astype(np.float64) * S
+    big = props[((props[:, 2] - props[:, 0]) >= 32) & ((props[:, 3] - props[:, 1]) >= 32)]
+    boxes = np.rint(big[:40]).astype(np.int32)
+    n_gt = boxes.shape[0]
     caps = synth.captions_v1(seed + 2, n_gt, T, V, lmin=3, lmax=12).astype(np.int32)
     anchors = utils.generate_pyramid_anchors(cfg.RPN_ANCHOR_SCALES, cfg.RPN_ANCHOR_RATIOS, cfg.BACKBONE_SHAPES, cfg.BACKBONE_STRIDES, 1)
     match, deltas = build_rpn_targets(img[0].shape, anchors, caps, boxes, cfg, rng)
@@ -435,7 +439,7 @@ def main():
             "value": world * rois_per_step * args.steps / dt, "unit": "captions/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.joint_dtype == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[4]: dense_img_cap joint model train step: frozen ResNet-101 + trainable FPN/RPN + "
+            "config": {"positive_rois": inner.last_targets['npos'], "workload": "BASELINE configs[4]: dense_img_cap joint model train step: frozen ResNet-101 + trainable FPN/RPN + "
                                    "ProposalLayer(2000) + DetectionTargetLayer(200 RoIs) + RoIAlign + trainable RoI head + Model-3 decoder "
                                    "+ 4 losses + Adam(amsgrad, clipnorm 0.5); %dx%d synth image, 1 image/GPU, V=%d, %d-token captions"
                                    % (S, S, V, T), "images_per_gpu": 1, "rois_per_image": rois_per_step, "parallelism": "dp%d" % world,

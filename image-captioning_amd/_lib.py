@@ -47,7 +47,7 @@ class ConvDesc(C.Structure):
                 ("relu", C.c_int), ("split_k", C.c_int), ("accumulate", C.c_int), ("math", C.c_int), ("w_split", C.c_void_p)]
 
 
-MATH_F32, MATH_BF16X3, MATH_BF16X2 = 0, 1, 2
+MATH_F32, MATH_BF16X3, MATH_BF16X2, MATH_BF16 = 0, 1, 2, 3
 
 
 class RoiAlignDesc(C.Structure):
@@ -114,7 +114,8 @@ class AmsgradDesc(C.Structure):
     _fields_ = [("n", C.c_size_t), ("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p),
                 ("v", C.c_void_p), ("vhat", C.c_void_p),
                 ("lr_t", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("grad_scale", C.c_float), ("gnorm_sq", C.c_void_p), ("clipnorm", C.c_float)]
+                ("grad_scale", C.c_float), ("gnorm_sq", C.c_void_p), ("clipnorm", C.c_float),
+                ("p_bf16", C.c_void_p), ("n_bf16", C.c_size_t)]
 
 
 # name -> (restype, argtypes): every symbol include/dcap.h declares

@@ -156,8 +156,8 @@ extern "C" int dc_conv2d_nhwc_f32(const dc_conv_desc* d, void* workspace, size_t
     Epilogue ep{d->y, d->Cout, d->scale, d->shift, d->residual, d->Cout, d->res_mode, d->Ho, d->Wo, d->relu, 0, 0};
     ep.vec4 = (d->Cout & 3) == 0 && aligned16(d->y) && (!d->residual || aligned16(d->residual)) && (!d->scale || aligned16(d->scale)) &&
               (!d->shift || aligned16(d->shift));
-    DC_REQUIRE(d->math == DC_MATH_F32 || d->math == DC_MATH_BF16X3 || d->math == DC_MATH_BF16X2, DC_EINVAL, "dc_conv2d: unknown math mode %d",
-               d->math);
+    DC_REQUIRE(d->math == DC_MATH_F32 || d->math == DC_MATH_BF16X3 || d->math == DC_MATH_BF16X2 || d->math == DC_MATH_BF16, DC_EINVAL,
+               "dc_conv2d: unknown math mode %d", d->math);
     if (d->math != DC_MATH_F32) return conv2d_bf16x3(d, stem, ep, M, N, K, t.bm, t.bn, t.split, workspace, workspace_bytes, s);
     WeightKC bl{d->w, K, N, nullptr};
     if (stem) {

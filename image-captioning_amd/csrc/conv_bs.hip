@@ -18,6 +18,11 @@ static int bs_version() {
 template <class AL, class BL>
 static int dispatch_bs(const AL& al, const BL& bl, const Epilogue& ep, int M, int N, int K, int bm, int bn, int split, void* ws,
                        size_t wsb, hipStream_t s, int pieces) {
+    if (pieces == 1) {
+        if (bm == 128 && bn == 128) return launch_igemm_bs<128, 128, AL, BL, 1>(al, bl, ep, M, N, K, split, ws, wsb, s);
+        if (bm == 128 && bn == 64) return launch_igemm_bs<128, 64, AL, BL, 1>(al, bl, ep, M, N, K, split, ws, wsb, s);
+        return launch_igemm_bs<64, 64, AL, BL, 1>(al, bl, ep, M, N, K, split, ws, wsb, s);
+    }
     if (pieces == 2) {
         if (bm == 128 && bn == 128) return launch_igemm_bs<128, 128, AL, BL, 2>(al, bl, ep, M, N, K, split, ws, wsb, s);
         if (bm == 128 && bn == 64) return launch_igemm_bs<128, 64, AL, BL, 2>(al, bl, ep, M, N, K, split, ws, wsb, s);
@@ -48,7 +53,7 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
 
 int conv2d_bf16x3(const dc_conv_desc* d, bool stem, const Epilogue& ep, int M, int N, int K, int bm, int bn, int split, void* workspace,
                   size_t workspace_bytes, hipStream_t s) {
-    const int pieces = d->math == DC_MATH_BF16X2 ? 2 : 3;
+    const int pieces = d->math == DC_MATH_BF16 ? 1 : (d->math == DC_MATH_BF16X2 ? 2 : 3);
     if (stem) {
         WeightKCb bl{d->w, K, N, nullptr};
         StemKC al{d->x, d->H, d->W, d->Ho, d->Wo, M, (unsigned)((size_t)d->N * d->H * d->W * 4 * sizeof(float))};

@@ -60,10 +60,14 @@ __device__ __forceinline__ void store_split_kc(__bf16* S, const f4 (&r)[NR], int
     const int q = tid & 7, rr = tid >> 3;
 #pragma unroll
     for (int i = 0; i < BT / 32; ++i) {
+        __bf16* d = S + (rr + 32 * i) * LDB + 4 * q;
+        if constexpr (NP == 1) {                  // plain bf16 operands (DC_MATH_BF16): one rounding, no remainders
+            *reinterpret_cast<u32x2*>(d) = u32x2{cvt_pk_bf16(r[i][0], r[i][1]), cvt_pk_bf16(r[i][2], r[i][3])};
+            continue;
+        }
         unsigned a0, a1, a2, b0, b1, b2;
         split_pair(r[i][0], r[i][1], a0, a1, a2);
         split_pair(r[i][2], r[i][3], b0, b1, b2);
-        __bf16* d = S + (rr + 32 * i) * LDB + 4 * q;
         *reinterpret_cast<u32x2*>(d) = u32x2{a0, b0};
         *reinterpret_cast<u32x2*>(d + BT * LDB) = u32x2{a1, b1};
         if constexpr (NP == 3) *reinterpret_cast<u32x2*>(d + 2 * BT * LDB) = u32x2{a2, b2};      // NP == 2: the third piece is dead code
@@ -221,8 +225,10 @@ __global__ __launch_bounds__(256, 2) void igemm_bs_kernel(AL al, BL bl, Epilogue
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][1], c, 0, 0, 0);
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][2], c, 0, 0, 0);
                     }
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][1], c, 0, 0, 0);
+                    if constexpr (NP >= 2) {
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][1], b[tn][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][1], c, 0, 0, 0);
+                    }
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm][0], b[tn][0], c, 0, 0, 0);
                     acc[tm][tn] = c;
                 }

@@ -358,6 +358,11 @@ __global__ __launch_bounds__(256) void amsgrad_kernel(dc_amsgrad_desc d) {
         reinterpret_cast<float4*>(d.v)[i] = v;
         reinterpret_cast<float4*>(d.vhat)[i] = vh;
         reinterpret_cast<float4*>(d.p)[i] = p;
+        if (d.p_bf16 && 4 * i < d.n_bf16) {
+            typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+            auto bits = [](float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); };
+            reinterpret_cast<us4*>(d.p_bf16)[i] = us4{bits(p.x), bits(p.y), bits(p.z), bits(p.w)};
+        }
     }
     for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (size_t)gridDim.x * 256) {
         const float gg = d.g[i] * gscale;
@@ -527,6 +532,8 @@ extern "C" int dc_amsgrad_step_f32(const dc_amsgrad_desc* d, void* stream) {
     DC_REQUIRE(d && d->p && d->g && d->m && d->v && d->vhat && d->n > 0, DC_EINVAL, "dc_amsgrad_step: bad arguments");
     DC_REQUIRE(aligned16(d->p) && aligned16(d->g) && aligned16(d->m) && aligned16(d->v) && aligned16(d->vhat), DC_EALIGN,
                "dc_amsgrad_step: buffers must be 16-byte aligned");
+    DC_REQUIRE(!d->p_bf16 || ((d->n_bf16 & 3) == 0 && d->n_bf16 <= (d->n & ~(size_t)3) && (reinterpret_cast<uintptr_t>(d->p_bf16) & 7u) == 0), DC_EINVAL,
+               "dc_amsgrad_step: the bf16 shadow must be 8-byte aligned and cover a multiple of 4 elements inside the vectorised part of p");
     const int blocks = (int)std::min<size_t>((d->n / 4 + 255) / 256 + 1, (size_t)kNumCU * 8);
     hipLaunchKernelGGL(amsgrad_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), *d);
     return check_launch("amsgrad_kernel");

@@ -244,7 +244,11 @@ class DenseImageCapRCNN(object):
         "caption_only": r"imgcap\_.*",
     }
 
-    def __init__(self, mode, config, model_dir, device=None, stage4_blocks=22, seed=0, lstm_units=512, conv_math=None):
+    def __init__(self, mode, config, model_dir, device=None, stage4_blocks=22, seed=0, lstm_units=512, conv_math=None,
+                 compute_dtype="f32"):
+        """compute_dtype: 'f32', or 'bf16' = BASELINE configs[4]'s arithmetic for the RoI head, the caption decoder and the
+        vocabulary layers (bf16 copies of weights / activations on the bf16 matrix pipe, fp32 master weights and
+        accumulation; text_generation_model.CaptionModelV1).  conv_math selects the convolutions' arithmetic separately."""
         assert mode in ['training', 'inference']
         if config.IMAGES_PER_GPU != 1:
             raise ValueError("the joint model runs one image per GPU (train_dense_captions.py:27); scale out with ParallelModel")
@@ -255,6 +259,7 @@ class DenseImageCapRCNN(object):
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.stage4_blocks, self.units = stage4_blocks, lstm_units
         self.conv_math = conv_math          # None -> encoder default / DCAP_CONV_MATH; forward convs and data gradients
+        self.compute_dtype = compute_dtype
         self.epoch = 0
         self.A = len(config.RPN_ANCHOR_RATIOS)
         if 6 * self.A > HEAD_PAD:
@@ -285,7 +290,9 @@ class DenseImageCapRCNN(object):
         extra.append(("rpn_head/kernel", pack_conv_kernel(hk), True))
         extra.append(("rpn_head/bias", hb, True))
         self.caption_model = CaptionModelV1([cfg.POOL_SIZE, cfg.POOL_SIZE, 256], cfg, self.units, 'training', dev, seed,
-                                            extra_params=extra)
+                                            extra_params=extra, compute_dtype=self.compute_dtype)
+        # the L2 term and the trainable mask touch the whole gradient bucket after the decoder's backward: no early all-reduce
+        self.caption_model.overlap_sync = False
         self.store = self.caption_model.store
         self._plan = None
         self._reg_coef = None
@@ -297,6 +304,11 @@ class DenseImageCapRCNN(object):
             b = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
             self._bufs[key] = b
         return b
+
+    @property
+    def conv_math_name(self):
+        from .encoder import conv_math_name
+        return conv_math_name(self.plan().math)
 
     def plan(self):
         if self._plan is None:

@@ -26,9 +26,13 @@ def conv_math_mode(math=None):
     import os
     name = math if math is not None else os.environ.get("DCAP_CONV_MATH", DEFAULT_CONV_MATH)
     try:
-        return {"f32": _lib.MATH_F32, "bf16x3": _lib.MATH_BF16X3, "bf16x2": _lib.MATH_BF16X2}[name]
+        return {"f32": _lib.MATH_F32, "bf16x3": _lib.MATH_BF16X3, "bf16x2": _lib.MATH_BF16X2, "bf16": _lib.MATH_BF16}[name]
     except KeyError:
-        raise ValueError("conv math must be 'f32', 'bf16x3' or 'bf16x2', got %r" % (name,))
+        raise ValueError("conv math must be 'f32', 'bf16x3', 'bf16x2' or 'bf16', got %r" % (name,))
+
+
+def conv_math_name(mode):
+    return {_lib.MATH_F32: "f32", _lib.MATH_BF16X3: "bf16x3", _lib.MATH_BF16X2: "bf16x2", _lib.MATH_BF16: "bf16"}.get(mode, str(mode))
 
 
 def fuse_rpn_head(weights, channels=None):

@@ -573,7 +573,7 @@ def mean(x, out=None):
     return out
 
 
-def amsgrad_step(p, g, m, v, vhat, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, gnorm_sq=None, clipnorm=0.0):
+def amsgrad_step(p, g, m, v, vhat, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, gnorm_sq=None, clipnorm=0.0, p_bf16=None):
     lib = _lib.load()
     d = AmsgradDesc()
     d.n = p.numel()
@@ -582,4 +582,6 @@ def amsgrad_step(p, g, m, v, vhat, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_
     d.grad_scale = float(grad_scale)
     d.gnorm_sq = None if gnorm_sq is None else gnorm_sq.data_ptr()
     d.clipnorm = float(clipnorm or 0.0)
+    if p_bf16 is not None:
+        d.p_bf16, d.n_bf16 = _chk(p_bf16, BF16, "p_bf16").data_ptr(), p_bf16.numel()
     check(lib.dc_amsgrad_step_f32(C.byref(d), _stream()), "dc_amsgrad_step_f32")

@@ -35,16 +35,49 @@ class ParamStore:
             flat[o:o + a.size] = a.reshape(-1)
         self.flat = torch.tensor(flat, device=self.device)
         self.flat_grad = torch.zeros_like(self.flat)
+        self._ranges, covered = {}, {}
         for name, o, shape in layout:
             n = int(np.prod(shape))
+            layer = name.split('/')[0]
+            lo, hi = self._ranges.get(layer, (o, o))
+            self._ranges[layer] = (min(lo, o), max(hi, o + (n + 3) // 4 * 4))
+            covered[layer] = covered.get(layer, 0) + (n + 3) // 4 * 4
             self.w[name] = self.flat[o:o + n].view(*shape)
             self.grad[name] = self.flat_grad[o:o + n].view(*shape)
             self.trainable_names.append(name)
+        # a layer whose weights are not adjacent in the bucket has no range of its own
+        self._ranges = {k: r for k, r in self._ranges.items() if r[1] - r[0] == covered[k]}
         for name, a in self._frozen:
             self.w[name] = torch.tensor(a, device=self.device)
             self.frozen_names.append(name)
         self._train = self._frozen = None
+        self.flat_bf16, self.wb = None, {}
         return self
+
+    def enable_bf16_shadow(self, names=None):
+        """bf16 copies of the trainable weights `names` (default: all) for the bf16 GEMMs: ONE bf16 buffer mirroring the
+        head of the flat bucket up to the last of those weights (fp32 stays the master the optimizer updates; the AMSGrad
+        kernel refreshes the mirror in the same pass).  self.wb[name] are views shaped like self.w[name]."""
+        names = list(self.trainable_names if names is None else names)
+        base = self.flat.data_ptr()
+        end = max((self.w[n].data_ptr() - base) // 4 + (self.w[n].numel() + 3) // 4 * 4 for n in names)
+        self.flat_bf16 = torch.empty(end, dtype=torch.bfloat16, device=self.device)
+        for n in names:
+            o = (self.w[n].data_ptr() - base) // 4
+            self.wb[n] = self.flat_bf16[o:o + self.w[n].numel()].view(*self.w[n].shape)
+        self.refresh_shadow()
+        return self
+
+    def refresh_shadow(self):
+        if self.flat_bf16 is not None:
+            ops.to_bf16(self.flat[:self.flat_bf16.numel()], out=self.flat_bf16)
+
+    def layer_range(self, layer):
+        """[lo, hi) of the flat buckets holding every trainable weight of `layer` (a layer's weights are adjacent: the
+        bucket is laid out in name order).  The unit of the bucketed gradient all-reduce."""
+        if layer not in self._ranges:
+            raise KeyError("layer %r has no contiguous range in the parameter bucket" % layer)
+        return self._ranges[layer]
 
     def to_numpy(self):
         return {k: v.detach().cpu().numpy() for k, v in self.w.items()}
@@ -55,6 +88,8 @@ class ParamStore:
         if tuple(a.shape) != tuple(t.shape):
             raise ValueError("shape mismatch for %s: %s vs %s" % (name, a.shape, tuple(t.shape)))
         t.copy_(torch.tensor(a, device=self.device))
+        if self.flat_bf16 is not None and name in self.wb:
+            self.refresh_shadow()
 
 
 class Adam:
@@ -95,4 +130,4 @@ class Adam:
         if self.clipnorm:
             gn = ops.sumsq(store.flat_grad, out=self._gnorm)
         ops.amsgrad_step(store.flat, store.flat_grad, m, v, vh, self.lr_t(), self.beta_1, self.beta_2, self.epsilon,
-                         grad_scale=grad_scale, gnorm_sq=gn, clipnorm=self.clipnorm or 0.0)
+                         grad_scale=grad_scale, gnorm_sq=gn, clipnorm=self.clipnorm or 0.0, p_bf16=getattr(store, "flat_bf16", None))

@@ -144,15 +144,36 @@ def build_lstm_model(features_input, config, units, mode, device=None, seed=0):
     return CaptionModelV1(features_input, config, units, mode, device, seed)
 
 
+class _Act(object):
+    """An activation (or gradient) matrix with its lazily made bf16 copy (the operand the bf16 GEMMs read)."""
+    __slots__ = ("f", "_b", "_model", "_key")
+
+    def __init__(self, model, key, f, b=None):
+        self.f, self._b, self._model, self._key = f, b, model, key
+
+    @property
+    def b(self):
+        if self._b is None:
+            self._b = ops.to_bf16(self.f, out=self._model._buf(self._key + ':bf16', tuple(self.f.shape), torch.bfloat16))
+        return self._b
+
+
 class CaptionModelV1(KerasLikeModel):
     FEAT = 1024
     D1 = 1024
     HEAD = (("mrcnn_class_conv1", "mrcnn_class_bn1"), ("mrcnn_class_conv2", "mrcnn_class_bn2"))
+    overlap_sync = True        # data parallel: all-reduce a layer group's gradients as soon as its backward is enqueued
 
-    def __init__(self, features_input, config, units, mode, device=None, seed=0, extra_params=()):
+    def __init__(self, features_input, config, units, mode, device=None, seed=0, extra_params=(), compute_dtype="f32"):
         """extra_params: (name, array, trainable) entries that share this model's flat parameter bucket (the joint
-        model's FPN/RPN weights: one optimizer launch and one gradient all-reduce cover everything)."""
+        model's FPN/RPN weights: one optimizer launch and one gradient all-reduce cover everything).
+        compute_dtype: 'f32' (exact fp32 MFMA products, the separate-models configs) or 'bf16' (BASELINE configs[4]:
+        RoI head, decoder and vocabulary GEMMs on the bf16 matrix pipe from bf16 copies of weights and activations; fp32
+        master weights, fp32 accumulation, fp32 LSTM recurrence / gates / BN / softmax statistics)."""
+        if compute_dtype not in ("f32", "bf16"):
+            raise ValueError("compute_dtype must be 'f32' or 'bf16'")
         self.features_input, self.config, self.units, self.mode = list(features_input), config, units, mode
+        self.compute_dtype = compute_dtype
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.V, self.E, self.T = int(config.VOCABULARY_SIZE), int(config.EMBEDDING_SIZE), int(config.PADDING_SIZE)
         if self.E % 4 or self.V % 4:
@@ -162,12 +183,17 @@ class CaptionModelV1(KerasLikeModel):
         W.update(synth.v1_weights(seed + 2, self.V, self.E, units, self.FEAT))
         W['imgcap_embedding_layer/embeddings'] = np.asarray(config.EMBEDDING_WEIGHTS, np.float32)
         st = ParamStore(self.device)
+        own = []
         for k in sorted(W):
             frozen = k.startswith('imgcap_embedding') or 'moving_' in k
             st.add(k, W[k], not frozen)
+            if not frozen and k.endswith('kernel') and 'recurrent' not in k:
+                own.append(k)
         for name, array, trainable in extra_params:
             st.add(name, array, trainable)
         self.store = st.finalize()
+        if compute_dtype == "bf16":
+            st.enable_bf16_shadow(own)                    # GEMM kernels only: biases, BN parameters and the recurrences stay fp32
         self.grad_sync = None
         self._bufs = {}
 
@@ -176,44 +202,93 @@ class CaptionModelV1(KerasLikeModel):
 
     def _buf(self, key, shape, dtype=torch.float32):
         b = self._bufs.get(key)
-        if b is None or tuple(b.shape) != tuple(shape):
+        if b is None or tuple(b.shape) != tuple(shape) or b.dtype != dtype:
             b = torch.empty(shape, dtype=dtype, device=self.device)
             self._bufs[key] = b
         return b
 
+    def _grads_ready(self, *layers):
+        """Data parallel: these layers' gradients are final -- start their all-reduce while the backward goes on."""
+        if self.overlap_sync and self.grad_sync is not None and hasattr(self.grad_sync, 'ready'):
+            for layer in layers:
+                lo, hi = self.store.layer_range(layer)
+                self.grad_sync.ready(self.store.flat_grad, lo, hi)
+
     # ---------------------------------------------------------------------------------- engine
+    def _act(self, key, f):
+        return _Act(self, key, f)
+
+    def _wview(self, name, rows=None):
+        """(fp32 view, bf16 view or None) of a 2-D weight (conv kernels flattened to [k*k*cin, cout]), optionally a row range."""
+        w = self.store.w[name]
+        w = w.view(-1, w.shape[-1])
+        wb = self.store.wb.get(name)
+        if wb is not None:
+            wb = wb.view(-1, wb.shape[-1])
+        if rows is not None:
+            w = w[rows[0]:rows[1]]
+            wb = None if wb is None else wb[rows[0]:rows[1]]
+        return w, wb
+
+    def _mm(self, A, W, key=None, out=None, a_trans=False, b_trans=False, want_b=False, **ep):
+        """op(A) @ op(W) with the fused epilogue `ep`.  A: _Act; W: (fp32, bf16-or-None) weight views or an _Act.  Runs on
+        the bf16 matrix pipe when this model computes in bf16 and the shapes fit dc_gemm_bf16 (16-byte chunks along K),
+        else on the fp32 MFMA path.  Returns an _Act of the fp32 result (with its bf16 copy when want_b)."""
+        wf, wb = (W.f, None) if isinstance(W, _Act) else W
+        Af = A.f
+        M = Af.shape[1] if a_trans else Af.shape[0]
+        K = Af.shape[0] if a_trans else Af.shape[1]
+        N = wf.shape[0] if b_trans else wf.shape[1]
+        if out is None:
+            out = self._buf(key, (M, N))
+        use_b = (self.compute_dtype == "bf16" and K % 8 == 0 and Af.stride(0) % 8 == 0 and wf.stride(0) % 8 == 0 and
+                 (not a_trans or M % 8 == 0) and (b_trans or N % 8 == 0) and (isinstance(W, _Act) or wb is not None))
+        if use_b:
+            if isinstance(W, _Act):
+                wb = W.b
+            ob = self._buf((key or 'mm') + ':outb', (M, N), torch.bfloat16) if want_b else None
+            ops.gemm_bf16(A.b, wb, out=out, out_bf16=ob, a_trans=a_trans, b_trans=b_trans, **ep)
+            return _Act(self, key or 'mm', out, ob)
+        ops.gemm(Af, wf, out=out, a_trans=a_trans, b_trans=b_trans, **ep)
+        return _Act(self, key or 'mm', out)
+
     def _head_forward(self, X):
         w = self.store.w
         R = X.shape[0]
-        x = X
+        x = self._act('X', X)
+        self._head_in = []
         for li, (conv, bn) in enumerate(self.HEAD):
-            k = w[conv + '/kernel']
-            acc = ops.gemm(x, k.view(-1, k.shape[-1]), out=self._buf('acc%d' % li, (R, self.FEAT)))
-            x = ops.bn_relu_fwd(acc, w[conv + '/bias'], w[bn + '/gamma'], w[bn + '/beta'], w[bn + '/moving_mean'],
+            self._head_in.append(x)
+            acc = self._mm(x, self._wview(conv + '/kernel'), key='acc%d' % li).f
+            y = ops.bn_relu_fwd(acc, w[conv + '/bias'], w[bn + '/gamma'], w[bn + '/beta'], w[bn + '/moving_mean'],
                                 w[bn + '/moving_variance'], self._buf('hact%d' % li, (R, self.FEAT)))
+            x = self._act('hact%d' % li, y)
         return x
 
-    def _word_model(self, f, ids_tm, mask, B, T, want_grad_ctx=True):
-        """word_generation_model over time-major token ids: returns logits [T*B, V] (row t*B+b = output after
-        step t, i.e. for the prefix c_0..c_t)."""
+    def _hidden(self, f, ids_tm, mask, B, T):
+        """word_generation_model up to the Dense-1024 layer, over time-major token ids: a1 [T*B, 1024] (row t*B+b = the
+        state after step t, i.e. for the prefix c_0..c_t)."""
         w, u = self.store.w, self.units
-        W1 = w['imgcap_lstm1/kernel']
-        zf = ops.gemm(f, W1[self.E:], out=self._buf('zf', (B, 4 * u)))                       # per-RoI half of x.W
-        z1 = ops.gemm(w['imgcap_embedding_layer/embeddings'], W1[:self.E], gather=ids_tm, shift=w['imgcap_lstm1/bias'],
+        zf = self._mm(f, self._wview('imgcap_lstm1/kernel', (self.E, self.E + self.FEAT)), key='zf').f        # per-RoI half of x.W
+        z1 = ops.gemm(w['imgcap_embedding_layer/embeddings'], w['imgcap_lstm1/kernel'][:self.E], gather=ids_tm, shift=w['imgcap_lstm1/bias'],
                       residual=zf, res_rows=B, out=self._buf('z1', (T * B, 4 * u)))
         h1, c1 = ops.lstm_seq_fwd(z1, w['imgcap_lstm1/recurrent_kernel'], mask, B, T, self._buf('h1', (T * B, u)),
                                   self._buf('c1', (T * B, u)))
-        z2 = ops.gemm(h1, w['imgcap_lstm2/kernel'], shift=w['imgcap_lstm2/bias'], out=self._buf('z2', (T * B, 4 * u)))
+        self._h1 = self._act('h1', h1)
+        z2 = self._mm(self._h1, self._wview('imgcap_lstm2/kernel'), key='z2', shift=w['imgcap_lstm2/bias']).f
         h2, c2 = ops.lstm_seq_fwd(z2, w['imgcap_lstm2/recurrent_kernel'], mask, B, T, self._buf('h2', (T * B, u)),
                                   self._buf('c2', (T * B, u)))
-        Wd1 = w['imgcap_lstm_d1/kernel']
-        zdf = ops.gemm(f, Wd1[u:], out=self._buf('zdf', (B, self.D1)))
-        a1 = ops.gemm(h2, Wd1[:u], shift=w['imgcap_lstm_d1/bias'], residual=zdf, res_rows=B, relu=True,
-                      out=self._buf('a1', (T * B, self.D1)))
+        self._h2 = self._act('h2', h2)
+        zdf = self._mm(f, self._wview('imgcap_lstm_d1/kernel', (u, u + self.FEAT)), key='zdf').f
+        return self._mm(self._h2, self._wview('imgcap_lstm_d1/kernel', (0, u)), key='a1', shift=w['imgcap_lstm_d1/bias'], residual=zdf,
+                        res_rows=B, relu=True, want_b=True)
+
+    def _word_model(self, f, ids_tm, mask, B, T):
+        """Logits [T*B, V] of the whole word model (inference / predict path; training never materialises them)."""
+        a1 = self._hidden(f, ids_tm, mask, B, T)
+        w = self.store.w
         Vp = (self.V + 3) // 4 * 4
-        logits = ops.gemm(a1, w['imgcap_lstm_d2/kernel'], shift=w['imgcap_lstm_d2/bias'],
-                          out=self._buf('logits', (T * B, Vp))[:, :self.V])
-        return logits
+        return ops.gemm(a1.f, w['imgcap_lstm_d2/kernel'], shift=w['imgcap_lstm_d2/bias'], out=self._buf('logits', (T * B, Vp))[:, :self.V])
 
     def _tables(self, caps):
         caps = np.asarray(caps)
@@ -228,9 +303,9 @@ class CaptionModelV1(KerasLikeModel):
         ids_tm, mask, B, T = self._tables(caps)
         X = feat.reshape(B, -1)
         f = self._head_forward(X)
-        logits = self._word_model(f, ids_tm, mask, B, T)
+        a1 = self._hidden(f, ids_tm, mask, B, T)
+        w, g = self.store.w, self.store.grad
         N = T * B
-        probs = self._buf('probs', tuple(self._bufs['logits'].shape))[:, :self.V] if want_probs else None
         tg = loss_rows = None
         if targets is not None:
             tg = torch.tensor(np.ascontiguousarray(np.asarray(targets, np.int32).T.reshape(-1)), device=self.device)
@@ -238,60 +313,88 @@ class CaptionModelV1(KerasLikeModel):
         rw = None
         if row_weights is not None:
             rw = torch.tensor(np.ascontiguousarray(np.asarray(row_weights, np.float32).T.reshape(-1)), device=self.device)
-        ops.softmax_ce(logits, tg, probs, loss_rows, logits if want_grad else None, grad_scale=1.0 if rw is not None else 1.0 / N,
-                       row_weights=rw, keras_sparse=keras_sparse)
-        self._ctx = (X, f, ids_tm, mask, B, T)
+        gscale = 1.0 if rw is not None else 1.0 / N
+        Wv, Wvb = self._wview('imgcap_lstm_d2/kernel')
+        probs = dl = None
+        bf = Wvb is not None and a1._b is not None and N % 8 == 0 and ops.vocab_ce_supported(a1._b, Wvb)
+        if not want_probs and tg is not None and (bf or ops.vocab_ce_supported(a1.f, Wv)):
+            # Dense(V) + softmax + cross-entropy fused into the GEMM: no [N,V] logits; d(loss)/d(logits) in the compute dtype
+            if want_grad:
+                if bf:
+                    dl = _Act(self, 'dlogits', None, self._buf('dlogits:bf16', (N, (self.V + 7) // 8 * 8), torch.bfloat16)[:, :self.V])
+                else:
+                    dl = self._act('dlogits', self._buf('dlogits', (N, (self.V + 3) // 4 * 4))[:, :self.V])
+            ops.vocab_ce(a1._b if bf else a1.f, Wvb if bf else Wv, w['imgcap_lstm_d2/bias'], tg, loss_rows=loss_rows,
+                         dlogits=None if dl is None else (dl._b if bf else dl.f), dbias=g['imgcap_lstm_d2/bias'] if want_grad else None,
+                         grad_scale=gscale, row_weights=rw, keras_sparse=keras_sparse)
+        else:
+            Vp = (self.V + 3) // 4 * 4
+            logits = ops.gemm(a1.f, Wv, shift=w['imgcap_lstm_d2/bias'], out=self._buf('logits', (N, Vp))[:, :self.V])
+            probs = self._buf('probs', (N, Vp))[:, :self.V] if want_probs else None
+            ops.softmax_ce(logits, tg, probs, loss_rows, logits if want_grad else None, grad_scale=gscale, row_weights=rw, keras_sparse=keras_sparse)
+            if want_grad:
+                dl = self._act('logits', logits)
+                ops.colsum(logits, out=g['imgcap_lstm_d2/bias'])
+        self._ctx = (X, f, a1, dl, ids_tm, mask, B, T)
         return loss_rows, probs
 
     def _backward(self, want_dx=False):
         """Gradients of every trainable weight into the flat bucket; with want_dx also returns the gradient w.r.t.
         the flattened RoI features [B, pool*pool*C] (the joint model backpropagates it through RoIAlign)."""
         w, g, u = self.store.w, self.store.grad, self.units
-        X, f, ids_tm, mask, B, T = self._ctx
+        X, f, a1, dl, ids_tm, mask, B, T = self._ctx
         bf = self._bufs
-        dlogits = bf['logits'][:, :self.V]
-        a1, h2, h1 = bf['a1'], bf['h2'], bf['h1']
+        h1, h2 = self._h1, self._h2
         N = T * B
-        ops.gemm(a1, dlogits, a_trans=True, out=g['imgcap_lstm_d2/kernel'])
-        ops.colsum(dlogits, out=g['imgcap_lstm_d2/bias'])
-        da1 = ops.gemm(dlogits, w['imgcap_lstm_d2/kernel'], b_trans=True, out=self._buf('da1', (N, self.D1)))
-        dz_d1 = ops.relu_bwd(da1, a1, da1)
-        Wd1, gWd1 = w['imgcap_lstm_d1/kernel'], g['imgcap_lstm_d1/kernel']
-        ops.gemm(h2, dz_d1, a_trans=True, out=gWd1[:u])
-        ops.colsum(dz_d1, out=g['imgcap_lstm_d1/bias'])
-        dzd_f = ops.fold_time(dz_d1, T, B, self._buf('dzd_f', (B, self.D1)))
-        ops.gemm(f, dzd_f, a_trans=True, out=gWd1[u:])
-        df = ops.gemm(dzd_f, Wd1[u:], b_trans=True, out=self._buf('df', (B, self.FEAT)))
-        dh2 = ops.gemm(dz_d1, Wd1[:u], b_trans=True, out=self._buf('dh2', (N, u)))
+        if dl.f is None:                                   # bf16 gradient of the fused loss: both products on the bf16 pipe
+            ops.gemm_bf16(a1.b, dl.b, a_trans=True, out=g['imgcap_lstm_d2/kernel'])
+            da1 = ops.gemm_bf16(dl.b, self.store.wb['imgcap_lstm_d2/kernel'], b_trans=True, out=self._buf('da1', (N, self.D1)))
+        else:
+            ops.gemm(a1.f, dl.f, a_trans=True, out=g['imgcap_lstm_d2/kernel'])
+            da1 = ops.gemm(dl.f, w['imgcap_lstm_d2/kernel'], b_trans=True, out=self._buf('da1', (N, self.D1)))
+        self._grads_ready('imgcap_lstm_d2')
+        dz_d1 = self._act('dz_d1', ops.relu_bwd(da1, a1.f, da1))
+        gWd1 = g['imgcap_lstm_d1/kernel']
+        self._mm(h2, dz_d1, a_trans=True, out=gWd1[:u])
+        ops.colsum(dz_d1.f, out=g['imgcap_lstm_d1/bias'])
+        dzd_f = self._act('dzd_f', ops.fold_time(dz_d1.f, T, B, self._buf('dzd_f', (B, self.D1))))
+        self._mm(f, dzd_f, a_trans=True, out=gWd1[u:])
+        self._grads_ready('imgcap_lstm_d1')
+        df = self._mm(dzd_f, self._wview('imgcap_lstm_d1/kernel', (u, u + self.FEAT)), key='df', b_trans=True).f
+        dh2 = self._mm(dz_d1, self._wview('imgcap_lstm_d1/kernel', (0, u)), key='dh2', b_trans=True).f
         # lstm2
-        dz2, _ = ops.lstm_seq_bwd(bf['z2'], w['imgcap_lstm2/recurrent_kernel'], mask, h2, bf['c2'], B, T, dh_seq=dh2,
+        dz2, _ = ops.lstm_seq_bwd(bf['z2'], w['imgcap_lstm2/recurrent_kernel'], mask, h2.f, bf['c2'], B, T, dh_seq=dh2,
                                   dz=self._buf('dz2', (N, 4 * u)), dU=g['imgcap_lstm2/recurrent_kernel'])
-        ops.gemm(h1, dz2, a_trans=True, out=g['imgcap_lstm2/kernel'])
-        ops.colsum(dz2, out=g['imgcap_lstm2/bias'])
-        dh1 = ops.gemm(dz2, w['imgcap_lstm2/kernel'], b_trans=True, out=self._buf('dh1', (N, u)))
+        dz2 = self._act('dz2', dz2)
+        self._mm(h1, dz2, a_trans=True, out=g['imgcap_lstm2/kernel'])
+        ops.colsum(dz2.f, out=g['imgcap_lstm2/bias'])
+        self._grads_ready('imgcap_lstm2')
+        dh1 = self._mm(dz2, self._wview('imgcap_lstm2/kernel'), key='dh1', b_trans=True).f
         # lstm1
-        dz1, _ = ops.lstm_seq_bwd(bf['z1'], w['imgcap_lstm1/recurrent_kernel'], mask, h1, bf['c1'], B, T, dh_seq=dh1,
+        dz1, _ = ops.lstm_seq_bwd(bf['z1'], w['imgcap_lstm1/recurrent_kernel'], mask, h1.f, bf['c1'], B, T, dh_seq=dh1,
                                   dz=self._buf('dz1', (N, 4 * u)), dU=g['imgcap_lstm1/recurrent_kernel'])
-        W1, gW1 = w['imgcap_lstm1/kernel'], g['imgcap_lstm1/kernel']
+        gW1 = g['imgcap_lstm1/kernel']
         ops.gemm(w['imgcap_embedding_layer/embeddings'], dz1, a_trans=True, gather=ids_tm, out=gW1[:self.E])
         ops.colsum(dz1, out=g['imgcap_lstm1/bias'])
-        dzf = ops.fold_time(dz1, T, B, self._buf('dzf', (B, 4 * u)))
-        ops.gemm(f, dzf, a_trans=True, out=gW1[self.E:])
-        ops.gemm(dzf, W1[self.E:], b_trans=True, out=df, accumulate=True)
+        dzf = self._act('dzf', ops.fold_time(dz1, T, B, self._buf('dzf', (B, 4 * u))))
+        self._mm(f, dzf, a_trans=True, out=gW1[self.E:])
+        self._grads_ready('imgcap_lstm1')
+        self._mm(dzf, self._wview('imgcap_lstm1/kernel', (self.E, self.E + self.FEAT)), out=df, b_trans=True, accumulate=True)
         # trainable head (kernels, biases, BN gamma/beta; statistics frozen)
         dy = df
-        inputs = [X, bf['hact0']]
         for li in (1, 0):
             conv, bn = self.HEAD[li]
             dacc = ops.bn_relu_bwd(bf['acc%d' % li], w[conv + '/bias'], w[bn + '/gamma'], w[bn + '/beta'], w[bn + '/moving_mean'],
                                    w[bn + '/moving_variance'], dy, self._buf('dacc%d' % li, (B, self.FEAT)),
                                    g[bn + '/gamma'], g[bn + '/beta'], g[conv + '/bias'])
-            k, gk = w[conv + '/kernel'], g[conv + '/kernel']
-            ops.gemm(inputs[li], dacc, a_trans=True, out=gk.view(-1, gk.shape[-1]))
+            dacc = self._act('dacc%d' % li, dacc)
+            gk = g[conv + '/kernel']
+            self._mm(self._head_in[li], dacc, a_trans=True, out=gk.view(-1, gk.shape[-1]))
+            self._grads_ready(conv, bn)
             if li == 1:
-                dy = ops.gemm(dacc, k.view(-1, k.shape[-1]), b_trans=True, out=self._buf('dhact0', (B, self.FEAT)))
+                dy = self._mm(dacc, self._wview(conv + '/kernel'), key='dhact0', b_trans=True).f
             elif want_dx:
-                return ops.gemm(dacc, k.view(-1, k.shape[-1]), b_trans=True, out=self._buf('dX', tuple(X.shape)))
+                return self._mm(dacc, self._wview(conv + '/kernel'), key='dX', b_trans=True).f
         return None
 
     def train_step(self, feat, caps, targets):

@@ -272,12 +272,25 @@ class CaptionModelV2(KerasLikeModel):
                                        self._buf('h2', (N, u)), self._buf('c2', (N, u)))
         else:
             top = cat
+        Wv, bv = w['imgcap_d1/kernel'], w['imgcap_d1/bias']
         Vp = (self.V + 3) // 4 * 4
-        logits = ops.gemm(top, w['imgcap_d1/kernel'], shift=w['imgcap_d1/bias'], out=self._buf('logits', (N, Vp))[:, :self.V])
-        probs = self._buf('probs', (N, Vp))[:, :self.V] if want_probs else None
         loss_rows = self._buf('loss_rows', (N,)) if tb.targets is not None else None
-        ops.softmax_ce(logits, tb.targets, probs, loss_rows, logits if want_grad else None, grad_scale=1.0 / N)
-        self._ctx = (tb, zx, h_seq, c_seq, cat, top, logits)
+        probs = dlog = None
+        if not want_probs and tb.targets is not None and ops.vocab_ce_supported(top, Wv):
+            # training / evaluation: Dense(V) + softmax + categorical cross-entropy fused into the GEMM (dc_vocab_ce); the
+            # [N,V] logits are never written, only d(loss)/d(logits) (and its column sums = the bias gradient) when asked for
+            if want_grad:
+                dlog = self._buf('dlogits', (N, Vp))[:, :self.V]
+            ops.vocab_ce(top, Wv, bv, tb.targets, loss_rows=loss_rows, dlogits=dlog, dbias=self.store.grad['imgcap_d1/bias'] if want_grad else None,
+                         grad_scale=1.0 / N)
+        else:                                     # predict(): the probabilities themselves are the output
+            logits = ops.gemm(top, Wv, shift=bv, out=self._buf('dlogits', (N, Vp))[:, :self.V])
+            probs = self._buf('probs', (N, Vp))[:, :self.V] if want_probs else None
+            dlog = logits if want_grad else None
+            ops.softmax_ce(logits, tb.targets, probs, loss_rows, dlog, grad_scale=1.0 / N)
+            if want_grad:
+                ops.colsum(dlog, out=self.store.grad['imgcap_d1/bias'])
+        self._ctx = (tb, zx, h_seq, c_seq, cat, top, dlog)
         return loss_rows, probs
 
     def _backward(self):
@@ -286,8 +299,8 @@ class CaptionModelV2(KerasLikeModel):
         w, g = self.store.w, self.store.grad
         tb, zx, h_seq, c_seq, cat, top, dlogits = self._ctx
         N, T, Bw, U = tb.N, tb.T, tb.Bw, self.WORD_UNITS
-        ops.gemm(top, dlogits, a_trans=True, out=g['imgcap_d1/kernel'])
-        ops.colsum(dlogits, out=g['imgcap_d1/bias'])
+        ops.gemm(top, dlogits, a_trans=True, out=g['imgcap_d1/kernel'])          # (the bias gradient came with the forward)
+        self._grads_ready('imgcap_d1')
         dtop = ops.gemm(dlogits, w['imgcap_d1/kernel'], b_trans=True, out=self._buf('dtop', (N, top.shape[1])))
         if self.inject:
             u = self.units
@@ -296,6 +309,7 @@ class CaptionModelV2(KerasLikeModel):
                                       dz=self._buf('dz2', (N, 4 * u)), dU=g['imgcap_lstm/recurrent_kernel'])
             ops.gemm(cat, dz2, a_trans=True, out=g['imgcap_lstm/kernel'])
             ops.colsum(dz2, out=g['imgcap_lstm/bias'])
+            self._grads_ready('imgcap_lstm')
             dword = ops.gemm(dz2, w['imgcap_lstm/kernel'][self.FEAT:], b_trans=True, out=self._buf('dword', (N, U)))
         else:
             dword = dtop[:, self.FEAT:]
@@ -304,6 +318,12 @@ class CaptionModelV2(KerasLikeModel):
                                  dz=self._buf('dz', (T * Bw, 4 * U)), dU=g[V2_WORD_LSTM + '/recurrent_kernel'])
         ops.gemm(w['imgcap_embedding_layer/embeddings'], dz, a_trans=True, gather=tb.ids_tm, out=g[V2_WORD_LSTM + '/kernel'])
         ops.colsum(dz, out=g[V2_WORD_LSTM + '/bias'])
+
+    def _grads_ready(self, layer):
+        """Data parallel: this layer's gradients are final -- start their all-reduce while the backward goes on."""
+        if self.grad_sync is not None and hasattr(self.grad_sync, 'ready'):
+            lo, hi = self.store.layer_range(layer)
+            self.grad_sync.ready(self.store.flat_grad, lo, hi)
 
     def train_step(self, feat, tb):
         """forward + backward + (all-reduce) + AMSGrad; returns the loss as a DEVICE scalar (no sync)."""

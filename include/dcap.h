@@ -114,6 +114,7 @@ int dc_cast_f32_bf16_2d(const float* x, int ld_in, uint16_t* out, int ld_out, in
 #define DC_MATH_F32 0
 #define DC_MATH_BF16X3 1
 #define DC_MATH_BF16X2 2
+#define DC_MATH_BF16 3
 typedef struct {
     int N, H, W, Cin;
     int Cout, kh, kw, stride, pad_t, pad_l;
@@ -130,7 +131,9 @@ typedef struct {
     int math;                 /* forward only: DC_MATH_F32 = fp32 MFMA (exact fp32 products), DC_MATH_BF16X3 = every operand
                                  element split into three bf16 pieces, six bf16 MFMA products, fp32 accumulate (fp32-grade
                                  accuracy on the bf16 matrix pipe; csrc/igemm_bf16s.h); DC_MATH_BF16X2 = two pieces, three
-                                 products: a 16-bit-mantissa product (2^-16 relative; TF32 is 2^-11) at half the MFMAs */
+                                 products: a 16-bit-mantissa product (2^-16 relative; TF32 is 2^-11) at half the MFMAs;
+                                 DC_MATH_BF16 = operands rounded once to bf16, one product, fp32 accumulate -- plain bf16 compute,
+                                 the arithmetic BASELINE configs[4] names (2^-9 relative per operand) */
     const uint16_t* w_split;  /* optional with DC_MATH_BF16X3: the weights already split by dc_split_bf16x3_f32 into three bf16
                                  planes [3][Cout][kh*kw*Cin] (same packing as w); NULL = split on the fly from w */
 } dc_conv_desc;
@@ -430,6 +433,8 @@ typedef struct {
     float grad_scale;
     const float* gnorm_sq;
     float clipnorm;
+    uint16_t* p_bf16;         /* optional: bf16 shadow of p (the operand copy the bf16 GEMMs read), refreshed in the same pass */
+    size_t n_bf16;            /* the shadow covers p[0 .. n_bf16) (a multiple of 4) */
 } dc_amsgrad_desc;
 
 int dc_amsgrad_step_f32(const dc_amsgrad_desc* d, void* stream);

@@ -92,3 +92,84 @@ def test_decoder_edge_cases(ops):
     p1 = model.predict([feat[:1], np.zeros((1, T), np.int32)])        # all-padding prefix: word vector = zeros
     want, _ = M.v2_forward(Wt, feat[:1], np.zeros((1, T), np.int32))
     assert np.abs(p1 - want).max() < 1e-5
+
+
+def _full_size_joint(compute_dtype, V=50000):
+    """BASELINE configs[4] at its real size: 1024 x 1024 image, ResNet-101 + FPN + RPN, 2000 proposals -> 200 RoIs, 15-token
+    captions, V = 50 000 (the setup of bench.py --config joint)."""
+    from image_captioning_amd import synth, utils
+    from image_captioning_amd.config import Config
+    from image_captioning_amd.dense_model import DenseImageCapRCNN, build_rpn_targets
+    S, T = 1024, 15
+
+    class Cfg(Config):
+        NAME = "joint"
+        IMAGES_PER_GPU = 1
+        IMAGE_MIN_DIM = S
+        IMAGE_MAX_DIM = S
+        PADDING_SIZE = T
+        VOCABULARY_SIZE = V
+        EMBEDDING_SIZE = 300
+    cfg = Cfg()
+    cfg.EMBEDDING_WEIGHTS = synth.embedding_matrix(3, V)
+    model = DenseImageCapRCNN("training", cfg, "logs", compute_dtype=compute_dtype)
+    w = model.get_weights_dict()
+    model.set_weights({"rpn_conv_shared/kernel": w["rpn_conv_shared/kernel"] * np.float32(0.02),
+                       "rpn_bbox_pred/kernel": w["rpn_bbox_pred/kernel"] * np.float32(0.3),
+                       "mrcnn_class_conv1/kernel": w["mrcnn_class_conv1/kernel"] * np.float32(0.05)})
+    model.compile(1e-5)
+    rng = np.random.RandomState(0)
+    img = synth.images(7, 1, S, S)
+    # ground truth = 40 of the (random-weight) RPN's own proposals, so that DetectionTargetLayer finds positive RoIs
+    plan = model.plan()
+    plan.forward(torch.as_tensor(img))
+    props = plan.proposals()[0].cpu().numpy().astype(np.float64) * S
+    big = props[((props[:, 2] - props[:, 0]) >= 32) & ((props[:, 3] - props[:, 1]) >= 32)]
+    boxes = np.rint(big[:40]).astype(np.int32)
+    n_gt = boxes.shape[0]
+    assert n_gt >= 8, "the random RPN produced too few usable proposals"
+    caps = synth.captions_v1(9, n_gt, T, V, lmin=3, lmax=12).astype(np.int32)
+    anchors = utils.generate_pyramid_anchors(cfg.RPN_ANCHOR_SCALES, cfg.RPN_ANCHOR_RATIOS, cfg.BACKBONE_SHAPES, cfg.BACKBONE_STRIDES, 1)
+    match, deltas = build_rpn_targets(img[0].shape, anchors, caps, boxes, cfg, rng)
+    gt_caps = np.zeros((1, cfg.MAX_GT_INSTANCES, T), np.int32)
+    gt_boxes = np.zeros((1, cfg.MAX_GT_INSTANCES, 4), np.int32)
+    gt_caps[0, :n_gt], gt_boxes[0, :n_gt] = caps, boxes
+    return model, cfg, [img, np.zeros((1, 12)), match[None, :, None], deltas[None], gt_caps, gt_boxes]
+
+
+def test_full_size_joint_step_bf16_and_f32(ops):
+    """configs[4] as specified (bf16) next to the same step in fp32, at 1024 px / 2000 -> 200 RoIs / V = 50 000.  No oracle
+    finishes at this size, so the checks are properties: every loss finite; the RoI sample obeys DetectionTargetLayer's
+    budget (<= 200 RoIs, <= 66 positive, 1:2 ratio); the caption loss of a random-init model sits near ln V; the bf16 step's
+    four losses track the fp32 step's on identical inputs and weights (the decoder's bf16 tolerance, 2e-2); every gradient is
+    finite; the training path holds NO [rows, V] float32 logits buffer (the fused vocabulary softmax / cross-entropy wrote only
+    d(loss)/d(logits), in bf16 for the bf16 model); optimizer steps on the same image lower the caption loss."""
+    import math
+    out = {}
+    for dt in ("f32", "bf16"):
+        model, cfg, inputs = _full_size_joint(dt)
+        losses = model._loss_list(model.forward_backward(inputs, shuffle=None))
+        tg = model.last_targets
+        assert 0 < tg['npos'] <= int(cfg.TRAIN_ROIS_PER_IMAGE * cfg.ROI_POSITIVE_RATIO) and tg['npos'] + tg['nneg'] <= cfg.TRAIN_ROIS_PER_IMAGE
+        assert all(math.isfinite(v) for v in losses.values()), losses
+        assert abs(losses['imgcap_loss'] - math.log(cfg.VOCABULARY_SIZE)) < 1.0, losses
+        g = model.store.flat_grad
+        assert bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+        cm = model.caption_model
+        assert 'logits' not in cm._bufs and 'probs' not in cm._bufs
+        N = cfg.TRAIN_ROIS_PER_IMAGE * cfg.PADDING_SIZE
+        if dt == "bf16":
+            assert cm._bufs['dlogits:bf16'].dtype == torch.bfloat16 and 'dlogits' not in cm._bufs
+            assert cm._bufs['dlogits:bf16'].shape == (N, cfg.VOCABULARY_SIZE)
+        else:
+            assert cm._bufs['dlogits'].dtype == torch.float32
+        out[dt] = losses
+        if dt == "bf16":
+            first = model.train_on_batch(inputs)
+            for _ in range(5):
+                last = model.train_on_batch(inputs)
+            assert all(math.isfinite(v) for v in last) and last[3] < first[3], (first, last)      # [loss, rpn_class, rpn_bbox, imgcap]
+        del model
+        torch.cuda.empty_cache()
+    for k in ('imgcap_loss', 'rpn_class_loss', 'rpn_bbox_loss', 'reg_loss'):
+        assert abs(out['bf16'][k] - out['f32'][k]) < 2e-2 * max(1.0, abs(out['f32'][k])), (k, out)

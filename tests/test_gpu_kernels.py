@@ -104,7 +104,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("math", [0, 1, 2, 3], ids=["f32", "bf16x3", "bf16x3-presplit", "bf16x2"])
+@pytest.mark.parametrize("math", [0, 1, 2, 3, 4], ids=["f32", "bf16x3", "bf16x3-presplit", "bf16x2", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d_matches_oracle(ops, case, math):
     """math 0: fp32 MFMA products; math 1: operands split into three bf16 pieces, six matrix-pipe products -- held to the
@@ -129,8 +129,16 @@ def test_conv2d_matches_oracle(ops, case, math):
     pt, pl = (O.same_pad(H, k, stride)[0], O.same_pad(W, k, stride)[0]) if padding == 'same' else (0, 0)
     wp = dev(pack_conv_kernel(w))
     got = ops.conv2d(dev(x), wp, k, k, stride, pt, pl, Ho, Wo, dev(sc), dev(sh),
-                     None if res is None else dev(res), res_mode, relu, math={0: 0, 1: 1, 2: 1, 3: 2}[math],
+                     None if res is None else dev(res), res_mode, relu, math={0: 0, 1: 1, 2: 1, 3: 2, 4: 3}[math],
                      w_split=ops.split_bf16x3(wp) if math == 2 else None)
+    if math == 4:                                      # plain bf16 operands (configs[4]): exact against the oracle on bf16-rounded operands
+        yb = O.conv2d_nhwc(O.to_bf16(x), O.to_bf16(w), None, stride, padding) * sc + sh
+        if res_mode == 1:
+            yb = yb + res
+        elif res_mode == 2:
+            yb = yb + O.upsample2x(res)
+        close(got, np.maximum(yb, 0) if relu else yb, 3e-5)
+        return
     close(got, y, 2e-5 if math < 3 else 1e-4)          # bf16x2: 16-bit-mantissa products (2^-16), TF32 would need 2e-3
 
 
