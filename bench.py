@@ -283,6 +283,7 @@ class E2E(object):
         """Per-instantiation conv timing, in the pipeline's conditions and alone; the dominant kernel's roofline numbers."""
         plan = self.plan
         table = plan.conv_table()
+        self.inner.grad_sync = None        # rank 0 alone runs this leg (after the timed region): its decoder steps must not enter a collective
         beside = None
         if self.pipe is not None:
             s_dec, feat0 = self.pipe.s_dec, self.pipe.feat[0]
@@ -406,6 +407,9 @@ def run_joint(args, dev, rank, world, barrier):
 
 def main():
     args = parse()
+    if os.environ.get("DCAP_HANG_DUMP"):                 # diagnostics: dump every thread's Python stack after N seconds and exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["DCAP_HANG_DUMP"]), exit=True)
     from image_captioning_amd.parallel_model import init_process_group_from_env, GradAllReduce
     rank, world, local_rank = init_process_group_from_env()
     if world != args.gpus:
@@ -499,14 +503,17 @@ def main():
     if rank == 0 and world == 1 and not args.no_other_configs:
         other = {}
         try:
+            # configs[2] proper: ONE image per step, timed by a child process (a fresh context, like the alt_math legs)
+            import subprocess
             del e2e
             torch.cuda.empty_cache()
-            one = E2E(args, dev, rank, world, 1)          # configs[2] proper: ONE image per step
-            dt1, _ = one.timed(2, 10, barrier)
+            cmd1 = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-alt-math",
+                    "--no-cpu-baseline", "--no-other-configs", "--no-roofline", "--images-per-gpu", "1", "--rois", str(R), "--tokens", str(T),
+                    "--vocab", str(V), "--image-size", str(S), "--stage4-blocks", str(args.stage4_blocks)] + (["--no-pipeline"] if args.no_pipeline else [])
+            r1 = subprocess.run(cmd1, capture_output=True, text=True, timeout=300)
+            one = json.loads(r1.stdout.strip().splitlines()[-1])
             other["configs2_one_image"] = {"workload": "BASELINE configs[2] as defined: 1 image x %d RoI per step, same model" % R,
-                                           "value": R * 10 / dt1, "unit": "captions/s", "ms_per_step": 1e3 * dt1 / 10, "steps": 10}
-            del one
-            torch.cuda.empty_cache()
+                                           "value": one["value"], "unit": "captions/s", "ms_per_step": one["ms_per_step"], "steps": one["steps"]}
             other["configs1_gpu"] = gpu_configs1(dev)
         except Exception as e:
             other["error_gpu"] = repr(e)[:300]

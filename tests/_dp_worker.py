@@ -1,0 +1,53 @@
+"""Worker of tests/test_gpu_multirank.py: one rank of a 2-rank data-parallel run of the REAL caption decoder under
+ParallelModel (run as a child process: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* / DCAP_DIST_BACKEND in the environment)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def build(V, T, seed=0):
+    from image_captioning_amd import synth
+    from image_captioning_amd.text_generation_model_v2 import DenseCapConfig, build_model, Adam
+    cfg = DenseCapConfig(V, synth.embedding_matrix(seed + 3, V))
+    cfg.PADDING_SIZE = T
+    model = build_model((7, 7, 256), (T,), cfg, 256, True, seed=seed)
+    model.compile(optimizer=Adam(amsgrad=True), loss="categorical_crossentropy")
+    return model
+
+
+def batch(V, T, B, seed=11):
+    rng = np.random.default_rng(seed)
+    feat = rng.standard_normal((B, 7, 7, 256)).astype(np.float32)
+    words = np.zeros((B, T), np.int32)
+    for b in range(B):
+        L = int(rng.integers(0, T + 1))
+        if L:
+            words[b, T - L:] = rng.integers(3, V, L)
+    onehot = np.eye(V)[rng.integers(3, V, B)]
+    return feat, words, onehot
+
+
+def main():
+    out_dir, V, T, B, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    from image_captioning_amd.parallel_model import ParallelModel, init_process_group_from_env
+    import torch.distributed as dist
+    rank, world, _ = init_process_group_from_env()
+    model = build(V, T, seed=rank)                      # rank-dependent initial weights: the broadcast must make them rank 0's
+    pm = ParallelModel(model, world)
+    seen = model.grad_sync.check_ranks(model.device)
+    feat, words, onehot = batch(V, T, B)
+    losses = [pm.train_on_batch([feat, words], onehot) for _ in range(steps)]       # GLOBAL batch in, tf.split inside
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), flat=model.store.flat.cpu().numpy(), losses=np.array(losses),
+             seen=np.array([seen]), backend=np.array([dist.get_backend()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -120,3 +120,51 @@ def test_parallel_model_broadcast_loss_list_and_mean_gradient(tmp_path):
     a, b = np.load(tmp_path / "pm_0.npy"), np.load(tmp_path / "pm_1.npy")
     np.testing.assert_allclose(a, b)                                   # same losses and same weights on both ranks
     np.testing.assert_allclose(a[4:], 1.0 - 0.5 * (6.0 + 22.0) / 2.0)  # update used the MEAN over towers of the gradients
+
+
+def _worker_bucketed(rank, world, port, out_dir):
+    """GradAllReduce.ready(): ranges reduced early (asynchronously, in bucket pieces) + the finishing call that covers the
+    rest must equal one all-reduce of the whole bucket, whatever order and overlap the ranges come in."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from image_captioning_amd.parallel_model import GradAllReduce, init_process_group_from_env
+    init_process_group_from_env(backend="gloo")
+    n = 10007
+    g = torch.arange(n, dtype=torch.float64) * (rank + 1)
+    want = torch.arange(n, dtype=torch.float64) * sum(range(1, world + 1))
+    sync = GradAllReduce(bucket_bytes=4 * 1000)
+    sync.ready(g, 9000, 10007)                       # "last layer" first, as a backward pass produces them
+    sync.ready(g, 4000, 6500)
+    sync.ready(g, 0, 0)                              # empty range: ignored
+    scale = sync(g)                                  # the gaps [0,4000) and [6500,9000) go out here; then wait for everything
+    assert scale == 1.0 / world and torch.equal(g, want)
+    g2 = torch.ones(64, dtype=torch.float64) * (rank + 1)
+    assert sync(g2) == 1.0 / world and torch.equal(g2, torch.full((64,), float(sum(range(1, world + 1))), dtype=torch.float64))   # state was reset
+    assert sync.check_ranks(torch.device("cpu")) == world
+    np.save(os.path.join(out_dir, "ok_%d.npy" % rank), np.ones(1))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_async_allreduce_covers_the_bucket_exactly_once(tmp_path):
+    world = 2
+    mp.spawn(_worker_bucketed, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / ("ok_%d.npy" % r)).exists() for r in range(world))
+
+
+def test_param_store_layer_ranges_are_contiguous_layer_groups():
+    from image_captioning_amd.params import ParamStore
+    st = ParamStore("cpu")
+    st.add("a/kernel", np.ones((3, 5)), True)
+    st.add("a/bias", np.ones(5), True)
+    st.add("b/kernel", np.ones((2, 2)), True)
+    st.add("emb/embeddings", np.ones((4, 4)), False)
+    st.add("a/extra", np.ones(7), True)             # not adjacent to the rest of layer a: a has no range of its own
+    st.finalize()
+    assert st.layer_range("b") == (24, 28)
+    with pytest.raises(KeyError):
+        st.layer_range("a")
+    st2 = ParamStore("cpu")
+    for k, shp in (("a/bias", (5,)), ("a/kernel", (3, 5)), ("b/kernel", (2, 2))):
+        st2.add(k, np.ones(shp), True)
+    st2.finalize()
+    assert st2.layer_range("a") == (0, 24) and st2.layer_range("b") == (24, 28)

@@ -1,0 +1,53 @@
+"""Data parallelism with the REAL model on real devices (-m gpu): two ranks (RCCL when the box has two GPUs, otherwise the
+gloo backend with both ranks sharing the one GPU) wrap CaptionModelV2 in ParallelModel and train on a global batch; the
+weights after two steps must equal a single-rank run on the concatenated batch (the reference's ParallelModel semantics,
+parallel_model.py:58-102: tf.split the batch, mean over towers of the per-tower mean-loss gradients)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_parallel_model_two_ranks_match_single_rank_on_the_concatenated_batch(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    sys.path.insert(0, HERE)
+    import _dp_worker as W
+    V, T, B, steps, world = 1000, 6, 16, 2, 2
+    backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   DCAP_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dp_worker.py"), str(tmp_path), str(V), str(T), str(B), str(steps)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
+    r = [np.load(tmp_path / ("rank%d.npz" % k)) for k in range(world)]
+    assert int(r[0]["seen"][0]) == world and str(r[0]["backend"][0]) == backend
+    np.testing.assert_array_equal(r[0]["flat"], r[1]["flat"])            # replicas stay bit-identical
+    np.testing.assert_allclose(r[0]["losses"], r[1]["losses"], rtol=0, atol=0)
+    # single rank, whole batch, same initial weights (rank 0's seed)
+    model = W.build(V, T, seed=0)
+    feat, words, onehot = W.batch(V, T, B)
+    losses = [model.train_on_batch([feat, words], onehot) for _ in range(steps)]
+    single = model.store.flat.cpu().numpy()
+    np.testing.assert_allclose(r[0]["losses"], losses, rtol=2e-5)        # mean over towers of tower means == batch mean (equal shards)
+    scale = np.abs(single).max()
+    assert np.abs(r[0]["flat"] - single).max() < 2e-5 * scale
