@@ -27,7 +27,7 @@ import torch
 from . import ops, synth, utils
 from .encoder import EncoderPlan, fuse_rpn_head
 from .layers import resnet_fpn_convs
-from .modified_dense_model import load_weight_file
+from .modified_dense_model import load_weight_file, save_weight_file
 from .packing import pack_conv_kernel
 from .params import Adam
 from .text_generation_model import CaptionModelV1, caption_targets
@@ -391,8 +391,8 @@ class DenseImageCapRCNN(object):
 
     def save_weights(self, path):
         """Atomic: written beside the target and renamed, so a reader (or a second rank) never sees a torn file."""
-        tmp = path + ".tmp.npz"
-        np.savez(tmp, **self.get_weights_dict())
+        tmp = path + (".tmp.h5" if path.endswith((".h5", ".hdf5")) else ".tmp.npz")
+        save_weight_file(tmp, self.get_weights_dict())
         os.replace(tmp, path)
 
     def set_log_dir(self, model_path=None):

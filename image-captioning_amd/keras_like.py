@@ -7,7 +7,7 @@ import os
 
 import numpy as np
 
-from .modified_dense_model import load_weight_file
+from .modified_dense_model import load_weight_file, save_weight_file
 
 
 class ModelCheckpoint(object):
@@ -18,9 +18,7 @@ class ModelCheckpoint(object):
         self.filepath, self.verbose = filepath, verbose
 
     def on_epoch_end(self, model, epoch, logs):
-        path = self.filepath.format(epoch=epoch + 1, **logs)
-        if path.endswith(".h5"):
-            path = path[:-3] + ".npz"          # native format; same '<layer>/<weight>' keys
+        path = self.filepath.format(epoch=epoch + 1, **logs)      # '.h5' names get Keras-layout HDF5 files, anything else .npz
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
         model.save_weights(path)
         if self.verbose:
@@ -66,7 +64,7 @@ class KerasLikeModel(object):
         return self.store.to_numpy()
 
     def save_weights(self, path):
-        np.savez(path, **self.get_weights_dict())
+        save_weight_file(path, self.get_weights_dict())
 
     def load_weights(self, filepath, by_name=False, skip_mismatch=False):
         loaded = load_weight_file(filepath) if isinstance(filepath, str) else dict(filepath)

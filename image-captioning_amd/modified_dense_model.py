@@ -30,26 +30,26 @@ def mold_image(images, config):
 
 
 def load_weight_file(filepath):
-    """Checkpoint reader: '<layer>/<weight>' -> ndarray.  Native format is .npz with those keys;
-    Keras .h5 files need h5py (not in this image)."""
+    """Checkpoint reader: '<layer>/<weight>' -> ndarray.  .npz files hold those keys directly; Keras HDF5 weight files
+    (mask_rcnn_coco.h5, rcnn_coco.h5, model-47-1.74.h5, ... -- dense_img_cap/dense_model.py:1656-1692) are parsed by the
+    package's own HDF5 reader (hdf5_lite: no h5py needed)."""
     if filepath.endswith(".npz"):
         with np.load(filepath) as z:
             return {k: z[k] for k in z.files}
     if filepath.endswith(".h5") or filepath.endswith(".hdf5"):
-        try:
-            import h5py  # noqa: F401
-        except ImportError as e:
-            raise ImportError("reading Keras HDF5 weights needs h5py, which this environment lacks; "
-                              "convert the file to .npz ('<layer>/<weight>' keys)") from e
-        out = {}
-        with h5py.File(filepath, "r") as f:
-            g = f["model_weights"] if "model_weights" in f else f
-            for layer in g:
-                for wname in g[layer].attrs.get("weight_names", []):
-                    wname = wname.decode() if isinstance(wname, bytes) else wname
-                    out[layer + "/" + wname.split("/")[-1].split(":")[0]] = np.asarray(g[layer][wname])
-        return out
+        from .hdf5_lite import load_keras_weights
+        return load_keras_weights(filepath)
     raise ValueError("unknown weight file type: %s" % filepath)
+
+
+def save_weight_file(filepath, weights):
+    """Checkpoint writer: .npz, or a Keras-layout HDF5 weight file (Keras' ModelCheckpoint(save_weights_only=True) format)
+    when the name ends in .h5 / .hdf5."""
+    if filepath.endswith(".h5") or filepath.endswith(".hdf5"):
+        from .hdf5_lite import save_keras_weights
+        save_keras_weights(filepath, weights)
+    else:
+        np.savez(filepath, **weights)
 
 
 class DenseImageCapRCNN(object):

@@ -1,15 +1,10 @@
 """Vocabulary / caption encoding helpers (dense_img_cap_separate_models/preprocess.py:8-114).
-The reference tokenises with nltk.word_tokenize, which is not installable here; a regex tokenizer
-(words and single punctuation marks) stands in.  Data preparation is outside the hot path."""
-import re
-
+The reference tokenises with nltk.word_tokenize (not installable here): treebank.py restates its Penn Treebank rules
+(contractions, punctuation, quotes, brackets), so "man's" -> man + 's and "isn't" -> is + n't exactly as the reference's
+vocabulary and caption ids assume."""
 import numpy as np
 
-_TOKEN = re.compile(r"\w+|[^\w\s]")
-
-
-def word_tokenize(text):
-    return _TOKEN.findall(text)
+from .treebank import word_tokenize  # noqa: F401  (re-exported: the reference imports it into this module's namespace)
 
 
 def load_embeddings(file_name):

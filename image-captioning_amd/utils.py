@@ -33,26 +33,54 @@ class Dataset(object):
         return self.image_info[image_id]["path"]
 
     def load_image(self, image_id):
-        """[H,W,3] uint8.  The reference reads JPEGs with skimage (absent here); datasets that keep
-        decoded pixels put them under image_info[...]['pixels']."""
+        """[H,W,3] uint8 (utils.py:255-262: skimage.io.imread + gray2rgb for single-channel files).  Decoded with PIL, the
+        library behind skimage's default imread plugin; datasets that already hold decoded pixels put them under
+        image_info[...]['pixels']."""
         info = self.image_info[image_id]
         if "pixels" in info:
             img = np.asarray(info["pixels"])
         else:
-            raise IOError("no JPEG decoder in this environment: provide 'pixels' for %r" % (info["path"],))
+            img = imread(info["path"])
         if img.ndim != 3:
-            img = np.stack([img] * 3, axis=-1)
+            img = np.stack([img] * 3, axis=-1)      # skimage.color.gray2rgb
         return img
 
     def load_captions_and_rois(self, image_id):
         return np.empty([0, 0, 0, 0]), np.empty([0], np.float32)
 
 
+def imread(path):
+    """skimage.io.imread(path) for the formats the path meets (JPEG / PNG): the file's own channels as a uint8 array
+    ([H,W] for grayscale, [H,W,3] RGB, [H,W,4] RGBA); palette images are expanded like skimage's PIL plugin does."""
+    from PIL import Image
+    with Image.open(path) as im:
+        if im.mode == "P":
+            im = im.convert("RGBA" if "transparency" in im.info else "RGB")
+        elif im.mode not in ("L", "RGB", "RGBA"):
+            im = im.convert("RGB")
+        return np.asarray(im).copy()
+
+
+def imresize(arr, size):
+    """scipy.misc.imresize(arr, size) with its defaults (interp='bilinear', mode=None), size = (rows, cols): scipy's
+    function (removed in SciPy 1.3) was a thin wrapper over PIL -- toimage(arr) (uint8 data unchanged; other dtypes byte-scaled
+    to their min..max), Image.resize((cols, rows), resample=BILINEAR), back to an array -- and PIL is what runs here."""
+    from PIL import Image
+    a = np.asarray(arr)
+    if a.dtype != np.uint8:
+        lo, hi = float(a.min()), float(a.max())
+        span = (hi - lo) or 1.0
+        a = ((a - lo) * (255.0 / span)).clip(0, 255) + 0.5
+        a = a.astype(np.uint8)
+    im = Image.fromarray(a)
+    bilinear = getattr(Image, "Resampling", Image).BILINEAR
+    return np.asarray(im.resize((int(size[1]), int(size[0])), resample=bilinear))
+
+
 def resize_image(image, min_dim=None, max_dim=None, padding=False):
     """Scale so the short side reaches min_dim (never down-scale for it) while the long side stays
-    within max_dim, then zero-pad to max_dim x max_dim.  Returns (image, window, scale, padding).
-    Synthetic 1024x1024 inputs take the scale == 1 path; other sizes use nearest-neighbour
-    resampling here (the reference calls scipy.misc.imresize, which no longer exists)."""
+    within max_dim, then zero-pad to max_dim x max_dim.  Returns (image, window, scale, padding)
+    (utils.py:290-340; the resampling is scipy.misc.imresize's: PIL bilinear, see imresize)."""
     dtype = image.dtype
     h, w = image.shape[:2]
     window = (0, 0, h, w)
@@ -63,10 +91,7 @@ def resize_image(image, min_dim=None, max_dim=None, padding=False):
         if round(max(h, w) * scale) > max_dim:
             scale = max_dim / max(h, w)
     if scale != 1:
-        nh, nw = round(h * scale), round(w * scale)
-        yi = np.minimum((np.arange(nh) / scale).astype(int), h - 1)
-        xi = np.minimum((np.arange(nw) / scale).astype(int), w - 1)
-        image = image[yi][:, xi]
+        image = imresize(image, (round(h * scale), round(w * scale)))
     if padding:
         h, w = image.shape[:2]
         top = (max_dim - h) // 2

@@ -322,3 +322,189 @@ def test_joint_model_log_dir_and_epoch_from_checkpoint_name(tmp_path):
     assert m.checkpoint_path.format(epoch=12) == str(run / "img_cap_dense image captioning_0012.npz")
     J.set_log_dir(m, str(tmp_path / "mask_rcnn_coco.npz"))          # a foreign file: fresh run, epoch 0
     assert m.epoch == 0 and m.log_dir != str(run)
+
+
+# ---------------------------------------------------------------------------------------------
+# tokenisation, image decode and resize: the host-side steps in front of the GPU path
+# ---------------------------------------------------------------------------------------------
+
+def test_treebank_tokenizer_known_answers():
+    """The examples of NLTK's own documentation (TreebankWordTokenizer / word_tokenize docstrings) -- the published known
+    answers of the algorithm the reference's preprocess.py:52-72 calls -- plus the Visual-Genome-style cases that make the
+    difference to the vocabulary: possessives, n't, 'm / 're / 've / 'll / 'd, cannot, quotes, brackets, dashes."""
+    from image_captioning_amd.treebank import treebank_tokenize, word_tokenize
+    s = "Good muffins cost $3.88\nin New York.  Please buy me\ntwo of them.\nThanks."
+    assert treebank_tokenize(s, False) == ['Good', 'muffins', 'cost', '$', '3.88', 'in', 'New', 'York.', 'Please', 'buy', 'me', 'two', 'of',
+                                            'them.', 'Thanks', '.']
+    assert word_tokenize(s) == ['Good', 'muffins', 'cost', '$', '3.88', 'in', 'New', 'York', '.', 'Please', 'buy', 'me', 'two', 'of', 'them', '.',
+                                'Thanks', '.']
+    assert treebank_tokenize("They'll save and invest more.", False) == ['They', "'ll", 'save', 'and', 'invest', 'more', '.']
+    assert treebank_tokenize("hi, my name can't hello,", False) == ['hi', ',', 'my', 'name', 'ca', "n't", 'hello', ',']
+    assert word_tokenize("a man's hat. it's red, isn't it?") == ['a', 'man', "'s", 'hat', '.', 'it', "'s", 'red', ',', 'is', "n't", 'it', '?']
+    assert word_tokenize("the dog (brown) cannot jump -- i'm sure we've seen they're gonna") == \
+        ['the', 'dog', '(', 'brown', ')', 'can', 'not', 'jump', '--', 'i', "'m", 'sure', 'we', "'ve", 'seen', 'they', "'re", 'gon', 'na']
+    assert word_tokenize('the sign says "stop"') == ['the', 'sign', 'says', '``', 'stop', "''"]
+    assert word_tokenize("clock reads 10:30, price is 1,000 dollars") == ['clock', 'reads', '10:30', ',', 'price', 'is', '1,000', 'dollars']
+    assert word_tokenize("") == [] and word_tokenize("   ") == []
+    assert word_tokenize("dr. who's tardis") == ['dr.', 'who', "'s", 'tardis']          # abbreviation: no sentence break
+
+
+def test_caption_encoding_uses_treebank_tokens():
+    from image_captioning_amd.preprocess import encode_caption, encode_caption_v2
+    w2i = {'<unk>': 0, '<start>': 1, '<end>': 2, 'man': 3, "'s": 4, 'hat': 5, 'is': 6, "n't": 7, 'red': 8}
+    np.testing.assert_array_equal(encode_caption("Man's hat isn't RED.", w2i), [3, 4, 5, 6, 7, 8])      # '.' is out of vocabulary: dropped
+    rows = encode_caption_v2("man's blue hat", w2i)                                                     # 'blue' -> <unk> row -> dropped
+    assert rows.shape == (3, len(w2i)) and rows.argmax(1).tolist() == [3, 4, 5]
+
+
+def test_imresize_is_pil_bilinear_and_resize_image_geometry():
+    """resize_image's resampling is scipy.misc.imresize's, i.e. PIL Image.resize(BILINEAR) (utils.py:327): pinned to PIL's
+    documented call and to the properties bilinear resampling has; the geometry (scale, window, padding) per utils.py:290-340."""
+    from PIL import Image
+    from image_captioning_amd import utils
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (60, 80, 3), dtype=np.uint8)
+    got = utils.imresize(img, (90, 120))
+    want = np.asarray(Image.fromarray(img).resize((120, 90), resample=getattr(Image, "Resampling", Image).BILINEAR))
+    np.testing.assert_array_equal(got, want)
+    assert utils.imresize(np.full((10, 12, 3), 77, np.uint8), (25, 31)).tolist() == np.full((25, 31, 3), 77).tolist()      # constants survive
+    ramp = np.tile(np.arange(0, 200, 2, dtype=np.uint8)[None, :, None], (8, 1, 3))
+    up = utils.imresize(ramp, (16, 200)).astype(int)
+    assert (np.diff(up[0, :, 0]) >= 0).all() and abs(int(up[0, 100, 0]) - 100) <= 2                                        # a ramp stays a ramp
+    f = utils.imresize(np.linspace(0.0, 1.0, 48).reshape(6, 8), (6, 8))                   # non-uint8: byte-scaled to min..max like scipy's toimage
+    assert f.dtype == np.uint8 and f.min() == 0 and f.max() == 255
+    out, window, scale, padding = utils.resize_image(rng.integers(0, 256, (600, 800, 3), dtype=np.uint8), min_dim=800, max_dim=1024, padding=True)
+    assert out.shape == (1024, 1024, 3) and window == (128, 0, 896, 1024) and scale == 1.28 and padding == [(128, 128), (0, 0), (0, 0)]
+    assert not out[:128].any() and not out[896:].any() and out[128:896].any()
+    small, window, scale, _ = utils.resize_image(np.zeros((200, 100, 3), np.uint8), min_dim=800, max_dim=1024, padding=True)
+    assert scale == 1024 / 200 and window == (0, 256, 1024, 768)                          # the long side caps the up-scaling
+
+
+def test_jpeg_decode_and_grayscale_expansion(tmp_path):
+    from PIL import Image
+    from image_captioning_amd import utils
+    rng = np.random.default_rng(1)
+    rgb = rng.integers(0, 256, (40, 56, 3), dtype=np.uint8)
+    Image.fromarray(rgb).save(tmp_path / "a.png")
+    Image.fromarray(rgb[..., 0]).save(tmp_path / "g.jpg", quality=95)
+    ds = utils.Dataset()
+    ds.add_image("t", image_id=0, path=str(tmp_path / "a.png"))
+    ds.add_image("t", image_id=1, path=str(tmp_path / "g.jpg"))
+    ds.add_image("t", image_id=2, path=None, pixels=rgb)
+    ds.prepare()
+    np.testing.assert_array_equal(ds.load_image(0), rgb)                                   # lossless round trip
+    g = ds.load_image(1)
+    assert g.shape == (40, 56, 3) and g.dtype == np.uint8 and (g[..., 0] == g[..., 1]).all() and (g[..., 1] == g[..., 2]).all()
+    np.testing.assert_array_equal(ds.load_image(2), rgb)
+
+
+def test_reference_sample_images_decode_and_resize_to_the_committed_fixture():
+    """The six Visual Genome JPEGs the reference ships (dataset/visual genome/): decoded size, pixel checksum and the resized
+    1024 x 1024 input of the model are pinned in tests/golden/vg_sample_images.json (made by tests/golden/make_image_fixtures.py).
+    Needs the reference checkout; skipped where it is absent (the GPU box)."""
+    import json
+    ref = "/root/reference/dataset/visual genome"
+    if not os.path.isdir(ref):
+        pytest.skip("reference checkout not present")
+    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_image_fixtures", os.path.join(sys_path, "make_image_fixtures.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(sys_path, "vg_sample_images.json")))
+    assert len(want) == 6
+    for name, row in want.items():
+        got = mod.describe(os.path.join(ref, name))
+        assert got["shape"] == row["shape"] and got["sha1"] == row["sha1"], name
+        assert got["resized_shape"] == [1024, 1024, 3] and got["window"] == row["window"] and got["scale"] == row["scale"], name
+        assert got["resized_sha1"] == row["resized_sha1"], name
+        assert abs(got["resized_mean"] - got["mean"]) < 0.5                                # bilinear resampling preserves the mean
+
+
+# ---------------------------------------------------------------------------------------------
+# Keras HDF5 weight files without h5py (hdf5_lite)
+# ---------------------------------------------------------------------------------------------
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _fixture_value(L, shape):
+    n = int(np.prod(shape))
+    return (((7 * np.arange(n) + 3 * L) % 101).astype(np.float32) / np.float32(8.0) - np.float32(5.0)).reshape(shape)
+
+
+def test_hdf5_reader_on_a_file_written_by_libhdf5_in_keras_layout():
+    """tests/golden/keras_weights_sample.h5 was written by the real HDF5 library (tests/golden/make_h5_fixture.c) in the layout
+    Keras' save_weights produces: layer_names / weight_names attributes, nested weight paths, 13 layers (a multi-leaf group
+    B-tree), a weightless layer, a nested sub-model layer, one chunked dataset, variable-length string attributes.  The reader
+    must return every array by its own name scope with the values the generator's formula gives."""
+    from image_captioning_amd import hdf5_lite as H
+    path = os.path.join(GOLDEN, "keras_weights_sample.h5")
+    f = H.H5File(path)
+    layers = [v.decode() for v in f.attrs["layer_names"]]
+    assert layers[:3] == ["input_1", "conv1", "bn_conv1"] and len(layers) == 13 and f.keys() == sorted(layers)
+    assert f.attrs["backend"] is None                                      # variable-length string: present, not decoded
+    assert f["input_1"].attrs["weight_names"].shape == (0,)
+    assert f["conv1/conv1/kernel:0"].shape == (3, 3, 2, 6) and f["conv1/conv1/kernel:0"].dtype == np.dtype("<f4")
+    w = H.load_keras_weights(path)
+    assert len(w) == 34
+    order = []                                                              # the generator's dataset order
+    for name in layers[1:]:
+        if name.startswith("bn") or "_bn" in name:
+            order += [(name + "/" + k, (6,)) for k in ("gamma", "beta", "moving_mean", "moving_variance")]
+        elif name == "imgcap_caption_td":
+            order += [("imgcap_lstm1/kernel", (10, 16)), ("imgcap_lstm1/recurrent_kernel", (4, 16)), ("imgcap_lstm1/bias", (16,)),
+                      ("imgcap_lstm_d2/kernel", (8, 12)), ("imgcap_lstm_d2/bias", (12,))]
+        elif name == "imgcap_embedding_layer":
+            order += [("imgcap_embedding_layer/embeddings", (9, 5))]
+        else:
+            order += [(name + "/kernel", (3, 3, 2, 6)), (name + "/bias", (6,))]
+    assert sorted(k for k, _ in order) == sorted(w)
+    for L, (key, shape) in enumerate(order):
+        np.testing.assert_array_equal(w[key], _fixture_value(L, shape), err_msg=key)
+
+
+def test_hdf5_writer_round_trip_and_libhdf5_tools_read_it(tmp_path):
+    """save_keras_weights -> load_keras_weights is the identity (incl. > 8 layers: multi-level group B-tree, and a
+    layer_names attribute split like Keras splits it); where libhdf5's command line tools exist (the build container's
+    /opt/conda) h5ls / h5dump must list every dataset and print a weight's values."""
+    import shutil
+    import subprocess
+    from image_captioning_amd import hdf5_lite as H
+    from image_captioning_amd.modified_dense_model import load_weight_file, save_weight_file
+    rng = np.random.default_rng(0)
+    W = {}
+    for i in range(300):
+        W["res%03d_branch2a_with_a_long_layer_name/kernel" % i] = rng.standard_normal((1, 1, 4, 3)).astype(np.float32)
+        W["res%03d_branch2a_with_a_long_layer_name/bias" % i] = rng.standard_normal(3).astype(np.float32)
+    W["imgcap_lstm1/recurrent_kernel"] = rng.standard_normal((8, 32)).astype(np.float32)
+    path = str(tmp_path / "w.h5")
+    save_weight_file(path, W)
+    back = load_weight_file(path)
+    assert set(back) == set(W) and all(np.array_equal(back[k], W[k]) and back[k].dtype == np.float32 for k in W)
+    big = {"l%05d/w" % i: np.float32([i]) for i in range(12000)}            # layer_names > 64 KB: split into layer_names0, 1, ...
+    H.save_keras_weights(str(tmp_path / "big.h5"), big)
+    f = H.H5File(str(tmp_path / "big.h5"))
+    assert "layer_names" not in f.attrs and "layer_names0" in f.attrs and "layer_names1" in f.attrs
+    assert H.load_keras_weights(str(tmp_path / "big.h5"))["l11999/w"] == np.float32(11999)
+    h5ls = shutil.which("h5ls") or ("/opt/conda/bin/h5ls" if os.path.exists("/opt/conda/bin/h5ls") else None)
+    if h5ls is None:
+        return
+    listing = subprocess.run([h5ls, "-r", path], capture_output=True, text=True)
+    assert listing.returncode == 0 and sum("Dataset" in l for l in listing.stdout.splitlines()) == len(W), listing.stderr[:500]
+    dump = subprocess.run([os.path.join(os.path.dirname(h5ls), "h5dump"), "-d", "/imgcap_lstm1/imgcap_lstm1/recurrent_kernel:0", path],
+                          capture_output=True, text=True)
+    assert dump.returncode == 0 and "H5T_IEEE_F32LE" in dump.stdout and "( 8, 32 )" in dump.stdout
+    first = float(dump.stdout.split("(0,0):")[1].split(",")[0])
+    assert abs(first - float(W["imgcap_lstm1/recurrent_kernel"][0, 0])) < 1e-4 * max(1.0, abs(first))
+
+
+def test_hdf5_reader_rejects_what_it_does_not_implement(tmp_path):
+    from image_captioning_amd import hdf5_lite as H
+    with pytest.raises(H.Hdf5Error):
+        H.H5File(b"not an hdf5 file" * 64)
+    good = open(os.path.join(GOLDEN, "keras_weights_sample.h5"), "rb").read()
+    bad = bytearray(good)
+    bad[8] = 3                                                              # superblock version 3 (libver='latest')
+    with pytest.raises(NotImplementedError):
+        H.H5File(bytes(bad))
