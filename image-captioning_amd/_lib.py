@@ -60,7 +60,7 @@ class RoiAlignDesc(C.Structure):
 class LstmFwdDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("U", C.c_int),
                 ("z", C.c_void_p), ("U_rec", C.c_void_p), ("mask", C.c_void_p),
-                ("h_seq", C.c_void_p), ("c_seq", C.c_void_p)]
+                ("h_seq", C.c_void_p), ("c_seq", C.c_void_p), ("rec_masks", C.c_void_p)]
 
 
 class LstmBwdDesc(C.Structure):
@@ -68,7 +68,7 @@ class LstmBwdDesc(C.Structure):
                 ("z", C.c_void_p), ("U_rec", C.c_void_p), ("mask", C.c_void_p),
                 ("h_seq", C.c_void_p), ("c_seq", C.c_void_p),
                 ("dh_seq", C.c_void_p), ("dh_last", C.c_void_p),
-                ("dz", C.c_void_p), ("dU_rec", C.c_void_p), ("accumulate_dU", C.c_int)]
+                ("dz", C.c_void_p), ("dU_rec", C.c_void_p), ("accumulate_dU", C.c_int), ("rec_masks", C.c_void_p)]
 
 
 class SoftmaxCeDesc(C.Structure):

@@ -178,6 +178,36 @@ __global__ __launch_bounds__(256) void lstm_step_fused2_kernel(float* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// recurrent_dropout (Keras LSTM(recurrent_dropout=0.2), text_generation_model.py:141-142): in the training phase
+// h_{t-1} enters each gate through its own inverted-dropout mask, drawn once per call and fixed over the timesteps:
+//   z_g = x W_g + (h_{t-1} * m_g) U_g + b_g,   g in {i, f, c, o},  m_g in {0, 1/(1-rate)}^[B,U]
+// Four masked copies of h and four U x U products per step replace the single h * U_rec product; this path is taken only
+// when the caller passes masks (training with dropout on), the fused step kernel otherwise.
+// ------------------------------------------------------------------------------------------------
+// out[g][r][u] = x[r][u] * masks[g][r % B][u]   (rows = B for one step, (T-1)*B for the weight-gradient operand)
+__global__ __launch_bounds__(256) void lstm_mask_rows_kernel(const float* __restrict__ x, const float* __restrict__ masks, float* __restrict__ out,
+                                                             long rows, int B, int U) {
+    const long n = rows * U, per = (long)B * U;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+        const long r = idx / U;
+        const long mo = (r % B) * U + (idx - r * U);
+        const float v = x[idx];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) out[g * n + idx] = v * masks[g * per + mo];
+    }
+}
+
+// dh[b][u] += sum_g masks[g][b][u] * tmp[g][b][u]
+__global__ __launch_bounds__(256) void lstm_masked_acc_kernel(float* __restrict__ dh, const float* __restrict__ masks, const float* __restrict__ tmp, long n) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+        float s = dh[idx];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) s += masks[g * n + idx] * tmp[g * n + idx];
+        dh[idx] = s;
+    }
+}
+
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static dc_gemm_desc hU_desc(int B, int U, const float* h_prev, const float* U_rec, float* z_t) {
@@ -225,7 +255,10 @@ extern "C" size_t dc_lstm_seq_workspace_bytes(int B, int T, int U) {
     }
     const size_t bwd = align_up(g) + 2 * align_up((size_t)B * U * sizeof(float));
     const size_t fwd = align_up(g) + ((U & 31) == 0 ? align_up((size_t)4 * U * U * sizeof(float)) : 0);     // + the repacked U_rec
-    return std::max(fwd, bwd);
+    // recurrent-dropout path: four masked copies of h (forward), of dz * U^T and of h_seq (backward)
+    const size_t drop = align_up(g) + 2 * align_up((size_t)B * U * sizeof(float)) + align_up((size_t)4 * B * U * sizeof(float)) +
+                        align_up((size_t)4 * (size_t)std::max(T - 1, 1) * B * U * sizeof(float)) + 1024;
+    return std::max(std::max(fwd, bwd), drop);
 }
 
 extern "C" int dc_lstm_seq_fwd_f32(const dc_lstm_fwd_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
@@ -235,8 +268,16 @@ extern "C" int dc_lstm_seq_fwd_f32(const dc_lstm_fwd_desc* d, void* workspace, s
                DC_EWORKSPACE, "dc_lstm_seq_fwd: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int B = d->B, U = d->U, n = B * U, blocks = (n + 255) / 256;
-    const bool fused = (U & 31) == 0 && d->T > 1;
+    const bool fused = (U & 31) == 0 && d->T > 1 && !d->rec_masks;
     float* Upk = nullptr;
+    float* hm = nullptr;                            // dropout: [4][B][U] masked copies of h_{t-1}, at the END of the workspace
+    void* gws = workspace;
+    size_t gws_bytes = workspace_bytes;
+    if (d->rec_masks) {
+        const size_t hm_bytes = align_up((size_t)4 * n * sizeof(float));
+        hm = reinterpret_cast<float*>(static_cast<char*>(workspace) + (workspace_bytes - hm_bytes) / 256 * 256);
+        gws_bytes = (workspace_bytes - hm_bytes) / 256 * 256;
+    }
     if (fused) {                                   // line-contiguous copy of the recurrent weights at the END of the workspace
         const size_t pack_bytes = align_up((size_t)4 * U * U * sizeof(float));
         Upk = reinterpret_cast<float*>(static_cast<char*>(workspace) + (workspace_bytes - pack_bytes) / 256 * 256);
@@ -256,7 +297,21 @@ extern "C" int dc_lstm_seq_fwd_f32(const dc_lstm_fwd_desc* d, void* workspace, s
             if (rc) return rc;
             continue;
         }
-        if (t) {
+        if (t && d->rec_masks) {
+            hipLaunchKernelGGL(lstm_mask_rows_kernel, dim3(std::min(blocks, kNumCU * 8)), dim3(256), 0, s, hp, d->rec_masks, hm, (long)B, B, U);
+            int rc = check_launch("lstm_mask_rows_kernel");
+            if (rc) return rc;
+            for (int gate = 0; gate < 4; ++gate) {           // z_t[:, gate] += (h * m_gate) U_gate
+                dc_gemm_desc g{};
+                g.M = B; g.N = U; g.K = U;
+                g.A = hm + (size_t)gate * n; g.lda = U;
+                g.B = d->U_rec + (size_t)gate * U; g.ldb = 4 * U;
+                g.C = z_t + (size_t)gate * U; g.ldc = 4 * U;
+                g.accumulate = 1;
+                rc = dc_gemm_f32(&g, gws, gws_bytes, stream);
+                if (rc) return rc;
+            }
+        } else if (t) {
             dc_gemm_desc g = hU_desc(B, U, hp, d->U_rec, z_t);
             int rc = dc_gemm_f32(&g, workspace, workspace_bytes, stream);
             if (rc) return rc;
@@ -281,7 +336,16 @@ extern "C" int dc_lstm_seq_bwd_f32(const dc_lstm_bwd_desc* d, void* workspace, s
     float* dh = reinterpret_cast<float*>(wsp);
     float* dc = reinterpret_cast<float*>(wsp + state_bytes);
     void* gws = wsp + 2 * state_bytes;
-    const size_t gws_bytes = workspace_bytes - 2 * state_bytes;
+    size_t gws_bytes = workspace_bytes - 2 * state_bytes;
+    float* tmp4 = nullptr;                          // dropout: [4][B][U] per-gate dz_g * U_g^T, then [4][(T-1)B][U] masked h_seq
+    float* hm_seq = nullptr;
+    if (d->rec_masks) {
+        const size_t t4 = align_up((size_t)4 * n * sizeof(float)), hs = align_up((size_t)4 * (size_t)std::max(T - 1, 1) * n * sizeof(float));
+        char* end = wsp + workspace_bytes / 256 * 256;
+        hm_seq = reinterpret_cast<float*>(end - hs);
+        tmp4 = reinterpret_cast<float*>(end - hs - t4);
+        gws_bytes = (size_t)(reinterpret_cast<char*>(tmp4) - static_cast<char*>(gws));
+    }
     hipError_t e = hipMemsetAsync(wsp, 0, 2 * state_bytes, s);
     DC_REQUIRE(e == hipSuccess, DC_ELAUNCH, "dc_lstm_seq_bwd: memset failed: %s", hipGetErrorString(e));
     for (int t = T - 1; t >= 0; --t) {
@@ -292,11 +356,42 @@ extern "C" int dc_lstm_seq_bwd_f32(const dc_lstm_bwd_desc* d, void* workspace, s
                            d->dh_seq ? d->dh_seq + (long)t * n : nullptr, (t == T - 1) ? d->dh_last : nullptr, dh, dc, dz_t, B, U);
         int rc = check_launch("lstm_gate_bwd_kernel");
         if (rc) return rc;
-        if (t) {
+        if (t && d->rec_masks) {                                // dh_{t-1} += sum_g m_g * (dz_g U_g^T)
+            for (int gate = 0; gate < 4; ++gate) {
+                dc_gemm_desc g{};
+                g.M = B; g.N = U; g.K = U;
+                g.A = dz_t + (size_t)gate * U; g.lda = 4 * U;
+                g.B = d->U_rec + (size_t)gate * U; g.ldb = 4 * U; g.b_trans = 1;
+                g.C = tmp4 + (size_t)gate * n; g.ldc = U;
+                rc = dc_gemm_f32(&g, gws, gws_bytes, stream);
+                if (rc) return rc;
+            }
+            hipLaunchKernelGGL(lstm_masked_acc_kernel, dim3(std::min(blocks, kNumCU * 8)), dim3(256), 0, s, dh, d->rec_masks, tmp4, (long)n);
+            rc = check_launch("lstm_masked_acc_kernel");
+            if (rc) return rc;
+        } else if (t) {
             dc_gemm_desc g = dzUt_desc(B, U, dz_t, d->U_rec, dh);
             rc = dc_gemm_f32(&g, gws, gws_bytes, stream);
             if (rc) return rc;
         }
+    }
+    if (T > 1 && d->rec_masks) {                                // dU_g = sum_t (h_{t-1} * m_g)^T dz_{t,g}
+        const long rows = (long)(T - 1) * B;
+        hipLaunchKernelGGL(lstm_mask_rows_kernel, dim3((int)std::min<long>((rows * U + 255) / 256, (long)kNumCU * 8)), dim3(256), 0, s, d->h_seq,
+                           d->rec_masks, hm_seq, rows, B, U);
+        int rc = check_launch("lstm_mask_rows_kernel");
+        if (rc) return rc;
+        for (int gate = 0; gate < 4; ++gate) {
+            dc_gemm_desc g{};
+            g.M = U; g.N = U; g.K = (int)rows;
+            g.A = hm_seq + (size_t)gate * rows * U; g.lda = U; g.a_trans = 1;
+            g.B = d->dz + (size_t)B * 4 * U + (size_t)gate * U; g.ldb = 4 * U;
+            g.C = d->dU_rec + (size_t)gate * U; g.ldc = 4 * U;
+            g.accumulate = d->accumulate_dU;
+            rc = dc_gemm_f32(&g, gws, gws_bytes, stream);
+            if (rc) return rc;
+        }
+        return DC_OK;
     }
     if (T > 1) {
         dc_gemm_desc g = dU_desc(B, T, U, d->h_seq, d->dz, d->dU_rec, d->accumulate_dU);

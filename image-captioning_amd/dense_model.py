@@ -293,6 +293,7 @@ class DenseImageCapRCNN(object):
                                             extra_params=extra, compute_dtype=self.compute_dtype)
         # the L2 term and the trainable mask touch the whole gradient bucket after the decoder's backward: no early all-reduce
         self.caption_model.overlap_sync = False
+        self.caption_model.recurrent_dropout = float(getattr(cfg, "RECURRENT_DROPOUT", 0.0))    # opt-in: dense_model.py:769-770 uses 0.2
         self.store = self.caption_model.store
         self._plan = None
         self._reg_coef = None

@@ -329,8 +329,17 @@ def rpn_proposals(heads, anchors, image_hw, proposal_count, nms_threshold, std_d
     return (out, extra) if debug else out
 
 
-def lstm_seq_fwd(z, U_rec, mask, B, T, h_seq=None, c_seq=None):
-    """z [T*B,4U] (x-projection + bias, overwritten with the full pre-activation) -> h_seq, c_seq [T*B,U]."""
+def _rec_masks(rec_masks, B, U):
+    if rec_masks is None:
+        return None
+    if tuple(_chk(rec_masks, name="rec_masks").shape) != (4, B, U) or not rec_masks.is_contiguous():
+        raise _lib.DcapError("rec_masks must be a contiguous float32 [4,B,U] tensor")
+    return rec_masks.data_ptr()
+
+
+def lstm_seq_fwd(z, U_rec, mask, B, T, h_seq=None, c_seq=None, rec_masks=None):
+    """z [T*B,4U] (x-projection + bias, overwritten with the full pre-activation) -> h_seq, c_seq [T*B,U].
+    rec_masks [4,B,U]: Keras recurrent_dropout masks (training phase); None = no dropout."""
     lib = _lib.load()
     U = U_rec.shape[0]
     _chk(z, name="z"), _chk(U_rec, name="U_rec")
@@ -345,12 +354,13 @@ def lstm_seq_fwd(z, U_rec, mask, B, T, h_seq=None, c_seq=None):
     d.z, d.U_rec = z.data_ptr(), U_rec.data_ptr()
     d.mask = None if mask is None else _chk(mask, torch.uint8, "mask").data_ptr()
     d.h_seq, d.c_seq = h_seq.data_ptr(), c_seq.data_ptr()
+    d.rec_masks = _rec_masks(rec_masks, B, U)
     ws, wsb = WORKSPACE.get(lib.dc_lstm_seq_workspace_bytes(B, T, U), z.device)
     check(lib.dc_lstm_seq_fwd_f32(C.byref(d), _ptr(ws), wsb, _stream()), "dc_lstm_seq_fwd_f32")
     return h_seq, c_seq
 
 
-def lstm_seq_bwd(z, U_rec, mask, h_seq, c_seq, B, T, dh_seq=None, dh_last=None, dz=None, dU=None, accumulate_dU=False):
+def lstm_seq_bwd(z, U_rec, mask, h_seq, c_seq, B, T, dh_seq=None, dh_last=None, dz=None, dU=None, accumulate_dU=False, rec_masks=None):
     lib = _lib.load()
     U = U_rec.shape[0]
     if dz is None:
@@ -368,6 +378,7 @@ def lstm_seq_bwd(z, U_rec, mask, h_seq, c_seq, B, T, dh_seq=None, dh_last=None, 
     d.dh_seq = None if dh_seq is None else dh_seq.data_ptr()
     d.dh_last = None if dh_last is None else dh_last.data_ptr()
     d.dz, d.dU_rec, d.accumulate_dU = dz.data_ptr(), _chk(dU, name="dU").data_ptr(), int(accumulate_dU)
+    d.rec_masks = _rec_masks(rec_masks, B, U)
     ws, wsb = WORKSPACE.get(lib.dc_lstm_seq_workspace_bytes(B, T, U), z.device)
     check(lib.dc_lstm_seq_bwd_f32(C.byref(d), _ptr(ws), wsb, _stream()), "dc_lstm_seq_bwd_f32")
     return dz, dU

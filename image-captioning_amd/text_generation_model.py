@@ -163,6 +163,13 @@ class CaptionModelV1(KerasLikeModel):
     D1 = 1024
     HEAD = (("mrcnn_class_conv1", "mrcnn_class_bn1"), ("mrcnn_class_conv2", "mrcnn_class_bn2"))
     overlap_sync = True        # data parallel: all-reduce a layer group's gradients as soon as its backward is enqueued
+    # Keras recurrent_dropout of imgcap_lstm1 / imgcap_lstm2 (:141-142).  0.0 (default) = the deterministic graph every parity
+    # test and the benchmark run; 0.2 = the reference's training-phase behaviour: per train step four inverted-dropout masks
+    # [B, units] per LSTM (one per gate i,f,c,o), fixed over the timesteps, drawn from a seeded generator.  One mask set per RoI
+    # serves all T prefixes of its caption (Keras draws one per (RoI, prefix) row of the TimeDistributed batch -- the same
+    # marginal distribution; per-RoI masks are what keeps the T-prefix graph equal to a single pass).  Never applied in
+    # predict / test_on_batch / generate (Keras' learning phase 0).
+    recurrent_dropout = 0.0
 
     def __init__(self, features_input, config, units, mode, device=None, seed=0, extra_params=(), compute_dtype="f32"):
         """extra_params: (name, array, trainable) entries that share this model's flat parameter bucket (the joint
@@ -196,9 +203,22 @@ class CaptionModelV1(KerasLikeModel):
             st.enable_bf16_shadow(own)                    # GEMM kernels only: biases, BN parameters and the recurrences stay fp32
         self.grad_sync = None
         self._bufs = {}
+        self._drop_rng = np.random.default_rng(seed + 77)
+        self._rec_masks = (None, None)           # device masks of the current train step (lstm1, lstm2) or None
+        self.last_rec_masks = None               # their host copies (tests feed them to the oracle)
 
     def compile(self, optimizer, loss=None):
         self.optimizer, self.loss = optimizer, loss
+
+    def _draw_rec_masks(self, B, training):
+        """Keras LSTMCell._generate_recurrent_dropout_mask for both LSTMs: K.dropout(ones, rate) x 4 in the training phase."""
+        rate = float(self.recurrent_dropout or 0.0)
+        if not training or rate <= 0.0:
+            self._rec_masks, self.last_rec_masks = (None, None), None
+            return
+        host = [(self._drop_rng.random((4, B, self.units)) >= rate).astype(np.float32) / np.float32(1.0 - rate) for _ in range(2)]
+        self.last_rec_masks = host
+        self._rec_masks = tuple(torch.tensor(m, device=self.device) for m in host)
 
     def _buf(self, key, shape, dtype=torch.float32):
         b = self._bufs.get(key)
@@ -273,11 +293,11 @@ class CaptionModelV1(KerasLikeModel):
         z1 = ops.gemm(w['imgcap_embedding_layer/embeddings'], w['imgcap_lstm1/kernel'][:self.E], gather=ids_tm, shift=w['imgcap_lstm1/bias'],
                       residual=zf, res_rows=B, out=self._buf('z1', (T * B, 4 * u)))
         h1, c1 = ops.lstm_seq_fwd(z1, w['imgcap_lstm1/recurrent_kernel'], mask, B, T, self._buf('h1', (T * B, u)),
-                                  self._buf('c1', (T * B, u)))
+                                  self._buf('c1', (T * B, u)), rec_masks=self._rec_masks[0])
         self._h1 = self._act('h1', h1)
         z2 = self._mm(self._h1, self._wview('imgcap_lstm2/kernel'), key='z2', shift=w['imgcap_lstm2/bias']).f
         h2, c2 = ops.lstm_seq_fwd(z2, w['imgcap_lstm2/recurrent_kernel'], mask, B, T, self._buf('h2', (T * B, u)),
-                                  self._buf('c2', (T * B, u)))
+                                  self._buf('c2', (T * B, u)), rec_masks=self._rec_masks[1])
         self._h2 = self._act('h2', h2)
         zdf = self._mm(f, self._wview('imgcap_lstm_d1/kernel', (u, u + self.FEAT)), key='zdf').f
         return self._mm(self._h2, self._wview('imgcap_lstm_d1/kernel', (0, u)), key='a1', shift=w['imgcap_lstm_d1/bias'], residual=zdf,
@@ -301,6 +321,7 @@ class CaptionModelV1(KerasLikeModel):
         """row_weights [B,T] + keras_sparse: the joint model's masked K.sparse_categorical_crossentropy
         (dense_img_cap/dense_model.py:936-946); loss rows and dlogits are then weighted per row instead of 1/N."""
         ids_tm, mask, B, T = self._tables(caps)
+        self._draw_rec_masks(B, training=want_grad)
         X = feat.reshape(B, -1)
         f = self._head_forward(X)
         a1 = self._hidden(f, ids_tm, mask, B, T)
@@ -364,7 +385,7 @@ class CaptionModelV1(KerasLikeModel):
         dh2 = self._mm(dz_d1, self._wview('imgcap_lstm_d1/kernel', (0, u)), key='dh2', b_trans=True).f
         # lstm2
         dz2, _ = ops.lstm_seq_bwd(bf['z2'], w['imgcap_lstm2/recurrent_kernel'], mask, h2.f, bf['c2'], B, T, dh_seq=dh2,
-                                  dz=self._buf('dz2', (N, 4 * u)), dU=g['imgcap_lstm2/recurrent_kernel'])
+                                  dz=self._buf('dz2', (N, 4 * u)), dU=g['imgcap_lstm2/recurrent_kernel'], rec_masks=self._rec_masks[1])
         dz2 = self._act('dz2', dz2)
         self._mm(h1, dz2, a_trans=True, out=g['imgcap_lstm2/kernel'])
         ops.colsum(dz2.f, out=g['imgcap_lstm2/bias'])
@@ -372,7 +393,7 @@ class CaptionModelV1(KerasLikeModel):
         dh1 = self._mm(dz2, self._wview('imgcap_lstm2/kernel'), key='dh1', b_trans=True).f
         # lstm1
         dz1, _ = ops.lstm_seq_bwd(bf['z1'], w['imgcap_lstm1/recurrent_kernel'], mask, h1.f, bf['c1'], B, T, dh_seq=dh1,
-                                  dz=self._buf('dz1', (N, 4 * u)), dU=g['imgcap_lstm1/recurrent_kernel'])
+                                  dz=self._buf('dz1', (N, 4 * u)), dU=g['imgcap_lstm1/recurrent_kernel'], rec_masks=self._rec_masks[0])
         gW1 = g['imgcap_lstm1/kernel']
         ops.gemm(w['imgcap_embedding_layer/embeddings'], dz1, a_trans=True, gather=ids_tm, out=gW1[:self.E])
         ops.colsum(dz1, out=g['imgcap_lstm1/bias'])
@@ -448,6 +469,7 @@ class CaptionModelV1(KerasLikeModel):
         model) returns (probs or None, ids, word_scores [B,T] = the probability of each chosen word)."""
         feat = self._dev_feat(feat)
         B, T = feat.shape[0], self.T
+        self._draw_rec_masks(B, training=False)
         f = self._head_forward(feat.reshape(B, -1))
         prefix = np.zeros((B, T), np.float32)
         prefix[:, 0] = 1

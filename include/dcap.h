@@ -249,6 +249,9 @@ typedef struct {
     const uint8_t* mask;
     float* h_seq;
     float* c_seq;
+    const float* rec_masks;   /* optional [4][B][U]: Keras recurrent_dropout masks (values 0 or 1/(1-rate)), one per gate i,f,c,o,
+                                 fixed over the timesteps: z_g = x W_g + (h_{t-1} * m_g) U_g + b_g  (training phase of
+                                 LSTM(recurrent_dropout=0.2), text_generation_model.py:141-142).  NULL = no dropout. */
 } dc_lstm_fwd_desc;
 
 size_t dc_lstm_seq_workspace_bytes(int B, int T, int U);
@@ -270,6 +273,7 @@ typedef struct {
     float* dz;
     float* dU_rec;
     int accumulate_dU;
+    const float* rec_masks;   /* the masks of the forward call (or NULL) */
 } dc_lstm_bwd_desc;
 
 int dc_lstm_seq_bwd_f32(const dc_lstm_bwd_desc* d, void* workspace, size_t workspace_bytes, void* stream);

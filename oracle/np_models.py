@@ -232,16 +232,18 @@ def v2_greedy_decode(Wt, feat_one, window, steps):
 # v1 decoder (Model 3, par-inject): text_generation_model.py:130-294
 # --------------------------------------------------------------------------------------------
 
-def v1_word_model_forward(Wt, f, prefix):
+def v1_word_model_forward(Wt, f, prefix, rec_masks=None):
     """word_generation_model (text_generation_model.py:130-156): f [B,1024], prefix [B,T] float
-    token ids (0 = pad) -> probs [B,V]."""
+    token ids (0 = pad) -> probs [B,V].  rec_masks = (masks of imgcap_lstm1, masks of imgcap_lstm2), each [4,B,512]: the
+    training phase of recurrent_dropout=0.2 (:141-142) with those masks; None = dropout off."""
     emb, mask = O.embedding(prefix, Wt['imgcap_embedding_layer/embeddings'])
     T = prefix.shape[1]
     x = np.concatenate([emb, np.repeat(f[:, None, :], T, axis=1)], axis=2)      # [emb(300) | f(1024)]
+    m1, m2 = (None, None) if rec_masks is None else rec_masks
     H1, c1 = O.lstm_forward(x, mask, Wt['imgcap_lstm1/kernel'], Wt['imgcap_lstm1/recurrent_kernel'],
-                            Wt['imgcap_lstm1/bias'])
+                            Wt['imgcap_lstm1/bias'], rec_masks=m1)
     H2, c2 = O.lstm_forward(H1, mask, Wt['imgcap_lstm2/kernel'], Wt['imgcap_lstm2/recurrent_kernel'],
-                            Wt['imgcap_lstm2/bias'])
+                            Wt['imgcap_lstm2/bias'], rec_masks=m2)
     cat = np.concatenate([H2[:, -1], f], axis=1)                                 # [lstm2(512) | f(1024)]
     z1 = cat @ np.asarray(Wt['imgcap_lstm_d1/kernel'], F64) + np.asarray(Wt['imgcap_lstm_d1/bias'], F64)
     a1 = O.relu(z1)
@@ -284,23 +286,25 @@ def v1_targets(caps):
     return np.concatenate([caps[:, 1:], np.zeros((caps.shape[0], 1))], axis=1).astype(np.int32)
 
 
-def v1_training_forward(Wt, feat, caps):
-    """build_lstm_model(..., 'training').predict([feat, caps]) -> [B,T,V] (dropout off)."""
+def v1_training_forward(Wt, feat, caps, rec_masks=None):
+    """build_lstm_model(..., 'training').predict([feat, caps]) -> [B,T,V].  rec_masks: see v1_word_model_forward; the SAME
+    per-RoI masks are applied to every prefix of a RoI (Keras draws them per (RoI, prefix) row of the TimeDistributed batch:
+    same marginal distribution, but only per-RoI masks keep the T-prefix graph equal to one masked pass over the caption)."""
     f, hc = roi_head_forward(feat, Wt)
     P = v1_prefixes(caps)
     T = P.shape[1]
     outs, caches = [], []
     for j in range(T):
-        p, c = v1_word_model_forward(Wt, f, P[:, j])
+        p, c = v1_word_model_forward(Wt, f, P[:, j], rec_masks)
         outs.append(p)
         caches.append(c)
     return np.stack(outs, axis=1), dict(head=hc, f=f, caches=caches)
 
 
-def v1_loss_and_grads(Wt, feat, caps):
+def v1_loss_and_grads(Wt, feat, caps, rec_masks=None):
     """roi_caption_loss (text_generation_model.py:286-294): every row has sum(y_true)=1>0, so the
     loss is the mean CE over all B*T rows.  Gradients of all trainable weights (decoder + head)."""
-    probs, c = v1_training_forward(Wt, feat, caps)
+    probs, c = v1_training_forward(Wt, feat, caps, rec_masks)
     tg = v1_targets(caps)
     B, T, V = probs.shape
     loss = O.categorical_crossentropy(tg, probs).mean()

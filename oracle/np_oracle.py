@@ -278,10 +278,18 @@ def embedding(ids, table):
     return np.asarray(table, F64)[ids], ids != 0
 
 
-def lstm_forward(x, mask, W, U, b, h0=None, c0=None):
+def recurrent_dropout_masks(rng, B, Uh, rate):
+    """Keras LSTMCell._generate_recurrent_dropout_mask (training phase): four masks K.dropout(ones[B,Uh], rate) -- kept units
+    scaled by 1/(1-rate) -- one per gate i,f,c,o, drawn once per call and reused at every timestep."""
+    return (rng.random((4, B, Uh)) >= rate).astype(F64) / (1.0 - rate)
+
+
+def lstm_forward(x, mask, W, U, b, h0=None, c0=None, rec_masks=None):
     """Keras LSTM (gate blocks i,f,c,o; hard-sigmoid gates; tanh) with mask carry.
     x [B,T,I], mask [B,T] bool or None.  Returns (H [B,T,Uh] -- output per step with carry, zeros
-    before the first unmasked step --, cache)."""
+    before the first unmasked step --, cache).
+    rec_masks [4,B,Uh] (optional): recurrent_dropout in the training phase (Keras 2.1 LSTMCell.call, implementation 1):
+    h_{t-1} enters gate g as h_{t-1} * rec_masks[g]  (text_generation_model.py:141-142)."""
     x = np.asarray(x, F64)
     B, T, _ = x.shape
     Uh = U.shape[0]
@@ -291,9 +299,13 @@ def lstm_forward(x, mask, W, U, b, h0=None, c0=None):
     if mask is None:
         mask = np.ones((B, T), bool)
     H = np.zeros((B, T, Uh))
-    cache = dict(x=x, mask=mask, W=W, U=U, steps=[])
+    rm = None if rec_masks is None else np.asarray(rec_masks, F64)
+    cache = dict(x=x, mask=mask, W=W, U=U, steps=[], rec_masks=rm)
     for t in range(T):
-        z = x[:, t] @ W + h @ U + b
+        if rm is None:
+            z = x[:, t] @ W + h @ U + b
+        else:
+            z = x[:, t] @ W + b + np.concatenate([(h * rm[g]) @ U[:, g * Uh:(g + 1) * Uh] for g in range(4)], axis=1)
         zi, zf, zc, zo = z[:, :Uh], z[:, Uh:2 * Uh], z[:, 2 * Uh:3 * Uh], z[:, 3 * Uh:]
         i, f, g, o = hard_sigmoid(zi), hard_sigmoid(zf), np.tanh(zc), hard_sigmoid(zo)
         cn = f * c + i * g
@@ -318,6 +330,7 @@ def lstm_backward(dH, cache, dh_last=None):
     dW, dU, db = np.zeros_like(W), np.zeros_like(U), np.zeros(4 * Uh)
     dh = np.zeros((B, Uh)) if dh_last is None else np.asarray(dh_last, F64).copy()
     dc = np.zeros((B, Uh))
+    rm = cache.get('rec_masks')
     for t in reversed(range(T)):
         if dH is not None:
             dh = dh + dH[:, t]
@@ -333,10 +346,18 @@ def lstm_backward(dH, cache, dh_last=None):
             do * hard_sigmoid_grad(z[:, 3 * Uh:]),
         ], axis=1)
         dW += x[:, t].T @ dz
-        dU += hp.T @ dz
         db += dz.sum(0)
         dx[:, t] = dz @ W.T
-        dh = dh * (1.0 - m) + dz @ U.T
+        if rm is None:
+            dU += hp.T @ dz
+            dh_rec = dz @ U.T
+        else:
+            dh_rec = np.zeros_like(dh)
+            for g in range(4):
+                sl = slice(g * Uh, (g + 1) * Uh)
+                dU[:, sl] += (hp * rm[g]).T @ dz[:, sl]
+                dh_rec += rm[g] * (dz[:, sl] @ U[:, sl].T)
+        dh = dh * (1.0 - m) + dh_rec
         dc = dc * (1.0 - m) + dcn * f
     return dx, dW, dU, db
 

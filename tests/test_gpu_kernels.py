@@ -240,6 +240,40 @@ def test_lstm_seq_forward_backward(ops, B, T, I, U, masked):
     close(ops.gemm(dz, dev(W), b_trans=True).view(T, B, I).permute(1, 0, 2), dx, 5e-5)   # dx = dz kernel^T
 
 
+@pytest.mark.parametrize("B,T,I,U", [(6, 5, 16, 32), (64, 10, 64, 512), (200, 4, 32, 128)])
+def test_lstm_recurrent_dropout_matches_oracle(ops, B, T, I, U):
+    """Keras recurrent_dropout in the training phase: given the four per-gate masks, forward states and every gradient of the
+    recurrence equal the oracle's (which finite differences pin, tests/test_oracle_kat.py)."""
+    rng = np.random.default_rng(B + T + U)
+    x = rng.standard_normal((B, T, I))
+    W = rng.standard_normal((I, 4 * U)) / np.sqrt(I)
+    Ur = rng.standard_normal((U, 4 * U)) / np.sqrt(U)
+    b = 0.1 * rng.standard_normal(4 * U)
+    mask = rng.random((B, T)) > 0.25
+    mask[0] = False
+    mask[1] = True
+    rm = O.recurrent_dropout_masks(rng, B, U, 0.2)
+    H, cache = O.lstm_forward(x, mask, W, Ur, b, rec_masks=rm)
+    dH = rng.standard_normal((B, T, U))
+    dx, dW, dU, db = O.lstm_backward(dH, cache)
+    xt = dev(np.transpose(x, (1, 0, 2)).reshape(T * B, I))
+    z = ops.gemm(xt, dev(W), shift=dev(b))
+    mk = dev(mask.T.reshape(-1), torch.uint8)
+    Ud, rmd = dev(Ur), dev(rm)
+    h_seq, c_seq = ops.lstm_seq_fwd(z, Ud, mk, B, T, rec_masks=rmd)
+    close(h_seq.view(T, B, U).permute(1, 0, 2), H)
+    dz, dUd = ops.lstm_seq_bwd(z, Ud, mk, h_seq, c_seq, B, T, dh_seq=dev(np.transpose(dH, (1, 0, 2)).reshape(T * B, U)), rec_masks=rmd)
+    close(dUd, dU, 5e-5)
+    close(ops.gemm(xt, dz, a_trans=True), dW, 5e-5)
+    close(ops.colsum(dz), db, 5e-5)
+    ones = torch.ones_like(rmd)                                        # masks of ones == the plain (fused) recurrence
+    z2 = ops.gemm(xt, dev(W), shift=dev(b))
+    z3 = z2.clone()
+    h_a, _ = ops.lstm_seq_fwd(z2, Ud, mk, B, T, rec_masks=ones)
+    h_b, _ = ops.lstm_seq_fwd(z3, Ud, mk, B, T)
+    close(h_a, h_b.cpu().numpy(), 1e-5)
+
+
 @pytest.mark.parametrize("M,V", [(7, 1000), (64, 10000), (5, 1003)])
 def test_softmax_ce(ops, M, V):
     rng = np.random.default_rng(V)

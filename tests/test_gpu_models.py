@@ -23,6 +23,15 @@ def gpu():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(params=["f32", "bf16x3"])
+def conv_math(request, monkeypatch):
+    """Every model-level test that runs convolutions runs twice: with exact fp32 MFMA products and with the split-bf16
+    arithmetic (three bf16 pieces per operand, six matrix-pipe products) -- held to the SAME tolerances, which is the
+    "fp32-grade" claim of DESIGN.md section 5.  The encoder plan reads DCAP_CONV_MATH when it is built."""
+    monkeypatch.setenv("DCAP_CONV_MATH", request.param)
+    return request.param
+
+
 def rel_err(got, want):
     got = np.asarray(got, np.float64)
     want = np.asarray(want, np.float64)
@@ -41,7 +50,7 @@ def make_v2(V, inject, Tw, seed=0):
     return model, Wt
 
 
-def test_encoder_matches_oracle(gpu):
+def test_encoder_matches_oracle(gpu, conv_math):
     from image_captioning_amd import synth
     from image_captioning_amd.config import Config
     from image_captioning_amd.modified_dense_model import DenseImageCapRCNN
@@ -126,7 +135,7 @@ def test_v2_greedy_decode_ids_bit_exact(gpu):
         assert np.abs(rows - want_rows).max() < 1e-5
 
 
-def test_full_size_properties(gpu):
+def test_full_size_properties(gpu, conv_math):
     """BASELINE-size decoder step (64 captions x 15 tokens, V=10000): properties that need no oracle run:
     probabilities sum to 1, loss at step 0 ~ ln V for near-uniform init, the loss falls over steps,
     and two models fed the same data stay bit-identical (determinism)."""
@@ -189,6 +198,41 @@ def test_v1_training_graph_matches_as_written_oracle(gpu):
             assert np.abs(model.store.w[k].cpu().numpy() - Wt[k]).max() < 2e-5, (k, step)
 
 
+def test_v1_recurrent_dropout_is_opt_in_seeded_and_matches_the_oracle_given_its_masks(gpu):
+    """recurrent_dropout=0.2 (text_generation_model.py:141-142): off by default; when switched on, a train step draws seeded
+    per-gate masks for both LSTMs, and loss + every gradient equal the oracle's T-prefix graph run with those masks;
+    test_on_batch / predict (learning phase 0) never apply them."""
+    from image_captioning_amd import synth
+    from image_captioning_amd.text_generation_model import DenseCapConfig, build_lstm_model, Adam, caption_targets
+    V, T, B = 40, 6, 4
+    cfg = DenseCapConfig(V, synth.embedding_matrix(3, V), B)
+    cfg.PADDING_SIZE = T
+    model = build_lstm_model([7, 7, 256], cfg, 512, 'training', seed=0)
+    model.compile(optimizer=Adam(amsgrad=True), loss="roi_caption_loss")
+    assert model.recurrent_dropout == 0.0
+    Wt = {k: v.astype(np.float64) for k, v in model.get_weights_dict().items()}
+    rng = np.random.default_rng(1)
+    feat = rng.standard_normal((B, 7, 7, 256)).astype(np.float32)
+    caps = synth.captions_v1(2, B, T, V, lmin=1, lmax=3)
+    tg = caption_targets(caps)
+    plain = model.test_on_batch([feat, caps], tg)
+    model.recurrent_dropout = 0.2
+    assert model.test_on_batch([feat, caps], tg) == plain and model.last_rec_masks is None      # evaluation: no dropout
+    loss_rows, _ = model._forward_train(model._dev_feat(feat), caps, tg, want_grad=True)
+    model._backward()
+    masks = [m.astype(np.float64) for m in model.last_rec_masks]
+    assert all(set(np.unique(m)) <= {0.0, 1.25} and m.shape == (4, B, 512) for m in masks) and abs(masks[0].mean() - 1.0) < 0.05
+    want_loss, G, _ = M.v1_loss_and_grads(Wt, feat.astype(np.float64), caps, rec_masks=tuple(masks))
+    got_loss = float(loss_rows.mean().item())
+    assert abs(got_loss - want_loss) < 1e-5 * max(1.0, abs(want_loss)) and abs(got_loss - plain) > 2e-6            # dropout did change the forward pass
+    for k, g in G.items():
+        assert rel_err(model.store.grad[k].cpu().numpy(), g) < 3e-4, k
+    again = build_lstm_model([7, 7, 256], cfg, 512, 'training', seed=0)                          # same seed: same masks
+    again.recurrent_dropout = 0.2
+    again._forward_train(again._dev_feat(feat), caps, tg, want_grad=True)
+    assert all(np.array_equal(a, b) for a, b in zip(again.last_rec_masks, model.last_rec_masks))
+
+
 def test_v1_greedy_inference_ids_bit_exact(gpu):
     from image_captioning_amd import synth
     from image_captioning_amd.text_generation_model import DenseCapConfig, build_lstm_model
@@ -205,7 +249,7 @@ def test_v1_greedy_inference_ids_bit_exact(gpu):
     assert np.abs(probs - want_p).max() < 1e-5
 
 
-def test_image_level_features_with_rpn_proposals(gpu):
+def test_image_level_features_with_rpn_proposals(gpu, conv_math):
     """feature_generation/ variant: RPN + ProposalLayer + RoIAlign + mean over RoIs.  Scores reach the sort with
     fp32 rounding differences, so near-tied candidates may swap: the proposal SETS must agree almost everywhere and
     the pooled 12 544-vector within 1e-3."""
@@ -305,7 +349,7 @@ def joint_grads_as_reference(model):
     return out
 
 
-def test_joint_model_step_matches_oracle(gpu):
+def test_joint_model_step_matches_oracle(gpu, conv_math):
     """One image through FPN + RPN + proposals + detection targets + RoIAlign + head + Model-3 decoder: the four loss
     terms and the gradient of every trainable weight against the oracle's hand-written backward (which
     tests/test_oracle_vs_torch.py ties to torch autograd), given the RoI sample the device drew."""
@@ -355,7 +399,7 @@ def test_joint_model_bf16_step_tracks_the_fp32_oracle(gpu):
     assert torch.equal(st.flat_bf16, st.flat[:st.flat_bf16.numel()].to(torch.bfloat16))
 
 
-def test_joint_model_training_reduces_loss_and_round_trips_weights(gpu, tmp_path):
+def test_joint_model_training_reduces_loss_and_round_trips_weights(gpu, tmp_path, conv_math):
     S, V, T, blocks = 128, 24, 5, 1
     model, cfg, Wt = make_joint(S, V, T, blocks)
     back = model.get_weights_dict()
@@ -383,7 +427,7 @@ def test_joint_model_training_reduces_loss_and_round_trips_weights(gpu, tmp_path
     assert not np.array_equal(b['imgcap_lstm_d2/kernel'], c['imgcap_lstm_d2/kernel'])
 
 
-def test_joint_model_inference_captions(gpu):
+def test_joint_model_inference_captions(gpu, conv_math):
     """Inference graph of the joint model: proposals -> RoI features -> greedy decoder -> GenerationMatchLayer.  The decoded
     ids of the surviving boxes against the oracle's greedy decoder run on the oracle's features of the same proposals."""
     from image_captioning_amd import synth
@@ -447,7 +491,7 @@ def test_encoder_conv_math_modes(gpu, math, tol):
     assert err < tol, (math, err)
 
 
-def test_joint_model_degenerate_batches(gpu):
+def test_joint_model_degenerate_batches(gpu, conv_math):
     """No positive RoI (no GT box overlaps a proposal), no RPN anchors selected: the caption and RPN losses are exactly 0,
     the gradient is the L2 regulariser's alone, nothing is NaN, and an optimizer step still works."""
     S, V, T, blocks = 128, 24, 5, 1

@@ -134,6 +134,38 @@ def test_lstm_backward_matches_finite_differences():
         assert abs(num - grad[idx]) < 1e-6 * max(1, abs(num))
 
 
+def test_lstm_recurrent_dropout_masks_and_gradients():
+    """Keras recurrent_dropout (training phase): masks of ones reproduce the plain LSTM; kept units are scaled by 1/(1-rate); the
+    hand-written backward with masks matches finite differences (incl. through masked timesteps)."""
+    rng = np.random.default_rng(9)
+    B, T, I, Uh = 3, 4, 5, 2
+    x = rng.standard_normal((B, T, I))
+    mask = np.array([[1, 1, 0, 1], [0, 1, 1, 0], [1, 1, 1, 1]], bool)
+    W, U, b = 0.5 * rng.standard_normal((I, 4 * Uh)), 0.5 * rng.standard_normal((Uh, 4 * Uh)), 0.1 * rng.standard_normal(4 * Uh)
+    H0, _ = O.lstm_forward(x, mask, W, U, b)
+    H1, _ = O.lstm_forward(x, mask, W, U, b, rec_masks=np.ones((4, B, Uh)))
+    np.testing.assert_allclose(H0, H1, rtol=0, atol=1e-15)
+    rm = O.recurrent_dropout_masks(np.random.default_rng(1), B, Uh, 0.2)
+    assert set(np.unique(rm)) <= {0.0, 1.25} and rm.shape == (4, B, Uh)
+    big = O.recurrent_dropout_masks(np.random.default_rng(2), 200, 512, 0.2)
+    assert abs(big.mean() - 1.0) < 5e-3 and abs((big == 0).mean() - 0.2) < 5e-3           # inverted dropout keeps the expectation
+    R = rng.standard_normal((B, T, Uh))
+
+    def loss(W_, U_, b_, x_):
+        H, _ = O.lstm_forward(x_, mask, W_, U_, b_, rec_masks=rm)
+        return (H * R).sum()
+    H, cache = O.lstm_forward(x, mask, W, U, b, rec_masks=rm)
+    assert np.abs(H - H0).max() > 1e-3
+    dx, dW, dU, db = O.lstm_backward(R, cache)
+    eps = 1e-6
+    for arr, grad, idx in [(W, dW, (1, 3)), (U, dU, (0, 5)), (U, dU, (1, 2)), (b, db, (2,)), (x, dx, (0, 1, 2)), (x, dx, (2, 0, 0))]:
+        a2 = arr.copy(); a2[idx] += eps
+        a3 = arr.copy(); a3[idx] -= eps
+        args = lambda a: (a if arr is W else W, a if arr is U else U, a if arr is b else b, a if arr is x else x)
+        num = (loss(*args(a2)) - loss(*args(a3))) / (2 * eps)
+        assert abs(num - grad[idx]) < 1e-6 * max(1, abs(num))
+
+
 def test_cce_uniform_and_clip():
     V = 1000
     p = np.full((2, V), 1.0 / V)
