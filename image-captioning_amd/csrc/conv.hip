@@ -66,6 +66,10 @@ static inline void conv_dims(const dc_conv_desc* d, bool stem, int& M, int& N, i
 
 using WeightKC = DenseKCT<true>;   // packed weights: K = kh*kw*Cin is a multiple of 32, rows 16-byte aligned
 
+static inline bool conv_is_pointwise(const dc_conv_desc* d) {
+    return d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && d->Ho == d->H && d->Wo == d->W;
+}
+
 template <class AL, class BL>
 static int conv_dispatch(const AL& al, const BL& bl, const Epilogue& ep, int M, int N, int K, const TileChoice& t, void* ws,
                          size_t wsb, hipStream_t s) {
@@ -145,6 +149,8 @@ extern "C" int dc_conv2d_tile_config(const dc_conv_desc* d, int* bm, int* bn, in
     return DC_OK;
 }
 
+extern "C" int dc_conv2d_is_pointwise(const dc_conv_desc* d) { return d && d->Cin != 4 && d->math == DC_MATH_F32 && conv_is_pointwise(d) ? 1 : 0; }
+
 extern "C" int dc_conv2d_nhwc_f32(const dc_conv_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
     bool stem;
     int rc = conv_validate(d, stem);
@@ -162,6 +168,13 @@ extern "C" int dc_conv2d_nhwc_f32(const dc_conv_desc* d, void* workspace, size_t
     WeightKC bl{d->w, K, N, nullptr};
     if (stem) {
         StemKC al{d->x, d->H, d->W, d->Ho, d->Wo, M, (unsigned)((size_t)d->N * d->H * d->W * 4 * sizeof(float))};
+        return conv_dispatch(al, bl, ep, M, N, K, t, workspace, workspace_bytes, s);
+    }
+    if (conv_is_pointwise(d)) {
+        // 1x1 / stride 1 / no padding: the im2col matrix IS the activation tensor [pixels][Cin] -- the dense K-contiguous loader
+        // (no per-row pixel decode, no tap masks at block start: on the short-K layers, K = 64..256, that set-up was a
+        // visible share of a block's life)
+        DenseKCT<true> al{d->x, d->Cin, M, nullptr};
         return conv_dispatch(al, bl, ep, M, N, K, t, workspace, workspace_bytes, s);
     }
     Im2colKC al{d->x, d->H, d->W, d->Cin, d->Ho, d->Wo, d->stride, d->pad_t, d->pad_l, d->kw, d->kh * d->kw, M,

@@ -609,7 +609,11 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[TM][TN], float* smem, c
     const int c4 = tid % CPR, rp = tid / CPR;
     const int col = n0 + 4 * c4;
     const bool full = !partial && ep.vec4 && col + 3 < N;
+#ifdef DCAP_EXP_NORES       // ablation builds only (tools/build_variant.sh): the residual operand is not fetched
+    const bool pre_res = false, pre_acc = full && ep.accumulate;
+#else
     const bool pre_res = full && ep.res_mode != 0, pre_acc = full && ep.accumulate;
+#endif
     f4 qres[G], qacc[G];
     auto prefetch = [&](int p0) {
 #pragma unroll
@@ -667,7 +671,12 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[TM][TN], float* smem, c
                 if (pre_res) { v.x += qres[g][0]; v.y += qres[g][1]; v.z += qres[g][2]; v.w += qres[g][3]; }
                 if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 if (pre_acc) { v.x += qacc[g][0]; v.y += qacc[g][1]; v.z += qacc[g][2]; v.w += qacc[g][3]; }
+#ifdef DCAP_EXP_NOSTORE     // ablation builds only: the finished values are kept alive but not written
+                asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+                if (row < 0) {
+#else
                 if (row < M) {
+#endif
                     if (ep.C) *reinterpret_cast<float4*>(ep.C + (long)row * ep.ldc + col) = v;
                     if (ep.Cb) {
                         typedef unsigned short us4 __attribute__((ext_vector_type(4)));
@@ -721,7 +730,11 @@ __device__ __forceinline__ void igemm_mainloop(const AL& al, const BL& bl, float
 
     constexpr int KT = tiles_per_sync<BM, BN>();
     f4 ra[KT][BM / 32], rb[KT][BN / 32];
+#ifdef DCAP_EXP_NOMAIN      // ablation builds only: one K-tile instead of all (prologue + epilogue cost)
+    const int nkt = 1;
+#else
     const int nkt = (kend - kbeg + BK - 1) / BK;
+#endif
 #pragma unroll
     for (int j = 0; j < KT; ++j)
         if (j < nkt) {
