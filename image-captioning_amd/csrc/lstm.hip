@@ -100,7 +100,10 @@ __global__ __launch_bounds__(256) void lstm_step_fused2_kernel(float* __restrict
                                                                const float* __restrict__ h_prev, const float* __restrict__ c_prev,
                                                                const uint8_t* __restrict__ mask_t, float* __restrict__ h_t,
                                                                float* __restrict__ c_t, int B, int U) {
-    __shared__ float part[4][64][33];
+    // 16.9 KB of LDS (two partial tiles, not four): in the training pipeline this kernel runs beside the encoder's convolutions,
+    // whose two resident blocks leave ~19 KB of a CU's LDS -- with the 33.8 KB of the first version its blocks could only start
+    // at conv-kernel boundaries (78-100 us per step in the pipeline against 18 us alone).
+    __shared__ float part[2][64][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ub = blockIdx.x, u0 = ub * 8, r0 = blockIdx.y * 64;
     const int i = lane & 31, h = lane >> 5;
@@ -146,11 +149,22 @@ __global__ __launch_bounds__(256) void lstm_step_fused2_kernel(float* __restrict
             }
         }
     }
+    if (wave >= 2) {                                   // round 1: waves 2, 3 publish their K-quarter's partial tiles
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
-        part[wave][rr][i] = acc0[r];
-        part[wave][32 + rr][i] = acc1[r];
+        for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+            part[wave - 2][rr][i] = acc0[r];
+            part[wave - 2][32 + rr][i] = acc1[r];
+        }
+    }
+    __syncthreads();
+    if (wave < 2) {                                    // round 2: waves 0, 1 add theirs on top (same lane owns the same elements)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+            part[wave][rr][i] += acc0[r];
+            part[wave][32 + rr][i] += acc1[r];
+        }
     }
     __syncthreads();
     // gate math: 64 rows x 8 units = 512 items, two per thread
@@ -164,7 +178,7 @@ __global__ __launch_bounds__(256) void lstm_step_fused2_kernel(float* __restrict
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int col = g * 8 + uu;
-            zg[g] = zrow[(long)g * U] + ((part[0][row][col] + part[1][row][col]) + (part[2][row][col] + part[3][row][col]));
+            zg[g] = zrow[(long)g * U] + (part[0][row][col] + part[1][row][col]);
             zrow[(long)g * U] = zg[g];
         }
         const long o = (long)brow * U + u0 + uu;
@@ -255,7 +269,20 @@ extern "C" size_t dc_lstm_seq_workspace_bytes(int B, int T, int U) {
     }
     const size_t bwd = align_up(g) + 2 * align_up((size_t)B * U * sizeof(float));
     const size_t fwd = align_up(g) + ((U & 31) == 0 ? align_up((size_t)4 * U * U * sizeof(float)) : 0);     // + the repacked U_rec
-    // recurrent-dropout path: four masked copies of h (forward), of dz * U^T and of h_seq (backward)
+    // recurrent-dropout path: four masked copies of h (forward), of dz * U^T and of h_seq (backward); its per-gate GEMMs
+    // ([B,U] x [U,U] and [U,(T-1)B] x [(T-1)B,U]) choose their own split-K slabs
+    {
+        dc_gemm_desc a{};
+        a.M = B; a.N = U; a.K = U; a.lda = U; a.ldb = 4 * U; a.ldc = 4 * U;
+        g = std::max(g, dc_gemm_workspace_bytes(&a));
+        a.b_trans = 1; a.lda = 4 * U; a.ldc = U;
+        g = std::max(g, dc_gemm_workspace_bytes(&a));
+        if (T > 1) {
+            dc_gemm_desc c{};
+            c.M = U; c.N = U; c.K = (T - 1) * B; c.lda = U; c.a_trans = 1; c.ldb = 4 * U; c.ldc = 4 * U;
+            g = std::max(g, dc_gemm_workspace_bytes(&c));
+        }
+    }
     const size_t drop = align_up(g) + 2 * align_up((size_t)B * U * sizeof(float)) + align_up((size_t)4 * B * U * sizeof(float)) +
                         align_up((size_t)4 * (size_t)std::max(T - 1, 1) * B * U * sizeof(float)) + 1024;
     return std::max(std::max(fwd, bwd), drop);
