@@ -174,15 +174,14 @@ __device__ __forceinline__ void lgkm_wait() {
 }
 
 // The main loop: accumulates A[m0.., kbeg..kend) * B[kbeg..kend), n0..] into acc (MFMA layout, wave origin wm, wn).
-template <bool AKC, bool BKC>
-__device__ __forceinline__ void bgemm_mainloop(const BOperand& a, const BOperand& b, char* smem, int m0, int n0, int kbeg, int kend,
-                                               f32x16 (&acc)[2][2], int wm, int wn) {
+// LA / LB: operand loaders with  static constexpr bool KC  (which LDS image they fill) and
+//   issue(char* img, int k0, int kend, int wave)  -- the LDS-DMA of one K-tile (BLoadOp below wraps BLoad + its operand;
+//   BLoadIm2col gathers the K-major im2col matrix of a weight gradient).
+template <class LA, class LB>
+__device__ __forceinline__ void bgemm_mainloop_t(LA& la, LB& lb, char* smem, int kbeg, int kend, f32x16 (&acc)[2][2], int wm, int wn) {
+    constexpr bool AKC = LA::KC, BKC = LB::KC;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // provably uniform: LDS-DMA destinations live in M0
-    BLoad<AKC> la;
-    BLoad<BKC> lb;
-    la.init(a, m0, lane, wave);
-    lb.init(b, n0, lane, wave);
     const unsigned lds0 = (unsigned)(size_t)(DC_LDS char*)smem;
     BFrag<AKC> fa;
     BFrag<BKC> fb;
@@ -195,8 +194,8 @@ __device__ __forceinline__ void bgemm_mainloop(const BOperand& a, const BOperand
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
     const int nkt = (kend - kbeg + BKB - 1) / BKB;
-    la.issue(a, smem, kbeg, kend, wave);
-    lb.issue(b, smem + B_IMG, kbeg, kend, wave);
+    la.issue(smem, kbeg, kend, wave);
+    lb.issue(smem + B_IMG, kbeg, kend, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     constexpr int RA = BFrag<AKC>::READS, RB = BFrag<BKC>::READS, RS = RA + RB;      // ds reads per k-step
@@ -212,8 +211,8 @@ __device__ __forceinline__ void bgemm_mainloop(const BOperand& a, const BOperand
         constexpr int CUR = decltype(cur_c)::value;
         if (kt + 1 < nkt) {                                               // the other stage was released by the last barrier
             const int k0 = kbeg + (kt + 1) * BKB;
-            la.issue(a, smem + (B_STAGE - CUR), k0, kend, wave);
-            lb.issue(b, smem + (B_STAGE - CUR) + B_IMG, k0, kend, wave);
+            la.issue(smem + (B_STAGE - CUR), k0, kend, wave);
+            lb.issue(smem + (B_STAGE - CUR) + B_IMG, k0, kend, wave);
         }
         BFragRegs a0, b0, a1, b1;                                         // k-steps ping-pong between the two register sets
         bfrag_issue<AKC, CUR, 0>(fa, a0);
@@ -241,6 +240,82 @@ __device__ __forceinline__ void bgemm_mainloop(const BOperand& a, const BOperand
         if (kt + 1 < nkt) tile(kt + 1, std::integral_constant<int, B_STAGE>{});
     }
 }
+
+template <bool KC_>
+struct BLoadOp {                                   // a dense operand: BLoad + the operand it reads
+    static constexpr bool KC = KC_;
+    BLoad<KC_> l;
+    BOperand o;
+    __device__ __forceinline__ void init(const BOperand& op, int origin, int lane, int wave) { o = op; l.init(op, origin, lane, wave); }
+    __device__ __forceinline__ void issue(char* img, int k0, int kend, int wave) const { l.issue(o, img, k0, kend, wave); }
+};
+
+template <bool AKC, bool BKC>
+__device__ __forceinline__ void bgemm_mainloop(const BOperand& a, const BOperand& b, char* smem, int m0, int n0, int kbeg, int kend,
+                                               f32x16 (&acc)[2][2], int wm, int wn) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    BLoadOp<AKC> la;
+    BLoadOp<BKC> lb;
+    la.init(a, m0, lane, wave);
+    lb.init(b, n0, lane, wave);
+    bgemm_mainloop_t(la, lb, smem, kbeg, kend, acc, wm, wn);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of a convolution on the bf16 pipe:  dW[cout][(tap, ci)] = sum over output pixels p of
+// dy[p][cout] * x[pixel(p) + tap][ci]  =  dy^T (K-major: rows = pixels) times the im2col matrix, K-major as well: K row p is the
+// run of Cin channels of ONE (shifted) input pixel, so a 128-column tile inside one tap (Cin % 128 == 0) is a contiguous 256 bytes
+// of x.  The loader keeps (n, oy, ox) of each of its four K rows and walks them 64 pixels per K-tile (add + wrap, no division);
+// taps that fall outside the image and pixels past the end load hardware zeros.
+// ------------------------------------------------------------------------------------------------
+struct BIm2col {
+    const unsigned short* x;       // bf16 [N, H, W, Cin]
+    int H, W, Cin, Ho, Wo, stride, pad_t, pad_l, kw, P;      // P = N*Ho*Wo output pixels (the K extent)
+    unsigned bytes;
+};
+
+struct BLoadIm2col {
+    static constexpr bool KC = false;
+    __amdgpu_buffer_rsrc_t rsrc;
+    BIm2col c;
+    int n[B_NP], oy[B_NP], ox[B_NP];
+    int dy, dx;                    // tap offset of this column tile (block-uniform)
+    int ci_base;                   // first channel of this column tile inside its tap
+    __device__ __forceinline__ void init(const BIm2col& cc, int col0, int kbeg, int lane, int wave) {
+        c = cc;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(c.x), 0, (int)c.bytes, 0x00020000);
+        const int tap = col0 / c.Cin, ci0 = col0 - tap * c.Cin;
+        const int ky = tap / c.kw, kx = tap - ky * c.kw;
+        dy = ky - c.pad_t;
+        dx = kx - c.pad_l;
+        ci_base = ci0;
+#pragma unroll
+        for (int j = 0; j < B_NP; ++j) {
+            const int k = 4 * (wave * B_NP + j) + (lane >> 4);              // K row inside the tile
+            const int p = kbeg + k;
+            const int nn = p / (c.Ho * c.Wo), rem = p - nn * (c.Ho * c.Wo);
+            n[j] = nn;
+            oy[j] = rem / c.Wo;
+            ox[j] = rem - oy[j] * c.Wo;
+        }
+    }
+    __device__ __forceinline__ void issue(char* img, int k0, int kend, int wave) {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int j = 0; j < B_NP; ++j) {
+            const int k = 4 * (wave * B_NP + j) + (lane >> 4);
+            const int ch = (lane & 15) ^ (((k & 3) << 2) | ((k >> 2) & 3));
+            const int iy = oy[j] * c.stride + dy, ix = ox[j] * c.stride + dx;
+            const bool in = (unsigned)iy < (unsigned)c.H && (unsigned)ix < (unsigned)c.W && k0 + k < min(c.P, kend);
+            const unsigned off = (unsigned)(((((long)n[j] * c.H + iy) * c.W + ix) * c.Cin + ci_base + 8 * ch) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (DC_LDS void*)(img + (wave * B_NP + j) * 1024), 16, (int)(in ? off : kOobOffset), 0, 0, 0);
+            ox[j] += BKB;                                                   // next K-tile: 64 pixels further along the row-major walk
+            while (ox[j] >= c.Wo) { ox[j] -= c.Wo; ++oy[j]; }
+            while (oy[j] >= c.Ho) { oy[j] -= c.Ho; ++n[j]; }
+        }
+    }
+};
 
 template <bool AKC, bool BKC>
 __global__ __launch_bounds__(256, 2) void bgemm_kernel(BOperand a, BOperand b, Epilogue ep, int M, int N, int K, int klen,

@@ -6,6 +6,27 @@
 
 namespace dcap {
 
+// dW tile [128 cout][128 (tap, ci)] over the pixel range of this split-K slice
+__global__ __launch_bounds__(256, 2) void bgemm_wgrad_kernel(BOperand dy, BIm2col xc, Epilogue ep, int M, int N, int K, int klen,
+                                                          float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    char* smem = reinterpret_cast<char*>(smem_f);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tiles_n = (N + BT - 1) / BT;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (lid / tiles_n) * BT, n0 = (lid % tiles_n) * BT;
+    const int kbeg = blockIdx.z * klen, kend = min(K, kbeg + klen);
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    BLoadOp<false> la;
+    BLoadIm2col lb;
+    la.init(dy, m0, lane, wave);
+    lb.init(xc, n0, kbeg, lane, wave);
+    f32x16 acc[2][2];
+    bgemm_mainloop_t(la, lb, smem, kbeg, kend, acc, wm, wn);
+    store_tile<BT, BT>(acc, smem_f, ep, partial, M, N, m0, n0, wm, wn);
+}
+
 static int bgemm_validate(const dc_gemm_bf16_desc* d) {
     DC_REQUIRE(d != nullptr, DC_EINVAL, "dc_gemm_bf16: null descriptor");
     DC_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, DC_EINVAL, "dc_gemm_bf16: M,N,K must be positive (got %d,%d,%d)", d->M, d->N, d->K);
@@ -84,6 +105,55 @@ extern "C" int dc_gemm_bf16(const dc_gemm_bf16_desc* d, void* workspace, size_t 
     if (!d->a_trans && d->b_trans) return launch_bgemm<true, true>(a, b, ep, d->M, d->N, d->K, d->split_k, workspace, workspace_bytes, s);
     if (d->a_trans && !d->b_trans) return launch_bgemm<false, false>(a, b, ep, d->M, d->N, d->K, d->split_k, workspace, workspace_bytes, s);
     return launch_bgemm<false, true>(a, b, ep, d->M, d->N, d->K, d->split_k, workspace, workspace_bytes, s);
+}
+
+static int wgrad_bf16_validate(const dc_conv_wgrad_bf16_desc* d) {
+    DC_REQUIRE(d && d->x && d->dy && d->dw, DC_EINVAL, "dc_conv2d_wgrad_bf16: x, dy and dw must be non-null");
+    DC_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->kh >= 1 && d->kw >= 1 && d->stride >= 1, DC_EINVAL,
+               "dc_conv2d_wgrad_bf16: bad shape");
+    DC_REQUIRE(d->Cin % 128 == 0 && d->Cout % 8 == 0, DC_EINVAL,
+               "dc_conv2d_wgrad_bf16: needs Cin %% 128 == 0 (a 128-column tile inside one tap) and Cout %% 8 == 0");
+    DC_REQUIRE(aligned16(d->x) && aligned16(d->dy) && aligned16(d->dw), DC_EALIGN, "dc_conv2d_wgrad_bf16: pointers must be 16-byte aligned");
+    DC_REQUIRE((size_t)d->N * d->H * d->W * d->Cin * 2 < (size_t)0x7FFFFFF0u && (size_t)d->N * d->Ho * d->Wo * d->Cout * 2 < (size_t)0x7FFFFFF0u,
+               DC_EINVAL, "dc_conv2d_wgrad_bf16: x and dy must span < 2 GiB");
+    return DC_OK;
+}
+
+extern "C" size_t dc_conv2d_wgrad_bf16_workspace_bytes(const dc_conv_wgrad_bf16_desc* d) {
+    if (!d || wgrad_bf16_validate(d)) return 0;
+    const int M = d->Cout, N = d->kh * d->kw * d->Cin, K = d->N * d->Ho * d->Wo;
+    const BSplit sp = bgemm_split(M, N, K, d->split_k);
+    return sp.split > 1 ? (size_t)sp.split * M * N * sizeof(float) : 0;
+}
+
+extern "C" int dc_conv2d_wgrad_bf16(const dc_conv_wgrad_bf16_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = wgrad_bf16_validate(d);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int M = d->Cout, N = d->kh * d->kw * d->Cin, K = d->N * d->Ho * d->Wo;
+    const BSplit sp = bgemm_split(M, N, K, d->split_k);
+    float* partial = nullptr;
+    if (sp.split > 1) {
+        const size_t need = (size_t)sp.split * M * N * sizeof(float);
+        DC_REQUIRE(workspace != nullptr && workspace_bytes >= need, DC_EWORKSPACE, "dc_conv2d_wgrad_bf16 split-K needs %zu workspace bytes, got %zu",
+                   need, workspace_bytes);
+        partial = static_cast<float*>(workspace);
+    }
+    Epilogue ep{d->dw, N, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, d->accumulate, 1};
+    BOperand dy{d->dy, d->Cout, M, nullptr, (unsigned)((size_t)K * d->Cout * 2)};
+    BIm2col xc{d->x, d->H, d->W, d->Cin, d->Ho, d->Wo, d->stride, d->pad_t, d->pad_l, d->kw, K, (unsigned)((size_t)d->N * d->H * d->W * d->Cin * 2)};
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int tiles = ((M + BT - 1) / BT) * ((N + BT - 1) / BT);
+    hipLaunchKernelGGL(bgemm_wgrad_kernel, dim3(tiles, 1, sp.split), dim3(256), bgemm_lds_bytes(), s, dy, xc, ep, M, N, K, sp.klen, partial);
+    rc = check_launch("bgemm_wgrad_kernel");
+    if (rc || sp.split <= 1) return rc;
+    const long total = (long)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, s, partial, sp.split, M, N, ep);
+    return check_launch("splitk_reduce_kernel");
 }
 
 extern "C" int dc_cast_f32_bf16(const float* x, uint16_t* out, size_t n, void* stream) {

@@ -298,6 +298,7 @@ class DenseImageCapRCNN(object):
         self._plan = None
         self._reg_coef = None
         self._bufs = {}
+        self._bf16_cache = {}
 
     def _buf(self, key, shape, dtype=torch.float32, zero=False):
         b = self._bufs.get(key)
@@ -492,6 +493,20 @@ class DenseImageCapRCNN(object):
         return self._reg_coef, self._train_mask
 
     # ---- one training step ------------------------------------------------------------------
+    def _wgrad(self, x, dy, k, pad, out, accumulate=False, key=None):
+        """Packed weight gradient of a k x k / stride 1 convolution.  bf16 model: operands cast to bf16, products on the bf16
+        matrix pipe (fp32 accumulation) when the shapes allow; exact fp32 products otherwise.  key: cache slot of x's bf16 copy
+        (the shared RPN convolution reads every P level twice)."""
+        if self.compute_dtype == "bf16" and ops.wgrad_bf16_supported(x.shape, dy.shape):
+            xb = self._bf16_cache.get(key) if key is not None else None
+            if xb is None:
+                xb = ops.to_bf16(x, out=self._buf(("xb", key or id(x), tuple(x.shape)), tuple(x.shape), torch.bfloat16))
+                if key is not None:
+                    self._bf16_cache[key] = xb
+            dyb = ops.to_bf16(dy, out=self._buf(("dyb", tuple(dy.shape)), tuple(dy.shape), torch.bfloat16))
+            return ops.conv2d_wgrad_bf16(xb, dyb, k, k, 1, pad, pad, out=out, accumulate=accumulate)
+        return ops.conv2d_wgrad(x, dy, k, k, 1, pad, pad, out=out, accumulate=accumulate)
+
     def _images_u8(self, images):
         a = np.asarray(images)
         if a.dtype == np.uint8:
@@ -524,6 +539,7 @@ class DenseImageCapRCNN(object):
         up = lambda a, dt=torch.float32: torch.tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
 
         # ---- forward: backbone + FPN + RPN (hipGraph), proposals, detection targets, RoIAlign, head + decoder
+        self._bf16_cache = {}
         p.forward(torch.as_tensor(self._images_u8(images)))
         proposals = p.proposals()
         gt_norm = (np.asarray(gt_boxes[0], np.float32) / np.array([H, W, H, W], np.float32)).astype(np.float32)
@@ -565,12 +581,12 @@ class DenseImageCapRCNN(object):
         for i, (pm, sh, dh) in enumerate(zip(maps, p.rpn_shared, dheads)):
             _, h_, w_, _ = pm.shape
             acc = i > 0
-            ops.conv2d_wgrad(sh, dh, 1, 1, 1, 0, 0, out=g["rpn_head/kernel"], accumulate=acc)
+            ops.conv2d_wgrad(sh, dh, 1, 1, 1, 0, 0, out=g["rpn_head/kernel"], accumulate=acc)          # 20 output channels: fp32
             ops.colsum(dh.view(-1, HEAD_PAD), out=g["rpn_head/bias"], accumulate=acc)
             dsh = self._buf("dsh%d" % i, tuple(sh.shape))          # 1x1 head: its data gradient is a K = 20 GEMM on the packed weights
             ops.gemm(dh.view(-1, HEAD_PAD), w["rpn_head/kernel"], out=dsh.view(-1, 512))
             ops.relu_bwd(dsh.view(-1, 512), sh.view(-1, 512), dsh.view(-1, 512))
-            ops.conv2d_wgrad(pm, dsh, 3, 3, 1, 1, 1, out=g["rpn_conv_shared/kernel"], accumulate=acc)
+            self._wgrad(pm, dsh, 3, 1, g["rpn_conv_shared/kernel"], accumulate=acc, key="P%d" % i)
             ops.colsum(dsh.view(-1, 512), out=g["rpn_conv_shared/bias"], accumulate=acc)
             ops.conv2d(dsh, wd_shared, 3, 3, 1, 1, 1, h_, w_, residual=dP[i], res_mode=1, out=dP[i], math=p.math)     # dP += dgrad
         ops.scatter2_add(dP[4], dP[3])                       # P6 = MaxPooling2D(1, strides=2)(P5)
@@ -581,14 +597,14 @@ class DenseImageCapRCNN(object):
             name = "fpn_p%d" % (i + 2)
             wd = ops.conv_weight_dgrad_pack(w[name + "/kernel"], 3, 3, 256, out=self._buf("wd_" + name, (256, 9 * 256)))
             _, h_, w_, _ = dP[i].shape
-            ops.conv2d_wgrad(p.pre[i], dP[i], 3, 3, 1, 1, 1, out=g[name + "/kernel"])
+            self._wgrad(p.pre[i], dP[i], 3, 1, g[name + "/kernel"])
             ops.colsum(dP[i].view(-1, 256), out=g[name + "/bias"])
             dpre.append(ops.conv2d(dP[i], wd, 3, 3, 1, 1, 1, h_, w_, out=self._buf("dpre%d" % i, tuple(dP[i].shape)), math=p.math))
         for i in range(3):                                   # pre[k] = upsample(pre[k+1]) + lateral(C_k)
             ops.downsample2x_sum(dpre[i], out=dpre[i + 1], accumulate=True)
         for i, cmap in enumerate(p.C):
             name = "fpn_c%dp%d" % (i + 2, i + 2)
-            ops.conv2d_wgrad(cmap, dpre[i], 1, 1, 1, 0, 0, out=g[name + "/kernel"])
+            self._wgrad(cmap, dpre[i], 1, 0, g[name + "/kernel"])
             ops.colsum(dpre[i].view(-1, 256), out=g[name + "/bias"])
 
         # ---- regulariser (+ frozen subset when set_trainable narrowed the set)

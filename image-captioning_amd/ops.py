@@ -7,7 +7,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (AmsgradDesc, BnReluDesc, ConvDesc, GemmBf16Desc, VocabCeDesc, ProposalDesc, RpnLossDesc, GemmDesc, LstmBwdDesc, LstmFwdDesc, RoiAlignDesc,
+from ._lib import (AmsgradDesc, BnReluDesc, ConvDesc, ConvWgradBf16Desc, GemmBf16Desc, VocabCeDesc, ProposalDesc, RpnLossDesc, GemmDesc, LstmBwdDesc, LstmFwdDesc, RoiAlignDesc,
                    SoftmaxCeDesc, check)
 
 
@@ -208,6 +208,30 @@ def conv2d_wgrad(x, dy, kh, kw, stride, pad_t, pad_l, out=None, split_k=0, accum
     ws, wsb = WORKSPACE.get(lib.dc_conv2d_wgrad_workspace_bytes(C.byref(d)), x.device)
     check(lib.dc_conv2d_wgrad_f32(C.byref(d), _ptr(ws), wsb, _stream()), "dc_conv2d_wgrad_f32")
     return out
+
+
+def conv2d_wgrad_bf16(x, dy, kh, kw, stride, pad_t, pad_l, out=None, split_k=0, accumulate=False):
+    """conv2d_wgrad on the bf16 pipe: x [N,H,W,Cin] and dy [N,Ho,Wo,Cout] contiguous bf16; dw fp32 packed [Cout][kh*kw*Cin]."""
+    lib = _lib.load()
+    _chk(x, BF16, "x"), _chk(dy, BF16, "dy")
+    N, H, W, Cin = x.shape
+    _, Ho, Wo, Cout = dy.shape
+    if not x.is_contiguous() or not dy.is_contiguous():
+        raise _lib.DcapError("conv2d_wgrad_bf16: x and dy must be contiguous")
+    if out is None:
+        out = torch.empty((Cout, kh * kw * Cin), dtype=torch.float32, device=x.device)
+    d = ConvWgradBf16Desc()
+    d.N, d.H, d.W, d.Cin = N, H, W, Cin
+    d.Cout, d.kh, d.kw, d.stride, d.pad_t, d.pad_l, d.Ho, d.Wo = Cout, kh, kw, stride, pad_t, pad_l, Ho, Wo
+    d.x, d.dy, d.dw = x.data_ptr(), dy.data_ptr(), _chk(out, name="dw").data_ptr()
+    d.accumulate, d.split_k = int(accumulate), int(split_k)
+    ws, wsb = WORKSPACE.get(lib.dc_conv2d_wgrad_bf16_workspace_bytes(C.byref(d)), x.device)
+    check(lib.dc_conv2d_wgrad_bf16(C.byref(d), _ptr(ws), wsb, _stream()), "dc_conv2d_wgrad_bf16")
+    return out
+
+
+def wgrad_bf16_supported(x_shape, dy_shape):
+    return x_shape[-1] % 128 == 0 and dy_shape[-1] % 8 == 0
 
 
 def downsample2x_sum(fine, out=None, accumulate=False):

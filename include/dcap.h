@@ -95,6 +95,23 @@ typedef struct {
 size_t dc_gemm_bf16_workspace_bytes(const dc_gemm_bf16_desc* d);
 int    dc_gemm_bf16(const dc_gemm_bf16_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 
+/* conv2d weight gradient on the bf16 matrix pipe (configs[4]: the joint model's trainable FPN / RPN convolutions,
+ * dense_img_cap/dense_model.py:1829-1831): dw[cout][(ky,kx,ci)] (+)= sum over output pixels of dy[p][cout] * x[p*stride + tap - pad][ci],
+ * packed like the forward weights, fp32 accumulation and output.  x [N,H,W,Cin] and dy [N,Ho,Wo,Cout] are bf16 (dc_cast_f32_bf16 of the
+ * fp32 activations / gradients).  Cin % 128 == 0, Cout % 8 == 0.  Same sums as dc_conv2d_wgrad_f32 on operands rounded to bf16. */
+typedef struct {
+    int N, H, W, Cin;
+    int Cout, kh, kw, stride, pad_t, pad_l;
+    int Ho, Wo;
+    const uint16_t* x;
+    const uint16_t* dy;
+    float* dw;
+    int accumulate;
+    int split_k;
+} dc_conv_wgrad_bf16_desc;
+size_t dc_conv2d_wgrad_bf16_workspace_bytes(const dc_conv_wgrad_bf16_desc* d);
+int    dc_conv2d_wgrad_bf16(const dc_conv_wgrad_bf16_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+
 /* fp32 -> bf16 (round to nearest even): the bf16 shadow of weights / activations that feed dc_gemm_bf16.
  * _2d: rows x cols with row strides, output columns cols..cols_out-1 zero-filled (pads K to a multiple of 8). */
 int dc_cast_f32_bf16(const float* x, uint16_t* out, size_t n, void* stream);

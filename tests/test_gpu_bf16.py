@@ -199,3 +199,31 @@ def test_vocab_ce_masked_keras_sparse(ops, bf16, M, V, K):
     only_loss = torch.empty(M, device="cuda")
     ops.vocab_ce(Xd, Wd, dev(b), dev(t, torch.int32), loss_rows=only_loss, row_weights=dev(w), keras_sparse=True)      # forward only
     assert torch.equal(only_loss, loss)
+
+
+@pytest.mark.parametrize("case", [
+    # N, H, W, Cin, Cout, k, stride, padding
+    (1, 16, 16, 128, 64, 3, 1, 'same'),
+    (2, 12, 20, 256, 256, 3, 1, 'same'),       # pixel count not a multiple of the 64-deep K-tile
+    (1, 32, 32, 256, 512, 3, 1, 'same'),       # automatic split-K over the pixels
+    (2, 8, 8, 1024, 256, 1, 1, 'valid'),       # an FPN lateral
+    (1, 2, 2, 256, 256, 3, 1, 'same'),         # a P6-sized level: every tap partly outside
+])
+def test_conv2d_wgrad_bf16_matches_oracle(ops, case):
+    """Weight gradient on the bf16 pipe (K-major dy^T x K-major im2col, both through transposing LDS reads) against the oracle's
+    conv backward on operands rounded to bf16; accumulation over two pyramid levels like the shared RPN convolution."""
+    N, H, W, Cin, Cout, k, stride, padding = case
+    rng = np.random.default_rng(sum(int(v) * (i + 1) for i, v in enumerate(case) if not isinstance(v, str)))
+    x = rng.standard_normal((N, H, W, Cin))
+    w = rng.standard_normal((k, k, Cin, Cout))
+    y = O.conv2d_nhwc(x, w, None, stride, padding)
+    dy = rng.standard_normal(y.shape)
+    _, dw, _ = O.conv2d_nhwc_backward(O.to_bf16(x), w, O.to_bf16(dy), stride, padding)           # dw [k,k,Cin,Cout]
+    want = np.transpose(dw, (3, 0, 1, 2)).reshape(Cout, k * k * Cin)                             # packed [Cout][(ky,kx,ci)]
+    pt, pl = (O.same_pad(H, k, stride)[0], O.same_pad(W, k, stride)[0]) if padding == 'same' else (0, 0)
+    xb, dyb = ops.to_bf16(dev(x)), ops.to_bf16(dev(dy))
+    assert ops.wgrad_bf16_supported(xb.shape, dyb.shape)
+    got = ops.conv2d_wgrad_bf16(xb, dyb, k, k, stride, pt, pl)
+    close(got, want, 5e-5)
+    ops.conv2d_wgrad_bf16(xb, dyb, k, k, stride, pt, pl, out=got, accumulate=True)
+    close(got, 2 * want, 5e-5)
