@@ -377,7 +377,7 @@ int launch_bgemm(const BOperand& a, const BOperand& b, const Epilogue& ep, int M
     if (rc) return rc;
     if (sp.split > 1) {
         const long total = (long)M * N;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, stream, partial, sp.split, M, N, ep);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(splitk_reduce_blocks(total)), dim3(256), 0, stream, partial, sp.split, M, N, ep);
         rc = check_launch("splitk_reduce_kernel");
     }
     return rc;

@@ -152,7 +152,7 @@ extern "C" int dc_conv2d_wgrad_bf16(const dc_conv_wgrad_bf16_desc* d, void* work
     rc = check_launch("bgemm_wgrad_kernel");
     if (rc || sp.split <= 1) return rc;
     const long total = (long)M * N;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, s, partial, sp.split, M, N, ep);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(splitk_reduce_blocks(total)), dim3(256), 0, s, partial, sp.split, M, N, ep);
     return check_launch("splitk_reduce_kernel");
 }
 

@@ -414,8 +414,7 @@ int launch_igemm_bs2(const AL& al, const BL& bl, const Epilogue& ep, int M, int 
     if (rc) return rc;
     if (split_k > 1) {
         const long total = (long)M * N;
-        const int blocks = (int)((total + 255) / 256);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, split_k, M, N, ep);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(splitk_reduce_blocks(total)), dim3(256), 0, stream, partial, split_k, M, N, ep);
         rc = check_launch("splitk_reduce_kernel");
     }
     return rc;
@@ -450,8 +449,7 @@ int launch_igemm_bs(const AL& al, const BL& bl, const Epilogue& ep, int M, int N
     if (rc) return rc;
     if (split_k > 1) {
         const long total = (long)M * N;
-        const int blocks = (int)((total + 255) / 256);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, split_k, M, N, ep);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(splitk_reduce_blocks(total)), dim3(256), 0, stream, partial, split_k, M, N, ep);
         rc = check_launch("splitk_reduce_kernel");
     }
     return rc;

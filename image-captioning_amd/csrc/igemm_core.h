@@ -923,6 +923,7 @@ __global__ __launch_bounds__(512, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_pc_
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int splits, int M, int N, Epilogue ep);
+inline int splitk_reduce_blocks(long total) { return (int)((total + 1023) / 1024); }      // four elements per thread
 
 // conv forward on the split-bf16 main loop (conv_bs.hip)
 int conv2d_bf16x3(const dc_conv_desc* d, bool stem, const Epilogue& ep, int M, int N, int K, int bm, int bn, int split, void* workspace,
@@ -967,8 +968,7 @@ int launch_igemm(const AL& al, const BL& bl, const Epilogue& ep, int M, int N, i
     if (rc) return rc;
     if (split_k > 1) {
         const long total = (long)M * N;
-        const int blocks = (int)((total + 255) / 256);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, split_k, M, N, ep);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(splitk_reduce_blocks(total)), dim3(256), 0, stream, partial, split_k, M, N, ep);
         rc = check_launch("splitk_reduce_kernel");
     }
     return rc;
