@@ -265,6 +265,7 @@ class DenseImageCapRCNN(object):
         if 6 * self.A > HEAD_PAD:
             raise ValueError("at most 3 anchors per location")
         self._rng = np.random.RandomState(seed)
+        self._val_rng = np.random.RandomState(seed + 1)      # detection-target sampling of forward-only (validation) passes
         self.optimizer = None
         self.grad_sync = None
         self.is_chief = True               # ParallelModel clears it on ranks > 0: one rank prints and writes checkpoints
@@ -525,9 +526,12 @@ class DenseImageCapRCNN(object):
         level = np.searchsorted(bounds, idx, side="right") - 1
         return level.astype(np.int32), (idx - bounds[level]).astype(np.int32), m[idx].astype(np.int32)
 
-    def forward_backward(self, inputs, shuffle="rng"):
+    def forward_backward(self, inputs, shuffle="rng", backward=True):
         """Losses and gradients of one image into the flat gradient bucket (no optimizer step).
-        Returns the device tensor [rpn_class_loss, rpn_bbox_loss, imgcap_loss, reg_loss]."""
+        Returns the device tensor [rpn_class_loss, rpn_bbox_loss, imgcap_loss, reg_loss].
+        backward=False: the forward graph only (validation, Keras' test_on_batch): no gradient is computed, the gradient bucket is
+        left alone, no recurrent dropout, and the detection-target sample is drawn from a generator of its own so that an
+        evaluation between two train steps does not change the training run."""
         images, _meta, rpn_match, rpn_bbox, gt_caps, gt_boxes = inputs[:6]
         if len(images) != 1:
             raise ValueError("one image per step and GPU (IMAGES_PER_GPU = 1)")
@@ -543,7 +547,8 @@ class DenseImageCapRCNN(object):
         p.forward(torch.as_tensor(self._images_u8(images)))
         proposals = p.proposals()
         gt_norm = (np.asarray(gt_boxes[0], np.float32) / np.array([H, W, H, W], np.float32)).astype(np.float32)
-        mix = None if shuffle is None else (self._rng.permutation if shuffle == "rng" else shuffle)
+        rng = self._rng if backward else self._val_rng
+        mix = None if shuffle is None else (rng.permutation if shuffle == "rng" else shuffle)
         rois, caps, npos, nneg = detection_targets(proposals[0].cpu().numpy(), gt_caps[0], gt_norm, cfg, mix)
         self.last_targets = dict(rois=rois, caps=caps, npos=npos, nneg=nneg)
         boxes = up(rois[None])
@@ -552,9 +557,23 @@ class DenseImageCapRCNN(object):
         tg = caption_targets(caps)
         live = (tg > 0).astype(np.float32)
         count = float(live.sum())
-        loss_rows, _ = cm._forward_train(feats[0], caps, tg, want_grad=True, row_weights=live / max(count, 1.0), keras_sparse=True)
+        loss_rows, _ = cm._forward_train(feats[0], caps, tg, want_grad=backward, row_weights=live / max(count, 1.0), keras_sparse=True)
         losses = self._buf("losses", (4,))
         ops.mean(loss_rows, out=losses[2:3])                 # x rows below: the weights already carry 1/count
+        self._loss_scale = float(loss_rows.numel())
+        if not backward:
+            # RPN losses need the heads only (their gradient goes to scratch), the regulariser the weights only
+            lvl, idx, mt = self._rpn_selection(rpn_match[0])
+            n_pos = int((mt == 1).sum())
+            scratch = [self._buf("dhead%d" % i, tuple(h.shape)) for i, h in enumerate(p.rpn_heads)]
+            for t in scratch:
+                t.zero_()
+            tdl = np.asarray(rpn_bbox[0], np.float32)
+            ops.rpn_loss_grad(p.rpn_heads, scratch, up(lvl, torch.int32), up(idx, torch.int32), up(mt, torch.int32),
+                              up(tdl if tdl.size else np.zeros((1, 4), np.float32)), n_pos, losses[0:2], anchors_per_loc=self.A)
+            coef, _ = self._masks()
+            ops.l2_reg(st.flat, coef, None, loss=losses[3:4])
+            return losses
 
         # ---- backward: decoder + head -> RoI features -> pyramid
         dX = cm._backward(want_dx=True)
@@ -634,7 +653,8 @@ class DenseImageCapRCNN(object):
         return [d["loss"], d["rpn_class_loss"], d["rpn_bbox_loss"], d["imgcap_loss"]]
 
     def test_on_batch(self, inputs, targets=None):
-        self.last_losses = d = self._loss_list(self.forward_backward(inputs))
+        """Forward only (Keras test_on_batch): losses of the batch, no gradient, no effect on the training state."""
+        self.last_losses = d = self._loss_list(self.forward_backward(inputs, backward=False))
         return [d["loss"], d["rpn_class_loss"], d["rpn_bbox_loss"], d["imgcap_loss"]]
 
     # ---- inference -------------------------------------------------------------------------

@@ -427,6 +427,25 @@ def test_joint_model_training_reduces_loss_and_round_trips_weights(gpu, tmp_path
     assert not np.array_equal(b['imgcap_lstm_d2/kernel'], c['imgcap_lstm_d2/kernel'])
 
 
+def test_joint_model_validation_is_forward_only(gpu):
+    """test_on_batch (what train() validates with, like Keras): no gradient, the gradient bucket and the training run's
+    detection-target generator untouched, and the same four losses as the training graph's forward on the same RoI sample."""
+    S, V, T, blocks = 128, 24, 5, 1
+    model, cfg, Wt = make_joint(S, V, T, blocks)
+    inputs = joint_inputs(S, V, T)
+    model.forward_backward(inputs)                                   # some gradient in the bucket
+    g0 = model.store.flat_grad.clone()
+    state = model._rng.get_state()
+    out = model.test_on_batch(inputs)
+    assert len(out) == 4 and np.isfinite(out).all()
+    assert torch.equal(model.store.flat_grad, g0)
+    assert all(np.array_equal(a, b) for a, b in zip(state[1:2], model._rng.get_state()[1:2])) and state[2] == model._rng.get_state()[2]
+    fwd = model._loss_list(model.forward_backward(inputs, shuffle=None, backward=False))
+    full = model._loss_list(model.forward_backward(inputs, shuffle=None))
+    for k in full:
+        assert abs(fwd[k] - full[k]) < 1e-6 * max(1.0, abs(full[k])), (k, fwd[k], full[k])
+
+
 def test_joint_model_inference_captions(gpu, conv_math):
     """Inference graph of the joint model: proposals -> RoI features -> greedy decoder -> GenerationMatchLayer.  The decoded
     ids of the surviving boxes against the oracle's greedy decoder run on the oracle's features of the same proposals."""
