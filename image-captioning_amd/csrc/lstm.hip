@@ -1,10 +1,14 @@
 // lstm.hip -- Keras-2.1 LSTM recurrence over a whole sequence (forward and backward), time-major.
-// Per timestep: the skinny h_{t-1} * U_rec product runs on the MFMA GEMM (split-K so that a
-// B x 4U problem still covers the chip), then one fused pointwise kernel applies the hard-sigmoid /
-// tanh gates, the cell update and the Keras mask carry.  The caller batches the x * kernel + bias
-// projection for all T steps into one GEMM beforehand (dcap.h).
+// One launch per timestep in each direction (U % 32 == 0 forward, U % 16 == 0 backward, no recurrent dropout): the skinny
+// recurrent product (h_{t-1} * U_rec forward, dz_{t+1} * U_rec^T backward) streams its operands straight from L2 into MFMA
+// fragments, the K split over the block's waves meets in LDS, and the same threads finish the hard-sigmoid / tanh gate math,
+// the cell update and the Keras mask carry.  Other shapes and the recurrent-dropout path use the split-K MFMA GEMM plus
+// pointwise gate kernels.  The caller batches the x * kernel + bias projection for all T steps into one GEMM beforehand
+// (dcap.h); the recurrent weight gradient is one GEMM over all steps at the end.
 #include "dcap_internal.h"
 #include <algorithm>
+#include <cstdlib>
+#include <string>
 
 namespace dcap {
 
@@ -96,99 +100,239 @@ __global__ __launch_bounds__(256) void lstm_pack_urec_kernel(const float* __rest
     }
 }
 
-__global__ __launch_bounds__(256) void lstm_step_fused2_kernel(float* __restrict__ z_t, const float* __restrict__ Upk,
-                                                               const float* __restrict__ h_prev, const float* __restrict__ c_prev,
-                                                               const uint8_t* __restrict__ mask_t, float* __restrict__ h_t,
-                                                               float* __restrict__ c_t, int B, int U) {
-    // 16.9 KB of LDS (two partial tiles, not four): in the training pipeline this kernel runs beside the encoder's convolutions,
-    // whose two resident blocks leave ~19 KB of a CU's LDS -- with the 33.8 KB of the first version its blocks could only start
-    // at conv-kernel boundaries (78-100 us per step in the pipeline against 18 us alone).
-    __shared__ float part[2][64][33];
+// RT = 32-row MFMA blocks per workgroup, NW = waves that split K = U.  The gate phase's operands (zx, h, c of the block's own
+// (row, unit) items) are requested before the K loop, so their latency hides behind it.  LDS: NW/2 partial tiles (waves
+// NW/2.. publish, waves 0..NW/2-1 add theirs on top): 16.9 KB at <1,8> and <2,4> -- in the training pipeline this kernel runs
+// beside the encoder's convolutions, whose two resident blocks leave ~19 KB of a CU's LDS; with 33.8 KB its blocks could only
+// start at conv-kernel boundaries (78-100 us per step in the pipeline against 18 us alone).
+template <int RT, int NW>
+__global__ __launch_bounds__(NW * 64) void lstm_step_fused_kernel(float* __restrict__ z_t, const float* __restrict__ Upk,
+                                                                  const float* __restrict__ h_prev, const float* __restrict__ c_prev,
+                                                                  const uint8_t* __restrict__ mask_t, float* __restrict__ h_t,
+                                                                  float* __restrict__ c_t, int B, int U) {
+    constexpr int HALF = NW / 2, THREADS = NW * 64, ITEMS = RT * 256, IT = (ITEMS + THREADS - 1) / THREADS;
+    __shared__ float part[HALF][RT * 32][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ub = blockIdx.x, u0 = ub * 8, r0 = blockIdx.y * 64;
+    const int ub = blockIdx.x, u0 = ub * 8, r0 = blockIdx.y * (RT * 32);
     const int i = lane & 31, h = lane >> 5;
-    const int kq = U / 4, kbeg = wave * kq;
-    f32x16_t acc0, acc1;
+    const int kq = U / NW, kbeg = wave * kq;
+    const int nch = kq / 8;                                                   // 8 k values per chunk (4 MFMAs of K = 2)
+    f32x16_t acc[RT];
+    const float* ap[RT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    const float* ap0 = h_prev + (long)min(r0 + i, B - 1) * U + kbeg + 4 * h;
-    const float* ap1 = h_prev + (long)min(r0 + 32 + i, B - 1) * U + kbeg + 4 * h;
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+        ap[rt] = h_prev + (long)min(r0 + 32 * rt + i, B - 1) * U + kbeg + 4 * h;
+    }
     const long kstride = (long)(U / 8) * 32;                                  // floats between consecutive k rows of Upk
     const float* bp = Upk + (long)(kbeg + 4 * h) * kstride + (long)ub * 32 + i;
-    constexpr int PF = 4;
-    const int nch = kq / 8;
-    f4_t a0[PF], a1[PF];
+    constexpr int PF = 8;
+    f4_t a[PF][RT];
     float b[PF][4];
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
         const int c = min(p, nch - 1);
-        a0[p] = *reinterpret_cast<const f4_t*>(ap0 + 8 * c);
-        a1[p] = *reinterpret_cast<const f4_t*>(ap1 + 8 * c);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) a[p][rt] = *reinterpret_cast<const f4_t*>(ap[rt] + 8 * c);
 #pragma unroll
         for (int j = 0; j < 4; ++j) b[p][j] = bp[(long)(8 * c + j) * kstride];
+    }
+    float gz[IT][4], ghp[IT], gcp[IT];
+    bool gmk[IT];
+#pragma unroll
+    for (int q = 0; q < IT; ++q) {
+        const int e = tid + q * THREADS, row = e >> 3, uu = e & 7;
+        const int brow = min(r0 + row, B - 1);
+        const float* zrow = z_t + (long)brow * 4 * U + u0 + uu;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gz[q][g] = zrow[(long)g * U];
+        const long o = (long)brow * U + u0 + uu;
+        ghp[q] = h_prev[o];
+        gcp[q] = c_prev[o];
+        gmk[q] = mask_t ? (mask_t[brow] != 0) : true;
     }
     for (int c0 = 0; c0 < nch; c0 += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
-            const f4_t x0 = a0[p], x1 = a1[p];
-            const float b0 = b[p][0], b1 = b[p][1], b2 = b[p][2], b3 = b[p][3];
-            const int cn = min(c0 + p + PF, nch - 1);                 // prefetch (clamped: extra loads are discarded)
-            a0[p] = *reinterpret_cast<const f4_t*>(ap0 + 8 * cn);
-            a1[p] = *reinterpret_cast<const f4_t*>(ap1 + 8 * cn);
+            f4_t x[RT];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[p][j] = bp[(long)(8 * cn + j) * kstride];
+            for (int rt = 0; rt < RT; ++rt) x[rt] = a[p][rt];
+            const float b0 = b[p][0], b1 = b[p][1], b2 = b[p][2], b3 = b[p][3];
+            if (c0 + PF < nch) {                                              // the next ring of chunks (clamped at the end)
+                const int cn = min(c0 + p + PF, nch - 1);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) a[p][rt] = *reinterpret_cast<const f4_t*>(ap[rt] + 8 * cn);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[p][j] = bp[(long)(8 * cn + j) * kstride];
+            }
             if (c0 + p < nch) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.x, b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.x, b0, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, b1, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.y, b1, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.z, b2, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.z, b2, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.w, b3, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.w, b3, acc1, 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[rt].x, b0, acc[rt], 0, 0, 0);
+                    acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[rt].y, b1, acc[rt], 0, 0, 0);
+                    acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[rt].z, b2, acc[rt], 0, 0, 0);
+                    acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[rt].w, b3, acc[rt], 0, 0, 0);
+                }
             }
         }
     }
-    if (wave >= 2) {                                   // round 1: waves 2, 3 publish their K-quarter's partial tiles
+    if (wave >= HALF) {                                // round 1: the upper waves publish their K share's partial tiles
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
-            part[wave - 2][rr][i] = acc0[r];
-            part[wave - 2][32 + rr][i] = acc1[r];
-        }
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[wave - HALF][32 * rt + (r & 3) + 8 * (r >> 2) + 4 * h][i] = acc[rt][r];
     }
     __syncthreads();
-    if (wave < 2) {                                    // round 2: waves 0, 1 add theirs on top (same lane owns the same elements)
+    if (wave < HALF) {                                 // round 2: the lower waves add theirs on top (same lane owns the same elements)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
-            part[wave][rr][i] += acc0[r];
-            part[wave][32 + rr][i] += acc1[r];
-        }
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[wave][32 * rt + (r & 3) + 8 * (r >> 2) + 4 * h][i] += acc[rt][r];
     }
     __syncthreads();
-    // gate math: 64 rows x 8 units = 512 items, two per thread
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int row = (tid >> 3) + 32 * q, uu = tid & 7;
+    for (int q = 0; q < IT; ++q) {
+        const int e = tid + q * THREADS, row = e >> 3, uu = e & 7;
         const int brow = r0 + row;
-        if (brow >= B) continue;
+        if (e >= ITEMS || brow >= B) continue;
         float zg[4];
         float* zrow = z_t + (long)brow * 4 * U + u0 + uu;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int col = g * 8 + uu;
-            zg[g] = zrow[(long)g * U] + (part[0][row][col] + part[1][row][col]);
+            float rec = 0.f;
+#pragma unroll
+            for (int w = 0; w < HALF; ++w) rec += part[w][row][col];
+            zg[g] = gz[q][g] + rec;
             zrow[(long)g * U] = zg[g];
         }
         const long o = (long)brow * U + u0 + uu;
         const float ig = hard_sigmoid(zg[0]), fg = hard_sigmoid(zg[1]), gg = tanhf(zg[2]), og = hard_sigmoid(zg[3]);
-        const float hp = h_prev[o], cp = c_prev[o];
-        const float cn = fg * cp + ig * gg;
+        const float cn = fg * gcp[q] + ig * gg;
         const float hn = og * tanhf(cn);
-        const bool m = mask_t ? (mask_t[brow] != 0) : true;
-        h_t[o] = m ? hn : hp;
-        c_t[o] = m ? cn : cp;
+        h_t[o] = gmk[q] ? hn : ghp[q];
+        c_t[o] = gmk[q] ? cn : gcp[q];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused backward timestep (U % 16 == 0, t < T-1): the recurrent gradient dz_{t+1} * U_rec^T, the gate derivatives and the
+// mask carry in ONE launch (was: gate kernel + split-K GEMM + slab reducer = 3 launches, 27.6 us per step at B = 64, U = 512).
+// Block = RT*16 batch rows x 16 units; the K = 4U reduction is split over the 4 waves, each streaming its quarter of the 16 rows
+// of U_rec (a row of U_rec IS the B operand's K run: no repack) and of the dz rows straight from L2 into v_mfma_f32_16x16x4_f32
+// fragments (one 16-byte load per operand per 4 MFMAs, PF chunks in flight); the four partial tiles meet in LDS and the block's
+// threads finish the gate math for their (row, unit).  Every (row, unit) belongs to one thread of one block, so the carried
+// dh/dc state is updated in place.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <int RT, int NW>
+__global__ __launch_bounds__(NW * 64) void lstm_bwd_step_fused_kernel(const float* __restrict__ z_t, const float* __restrict__ c_prev,
+                                                                      const uint8_t* __restrict__ mask_t, const float* __restrict__ dh_out_t,
+                                                                      const float* __restrict__ dz_next, const float* __restrict__ U_rec,
+                                                                      float* __restrict__ dh_io, float* __restrict__ dc_io,
+                                                                      float* __restrict__ dz_t, int B, int U) {
+    __shared__ float part[NW][RT * 16][17];
+    constexpr int THREADS = NW * 64, ITEMS = RT * 256, IT = (ITEMS + THREADS - 1) / THREADS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int u0 = blockIdx.x * 16, r0 = blockIdx.y * (RT * 16);
+    const int m = lane & 15, kk = lane >> 4;
+    const long K = 4L * U;
+    const int kq = (4 * U) / NW, kbeg = wave * kq;              // this wave's share of K = 4U
+    const int nch = kq / 16;                                    // 16 k values per chunk
+    const float* bp = U_rec + (long)(u0 + m) * K + kbeg + 4 * kk;
+    const float* ap[RT];
+    f32x4_t acc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        ap[rt] = dz_next + (long)min(r0 + 16 * rt + m, B - 1) * K + kbeg + 4 * kk;
+        acc[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    constexpr int PF = (RT == 1) ? 16 : 8;
+    f4_t a[PF][RT], b[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        const int c = min(p, nch - 1);
+        b[p] = *reinterpret_cast<const f4_t*>(bp + 16 * c);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) a[p][rt] = *reinterpret_cast<const f4_t*>(ap[rt] + 16 * c);
+    }
+    // the gate phase's operands: issued now, consumed after the K loop
+    float gz[IT][4], gcp[IT], gdh[IT], gdc[IT];
+    bool gmk[IT];
+#pragma unroll
+    for (int q = 0; q < IT; ++q) {
+        const int e = tid + q * THREADS, row = e >> 4, uu = e & 15;
+        const int brow = min(r0 + row, B - 1), u = u0 + uu;
+        const long idx = (long)brow * U + u;
+        const float* z = z_t + (long)brow * K + u;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gz[q][g] = z[(long)g * U];
+        gcp[q] = c_prev ? c_prev[idx] : 0.f;
+        gdh[q] = dh_io[idx] + (dh_out_t ? dh_out_t[idx] : 0.f);
+        gdc[q] = dc_io[idx];
+        gmk[q] = mask_t ? (mask_t[brow] != 0) : true;
+    }
+    for (int c0 = 0; c0 < nch; c0 += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            f4_t x[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) x[rt] = a[p][rt];
+            const f4_t y = b[p];
+            if (c0 + PF < nch) {                                // block-uniform: the next ring of chunks (clamped at the end)
+                const int cn = min(c0 + p + PF, nch - 1);
+                b[p] = *reinterpret_cast<const f4_t*>(bp + 16 * cn);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) a[p][rt] = *reinterpret_cast<const f4_t*>(ap[rt] + 16 * cn);
+            }
+            if (c0 + p < nch) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[rt].x, y.x, acc[rt], 0, 0, 0);
+                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[rt].y, y.y, acc[rt], 0, 0, 0);
+                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[rt].z, y.z, acc[rt], 0, 0, 0);
+                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[rt].w, y.w, acc[rt], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave][16 * rt + 4 * kk + r][m] = acc[rt][r];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < IT; ++q) {
+        const int e = tid + q * THREADS, row = e >> 4, uu = e & 15;
+        const int brow = r0 + row;
+        if (e >= ITEMS || brow >= B) continue;
+        const int u = u0 + uu;
+        const long idx = (long)brow * U + u;
+        float rec = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) rec += part[w][row][uu];
+        const float zi = gz[q][0], zf = gz[q][1], zc = gz[q][2], zo = gz[q][3];
+        const float i = hard_sigmoid(zi), f = hard_sigmoid(zf), g = tanhf(zc), o = hard_sigmoid(zo);
+        const float cp = gcp[q];
+        const float tc = tanhf(f * cp + i * g);
+        const float dh = gdh[q] + rec;
+        const float dc = gdc[q];
+        float* dz = dz_t + (long)brow * K;
+        if (gmk[q]) {
+            const float dcn = dc + dh * o * (1.f - tc * tc);
+            dz[u] = dcn * g * hard_sigmoid_grad(zi);
+            dz[U + u] = dcn * cp * hard_sigmoid_grad(zf);
+            dz[2 * U + u] = dcn * i * (1.f - g * g);
+            dz[3 * U + u] = dh * tc * hard_sigmoid_grad(zo);
+            dh_io[idx] = 0.f;
+            dc_io[idx] = dcn * f;
+        } else {
+            dz[u] = 0.f; dz[U + u] = 0.f; dz[2 * U + u] = 0.f; dz[3 * U + u] = 0.f;
+            dh_io[idx] = dh;
+            dc_io[idx] = dc;
+        }
     }
 }
 
@@ -223,6 +367,20 @@ __global__ __launch_bounds__(256) void lstm_masked_acc_kernel(float* __restrict_
 }
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// DCAP_LSTM_BWD=steps selects the three-launch form of the backward timestep (measurements only).
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+static bool lstm_bwd_fused_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("DCAP_LSTM_BWD");
+        return !(e && std::string(e) == "steps");
+    }();
+    return on;
+}
 
 static dc_gemm_desc hU_desc(int B, int U, const float* h_prev, const float* U_rec, float* z_t) {
     dc_gemm_desc g{};
@@ -296,6 +454,11 @@ extern "C" int dc_lstm_seq_fwd_f32(const dc_lstm_fwd_desc* d, void* workspace, s
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int B = d->B, U = d->U, n = B * U, blocks = (n + 255) / 256;
     const bool fused = (U & 31) == 0 && d->T > 1 && !d->rec_masks;
+    static const int force_rt = env_int("DCAP_LSTM_FWD_RT", 0), force_nw = env_int("DCAP_LSTM_FWD_NW", 0);
+    int frt = ((U / 8) * ((B + 31) / 32) <= 2 * kNumCU) ? 1 : 2;      // 32- or 64-row blocks
+    int fnw = (frt == 2 && (U & 63) == 0) ? 8 : 4;                     // measured: 4 waves at 32 rows, 8 at 64
+    if (force_rt == 1 || force_rt == 2) frt = force_rt;
+    if (force_nw == 4 || (force_nw == 8 && (U & 63) == 0)) fnw = force_nw;
     float* Upk = nullptr;
     float* hm = nullptr;                            // dropout: [4][B][U] masked copies of h_{t-1}, at the END of the workspace
     void* gws = workspace;
@@ -318,9 +481,17 @@ extern "C" int dc_lstm_seq_fwd_f32(const dc_lstm_fwd_desc* d, void* workspace, s
         const float* hp = t ? d->h_seq + (long)(t - 1) * n : nullptr;
         const float* cp = t ? d->c_seq + (long)(t - 1) * n : nullptr;
         if (t && fused) {
-            hipLaunchKernelGGL(lstm_step_fused2_kernel, dim3(U / 8, (B + 63) / 64), dim3(256), 0, s, z_t, Upk, hp, cp,
-                               d->mask ? d->mask + (long)t * B : nullptr, d->h_seq + (long)t * n, d->c_seq + (long)t * n, B, U);
-            int rc = check_launch("lstm_step_fused2_kernel");
+            const uint8_t* mk = d->mask ? d->mask + (long)t * B : nullptr;
+            float* h_t = d->h_seq + (long)t * n;
+            float* c_t = d->c_seq + (long)t * n;
+            const dim3 grid(U / 8, (B + 32 * frt - 1) / (32 * frt));
+#define DCAP_FWD_STEP(RT_, NW_) hipLaunchKernelGGL((lstm_step_fused_kernel<RT_, NW_>), grid, dim3(NW_ * 64), 0, s, z_t, Upk, hp, cp, mk, h_t, c_t, B, U)
+            if (frt == 1 && fnw == 8) DCAP_FWD_STEP(1, 8);
+            else if (frt == 1) DCAP_FWD_STEP(1, 4);
+            else if (fnw == 8) DCAP_FWD_STEP(2, 8);
+            else DCAP_FWD_STEP(2, 4);
+#undef DCAP_FWD_STEP
+            int rc = check_launch("lstm_step_fused_kernel");
             if (rc) return rc;
             continue;
         }
@@ -375,10 +546,31 @@ extern "C" int dc_lstm_seq_bwd_f32(const dc_lstm_bwd_desc* d, void* workspace, s
     }
     hipError_t e = hipMemsetAsync(wsp, 0, 2 * state_bytes, s);
     DC_REQUIRE(e == hipSuccess, DC_ELAUNCH, "dc_lstm_seq_bwd: memset failed: %s", hipGetErrorString(e));
+    const bool fused = (U & 15) == 0 && !d->rec_masks && lstm_bwd_fused_enabled();
+    static const int force_rt = env_int("DCAP_LSTM_BWD_RT", 0), force_nw = env_int("DCAP_LSTM_BWD_NW", 0);
+    int rt_rows = ((U / 16) * ((B + 15) / 16) <= kNumCU) ? 16 : 32;      // measured: 200 x 512 is 1.2x faster with 32-row blocks
+    int nw = (U & 31) == 0 ? 8 : 4;
+    if (force_rt == 1 || force_rt == 2) rt_rows = 16 * force_rt;
+    if (force_nw == 4 || (force_nw == 8 && (U & 31) == 0)) nw = force_nw;
     for (int t = T - 1; t >= 0; --t) {
         const float* z_t = d->z + (long)t * B * 4 * U;
         float* dz_t = d->dz + (long)t * B * 4 * U;
         const float* cp = t ? d->c_seq + (long)(t - 1) * n : nullptr;
+        if (fused && t < T - 1) {                               // dh_t = carry + dz_{t+1} U_rec^T + dh_seq[t], gates, in one launch
+            const uint8_t* mk = d->mask ? d->mask + (long)t * B : nullptr;
+            const float* dho = d->dh_seq ? d->dh_seq + (long)t * n : nullptr;
+            const float* dz_next = dz_t + (long)B * 4 * U;
+            const dim3 grid(U / 16, (B + rt_rows - 1) / rt_rows);
+#define DCAP_BWD_STEP(RT_, NW_) hipLaunchKernelGGL((lstm_bwd_step_fused_kernel<RT_, NW_>), grid, dim3(NW_ * 64), 0, s, z_t, cp, mk, dho, dz_next, d->U_rec, dh, dc, dz_t, B, U)
+            if (rt_rows == 16 && nw == 8) DCAP_BWD_STEP(1, 8);
+            else if (rt_rows == 16) DCAP_BWD_STEP(1, 4);
+            else if (nw == 8) DCAP_BWD_STEP(2, 8);
+            else DCAP_BWD_STEP(2, 4);
+#undef DCAP_BWD_STEP
+            int rc = check_launch("lstm_bwd_step_fused_kernel");
+            if (rc) return rc;
+            continue;
+        }
         hipLaunchKernelGGL(lstm_gate_bwd_kernel, dim3(blocks), dim3(256), 0, s, z_t, cp, d->mask ? d->mask + (long)t * B : nullptr,
                            d->dh_seq ? d->dh_seq + (long)t * n : nullptr, (t == T - 1) ? d->dh_last : nullptr, dh, dc, dz_t, B, U);
         int rc = check_launch("lstm_gate_bwd_kernel");
@@ -396,7 +588,7 @@ extern "C" int dc_lstm_seq_bwd_f32(const dc_lstm_bwd_desc* d, void* workspace, s
             hipLaunchKernelGGL(lstm_masked_acc_kernel, dim3(std::min(blocks, kNumCU * 8)), dim3(256), 0, s, dh, d->rec_masks, tmp4, (long)n);
             rc = check_launch("lstm_masked_acc_kernel");
             if (rc) return rc;
-        } else if (t) {
+        } else if (t && !fused) {
             dc_gemm_desc g = dzUt_desc(B, U, dz_t, d->U_rec, dh);
             rc = dc_gemm_f32(&g, gws, gws_bytes, stream);
             if (rc) return rc;

@@ -209,7 +209,8 @@ def test_roi_align_pyramid(ops):
     close(got, want, 1e-5)
 
 
-@pytest.mark.parametrize("B,T,I,U,masked", [(3, 4, 8, 4, True), (64, 10, 300, 128, True), (8, 15, 64, 512, False), (5, 1, 2048, 256, False)])
+@pytest.mark.parametrize("B,T,I,U,masked", [(3, 4, 8, 4, True), (64, 10, 300, 128, True), (8, 15, 64, 512, False), (5, 1, 2048, 256, False),
+                                            (70, 6, 32, 512, True), (200, 4, 16, 256, True), (37, 3, 16, 16, True), (300, 3, 16, 512, False)])
 def test_lstm_seq_forward_backward(ops, B, T, I, U, masked):
     rng = np.random.default_rng(B + T + U)
     x = rng.standard_normal((B, T, I))
