@@ -298,10 +298,7 @@ class E2E(object):
             times = dict(plan.time_convs(reps=3, beside=b))
             torch.cuda.synchronize()
             groups = {}
-            for name, fl, bm, bn, sk, pointwise in table:
-                kind = "StemKC" if name == "conv1" else ("DenseKCT<true>" if pointwise else "Im2colKCT<false>")
-                kernel = "igemm_pc_kernel" if (bm, bn) == (64, 64) else "igemm_kernel"              # 64x64: producer/consumer waves
-                key = "%s<%d, %d, dcap::%s, dcap::DenseKCT<true> >" % (kernel, bm, bn, kind)         # rocprof's spelling
+            for name, fl, bm, bn, sk, key in table:                 # key: rocprof's spelling of the layer's kernel
                 g = groups.setdefault(key, {"flops": 0.0, "ms": 0.0, "launches": 0})
                 g["flops"] += fl
                 g["ms"] += times[name]
@@ -311,11 +308,11 @@ class E2E(object):
         groups, times = res[main]
         if args.layer_table:
             with open(args.layer_table, "w") as f:
-                f.write("layer\tgflop\tbm\tbn\tsplit_k\tus_%s\ttflops_%s\tus_isolated\n" % (main, main))
+                f.write("layer\tgflop\tbm\tbn\tsplit_k\tus_%s\ttflops_%s\tus_isolated\tkernel\n" % (main, main))
                 iso = res["isolated"][1]
-                for name, fl, bm, bn, sk, _pw in table:
-                    f.write("%s\t%.3f\t%d\t%d\t%d\t%.1f\t%.1f\t%.1f\n" % (name, fl / 1e9, bm, bn, sk, 1e3 * times[name],
-                                                                          fl / (times[name] * 1e-3) / 1e12, 1e3 * iso[name]))
+                for name, fl, bm, bn, sk, key in table:
+                    f.write("%s\t%.3f\t%d\t%d\t%d\t%.1f\t%.1f\t%.1f\t%s\n" % (name, fl / 1e9, bm, bn, sk, 1e3 * times[name],
+                                                                              fl / (times[name] * 1e-3) / 1e12, 1e3 * iso[name], key))
         dom = max(groups, key=lambda k: groups[k]["ms"])
         g = groups[dom]
         achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12

@@ -142,6 +142,7 @@ SYMBOLS = {
     "dc_conv2d_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_conv2d_tile_config": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dc_conv2d_is_pointwise": (C.c_int, [C.POINTER(ConvDesc)]),
+    "dc_conv2d_kernel_name": (C.c_int, [C.POINTER(ConvDesc), C.c_char_p, C.c_size_t]),
     "dc_conv2d_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "dc_conv2d_wgrad_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_roi_align_pyramid_bwd_f32": (C.c_int, [C.POINTER(RoiAlignDesc), C.c_void_p]),

@@ -4,6 +4,7 @@
 // B is the packed weight [Cout][K].  Frozen BN + bias + residual/upsample-add + ReLU ride in the
 // epilogue.  Plus the two bandwidth kernels of the stem: mold_image->RGBX and maxpool 3x3/s2 SAME.
 #include "igemm_core.h"
+#include <cstdio>
 #include <algorithm>
 
 namespace dcap {
@@ -54,8 +55,24 @@ static TileChoice conv_tile_bs(int M, int N, int K, int user_split) {
     return t;
 }
 
+static inline bool conv_is_pointwise(const dc_conv_desc* d) {
+    return d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && d->Ho == d->H && d->Wo == d->W;
+}
+
 static inline TileChoice conv_tile(const dc_conv_desc* d, int M, int N, int K) {
-    return d->math != DC_MATH_F32 ? conv_tile_bs(M, N, K, d->split_k) : choose_tile(M, N, K, d->split_k);
+    if (d->math != DC_MATH_F32) return conv_tile_bs(M, N, K, d->split_k);
+    TileChoice t = choose_tile(M, N, K, d->split_k);
+    // Measured on the encoder's layer shapes (tools/conv_bench.py): with 128-row tiles, K >= 128 and N >= 128 the producer /
+    // consumer kernel on 128x64 tiles beats the single-role 128x128 and 128x64 kernels (res4_2c 48.5 -> 42.5 us, fpn_p3
+    // 293.6 -> 276.8, res3_2b 88.1 -> 82.6): twice the blocks of a 128x128 grid, so a short-K layer no longer runs as one
+    // lock-step round, and no wave waits on its own loads.  DCAP_PW_RULE=0 restores the round-1 rule (measurements only).
+    static int rule = -1;
+    if (rule < 0) { const char* e = getenv("DCAP_PW_RULE"); rule = e ? atoi(e) : 1; }
+    if (rule && d->Cin != 4 && t.bm == 128 && t.split == 1 && K >= 128 && N >= 128) {
+        t.bn = 64;
+        t.pc = true;
+    }
+    return t;
 }
 
 static inline void conv_dims(const dc_conv_desc* d, bool stem, int& M, int& N, int& K) {
@@ -66,21 +83,33 @@ static inline void conv_dims(const dc_conv_desc* d, bool stem, int& M, int& N, i
 
 using WeightKC = DenseKCT<true>;   // packed weights: K = kh*kw*Cin is a multiple of 32, rows 16-byte aligned
 
-static inline bool conv_is_pointwise(const dc_conv_desc* d) {
-    return d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && d->Ho == d->H && d->Wo == d->W;
+// producer / consumer kernel or single-role kernel for this tile?  DCAP_PC (experiments): 0 = single-role everywhere,
+// 2 = producer/consumer on every 128x64 tile, 3 = also on 128x128.
+static bool conv_uses_pc(const TileChoice& t) {
+    static int pc = -1;
+    if (pc < 0) { const char* e = getenv("DCAP_PC"); pc = e ? atoi(e) : 1; }
+    if (t.bm == 128 && t.bn == 128) return pc == 3;
+    if (t.bm == 128 && t.bn == 64) return pc == 2 || (pc && t.pc);
+    return pc != 0;
+}
+
+static Epilogue conv_epilogue(const dc_conv_desc* d) {
+    Epilogue ep{d->y, d->Cout, d->scale, d->shift, d->residual, d->Cout, d->res_mode, d->Ho, d->Wo, d->relu, 0, 0};
+    ep.vec4 = (d->Cout & 3) == 0 && aligned16(d->y) && (!d->residual || aligned16(d->residual)) && (!d->scale || aligned16(d->scale)) &&
+              (!d->shift || aligned16(d->shift));
+    return ep;
 }
 
 template <class AL, class BL>
 static int conv_dispatch(const AL& al, const BL& bl, const Epilogue& ep, int M, int N, int K, const TileChoice& t, void* ws,
                          size_t wsb, hipStream_t s) {
-    static int pc = -1;              // experiment knob: DCAP_PC=0 runs the single-role kernels, 2 = producer/consumer on 128x64 too
-    if (pc < 0) { const char* e = getenv("DCAP_PC"); pc = e ? atoi(e) : 1; }
+    const bool pc = conv_uses_pc(t);
     if (t.bm == 128 && t.bn == 128) {
-        if (pc == 3) return launch_igemm<128, 128, AL, BL, true>(al, bl, ep, M, N, K, t.split, ws, wsb, s);
+        if (pc) return launch_igemm<128, 128, AL, BL, true>(al, bl, ep, M, N, K, t.split, ws, wsb, s);
         return launch_igemm<128, 128, AL, BL>(al, bl, ep, M, N, K, t.split, ws, wsb, s);
     }
     if (t.bm == 128 && t.bn == 64) {
-        if (pc == 2) return launch_igemm<128, 64, AL, BL, true>(al, bl, ep, M, N, K, t.split, ws, wsb, s);
+        if (pc) return launch_igemm<128, 64, AL, BL, true>(al, bl, ep, M, N, K, t.split, ws, wsb, s);
         return launch_igemm<128, 64, AL, BL>(al, bl, ep, M, N, K, t.split, ws, wsb, s);
     }
     if (pc) return launch_igemm<64, 64, AL, BL, true>(al, bl, ep, M, N, K, t.split, ws, wsb, s);
@@ -149,6 +178,28 @@ extern "C" int dc_conv2d_tile_config(const dc_conv_desc* d, int* bm, int* bn, in
     return DC_OK;
 }
 
+extern "C" int dc_conv2d_kernel_name(const dc_conv_desc* d, char* buf, size_t buf_bytes) {
+    bool stem;
+    int rc = conv_validate(d, stem);
+    if (rc) return rc;
+    DC_REQUIRE(buf && buf_bytes >= 96, DC_EINVAL, "dc_conv2d_kernel_name: need a buffer of >= 96 bytes");
+    int M, N, K;
+    conv_dims(d, stem, M, N, K);
+    const TileChoice t = conv_tile(d, M, N, K);
+    if (d->math != DC_MATH_F32) {
+        snprintf(buf, buf_bytes, "igemm_bs_kernel<%d, %d>", t.bm, t.bn);
+        return DC_OK;
+    }
+    const bool pw = !stem && conv_is_pointwise(d);
+    if (pw && t.split == 1 && conv_pw_stream_supported(d, conv_epilogue(d))) {
+        snprintf(buf, buf_bytes, "pwconv_stream_kernel<%d, %d>", d->Cin, d->res_mode);
+        return DC_OK;
+    }
+    snprintf(buf, buf_bytes, "%s<%d, %d, dcap::%s, dcap::DenseKCT<true> >", conv_uses_pc(t) ? "igemm_pc_kernel" : "igemm_kernel", t.bm, t.bn,
+             stem ? "StemKC" : (pw ? "DenseKCT<true>" : "Im2colKCT<false>"));
+    return DC_OK;
+}
+
 extern "C" int dc_conv2d_is_pointwise(const dc_conv_desc* d) { return d && d->Cin != 4 && d->math == DC_MATH_F32 && conv_is_pointwise(d) ? 1 : 0; }
 
 extern "C" int dc_conv2d_nhwc_f32(const dc_conv_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
@@ -159,9 +210,7 @@ extern "C" int dc_conv2d_nhwc_f32(const dc_conv_desc* d, void* workspace, size_t
     int M, N, K;
     conv_dims(d, stem, M, N, K);
     const TileChoice t = conv_tile(d, M, N, K);
-    Epilogue ep{d->y, d->Cout, d->scale, d->shift, d->residual, d->Cout, d->res_mode, d->Ho, d->Wo, d->relu, 0, 0};
-    ep.vec4 = (d->Cout & 3) == 0 && aligned16(d->y) && (!d->residual || aligned16(d->residual)) && (!d->scale || aligned16(d->scale)) &&
-              (!d->shift || aligned16(d->shift));
+    const Epilogue ep = conv_epilogue(d);
     DC_REQUIRE(d->math == DC_MATH_F32 || d->math == DC_MATH_BF16X3 || d->math == DC_MATH_BF16X2 || d->math == DC_MATH_BF16, DC_EINVAL,
                "dc_conv2d: unknown math mode %d", d->math);
     if (d->math != DC_MATH_F32) return conv2d_bf16x3(d, stem, ep, M, N, K, t.bm, t.bn, t.split, workspace, workspace_bytes, s);
@@ -174,6 +223,7 @@ extern "C" int dc_conv2d_nhwc_f32(const dc_conv_desc* d, void* workspace, size_t
         // 1x1 / stride 1 / no padding: the im2col matrix IS the activation tensor [pixels][Cin] -- the dense K-contiguous loader
         // (no per-row pixel decode, no tap masks at block start: on the short-K layers, K = 64..256, that set-up was a
         // visible share of a block's life)
+        if (t.split == 1 && conv_pw_stream_supported(d, ep)) return conv2d_pointwise_stream(d, ep, M, N, s);
         DenseKCT<true> al{d->x, d->Cin, M, nullptr};
         return conv_dispatch(al, bl, ep, M, N, K, t, workspace, workspace_bytes, s);
     }

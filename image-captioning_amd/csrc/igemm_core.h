@@ -929,6 +929,10 @@ inline int splitk_reduce_blocks(long total) { return (int)((total + 1023) / 1024
 int conv2d_bf16x3(const dc_conv_desc* d, bool stem, const Epilogue& ep, int M, int N, int K, int bm, int bn, int split, void* workspace,
                   size_t workspace_bytes, hipStream_t s);
 
+// short-K pointwise convolutions on the streaming kernel (conv_pw.hip)
+bool conv_pw_stream_supported(const dc_conv_desc* d, const Epilogue& ep);
+int conv2d_pointwise_stream(const dc_conv_desc* d, const Epilogue& ep, int M, int N, hipStream_t s);
+
 // Host-side launch helper.  PC = true selects the producer / consumer kernel (64x64 tiles).
 template <int BM, int BN, class AL, class BL, bool PC = false>
 int launch_igemm(const AL& al, const BL& bl, const Epilogue& ep, int M, int N, int K, int split_k, void* workspace,
@@ -978,6 +982,7 @@ int launch_igemm(const AL& al, const BL& bl, const Epilogue& ep, int M, int N, i
 // 64x64 tiles cannot fill the chip, split K (deterministic slab reduction).
 struct TileChoice {
     int bm, bn, split;
+    bool pc = false;       // 128x64 only: run the producer / consumer kernel (64x64 tiles always do)
 };
 // Tile / split-K choice.  Grids that fill the chip twice over keep the largest tile that does so; smaller ones run 64x64
 // tiles with split-K (the rule the encoder's layer table was tuned with).  Tall-K problems that under-fill the chip

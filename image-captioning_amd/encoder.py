@@ -230,17 +230,18 @@ class EncoderPlan:
                 ops.maxpool3x3s2_same(op[1], out=op[2])
 
     def conv_table(self):
-        """[(layer, flops, bm, bn, split_k, pointwise)] for every conv of the plan, in launch order (pointwise: the layer runs on the
-        dense A loader, i.e. under a different kernel instantiation than the im2col layers)."""
+        """[(layer, flops, bm, bn, split_k, kernel)] for every conv of the plan, in launch order; kernel = rocprof's spelling of the
+        template instantiation the library launches for the layer (dc_conv2d_kernel_name)."""
         rows = []
         for op in self._ops:
             if op[0] != "conv":
                 continue
             d, bm, bn, sk = op[1], C.c_int(), C.c_int(), C.c_int()
             check(self.lib.dc_conv2d_tile_config(C.byref(d), C.byref(bm), C.byref(bn), C.byref(sk)), "dc_conv2d_tile_config")
+            buf = C.create_string_buffer(128)
+            check(self.lib.dc_conv2d_kernel_name(C.byref(d), buf, 128), "dc_conv2d_kernel_name")
             s = self._specs[op[2]]
-            rows.append((op[2], 2.0 * d.N * d.Ho * d.Wo * d.Cout * s.k * s.k * s.cin, bm.value, bn.value, sk.value,
-                         bool(self.lib.dc_conv2d_is_pointwise(C.byref(d)))))
+            rows.append((op[2], 2.0 * d.N * d.Ho * d.Wo * d.Cout * s.k * s.k * s.cin, bm.value, bn.value, sk.value, buf.value.decode()))
         return rows
 
     def time_convs(self, reps=3, beside=None):

@@ -163,6 +163,9 @@ int    dc_conv2d_nhwc_f32(const dc_conv_desc* d, void* workspace, size_t workspa
 /* Profiling aid: the block tile (bm x bn) and split-K factor dc_conv2d_nhwc_f32 picks for `d`, i.e.
  * which igemm_kernel<bm,bn,...> instantiation runs (bench.py maps layers to rocprof kernel names). */
 int    dc_conv2d_tile_config(const dc_conv_desc* d, int* bm, int* bn, int* split_k);
+/* Profiling aid: rocprof's spelling (without the "void dcap::" prefix and the parameter list) of the kernel template
+ * instantiation that dc_conv2d_nhwc_f32 launches for `d`.  buf_bytes >= 96. */
+int    dc_conv2d_kernel_name(const dc_conv_desc* d, char* buf, size_t buf_bytes);
 /* 1 when `d` runs on the dense (pointwise: 1x1, stride 1, unpadded) A-operand loader instead of the im2col one. */
 int    dc_conv2d_is_pointwise(const dc_conv_desc* d);
 

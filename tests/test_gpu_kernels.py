@@ -101,6 +101,10 @@ CONV_CASES = [
     (1, 16, 16, 256, 256, 1, 1, 'valid', 2, False),      # FPN lateral + upsample-add
     (3, 7, 7, 256, 1024, 7, 1, 'valid', 0, True),        # RoI head conv as a conv
     (2, 64, 64, 64, 128, 3, 1, 'same', 1, True),         # 128-wide tiles
+    (1, 9, 7, 128, 512, 1, 1, 'valid', 1, True),         # streaming pointwise kernel: ragged last strip, two weight slices
+    (2, 16, 16, 256, 1024, 1, 1, 'valid', 1, True),      # ... Cin = 256, sixteen slices
+    (1, 16, 16, 256, 64, 1, 1, 'valid', 0, True),        # ... one 64-channel slice
+    (1, 8, 8, 128, 192, 1, 1, 'valid', 0, False),        # ... a partial last slice
 ]
 
 
