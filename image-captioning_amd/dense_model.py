@@ -509,11 +509,14 @@ class DenseImageCapRCNN(object):
         return ops.conv2d_wgrad(x, dy, k, k, 1, pad, pad, out=out, accumulate=accumulate)
 
     def _images_u8(self, images):
+        """uint8 [B,H,W,3] as a torch tensor: device-resident uint8 tensors pass through, host arrays are wrapped."""
+        if isinstance(images, torch.Tensor) and images.dtype == torch.uint8:
+            return images
         a = np.asarray(images)
         if a.dtype == np.uint8:
-            return a
+            return torch.as_tensor(a)
         # the generator yields molded float images (image - MEAN_PIXEL); the GPU molds from the uint8 original
-        return np.clip(np.rint(a.astype(np.float64) + np.asarray(self.config.MEAN_PIXEL, np.float64)), 0, 255).astype(np.uint8)
+        return torch.as_tensor(np.clip(np.rint(a.astype(np.float64) + np.asarray(self.config.MEAN_PIXEL, np.float64)), 0, 255).astype(np.uint8))
 
     def _rpn_selection(self, rpn_match):
         m = np.asarray(rpn_match).reshape(-1)
@@ -544,7 +547,7 @@ class DenseImageCapRCNN(object):
 
         # ---- forward: backbone + FPN + RPN (hipGraph), proposals, detection targets, RoIAlign, head + decoder
         self._bf16_cache = {}
-        p.forward(torch.as_tensor(self._images_u8(images)))
+        p.forward(self._images_u8(images))
         proposals = p.proposals()
         gt_norm = (np.asarray(gt_boxes[0], np.float32) / np.array([H, W, H, W], np.float32)).astype(np.float32)
         rng = self._rng if backward else self._val_rng

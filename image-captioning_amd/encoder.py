@@ -278,6 +278,10 @@ class EncoderPlan:
         """images_u8: [B,H,W,3] uint8 torch tensor (any device) or None to reuse self.images.
         Returns (P2, P3, P4, P5), plan-owned buffers valid until the next forward()."""
         if images_u8 is not None:
+            # host arrays arrive as pageable memory: the runtime moves one 1024x1024 image in ~64 KB pieces (48 copy kernels, 0.7 ms
+            # on the compute queue).  A pinned staging buffer + one DMA was tried and measured SLOWER inside the joint step (35 vs
+            # 12.9 ms: the DMA and the CPU-side refill of the buffer stall each other on this box); callers that care hand over a
+            # device-resident uint8 tensor (bench.py does, the data generator can prefetch one).
             self.images.copy_(images_u8, non_blocking=True)
         if not self.use_graph:
             self._run_ops()
