@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--vocab", type=int, default=None, help="default 10000 (e2e) / 50000 (joint)")
     ap.add_argument("--image-size", type=int, default=1024)
     ap.add_argument("--stage4-blocks", type=int, default=22, help="22 = ResNet-101 (the benchmark config)")
+    ap.add_argument("--backbone", default="resnet101", choices=["resnet101", "vgg16"],
+                    help="vgg16 = the 13-conv alternative backbone of the configs[2] label (no counterpart in the reference's dense-captioning paths)")
     ap.add_argument("--no-pipeline", action="store_true", help="run encoder and decoder back to back on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -234,11 +236,17 @@ class E2E(object):
             IMAGE_MIN_DIM = S
             IMAGE_MAX_DIM = S
 
-        enc = DenseImageCapRCNN("inference", EncCfg(), "logs", device=dev, stage4_blocks=args.stage4_blocks)
-        enc.set_weights(synth.encoder_weights(0, args.stage4_blocks))
+        if args.backbone == "vgg16":
+            from image_captioning_amd.encoder import Vgg16Plan
+            plan = Vgg16Plan(synth.vgg16_weights(0), B, S, S, dev)
+        else:
+            enc = DenseImageCapRCNN("inference", EncCfg(), "logs", device=dev, stage4_blocks=args.stage4_blocks)
+            enc.set_weights(synth.encoder_weights(0, args.stage4_blocks))
+            plan = enc.plan(B, S, S)
+        self.fc = fc = plan.feat_channels
         cfg = DenseCapConfig(V, synth.embedding_matrix(3, V))
         cfg.PADDING_SIZE = T
-        dec = build_model((7, 7, 256), (T,), cfg, 256, inject=True, device=dev, seed=0)
+        dec = build_model((7, 7, fc), (T,), cfg, 256, inject=True, device=dev, seed=0)
         dec.compile(optimizer=Adam(amsgrad=True), loss="categorical_crossentropy")
         self.sync = None
         if world > 1:
@@ -249,10 +257,10 @@ class E2E(object):
         rois = synth.rois(seed + 1, B, R, S, S)
         caps = synth.captions_v2(seed + 2, B * R, T, V, full=True)
         self.tables = SampleTables.from_captions(caps, dev)
-        self.plan = plan = enc.plan(B, S, S)
+        self.plan = plan
         plan.images.copy_(images)
         self.boxes = plan.normalize_boxes(rois)          # device-resident, normalised once
-        self.feat = torch.empty((B, R, 7, 7, 256), dtype=torch.float32, device=dev)
+        self.feat = torch.empty((B, R, 7, 7, fc), dtype=torch.float32, device=dev)
         self.inner = dec.inner_model if world > 1 else dec
         self.B, self.R = B, R
         self.pipe = None if args.no_pipeline else CaptionTrainPipeline(plan, self.inner, R)
@@ -262,7 +270,7 @@ class E2E(object):
             return self.pipe.step(None, self.boxes, self.tables)
         self.plan.forward(None)                       # images already resident in the plan's input buffer
         self.plan.roi_features(boxes_norm=self.boxes, out=self.feat)
-        return self.inner.train_step(self.feat.view(self.B * self.R, 7, 7, 256), self.tables)
+        return self.inner.train_step(self.feat.view(self.B * self.R, 7, 7, self.fc), self.tables)
 
     def flush(self):
         return self.pipe.flush() if self.pipe is not None else None
@@ -291,7 +299,7 @@ class E2E(object):
 
             def beside():                              # one decoder train step on the decoder's stream, like the pipeline
                 with torch.cuda.stream(s_dec):
-                    self.inner.train_step(feat0.view(-1, 7, 7, 256), self.tables)
+                    self.inner.train_step(feat0.view(-1, 7, 7, self.fc), self.tables)
         res = {}
         for label, b in (("pipeline", beside), ("isolated", None)):
             if label == "pipeline" and b is None:
@@ -319,7 +327,7 @@ class E2E(object):
         achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
         conv_ms = sum(v["ms"] for v in groups.values())
         traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
-        for tname in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for tname in (("r02_pmc_traffic.json", "r01_pmc_traffic.json") if args.backbone == "resnet101" else ()):
             tpath = os.path.join(ROOT, "profiles", tname)
             if traffic is None and os.path.exists(tpath):
                 for name, rec in json.load(open(tpath)).items():
@@ -464,6 +472,8 @@ def main():
             dist.destroy_process_group()
         return
 
+    if args.backbone != "resnet101":                      # the alternative backbone is one GPU leg: no CPU port, no extra legs
+        args.no_cpu_baseline = args.no_alt_math = args.no_other_configs = True
     e2e = E2E(args, dev, rank, world, B)
     dt, loss = e2e.timed(args.warmup, args.steps, barrier)
     dt = max_over_ranks(dt)
@@ -475,9 +485,13 @@ def main():
         "value": captions / dt, "unit": "captions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if os.environ.get("DCAP_CONV_MATH", "f32") == "f32" else "f32 (conv operands as bf16 pieces)", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[2] (configs[3] at 8 GPUs): frozen ResNet-101+FPN fwd + PyramidROIAlign + "
-                               "RoI head + v2-inject decoder fwd/bwd + AMSGrad, %dx%d synth images, %d RoI/img, %d-token captions, V=%d"
-                               % (S, S, R, T, V),
+        "config": {"workload": ("BASELINE configs[2] (configs[3] at 8 GPUs): frozen ResNet-101+FPN fwd + PyramidROIAlign + "
+                                "RoI head + v2-inject decoder fwd/bwd + AMSGrad, %dx%d synth images, %d RoI/img, %d-token captions, V=%d"
+                                if args.backbone == "resnet101" else
+                                "configs[2]'s label taken literally (alternative backbone, no counterpart in the reference's dense-captioning "
+                                "paths): frozen VGG16 13-conv fwd + RoIAlign 7x7x512 on block5_conv3 + RoI head + v2-inject decoder fwd/bwd "
+                                "+ AMSGrad, %dx%d synth images, %d RoI/img, %d-token captions, V=%d") % (S, S, R, T, V),
+                   "backbone": args.backbone,
                    "images_per_gpu": B, "global_batch_images": B * world, "captions_per_step": B * R * world,
                    "parallelism": "dp%d" % world, "stage4_blocks": args.stage4_blocks, "final_loss": final_loss,
                    "pipeline": "encoder(i+1) || decoder(i), 2 HIP streams" if e2e.pipe is not None else "single stream",
@@ -522,6 +536,14 @@ def main():
             other["configs2_one_image"] = {"workload": "BASELINE configs[2] as defined: 1 image x %d RoI per step, same model" % R,
                                            "value": one["value"], "unit": "captions/s", "ms_per_step": one["ms_per_step"], "steps": one["steps"]}
             other["configs1_gpu"] = gpu_configs1(dev)
+            # configs[2]'s label taken literally: the VGG16 13-conv backbone (child process; its roofline leg gives the conv TFLOP/s)
+            cmdv = [sys.executable, os.path.abspath(__file__), "--backbone", "vgg16", "--steps", str(max(5, args.steps // 2)), "--warmup", "2",
+                    "--images-per-gpu", str(B), "--rois", str(R), "--tokens", str(T), "--vocab", str(V), "--image-size", str(S)]
+            rv = subprocess.run(cmdv, capture_output=True, text=True, timeout=300)
+            vg = json.loads(rv.stdout.strip().splitlines()[-1])
+            other["configs2_vgg16"] = {"workload": vg["config"]["workload"], "value": vg["value"], "unit": "captions/s",
+                                       "ms_per_step": vg["ms_per_step"], "steps": vg["steps"], "images_per_gpu": B,
+                                       "all_conv": vg.get("roofline", {}).get("all_conv")}
         except Exception as e:
             other["error_gpu"] = repr(e)[:300]
         if not args.no_cpu_baseline:

@@ -144,6 +144,25 @@ __global__ void maxpool3x3s2_kernel(const float4* __restrict__ x, float4* __rest
     }
 }
 
+// ---- maxpool 2x2 / stride 2 / valid (VGG16's block pools; H and W even)
+__global__ void maxpool2x2s2_kernel(const float4* __restrict__ x, float4* __restrict__ y, int N, int H, int W, int C4) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long total = (long)N * Ho * Wo * C4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C4);
+        long p = idx / C4;
+        const int ox = (int)(p % Wo);
+        p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        const float4* r0 = x + (((long)n * H + 2 * oy) * W + 2 * ox) * C4 + c;
+        const float4* r1 = r0 + (long)W * C4;
+        const float4 a = r0[0], b = r0[C4], d = r1[0], e = r1[C4];
+        y[idx] = make_float4(fmaxf(fmaxf(a.x, b.x), fmaxf(d.x, e.x)), fmaxf(fmaxf(a.y, b.y), fmaxf(d.y, e.y)),
+                             fmaxf(fmaxf(a.z, b.z), fmaxf(d.z, e.z)), fmaxf(fmaxf(a.w, b.w), fmaxf(d.w, e.w)));
+    }
+}
+
 // ---- uint8 RGB -> float RGBX minus MEAN_PIXEL
 __global__ void mold_rgbx_kernel(const uint8_t* __restrict__ img, float4* __restrict__ out, long npix, float mr, float mg, float mb) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
@@ -364,6 +383,17 @@ extern "C" int dc_maxpool3x3s2_same_f32(const float* x, float* y, int N, int H, 
     hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), N, H, W, C / 4, Ho, Wo, pad_h / 2, pad_w / 2);
     return check_launch("maxpool3x3s2_kernel");
+}
+
+extern "C" int dc_maxpool2x2s2_f32(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+    DC_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && (H & 1) == 0 && (W & 1) == 0, DC_EINVAL,
+               "dc_maxpool2x2s2: bad arguments (C %% 4 == 0, even H and W)");
+    DC_REQUIRE(aligned16(x) && aligned16(y), DC_EALIGN, "dc_maxpool2x2s2: pointers must be 16-byte aligned");
+    const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+    const int blocks = (int)std::min<long>((total + 255) / 256, (long)kNumCU * 16);
+    hipLaunchKernelGGL(maxpool2x2s2_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), N, H, W, C / 4);
+    return check_launch("maxpool2x2s2_kernel");
 }
 
 extern "C" int dc_mold_image_rgbx_f32(const uint8_t* img, float* out, int N, int H, int W, float mean_r, float mean_g, float mean_b,

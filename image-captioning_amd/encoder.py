@@ -49,6 +49,8 @@ def fuse_rpn_head(weights, channels=None):
 
 
 class EncoderPlan:
+    feat_channels = 256              # channels of a RoI feature (the FPN depth)
+
     def __init__(self, weights, batch, height, width, device, stage4_blocks=22,
                  mean_pixel=(123.7, 116.8, 103.9), use_graph=True, rpn=None, external=None, math=None):
         """rpn: None (GT-RoI variant: the RPN is never evaluated) or a dict with the config values the
@@ -320,5 +322,93 @@ class EncoderPlan:
     def roi_features(self, rois_px=None, out=None, boxes_norm=None):
         """rois_px [B,R,4] (y1,x1,y2,x2) pixels of the molded image (or boxes_norm from
         normalize_boxes, device-resident) -> [B,R,7,7,256]."""
+        boxes = boxes_norm if boxes_norm is not None else self.normalize_boxes(rois_px)
+        return ops.roi_align_pyramid(list(self.P), boxes, float(self.H * self.W), 7, out=out)
+
+
+class Vgg16Plan(EncoderPlan):
+    """Alternative backbone for BASELINE configs[2]'s label ("VGG16 backbone + RoIAlign + inject-LSTM"): the 13 convolutions of
+    keras.applications VGG16 (`image captioning/vgg16.py:9-18` loads that model) at the benchmark's image size, RoIAlign
+    (crop_and_resize, 7x7) on block5_conv3 (stride 16, 512 channels).  No dense-captioning path of the reference runs VGG16
+    (SURVEY.md section 1), so this plan has no parity target of its own: every kernel in it is the one the ResNet-FPN plan is
+    validated with (conv 3x3 + bias + ReLU, RoIAlign) plus a 2x2 max pool checked against NumPy; 641.43 GFLOP per 1024x1024 image.
+    The first convolution reads the RGBX image zero-padded to 32 channels (the implicit-GEMM loader wants Cin % 32 == 0)."""
+    feat_channels = 512
+
+    def __init__(self, weights, batch, height, width, device, mean_pixel=(123.7, 116.8, 103.9), use_graph=True, math=None):
+        from .layers import vgg16_convs
+        if height % 16 or width % 16:
+            raise ValueError("Image size must be dividable by 16 (got %dx%d)" % (height, width))
+        self.lib = _lib.load()
+        self.math = conv_math_mode(math)
+        self.B, self.H, self.W = batch, height, width
+        self.device = torch.device(device)
+        self.mean_pixel = [float(v) for v in mean_pixel]
+        self.use_graph = use_graph
+        self._graph = None
+        self._warm = False
+        self._specs = {s.name: s for s in vgg16_convs()}
+        self.rpn = None
+        self._external = {}
+        self._w = {}
+        self._wsplit = {}
+        self._upload(weights)
+        self._build()
+
+    def _upload(self, W):
+        dev = self.device
+        for s in self._specs.values():
+            k = np.asarray(W[s.name + "/kernel"], np.float32)
+            if tuple(k.shape) != (s.k, s.k, s.cin, s.cout):
+                raise ValueError("%s/kernel has shape %s, expected %s" % (s.name, k.shape, (s.k, s.k, s.cin, s.cout)))
+            if s.cin == 3:                                  # R, G, B, then 29 zero input channels
+                k = np.concatenate([k, np.zeros((s.k, s.k, 29, s.cout), np.float32)], axis=2)
+            self._w[s.name] = (torch.tensor(pack_conv_kernel(k), device=dev), None,
+                               torch.tensor(np.asarray(W[s.name + "/bias"], np.float32), device=dev))
+
+    def _build(self):
+        B, H, W = self.B, self.H, self.W
+        self._ops, self._ws_bytes, self.flops, self._bufs = [], 0, 0.0, []
+        self.images = torch.empty((B, H, W, 3), dtype=torch.uint8, device=self.device)
+        rgbx = torch.empty((B, H, W, 4), dtype=torch.float32, device=self.device)
+        x32 = torch.zeros((B, H, W, 32), dtype=torch.float32, device=self.device)
+        self._bufs += [rgbx, x32]
+        self._ops.append(("mold", self.images, rgbx))
+        self._ops.append(("pad32", rgbx, x32))
+        x, h, w = x32, H, W
+        for b, (n, cout) in enumerate(((2, 64), (2, 128), (3, 256), (3, 512), (3, 512)), 1):
+            for i in range(1, n + 1):
+                y = self._buf(h, w, cout)
+                self._conv("block%d_conv%d" % (b, i), x, y)
+                x = y
+            if b < 5:
+                h, w = h // 2, w // 2
+                y = self._buf(h, w, cout)
+                self._ops.append(("pool2", x, y))
+                x = y
+        self.C = (x,)
+        self.P = (x, x, x, x)            # every RoI reads the one stride-16 map, whatever level its size routes it to
+        self.pre = None
+        self._ws = torch.empty(max(self._ws_bytes, 16), dtype=torch.uint8, device=self.device)
+
+    def _run_ops(self):
+        lib = self.lib
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        wsp, wsb = C.c_void_p(self._ws.data_ptr()), self._ws.numel()
+        for op in self._ops:
+            kind = op[0]
+            if kind == "conv":
+                rc = lib.dc_conv2d_nhwc_f32(C.byref(op[1]), wsp, wsb, stream)
+                if rc:
+                    check(rc, "dc_conv2d_nhwc_f32(%s)" % op[2])
+            elif kind == "mold":
+                ops.mold_image_rgbx(op[1], self.mean_pixel, out=op[2])
+            elif kind == "pad32":
+                op[2][..., :4].copy_(op[1])
+            else:
+                ops.maxpool2x2s2(op[1], out=op[2])
+
+    def roi_features(self, rois_px=None, out=None, boxes_norm=None):
+        """-> [B,R,7,7,512] crops of block5_conv3."""
         boxes = boxes_norm if boxes_norm is not None else self.normalize_boxes(rois_px)
         return ops.roi_align_pyramid(list(self.P), boxes, float(self.H * self.W), 7, out=out)

@@ -37,5 +37,17 @@ def resnet_fpn_convs(stage4_blocks=22):
     return L
 
 
+def vgg16_convs():
+    """The 13 convolutions of keras.applications VGG16 (block<b>_conv<i>, 3x3 'same' + bias + ReLU), the model
+    `image captioning/vgg16.py:9-18` loads.  Alternative-backbone benchmark config only: no dense-captioning path of the
+    reference runs it."""
+    L, cin = [], 3
+    for b, (n, cout) in enumerate(((2, 64), (2, 128), (3, 256), (3, 512), (3, 512)), 1):
+        for i in range(1, n + 1):
+            L.append(ConvSpec("block%d_conv%d" % (b, i), None, 3, cin, cout, 1, "same"))
+            cin = cout
+    return L
+
+
 HEAD_LAYERS = ("mrcnn_class_conv1", "mrcnn_class_bn1", "mrcnn_class_conv2", "mrcnn_class_bn2")
 V2_WORD_LSTM = "lstm_1"   # the unnamed KL.LSTM(1024) of text_generation_model_v2.py:157 (Keras auto name)

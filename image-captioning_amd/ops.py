@@ -271,6 +271,17 @@ def maxpool3x3s2_same(x, out=None):
     return out
 
 
+def maxpool2x2s2(x, out=None):
+    """MaxPooling2D((2, 2), strides 2) on NHWC float32 (even H, W)."""
+    lib = _lib.load()
+    _chk(x, name="x")
+    N, H, W, Cc = x.shape
+    if out is None:
+        out = torch.empty((N, H // 2, W // 2, Cc), dtype=torch.float32, device=x.device)
+    check(lib.dc_maxpool2x2s2_f32(_ptr(x), _ptr(out), N, H, W, Cc, _stream()), "dc_maxpool2x2s2_f32")
+    return out
+
+
 def mold_image_rgbx(img_u8, mean_pixel, out=None):
     lib = _lib.load()
     _chk(img_u8, torch.uint8, "images")

@@ -18,7 +18,8 @@ class CaptionTrainPipeline(object):
         self.s_enc = torch.cuda.Stream(device=dev)
         self.s_dec = torch.cuda.Stream(device=dev, priority=-1)      # its short kernels slot in between the convs
         B = plan.B
-        self.feat = [torch.empty((B, rois_per_image, 7, 7, 256), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.fc = fc = getattr(plan, "feat_channels", 256)
+        self.feat = [torch.empty((B, rois_per_image, 7, 7, fc), dtype=torch.float32, device=dev) for _ in range(2)]
         self.ev_feat = [torch.cuda.Event() for _ in range(2)]       # features of slot ready
         self.ev_free = [torch.cuda.Event() for _ in range(2)]       # decoder done reading slot
         self.pending = None                                          # (slot, tables) awaiting its decoder pass
@@ -39,7 +40,7 @@ class CaptionTrainPipeline(object):
         with torch.cuda.stream(self.s_dec):
             self.s_dec.wait_event(self.ev_feat[slot])
             f = self.feat[slot]
-            loss = self.dec.train_step(f.view(-1, 7, 7, 256), tables)
+            loss = self.dec.train_step(f.view(-1, 7, 7, self.fc), tables)
             self.ev_free[slot].record(self.s_dec)
         return loss
 

@@ -63,6 +63,17 @@ def encoder_weights(seed=0, stage4_blocks=22):
     return W
 
 
+def vgg16_weights(seed=0):
+    """He-style kernels (std sqrt(2 / fan_in)) keep the activations O(1) through 13 ReLU convolutions with random weights."""
+    from .layers import vgg16_convs
+    rng = np.random.default_rng(seed)
+    W = {}
+    for s in vgg16_convs():
+        W[s.name + "/kernel"] = (rng.standard_normal((s.k, s.k, s.cin, s.cout)) * np.sqrt(2.0 / (s.k * s.k * s.cin))).astype(F32)
+        W[s.name + "/bias"] = (0.01 * rng.standard_normal(s.cout)).astype(F32)
+    return W
+
+
 def rpn_weights(seed=4, anchors_per_loc=3, depth=256):
     """rpn_graph's three convolutions (feature_generation/dense_model.py:701-725)."""
     rng = np.random.default_rng(seed)

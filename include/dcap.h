@@ -184,6 +184,10 @@ int    dc_conv2d_wgrad_f32(const dc_conv_desc* d, void* workspace, size_t worksp
 /* KL.MaxPooling2D((3,3), strides 2, 'same') (dense_model.py:150); C % 4 == 0. */
 int dc_maxpool3x3s2_same_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
 
+/* KL.MaxPooling2D((2,2), strides 2) of keras.applications VGG16 (image captioning/vgg16.py:9-18 loads that model; the
+ * alternative-backbone benchmark config); C % 4 == 0, H and W even. */
+int dc_maxpool2x2s2_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
+
 /* mold_image (dense_model.py:2050-2055) fused with the RGBX repack the stem kernel wants:
  * out[n,h,w,0..2] = float(img_u8) - mean[c], out[...,3] = 0. */
 int dc_mold_image_rgbx_f32(const uint8_t* img, float* out, int N, int H, int W,

@@ -630,3 +630,13 @@ def test_degenerate_sizes_are_rejected_not_launched(ops):
         ops.conv2d(torch.zeros(1, 8, 8, 48, device="cuda"), torch.zeros(32, 48, device="cuda"), 1, 1, 1, 0, 0, 8, 8)       # Cin % 32 != 0
     with pytest.raises(DcapError):
         ops.lstm_seq_fwd(torch.zeros(0, 16, device="cuda"), torch.zeros(4, 16, device="cuda"), None, 0, 1)
+
+
+def test_maxpool2x2s2_matches_numpy(ops):
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((2, 6, 10, 8)).astype(np.float32)
+    want = x.reshape(2, 3, 2, 5, 2, 8).max(axis=(2, 4))
+    np.testing.assert_array_equal(ops.maxpool2x2s2(dev(x)).cpu().numpy(), want)
+    from image_captioning_amd._lib import DcapError
+    with pytest.raises(DcapError):
+        ops.maxpool2x2s2(dev(x[:, :5]))                 # odd height

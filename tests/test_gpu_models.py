@@ -580,3 +580,34 @@ def test_joint_model_train_loop_checkpoints_and_resumes(gpu, tmp_path):
     more = resumed.train(train, val, learning_rate=1e-5, epochs=3, layers="no_backbone")
     assert len(more) == 1 and resumed.epoch == 3
     assert set(os.listdir(folder)) - before == {"img_cap_%s_0003.npz" % name}
+
+
+def test_vgg16_plan_matches_oracle(gpu):
+    """The alternative backbone of the configs[2] label (13 convs + 2x2 pools + RoIAlign on block5_conv3) against the float64
+    oracle's conv / ReLU / crop_and_resize on a 64x64 image; eager, graph capture, graph replay."""
+    from image_captioning_amd import synth
+    from image_captioning_amd.encoder import Vgg16Plan
+    from image_captioning_amd.layers import vgg16_convs
+    B, S, R = 2, 64, 6
+    Wt = synth.vgg16_weights(3)
+    img = synth.images(4, B, S, S)
+    rois = synth.rois(5, B, R, S, S, lo=8, hi=64)
+    x = O.mold_image(img, MEAN)
+    specs = vgg16_convs()
+    for i, s in enumerate(specs):
+        x = O.relu(O.conv2d_nhwc(x, Wt[s.name + "/kernel"], Wt[s.name + "/bias"], 1, "same"))
+        last_of_block = i + 1 == len(specs) or specs[i + 1].name.split("_")[0] != s.name.split("_")[0]
+        if last_of_block and not s.name.startswith("block5"):
+            n, h, w, c = x.shape
+            x = x.reshape(n, h // 2, 2, w // 2, 2, c).max(axis=(2, 4))
+    assert x.shape == (B, S // 16, S // 16, 512)
+    boxes = O.normalize_boxes(rois, S, S)
+    want = np.stack([O.crop_and_resize(x, boxes[b], np.full(R, b), (7, 7)) for b in range(B)])
+    plan = Vgg16Plan(Wt, B, S, S, "cuda")
+    assert abs(plan.flops / B - sum(2.0 * S * S / 4 ** (int(s.name[5]) - 1) * 9 * s.cin * s.cout for s in specs)) < 1
+    for rep in range(3):
+        plan.forward(torch.as_tensor(img))
+        assert rel_err(plan.C[0].cpu().numpy(), x) < 2e-4, rep
+        got = plan.roi_features(rois).cpu().numpy()
+        assert got.shape == (B, R, 7, 7, 512)
+        assert rel_err(got, want) < 2e-4, rep

@@ -244,7 +244,7 @@ def test_joint_data_generator_layout():
     assert int((np.abs(inputs[5][0]).sum(axis=1) > 0).sum()) == 2                      # zero-padded
     # molded = image - MEAN_PIXEL: the model recovers the uint8 image exactly
     from image_captioning_amd.dense_model import DenseImageCapRCNN
-    u8 = DenseImageCapRCNN._images_u8(type("M", (), {"config": cfg})(), inputs[0])
+    u8 = DenseImageCapRCNN._images_u8(type("M", (), {"config": cfg})(), inputs[0]).numpy()      # a host uint8 torch tensor
     assert u8.dtype == np.uint8 and np.allclose(u8.astype(np.float32) - cfg.MEAN_PIXEL, inputs[0], atol=1e-4)
 
 
