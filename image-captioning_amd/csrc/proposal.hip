@@ -1,10 +1,10 @@
-// proposal.hip -- RPN scoring + ProposalLayer on the device: fg-score softmax, top-k by one stable radix
-// sort per image (rocPRIM), box decode / clip / normalise in TF's float32 operation order, and
+// proposal.hip -- RPN scoring + ProposalLayer on the device: fg-score softmax, tf.nn.top_k as a three-pass radix select of
+// the k-th score + an index-ordered compaction of exactly k candidates + one bitonic sort of those k in LDS (stable: score
+// descending, lower anchor index first among ties), box decode / clip / normalise in TF's float32 operation order, and
 // tf.image.non_max_suppression as a 64-bit suppression-mask kernel followed by a single-workgroup greedy
 // scan.  All index decisions (sort order, ties, IoU > threshold) are float32 like the TF graph.
 #include "dcap_internal.h"
 #include <string.h>
-#include <rocprim/device/device_radix_sort.hpp>
 #include <algorithm>
 
 namespace dcap {
@@ -237,8 +237,259 @@ __global__ __launch_bounds__(256) void rpn_loss_grad_kernel(dc_rpn_loss_desc d) 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// tf.nn.top_k(scores, k) per image (ProposalLayer, dense_model.py:259-262): the k largest scores in descending order, the
+// lower anchor index first among equal scores.  A full sort of the ~262 k anchors of a 1024^2 image is 40x more work than
+// needed for k = 6000:
+//   1. radix select: three histogram passes over the order-preserving 32-bit image of the scores (11 + 11 + 10 bits) find
+//      the k-th largest key T and how many keys equal to T belong to the top k (`need`);
+//   2. ordered compaction: every key > T plus the first `need` keys == T IN ANCHOR ORDER (per-block counts, a scan over the
+//      blocks, then each block writes at its offsets) -- exactly k candidates whatever the number of ties;
+//   3. one workgroup per image sorts the k candidates (64-bit: key, then ~index) with a bitonic network in LDS (k <= 8192) or,
+//      above that, stage by stage in global memory.
+// ------------------------------------------------------------------------------------------------
+constexpr int TK_BINS = 2048;
+constexpr int TK_CHUNK = 1024;          // anchors per block in the count / compaction passes (4 per thread)
+constexpr int TK_LDS_MAX = 8192;        // candidates the in-LDS sort holds (64 KB of 64-bit keys)
+
+struct TopkState {
+    unsigned hist[3][TK_BINS];
+    unsigned prefix;        // the high bits of T decided so far
+    unsigned remaining;     // how many of the top k lie in the bin chosen last (after pass 3: how many keys == T to take)
+    unsigned pad[2];
+};
+
+__device__ __forceinline__ unsigned tk_key(float f) {      // larger float <=> larger unsigned (-0 < +0, as in a bitwise radix sort)
+    const unsigned b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+// PASS 0: bits 31..21, PASS 1: bits 20..10 of the keys whose bits 31..21 equal the prefix, PASS 2: bits 9..0
+template <int PASS>
+__global__ __launch_bounds__(256) void topk_hist_kernel(const float* __restrict__ scores, int A_total, TopkState* __restrict__ st) {
+    __shared__ unsigned h[TK_BINS];
+    constexpr int SHIFT = PASS == 0 ? 21 : (PASS == 1 ? 10 : 0);
+    constexpr int BINS = PASS == 2 ? 1024 : 2048;
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < BINS; i += 256) h[i] = 0;
+    __syncthreads();
+    const unsigned prefix = PASS == 0 ? 0u : st[b].prefix;
+    const float* sc = scores + (long)b * A_total;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < A_total; i += gridDim.x * 256) {
+        const unsigned key = tk_key(sc[i]);
+        if (PASS == 0 || (key >> (SHIFT + (PASS == 1 ? 11 : 10))) == prefix) atomicAdd(&h[(key >> SHIFT) & (BINS - 1)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < BINS; i += 256)
+        if (h[i]) atomicAdd(&st[b].hist[PASS][i], h[i]);
+}
+
+// one block per image: walk the pass's histogram from the top bin down to the bin that holds the `remaining`-th largest key
+template <int PASS>
+__global__ __launch_bounds__(256) void topk_pick_kernel(TopkState* __restrict__ st, int k) {
+    constexpr int BINS = PASS == 2 ? 1024 : 2048, PER = BINS / 256, BITS = PASS == 2 ? 10 : 11;
+    __shared__ unsigned part[256];
+    TopkState& s = st[blockIdx.x];
+    const unsigned remaining = PASS == 0 ? (unsigned)k : s.remaining;
+    const int t = threadIdx.x;
+    const int top = BINS - 1 - t * PER;                 // thread t owns bins top, top-1, .., top-PER+1
+    unsigned sum = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) sum += s.hist[PASS][top - j];
+    part[t] = sum;
+    __syncthreads();
+    if (t == 0) {                                        // 256 partial sums: a serial walk is shorter than a scan's barriers
+        unsigned cum = 0;
+        int c = 0;
+        while (c < 255 && cum + part[c] < remaining) cum += part[c++];
+        int bin = BINS - 1 - c * PER;
+        const int last = bin - PER + 1;
+        while (bin > last && cum + s.hist[PASS][bin] < remaining) cum += s.hist[PASS][bin--];
+        s.prefix = PASS == 0 ? (unsigned)bin : ((s.prefix << BITS) | (unsigned)bin);
+        s.remaining = remaining - cum;
+    }
+}
+
+// per block of TK_CHUNK consecutive anchors: how many keys > T, how many == T
+__global__ __launch_bounds__(256) void topk_count_kernel(const float* __restrict__ scores, int A_total, const TopkState* __restrict__ st,
+                                                         unsigned* __restrict__ cnt, int nblk) {
+    __shared__ unsigned sg[4], se[4];
+    const int b = blockIdx.y, blk = blockIdx.x;
+    const unsigned T = st[b].prefix;
+    const float* sc = scores + (long)b * A_total;
+    unsigned g = 0, e = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = blk * TK_CHUNK + threadIdx.x * 4 + j;
+        if (i < A_total) {
+            const unsigned key = tk_key(sc[i]);
+            g += key > T;
+            e += key == T;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { g += __shfl_down(g, o); e += __shfl_down(e, o); }
+    if ((threadIdx.x & 63) == 0) { sg[threadIdx.x >> 6] = g; se[threadIdx.x >> 6] = e; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cnt[((long)b * nblk + blk) * 2] = sg[0] + sg[1] + sg[2] + sg[3];
+        cnt[((long)b * nblk + blk) * 2 + 1] = se[0] + se[1] + se[2] + se[3];
+    }
+}
+
+// exclusive scan of the per-block counts (one block per image, blocks in anchor order)
+__global__ __launch_bounds__(256) void topk_scan_kernel(unsigned* __restrict__ cnt, int nblk) {
+    __shared__ unsigned pg[256], pe[256];
+    unsigned* c = cnt + (long)blockIdx.x * nblk * 2;
+    const int per = (nblk + 255) / 256, t = threadIdx.x;
+    unsigned g = 0, e = 0;
+    for (int j = 0; j < per; ++j) {
+        const int i = t * per + j;
+        if (i < nblk) { g += c[2 * i]; e += c[2 * i + 1]; }
+    }
+    pg[t] = g; pe[t] = e;
+    __syncthreads();
+    if (t == 0) {
+        unsigned ag = 0, ae = 0;
+        for (int i = 0; i < 256; ++i) { const unsigned x = pg[i], y = pe[i]; pg[i] = ag; pe[i] = ae; ag += x; ae += y; }
+    }
+    __syncthreads();
+    g = pg[t]; e = pe[t];
+    for (int j = 0; j < per; ++j) {
+        const int i = t * per + j;
+        if (i < nblk) { const unsigned x = c[2 * i], y = c[2 * i + 1]; c[2 * i] = g; c[2 * i + 1] = e; g += x; e += y; }
+    }
+}
+
+// candidate = (key << 32) | ~index: a descending sort of it is score-descending, index-ascending
+__global__ __launch_bounds__(256) void topk_compact_kernel(const float* __restrict__ scores, int A_total, const TopkState* __restrict__ st,
+                                                           const unsigned* __restrict__ cnt, int nblk, int k,
+                                                           unsigned long long* __restrict__ cand, long cand_stride) {
+    __shared__ unsigned wg[4], we[4];
+    const int b = blockIdx.y, blk = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned T = st[b].prefix, need = st[b].remaining, n_greater = (unsigned)k - need;
+    const float* sc = scores + (long)b * A_total;
+    unsigned key[4];
+    unsigned g = 0, e = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = blk * TK_CHUNK + threadIdx.x * 4 + j;
+        key[j] = i < A_total ? tk_key(sc[i]) : 0u;
+        const bool in = i < A_total;
+        g += in && key[j] > T;
+        e += in && key[j] == T;
+    }
+    // exclusive prefix over the block's threads (wave scan + 4 wave totals)
+    unsigned ig = g, ie = e;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned a = __shfl_up(ig, o), c = __shfl_up(ie, o);
+        if (lane >= o) { ig += a; ie += c; }
+    }
+    if (lane == 63) { wg[wave] = ig; we[wave] = ie; }
+    __syncthreads();
+    unsigned og = cnt[((long)b * nblk + blk) * 2] + ig - g, oe = cnt[((long)b * nblk + blk) * 2 + 1] + ie - e;
+    for (int w = 0; w < wave; ++w) { og += wg[w]; oe += we[w]; }
+    unsigned long long* out = cand + (long)b * cand_stride;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = blk * TK_CHUNK + threadIdx.x * 4 + j;
+        if (i >= A_total) break;
+        const unsigned long long v = ((unsigned long long)key[j] << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+        if (key[j] > T) out[og++] = v;
+        else if (key[j] == T) { if (oe < need) out[n_greater + oe] = v; ++oe; }
+    }
+}
+
+// one block per image: bitonic sort (descending) of P = 2^m >= k candidates in LDS; writes the sorted anchor indices
+__global__ __launch_bounds__(1024) void topk_sort_lds_kernel(const unsigned long long* __restrict__ cand, long cand_stride, int k, int P,
+                                                             int* __restrict__ vals, float* __restrict__ keys, long out_stride) {
+    extern __shared__ unsigned long long sk[];
+    const int b = blockIdx.x;
+    const unsigned long long* in = cand + (long)b * cand_stride;
+    for (int i = threadIdx.x; i < P; i += 1024) sk[i] = i < k ? in[i] : 0ull;      // 0 sorts last: key 0 is below every finite score's key
+    __syncthreads();
+    for (int kk = 2; kk <= P; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < P / 2; t += 1024) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;       // the pair (lo, lo ^ j), lo without bit j
+                const bool desc = (lo & kk) == 0;
+                const unsigned long long a = sk[lo], c = sk[hi];
+                if ((a < c) == desc) { sk[lo] = c; sk[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < k; i += 1024) {
+        const unsigned long long v = sk[i];
+        vals[(long)b * out_stride + i] = (int)(0xFFFFFFFFu - (unsigned)(v & 0xFFFFFFFFull));
+        const unsigned key = (unsigned)(v >> 32), bits = key ^ ((key >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+        keys[(long)b * out_stride + i] = __uint_as_float(bits);
+    }
+}
+
+// k > TK_LDS_MAX: the same network, one launch per stage over the padded candidate array in global memory
+__global__ __launch_bounds__(256) void topk_pad_kernel(unsigned long long* __restrict__ cand, long cand_stride, int k, int P) {
+    for (int i = k + blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256) cand[(long)blockIdx.y * cand_stride + i] = 0ull;
+}
+__global__ __launch_bounds__(256) void topk_sort_step_kernel(unsigned long long* __restrict__ cand, long cand_stride, int P, int kk, int j) {
+    unsigned long long* a = cand + (long)blockIdx.y * cand_stride;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < P / 2; t += gridDim.x * 256) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+        const bool desc = (lo & kk) == 0;
+        const unsigned long long x = a[lo], y = a[hi];
+        if ((x < y) == desc) { a[lo] = y; a[hi] = x; }
+    }
+}
+__global__ __launch_bounds__(256) void topk_unpack_kernel(const unsigned long long* __restrict__ cand, long cand_stride, int k,
+                                                          int* __restrict__ vals, float* __restrict__ keys, long out_stride) {
+    const int b = blockIdx.y;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < k; i += gridDim.x * 256) {
+        const unsigned long long v = cand[(long)b * cand_stride + i];
+        vals[(long)b * out_stride + i] = (int)(0xFFFFFFFFu - (unsigned)(v & 0xFFFFFFFFull));
+        const unsigned key = (unsigned)(v >> 32), bits = key ^ ((key >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+        keys[(long)b * out_stride + i] = __uint_as_float(bits);
+    }
+}
+
+static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+// scores [B][A_total] -> vals / keys [B][A_total-strided], first k entries: the top k in tf.nn.top_k's order
+static int topk_select(const float* scores, int B, int A_total, int k, TopkState* st, unsigned* cnt, unsigned long long* cand,
+                       int* vals, float* keys, hipStream_t s) {
+    const int nblk = (A_total + TK_CHUNK - 1) / TK_CHUNK, P = next_pow2(k);
+    hipError_t e = hipMemsetAsync(st, 0, sizeof(TopkState) * (size_t)B, s);
+    DC_REQUIRE(e == hipSuccess, DC_ELAUNCH, "dc_proposals: memset failed: %s", hipGetErrorString(e));
+    const dim3 hgrid(std::min((A_total + 255) / 256, 128), B);
+    hipLaunchKernelGGL(topk_hist_kernel<0>, hgrid, dim3(256), 0, s, scores, A_total, st);
+    hipLaunchKernelGGL(topk_pick_kernel<0>, dim3(B), dim3(256), 0, s, st, k);
+    hipLaunchKernelGGL(topk_hist_kernel<1>, hgrid, dim3(256), 0, s, scores, A_total, st);
+    hipLaunchKernelGGL(topk_pick_kernel<1>, dim3(B), dim3(256), 0, s, st, k);
+    hipLaunchKernelGGL(topk_hist_kernel<2>, hgrid, dim3(256), 0, s, scores, A_total, st);
+    hipLaunchKernelGGL(topk_pick_kernel<2>, dim3(B), dim3(256), 0, s, st, k);
+    hipLaunchKernelGGL(topk_count_kernel, dim3(nblk, B), dim3(256), 0, s, scores, A_total, st, cnt, nblk);
+    hipLaunchKernelGGL(topk_scan_kernel, dim3(B), dim3(256), 0, s, cnt, nblk);
+    hipLaunchKernelGGL(topk_compact_kernel, dim3(nblk, B), dim3(256), 0, s, scores, A_total, st, cnt, nblk, k, cand, (long)P);
+    int rc = check_launch("top-k select kernels");
+    if (rc) return rc;
+    if (P <= TK_LDS_MAX) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_sort_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TK_LDS_MAX * 8);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(topk_sort_lds_kernel, dim3(B), dim3(1024), (size_t)P * 8, s, cand, (long)P, k, P, vals, keys, (long)A_total);
+        return check_launch("topk_sort_lds_kernel");
+    }
+    const dim3 sgrid(std::min((P / 2 + 255) / 256, kNumCU * 4), B);
+    hipLaunchKernelGGL(topk_pad_kernel, sgrid, dim3(256), 0, s, cand, (long)P, k, P);
+    for (int kk = 2; kk <= P; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) hipLaunchKernelGGL(topk_sort_step_kernel, sgrid, dim3(256), 0, s, cand, (long)P, P, kk, j);
+    hipLaunchKernelGGL(topk_unpack_kernel, sgrid, dim3(256), 0, s, cand, (long)P, k, vals, keys, (long)A_total);
+    return check_launch("top-k global sort kernels");
+}
+
 struct ProposalWs {
-    size_t scores, deltas, iota, keys, vals, boxes, mask, sort_tmp, total, sort_tmp_bytes;
+    size_t scores, deltas, iota, keys, vals, boxes, mask, tk_state, tk_cnt, tk_cand, total;
 };
 
 static ProposalWs proposal_layout(const dc_proposal_desc* d) {
@@ -252,10 +503,9 @@ static ProposalWs proposal_layout(const dc_proposal_desc* d) {
     w.vals = o;   o += up256((size_t)d->B * d->A_total * 4);
     w.boxes = o;  o += up256((size_t)d->B * k * 16);
     w.mask = o;   o += up256((size_t)d->B * k * words * 8);
-    size_t tmp = 0;
-    (void)rocprim::radix_sort_pairs_desc(nullptr, tmp, (const float*)nullptr, (float*)nullptr, (const int*)nullptr, (int*)nullptr,
-                                         (size_t)d->A_total, 0, 32, (hipStream_t) nullptr, false);
-    w.sort_tmp = o; w.sort_tmp_bytes = tmp; o += up256(tmp);
+    w.tk_state = o; o += up256(sizeof(TopkState) * (size_t)d->B);
+    w.tk_cnt = o;   o += up256((size_t)d->B * ((d->A_total + TK_CHUNK - 1) / TK_CHUNK) * 2 * sizeof(unsigned));
+    w.tk_cand = o;  o += up256((size_t)d->B * next_pow2(k) * sizeof(unsigned long long));
     w.total = o;
     return w;
 }
@@ -311,13 +561,9 @@ extern "C" int dc_proposals_f32(const dc_proposal_desc* d, void* workspace, size
     }
     rc = check_launch("rpn_score_kernel");
     if (rc) return rc;
-    for (int b = 0; b < d->B; ++b) {
-        size_t tmp = L.sort_tmp_bytes;
-        hipError_t e = rocprim::radix_sort_pairs_desc(ws + L.sort_tmp, tmp, (const float*)(scores + (long)b * d->A_total),
-                                                      keys + (long)b * d->A_total, (const int*)iota, vals + (long)b * d->A_total,
-                                                      (size_t)d->A_total, 0, 32, s, false);
-        DC_REQUIRE(e == hipSuccess, DC_ELAUNCH, "dc_proposals: radix sort failed: %s", hipGetErrorString(e));
-    }
+    rc = topk_select(scores, d->B, d->A_total, k, reinterpret_cast<TopkState*>(ws + L.tk_state), reinterpret_cast<unsigned*>(ws + L.tk_cnt),
+                     reinterpret_cast<unsigned long long*>(ws + L.tk_cand), vals, keys, s);
+    if (rc) return rc;
     hipLaunchKernelGGL(decode_kernel, dim3((d->B * k + 255) / 256), dim3(256), 0, s, *d, vals, deltas, boxes, k);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words, d->B), dim3(64), 0, s, boxes, mask, k, words, d->nms_threshold);
     if (words <= 128)

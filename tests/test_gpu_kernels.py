@@ -406,6 +406,36 @@ def test_rpn_proposals_bit_exact_given_scores(ops, B, S):
         assert np.all(props[b][len(kp):] == 0)                       # zero padding
 
 
+@pytest.mark.parametrize("kind,pre", [("all_equal", 600), ("few_values", 1000), ("random", 9000), ("few_values", 12000), ("all", 10 ** 6)])
+def test_rpn_topk_order_ties_and_sizes(ops, kind, pre):
+    """The hand-written top-k (radix select + ordered compaction + bitonic sort) against a stable descending argsort of the
+    device's own scores: massive ties (all scores equal; a handful of distinct values), k above the in-LDS sort's 8192, and
+    k = every anchor."""
+    S, B = 256, 2
+    rng = np.random.default_rng(len(kind) + pre)
+    strides, scales, ratios = [4, 8, 16, 32, 64], (32, 64, 128, 256, 512), [0.5, 1, 2]
+    shapes = [[S // s, S // s] for s in strides]
+    heads = []
+    for h, w in shapes:
+        hd = (0.1 * rng.standard_normal((B, h, w, 18))).astype(np.float32)
+        if kind == "all_equal":
+            hd[..., :6] = 0.0
+        elif kind == "few_values":
+            hd[..., :6] = rng.integers(0, 3, (B, h, w, 6)).astype(np.float32)
+        else:
+            hd[..., :6] = rng.standard_normal((B, h, w, 6)).astype(np.float32)
+        heads.append(hd)
+    anchors = O.generate_pyramid_anchors(scales, ratios, shapes, strides, 1).astype(np.float32)
+    A = anchors.shape[0]
+    k = min(pre, A)
+    props, (scores, order, keep) = ops.rpn_proposals([dev(h) for h in heads], dev(anchors), (S, S), 50, 0.7, pre_nms_limit=pre, debug=True)
+    scores, order = scores.cpu().numpy(), order.cpu().numpy()
+    assert order.shape == (B, k)
+    for b in range(B):
+        want = np.argsort(-scores[b].astype(np.float64), kind="stable")[:k]
+        np.testing.assert_array_equal(order[b], want)
+
+
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 3, 1), (1, 32, 32, 128, 256, 3, 1), (2, 16, 16, 256, 64, 1, 1), (1, 32, 32, 64, 128, 1, 2)])
 def test_conv2d_weight_and_data_gradients(ops, case):
     """Building blocks of the joint model's trainable convs: wgrad kernel and dgrad-as-forward-conv."""
