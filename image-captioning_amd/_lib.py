@@ -54,6 +54,15 @@ class ConvWgradBf16Desc(C.Structure):
                 ("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p), ("accumulate", C.c_int), ("split_k", C.c_int)]
 
 
+class ConvBf16Desc(C.Structure):
+    _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int),
+                ("Cout", C.c_int), ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int),
+                ("pad_t", C.c_int), ("pad_l", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
+                ("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p), ("y_bf16", C.c_void_p),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("residual", C.c_void_p), ("res_mode", C.c_int),
+                ("relu", C.c_int), ("split_k", C.c_int)]
+
+
 MATH_F32, MATH_BF16X3, MATH_BF16X2, MATH_BF16 = 0, 1, 2, 3
 
 
@@ -135,6 +144,8 @@ SYMBOLS = {
     "dc_gemm_bf16": (C.c_int, [C.POINTER(GemmBf16Desc), C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_conv2d_wgrad_bf16_workspace_bytes": (C.c_size_t, [C.POINTER(ConvWgradBf16Desc)]),
     "dc_conv2d_wgrad_bf16": (C.c_int, [C.POINTER(ConvWgradBf16Desc), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dc_conv2d_bf16_workspace_bytes": (C.c_size_t, [C.POINTER(ConvBf16Desc)]),
+    "dc_conv2d_bf16": (C.c_int, [C.POINTER(ConvBf16Desc), C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_cast_f32_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_cast_f32_bf16_2d": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dc_split_bf16x3_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

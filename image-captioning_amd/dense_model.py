@@ -501,12 +501,29 @@ class DenseImageCapRCNN(object):
         if self.compute_dtype == "bf16" and ops.wgrad_bf16_supported(x.shape, dy.shape):
             xb = self._bf16_cache.get(key) if key is not None else None
             if xb is None:
+                xb = self.plan().bf16_of(x)            # the forward already wrote a bf16 copy of this plan buffer
+            if xb is None:
                 xb = ops.to_bf16(x, out=self._buf(("xb", key or id(x), tuple(x.shape)), tuple(x.shape), torch.bfloat16))
                 if key is not None:
                     self._bf16_cache[key] = xb
             dyb = ops.to_bf16(dy, out=self._buf(("dyb", tuple(dy.shape)), tuple(dy.shape), torch.bfloat16))
             return ops.conv2d_wgrad_bf16(xb, dyb, k, k, 1, pad, pad, out=out, accumulate=accumulate)
         return ops.conv2d_wgrad(x, dy, k, k, 1, pad, pad, out=out, accumulate=accumulate)
+
+    def _dgrad(self, dy, wd, k, out, residual=None, key=None):
+        """Data gradient of a k x k / stride-1 'same' convolution = the forward convolution of dy with the rotated, transposed
+        kernel `wd` (packed [Cin, k*k*Cout] fp32).  bf16 model with bf16 storage: dy and wd are cast and the product runs on
+        dc_conv2d_bf16; otherwise dc_conv2d_nhwc_f32 in the plan's conv arithmetic.  residual: added (the accumulation into a
+        gradient map that already holds another path's contribution)."""
+        p = self.plan()
+        _, h_, w_, cout = dy.shape
+        pad = (k - 1) // 2
+        res_mode = 0 if residual is None else 1
+        if p.fast_bf16 and ops.conv_bf16_supported(cout):
+            dyb = ops.to_bf16(dy, out=self._buf(("dgb", tuple(dy.shape)), tuple(dy.shape), torch.bfloat16))
+            wdb = ops.to_bf16(wd, out=self._buf(("wdb", key or tuple(wd.shape)), tuple(wd.shape), torch.bfloat16))
+            return ops.conv2d_bf16(dyb, wdb, k, k, 1, pad, pad, h_, w_, residual=residual, res_mode=res_mode, out=out)[0]
+        return ops.conv2d(dy, wd, k, k, 1, pad, pad, h_, w_, residual=residual, res_mode=res_mode, out=out, math=p.math)
 
     def _images_u8(self, images):
         """uint8 [B,H,W,3] as a torch tensor: device-resident uint8 tensors pass through, host arrays are wrapped."""
@@ -610,7 +627,7 @@ class DenseImageCapRCNN(object):
             ops.relu_bwd(dsh.view(-1, 512), sh.view(-1, 512), dsh.view(-1, 512))
             self._wgrad(pm, dsh, 3, 1, g["rpn_conv_shared/kernel"], accumulate=acc, key="P%d" % i)
             ops.colsum(dsh.view(-1, 512), out=g["rpn_conv_shared/bias"], accumulate=acc)
-            ops.conv2d(dsh, wd_shared, 3, 3, 1, 1, 1, h_, w_, residual=dP[i], res_mode=1, out=dP[i], math=p.math)     # dP += dgrad
+            self._dgrad(dsh, wd_shared, 3, dP[i], residual=dP[i], key="rpn_shared")     # dP += dgrad
         ops.scatter2_add(dP[4], dP[3])                       # P6 = MaxPooling2D(1, strides=2)(P5)
 
         # ---- FPN backward
@@ -621,7 +638,7 @@ class DenseImageCapRCNN(object):
             _, h_, w_, _ = dP[i].shape
             self._wgrad(p.pre[i], dP[i], 3, 1, g[name + "/kernel"])
             ops.colsum(dP[i].view(-1, 256), out=g[name + "/bias"])
-            dpre.append(ops.conv2d(dP[i], wd, 3, 3, 1, 1, 1, h_, w_, out=self._buf("dpre%d" % i, tuple(dP[i].shape)), math=p.math))
+            dpre.append(self._dgrad(dP[i], wd, 3, self._buf("dpre%d" % i, tuple(dP[i].shape)), key=name))
         for i in range(3):                                   # pre[k] = upsample(pre[k+1]) + lateral(C_k)
             ops.downsample2x_sum(dpre[i], out=dpre[i + 1], accumulate=True)
         for i, cmap in enumerate(p.C):

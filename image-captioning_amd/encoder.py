@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops
-from ._lib import ConvDesc, check
+from ._lib import ConvBf16Desc, ConvDesc, check
 from .layers import ConvSpec, resnet_fpn_convs
 from .packing import fold_bn, pack_conv_kernel, pack_stem_kernel
 
@@ -50,6 +50,7 @@ def fuse_rpn_head(weights, channels=None):
 
 class EncoderPlan:
     feat_channels = 256              # channels of a RoI feature (the FPN depth)
+    fast_bf16 = False                # bf16 STORAGE between the convolutions (math = 'bf16' only; see __init__)
 
     def __init__(self, weights, batch, height, width, device, stage4_blocks=22,
                  mean_pixel=(123.7, 116.8, 103.9), use_graph=True, rpn=None, external=None, math=None):
@@ -64,6 +65,14 @@ class EncoderPlan:
         # conv arithmetic: 'f32' (fp32 MFMA products) or 'bf16x3' (three-piece bf16 split, six matrix-pipe products, fp32
         # accumulate); DCAP_CONV_MATH overrides the default for experiments
         self.math = conv_math_mode(math)
+        # math = 'bf16' (BASELINE configs[4]): activations travel between the convolutions as bf16 tensors and every convolution with
+        # Cin % 64 == 0 runs on dc_conv2d_bf16 (LDS-DMA im2col on the bf16 GEMM core); fp32 copies are written only where something
+        # reads fp32 (residual adds, RoIAlign, the joint model's backward).  DCAP_BF16_CONV=0 keeps fp32 activations and the
+        # split-bf16 loop with one product (the round-2 start; measurements only).
+        import os
+        self.fast_bf16 = self.math == _lib.MATH_BF16 and os.environ.get("DCAP_BF16_CONV", "1") != "0"
+        self._twin = {}
+        self._wb = {}
         self.B, self.H, self.W = batch, height, width
         self.device = torch.device(device)
         self.mean_pixel = [float(v) for v in mean_pixel]
@@ -113,8 +122,51 @@ class EncoderPlan:
         self._bufs.append(t)          # descriptors hold raw pointers: the plan must own every buffer
         return t
 
-    def _conv(self, name, x, y, residual=None, res_mode=0, relu=True):
+    def _bf(self, t):
+        """The bf16 twin of a plan buffer (allocated on first use; the plan owns it)."""
+        k = t.data_ptr()
+        if k not in self._twin:
+            self._twin[k] = torch.empty(tuple(t.shape), dtype=torch.bfloat16, device=self.device)
+        return self._twin[k]
+
+    def bf16_of(self, t):
+        """bf16 twin of plan buffer `t` if the last forward() wrote one, else None (the joint model's backward reuses them)."""
+        return self._twin.get(t.data_ptr()) if self.fast_bf16 else None
+
+    def _conv_bf16(self, name, x, y, residual, res_mode, relu, f32, bf16):
         s = self._specs[name]
+        wp, sc, sh = self._w[name]
+        N, H, W, Cin = x.shape
+        _, Ho, Wo, Cout = y.shape
+        if x.data_ptr() not in self._twin:
+            raise RuntimeError("%s: its input has no bf16 twin (the producing op must be built with bf16=True)" % name)
+        if name not in self._wb:
+            if name in self._external:                 # trainable weights change every step: re-cast inside the forward, once
+                self._wb[name] = torch.empty(tuple(wp.shape), dtype=torch.bfloat16, device=self.device)
+                self._ops.append(("cast", wp, self._wb[name]))
+            else:                                      # frozen weights: rounded once
+                self._wb[name] = ops.to_bf16(wp)
+        pad = (s.k - 1) // 2 if s.padding == "same" else (3 if s.padding == "pad3" else 0)
+        d = ConvBf16Desc()
+        d.N, d.H, d.W, d.Cin = N, H, W, Cin
+        d.Cout, d.kh, d.kw, d.stride, d.pad_t, d.pad_l, d.Ho, d.Wo = Cout, s.k, s.k, s.stride, pad, pad, Ho, Wo
+        d.x, d.w = self._twin[x.data_ptr()].data_ptr(), self._wb[name].data_ptr()
+        d.y = y.data_ptr() if f32 else None
+        d.y_bf16 = self._bf(y).data_ptr() if bf16 else None
+        d.scale = None if sc is None else sc.data_ptr()
+        d.shift = sh.data_ptr()
+        d.residual = None if residual is None else residual.data_ptr()
+        d.res_mode, d.relu, d.split_k = res_mode, int(relu), 0
+        self._ws_bytes = max(self._ws_bytes, self.lib.dc_conv2d_bf16_workspace_bytes(C.byref(d)))
+        self._ops.append(("bconv", d, name))
+        self.flops += 2.0 * N * Ho * Wo * Cout * s.k * s.k * s.cin
+
+    def _conv(self, name, x, y, residual=None, res_mode=0, relu=True, f32=True, bf16=False):
+        """f32 / bf16: which copies of the output its consumers read (only the bf16-storage mode acts on them: there a layer
+        whose consumers are all convolutions writes no fp32 copy at all)."""
+        s = self._specs[name]
+        if self.fast_bf16 and s.cin % 64 == 0 and s.stride in (1, 2) and (s.padding != "same" or s.stride == 1):
+            return self._conv_bf16(name, x, y, residual, res_mode, relu, f32, bf16)
         wp, sc, sh = self._w[name]
         N, H, W, Cin = x.shape
         _, Ho, Wo, Cout = y.shape
@@ -141,11 +193,14 @@ class EncoderPlan:
             d.w_split = self._wsplit[name].data_ptr()
         self._ws_bytes = max(self._ws_bytes, self.lib.dc_conv2d_workspace_bytes(C.byref(d)))
         self._ops.append(("conv", d, name))
+        if self.fast_bf16 and bf16:                    # a layer the bf16 kernel does not take (the stem): cast its output
+            self._ops.append(("cast", y, self._bf(y)))
         self.flops += 2.0 * N * Ho * Wo * Cout * s.k * s.k * s.cin
 
     def _build(self):
         B, H, W = self.B, self.H, self.W
         self._ops, self._ws_bytes, self.flops, self._bufs = [], 0, 0.0, []
+        self._twin, self._wb = {}, {}
         self.images = torch.empty((B, H, W, 3), dtype=torch.uint8, device=self.device)
         rgbx = torch.empty((B, H, W, 4), dtype=torch.float32, device=self.device)
         self._ops.append(("mold", self.images, rgbx))
@@ -153,6 +208,8 @@ class EncoderPlan:
         self._conv("conv1", rgbx, c1)
         x = self._buf(H // 4, W // 4, 64)
         self._ops.append(("pool", c1, x))
+        if self.fast_bf16:
+            self._ops.append(("cast", x, self._bf(x)))
 
         def stage(s, blocks, mid, cout, stride, x):
             h, w = x.shape[1] // stride, x.shape[2] // stride
@@ -162,13 +219,13 @@ class EncoderPlan:
             for i, blk in enumerate(blocks):
                 cn = "res%d%s_branch" % (s, blk)
                 out = final if i == len(blocks) - 1 else pp[i & 1]
-                self._conv(cn + "2a", x, m1)
-                self._conv(cn + "2b", m1, m2)
+                self._conv(cn + "2a", x, m1, f32=False, bf16=True)               # read by the next convolution only
+                self._conv(cn + "2b", m1, m2, f32=False, bf16=True)
                 if i == 0:
-                    self._conv(cn + "1", x, sc, relu=False)
-                    self._conv(cn + "2c", m2, out, residual=sc, res_mode=1)
+                    self._conv(cn + "1", x, sc, relu=False)                        # read as a residual only
+                    self._conv(cn + "2c", m2, out, residual=sc, res_mode=1, bf16=True)
                 else:
-                    self._conv(cn + "2c", m2, out, residual=x, res_mode=1)
+                    self._conv(cn + "2c", m2, out, residual=x, res_mode=1, bf16=True)   # fp32 for the next residual add, bf16 for the next conv
                 x = out
             return x
 
@@ -180,28 +237,31 @@ class EncoderPlan:
         self.pre = None
         t5, t4 = self._buf(H // 32, W // 32, 256), self._buf(H // 16, W // 16, 256)
         t3, t2 = self._buf(H // 8, W // 8, 256), self._buf(H // 4, W // 4, 256)
-        self._conv("fpn_c5p5", C5, t5, relu=False)
-        self._conv("fpn_c4p4", C4, t4, residual=t5, res_mode=2, relu=False)
-        self._conv("fpn_c3p3", C3, t3, residual=t4, res_mode=2, relu=False)
-        self._conv("fpn_c2p2", C2, t2, residual=t3, res_mode=2, relu=False)
+        self._conv("fpn_c5p5", C5, t5, relu=False, bf16=True)
+        self._conv("fpn_c4p4", C4, t4, residual=t5, res_mode=2, relu=False, bf16=True)
+        self._conv("fpn_c3p3", C3, t3, residual=t4, res_mode=2, relu=False, bf16=True)
+        self._conv("fpn_c2p2", C2, t2, residual=t3, res_mode=2, relu=False, bf16=True)
         P2, P3 = self._buf(H // 4, W // 4, 256), self._buf(H // 8, W // 8, 256)
         P4, P5 = self._buf(H // 16, W // 16, 256), self._buf(H // 32, W // 32, 256)
-        self._conv("fpn_p2", t2, P2, relu=False)
-        self._conv("fpn_p3", t3, P3, relu=False)
-        self._conv("fpn_p4", t4, P4, relu=False)
-        self._conv("fpn_p5", t5, P5, relu=False)
+        rp = self.rpn is not None                       # the RPN's shared convolution reads the pyramid maps
+        self._conv("fpn_p2", t2, P2, relu=False, bf16=rp)
+        self._conv("fpn_p3", t3, P3, relu=False, bf16=rp)
+        self._conv("fpn_p4", t4, P4, relu=False, bf16=rp)
+        self._conv("fpn_p5", t5, P5, relu=False, bf16=rp)
         self.P = (P2, P3, P4, P5)
         self.pre = (t2, t3, t4, t5)                        # top-down sums: the inputs of fpn_p2..p5 (kept for the joint backward)
         if self.rpn is not None:
             from .utils import generate_pyramid_anchors
             P6 = self._buf(H // 64, W // 64, 256)
             self._ops.append(("sub2", P5, P6))
+            if self.fast_bf16:
+                self._ops.append(("cast", P6, self._bf(P6)))
             self.P6 = P6
             self.rpn_heads, self.rpn_shared = [], []
             for p in (P2, P3, P4, P5, P6):
                 sh = self._buf(p.shape[1], p.shape[2], 512)
                 hd = self._buf(p.shape[1], p.shape[2], self.head_channels)
-                self._conv("rpn_conv_shared", p, sh)
+                self._conv("rpn_conv_shared", p, sh, bf16=True)
                 self._conv("rpn_head", sh, hd, relu=False)
                 self.rpn_heads.append(hd)
                 self.rpn_shared.append(sh)
@@ -224,6 +284,12 @@ class EncoderPlan:
                 rc = lib.dc_conv2d_nhwc_f32(C.byref(op[1]), wsp, wsb, stream)
                 if rc:
                     check(rc, "dc_conv2d_nhwc_f32(%s)" % op[2])
+            elif kind == "bconv":
+                rc = lib.dc_conv2d_bf16(C.byref(op[1]), wsp, wsb, stream)
+                if rc:
+                    check(rc, "dc_conv2d_bf16(%s)" % op[2])
+            elif kind == "cast":
+                ops.to_bf16(op[1], out=op[2])
             elif kind == "mold":
                 ops.mold_image_rgbx(op[1], self.mean_pixel, out=op[2])
             elif kind == "sub2":

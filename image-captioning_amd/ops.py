@@ -7,7 +7,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (AmsgradDesc, BnReluDesc, ConvDesc, ConvWgradBf16Desc, GemmBf16Desc, VocabCeDesc, ProposalDesc, RpnLossDesc, GemmDesc, LstmBwdDesc, LstmFwdDesc, RoiAlignDesc,
+from ._lib import (ConvBf16Desc, AmsgradDesc, BnReluDesc, ConvDesc, ConvWgradBf16Desc, GemmBf16Desc, VocabCeDesc, ProposalDesc, RpnLossDesc, GemmDesc, LstmBwdDesc, LstmFwdDesc, RoiAlignDesc,
                    SoftmaxCeDesc, check)
 
 
@@ -228,6 +228,39 @@ def conv2d_wgrad_bf16(x, dy, kh, kw, stride, pad_t, pad_l, out=None, split_k=0, 
     ws, wsb = WORKSPACE.get(lib.dc_conv2d_wgrad_bf16_workspace_bytes(C.byref(d)), x.device)
     check(lib.dc_conv2d_wgrad_bf16(C.byref(d), _ptr(ws), wsb, _stream()), "dc_conv2d_wgrad_bf16")
     return out
+
+
+def conv2d_bf16(x, w, kh, kw, stride, pad_t, pad_l, Ho, Wo, scale=None, shift=None, residual=None, res_mode=0, relu=False,
+                out=None, out_bf16=None, want_f32=True, want_bf16=False, split_k=0):
+    """conv2d with bf16 storage (dc_conv2d_bf16): x [N,H,W,Cin] bf16 (Cin % 64 == 0), w packed [Cout, kh*kw*Cin] bf16; the fp32
+    epilogue operands as in conv2d.  Returns (fp32 output or None, bf16 output or None)."""
+    lib = _lib.load()
+    _chk(x, BF16, "x"), _chk(w, BF16, "w")
+    N, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    if not x.is_contiguous() or not w.is_contiguous() or w.shape[1] != kh * kw * Cin:
+        raise _lib.DcapError("conv2d_bf16: x must be contiguous NHWC, w contiguous [Cout, kh*kw*Cin]")
+    if out is None and want_f32:
+        out = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+    if out_bf16 is None and want_bf16:
+        out_bf16 = torch.empty((N, Ho, Wo, Cout), dtype=BF16, device=x.device)
+    d = ConvBf16Desc()
+    d.N, d.H, d.W, d.Cin = N, H, W, Cin
+    d.Cout, d.kh, d.kw, d.stride, d.pad_t, d.pad_l, d.Ho, d.Wo = Cout, kh, kw, stride, pad_t, pad_l, Ho, Wo
+    d.x, d.w = x.data_ptr(), w.data_ptr()
+    d.y = None if out is None else _chk(out, name="out").data_ptr()
+    d.y_bf16 = None if out_bf16 is None else _chk(out_bf16, BF16, "out_bf16").data_ptr()
+    d.scale = None if scale is None else _chk(scale, name="scale").data_ptr()
+    d.shift = None if shift is None else _chk(shift, name="shift").data_ptr()
+    d.residual = None if residual is None else _chk(residual, name="residual").data_ptr()
+    d.res_mode, d.relu, d.split_k = int(res_mode), int(relu), int(split_k)
+    ws, wsb = WORKSPACE.get(lib.dc_conv2d_bf16_workspace_bytes(C.byref(d)), x.device)
+    check(lib.dc_conv2d_bf16(C.byref(d), _ptr(ws), wsb, _stream()), "dc_conv2d_bf16")
+    return out, out_bf16
+
+
+def conv_bf16_supported(cin):
+    return cin % 64 == 0
 
 
 def wgrad_bf16_supported(x_shape, dy_shape):

@@ -112,6 +112,30 @@ typedef struct {
 size_t dc_conv2d_wgrad_bf16_workspace_bytes(const dc_conv_wgrad_bf16_desc* d);
 int    dc_conv2d_wgrad_bf16(const dc_conv_wgrad_bf16_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 
+/* conv2d forward with bf16 STORAGE (configs[4]: "bf16"): bf16 NHWC activations and bf16 packed weights in HBM, fp32 accumulation,
+ * the same fused epilogue as dc_conv2d_nhwc_f32 (frozen-BN scale / shift, residual (fp32), ReLU), output in fp32 (y), bf16 (y_bf16: the
+ * next convolution's input) or both.  Replaces the same Keras layers as dc_conv2d_nhwc_f32 (feature_generation/dense_model.py:85-100,
+ * :120-139, :1406-1421) for the joint model's bf16 mode; on weights rotated by dc_conv_weight_dgrad_pack it is the data gradient.
+ *   x [N,H,W,Cin] bf16, Cin % 64 == 0;  w PACKED [Cout][kh*kw*Cin] bf16;  y / y_bf16 [N,Ho,Wo,Cout];
+ *   res_mode: 0 none, 1 residual of the output's shape, 2 residual on the 2x coarser map (nearest-upsampled), as for the fp32
+ *   convolution.  Taps in the padding read zeros. */
+typedef struct {
+    int N, H, W, Cin;
+    int Cout, kh, kw, stride, pad_t, pad_l;
+    int Ho, Wo;
+    const uint16_t* x;
+    const uint16_t* w;
+    float*          y;        /* may be NULL when y_bf16 is given */
+    uint16_t*       y_bf16;   /* may be NULL when y is given */
+    const float* scale;
+    const float* shift;
+    const float* residual;  int res_mode;
+    int relu;
+    int split_k;
+} dc_conv_bf16_desc;
+size_t dc_conv2d_bf16_workspace_bytes(const dc_conv_bf16_desc* d);
+int    dc_conv2d_bf16(const dc_conv_bf16_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+
 /* fp32 -> bf16 (round to nearest even): the bf16 shadow of weights / activations that feed dc_gemm_bf16.
  * _2d: rows x cols with row strides, output columns cols..cols_out-1 zero-filled (pads K to a multiple of 8). */
 int dc_cast_f32_bf16(const float* x, uint16_t* out, size_t n, void* stream);

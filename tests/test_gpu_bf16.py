@@ -227,3 +227,60 @@ def test_conv2d_wgrad_bf16_matches_oracle(ops, case):
     close(got, want, 5e-5)
     ops.conv2d_wgrad_bf16(xb, dyb, k, k, stride, pt, pl, out=got, accumulate=True)
     close(got, 2 * want, 5e-5)
+
+
+BCONV_CASES = [
+    # N,H,W,Cin,Cout,k,stride,padding,res_mode,relu
+    (1, 16, 16, 64, 64, 1, 1, 'valid', 0, True),
+    (2, 16, 24, 64, 256, 1, 1, 'valid', 1, True),
+    (1, 32, 32, 256, 128, 1, 2, 'valid', 0, True),          # strided 1x1 (stage-entry branches)
+    (2, 12, 20, 64, 64, 3, 1, 'same', 0, True),             # ragged pixel count, borders
+    (1, 16, 16, 128, 128, 3, 1, 'same', 0, False),
+    (1, 8, 8, 512, 512, 3, 1, 'same', 0, True),             # small M, long K: split-K
+    (1, 16, 16, 256, 256, 1, 1, 'valid', 2, False),         # FPN lateral + upsample-add
+    (2, 9, 7, 128, 20, 1, 1, 'valid', 0, False),            # the padded RPN head: Cout = 20
+    (1, 40, 40, 64, 192, 3, 1, 'same', 1, True),            # two column tiles, the second partial
+]
+
+
+@pytest.mark.parametrize("outs", ["f32", "bf16", "both"])
+@pytest.mark.parametrize("case", BCONV_CASES)
+def test_conv2d_bf16_matches_oracle(ops, case, outs):
+    """dc_conv2d_bf16 (bf16 activations and weights in memory, LDS-DMA im2col) against the float64 oracle on the same
+    bf16-rounded operands: only fp32 accumulation order separates them.  fp32 output, bf16 output (one more rounding) or both."""
+    from image_captioning_amd.packing import pack_conv_kernel
+    N, H, W, Cin, Cout, k, stride, padding, res_mode, relu = case
+    rng = np.random.default_rng(sum(case[:7]))
+    x = O.to_bf16(rng.standard_normal((N, H, W, Cin)))
+    w = O.to_bf16(rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin))
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = (0.1 * rng.standard_normal(Cout)).astype(np.float32)
+    y = O.conv2d_nhwc(x, w, None, stride, padding) * scale + shift
+    Ho, Wo = y.shape[1:3]
+    res = None
+    if res_mode == 1:
+        res = rng.standard_normal(y.shape).astype(np.float32)
+        y = y + res
+    elif res_mode == 2:
+        res = rng.standard_normal((N, Ho // 2, Wo // 2, Cout)).astype(np.float32)
+        y = y + res.repeat(2, axis=1).repeat(2, axis=2)
+    if relu:
+        y = np.maximum(y, 0)
+    pad = (k - 1) // 2 if padding == 'same' else 0
+    xb = ops.to_bf16(dev(x))
+    wb = ops.to_bf16(dev(pack_conv_kernel(w.astype(np.float32))))
+    got, gotb = ops.conv2d_bf16(xb, wb, k, k, stride, pad, pad, Ho, Wo, scale=dev(scale), shift=dev(shift),
+                                residual=None if res is None else dev(res), res_mode=res_mode, relu=relu,
+                                want_f32=outs != "bf16", want_bf16=outs != "f32")
+    if outs != "bf16":
+        close(got, y, 3e-5)
+    else:
+        assert got is None
+    if outs != "f32":
+        want_b = O.to_bf16(got.cpu().numpy()) if outs == "both" else None
+        gb = gotb.float().cpu().numpy()
+        if want_b is not None:
+            np.testing.assert_array_equal(gb, want_b)            # the bf16 copy is the rounded fp32 output, element for element
+        assert np.abs(gb - y).max() <= 2.0 ** -8 * np.abs(y).max() + 1e-6
+    else:
+        assert gotb is None
