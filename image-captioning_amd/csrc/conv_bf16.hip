@@ -10,6 +10,7 @@
 // way to LDS and synchronised every 32 k -- 250 TFLOP/s on the joint model's layers.
 #include "bgemm_core.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace dcap {
 
@@ -92,6 +93,23 @@ static int conv_bf16_validate(const dc_conv_bf16_desc* d) {
     return DC_OK;
 }
 
+// split-K for the convolution: `target` blocks on the chip (DCAP_BCONV_BLOCKS, default 2 per CU), >= 4 K-tiles per slice
+static BSplit bconv_split(int M, int N, int K, int user_split) {
+    static int target = -1;
+    if (target < 0) { const char* e = getenv("DCAP_BCONV_BLOCKS"); target = e ? atoi(e) : 2 * kNumCU; }
+    if (user_split > 0) return bgemm_split(M, N, K, user_split);
+    const int tiles = ((M + BT - 1) / BT) * ((N + BT - 1) / BT);
+    const int ktiles = (K + BKB - 1) / BKB;
+    int s = 1;
+    if (tiles < target && ktiles >= 8) {
+        s = (target + tiles - 1) / tiles;
+        s = std::min(s, std::min(ktiles / 4, 32));
+        s = std::max(s, 1);
+    }
+    const int klen = ((ktiles + s - 1) / s) * BKB;
+    return BSplit{(K + klen - 1) / klen, klen};
+}
+
 }  // namespace dcap
 
 using namespace dcap;
@@ -99,7 +117,7 @@ using namespace dcap;
 extern "C" size_t dc_conv2d_bf16_workspace_bytes(const dc_conv_bf16_desc* d) {
     if (!d || conv_bf16_validate(d)) return 0;
     const int M = d->N * d->Ho * d->Wo, N = d->Cout, K = d->kh * d->kw * d->Cin;
-    const BSplit sp = bgemm_split(M, N, K, d->split_k);
+    const BSplit sp = bconv_split(M, N, K, d->split_k);
     return sp.split > 1 ? (size_t)sp.split * M * N * sizeof(float) : 0;
 }
 
@@ -108,7 +126,7 @@ extern "C" int dc_conv2d_bf16(const dc_conv_bf16_desc* d, void* workspace, size_
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int M = d->N * d->Ho * d->Wo, N = d->Cout, K = d->kh * d->kw * d->Cin;
-    const BSplit sp = bgemm_split(M, N, K, d->split_k);
+    const BSplit sp = bconv_split(M, N, K, d->split_k);
     float* partial = nullptr;
     if (sp.split > 1) {
         const size_t need = (size_t)sp.split * M * N * sizeof(float);
