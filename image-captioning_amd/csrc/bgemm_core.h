@@ -366,11 +366,7 @@ int launch_bgemm(const BOperand& a, const BOperand& b, const Epilogue& ep, int M
                    workspace_bytes);
         partial = static_cast<float*>(workspace);
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_kernel<AKC, BKC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    DC_ENSURE_DYN_LDS((&bgemm_kernel<AKC, BKC>), 160 * 1024);
     const int tiles = ((M + BT - 1) / BT) * ((N + BT - 1) / BT);
     hipLaunchKernelGGL((bgemm_kernel<AKC, BKC>), dim3(tiles, 1, sp.split), dim3(256), bgemm_lds_bytes(), stream, a, b, ep, M, N, K, sp.klen, partial);
     int rc = check_launch("bgemm_kernel");

@@ -140,11 +140,7 @@ extern "C" int dc_conv2d_bf16(const dc_conv_bf16_desc* d, void* workspace, size_
     ep.ldcb = d->Cout;
     BConvA a{d->x, d->H, d->W, d->Cin, d->Ho, d->Wo, d->stride, d->pad_t, d->pad_l, d->kw, M, (unsigned)((size_t)d->N * d->H * d->W * d->Cin * 2)};
     BOperand b{d->w, K, N, nullptr, (unsigned)((size_t)N * K * 2)};
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bconv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    DC_ENSURE_DYN_LDS(&bconv_kernel, 160 * 1024);
     const int tiles = ((M + BT - 1) / BT) * ((N + BT - 1) / BT);
     hipLaunchKernelGGL(bconv_kernel, dim3(tiles, 1, sp.split), dim3(256), bgemm_lds_bytes(), s, a, b, ep, M, N, K, sp.klen, partial);
     rc = check_launch("bconv_kernel");

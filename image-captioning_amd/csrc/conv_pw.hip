@@ -117,12 +117,7 @@ static int launch_pw(const dc_conv_desc* d, const Epilogue& ep, int M, int N, hi
     const dim3 grid(gx, gy);
 #define DCAP_PW_LAUNCH(RES_)                                                                                                          \
     do {                                                                                                                              \
-        static bool attr_set = false;                                                                                                 \
-        if (!attr_set) {                                                                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_stream_kernel<K, RES_>),                                  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                        \
-            attr_set = true;                                                                                                          \
-        }                                                                                                                             \
+        DC_ENSURE_DYN_LDS((&pwconv_stream_kernel<K, RES_>), 160 * 1024);                                                              \
         hipLaunchKernelGGL((pwconv_stream_kernel<K, RES_>), grid, dim3(256), lds, s, d->x, d->w, ep, M, N);                           \
     } while (0)
     if (ep.res_mode == 0) DCAP_PW_LAUNCH(0);

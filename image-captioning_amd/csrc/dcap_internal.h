@@ -4,11 +4,27 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 #include "../../include/dcap.h"
 
 namespace dcap {
 
 void set_error(const char* fmt, ...);
+
+// Kernels that use more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised once per (kernel, device):
+// the static below is per expansion site (per template instantiation), one bit per device ordinal, so a host process that drives
+// several GPUs sets the attribute on each of them.
+#define DC_ENSURE_DYN_LDS(fn, bytes)                                                                                                  \
+    do {                                                                                                                              \
+        static std::atomic<unsigned long long> dc_done_{0};                                                                           \
+        int dc_dev_ = 0;                                                                                                              \
+        (void)hipGetDevice(&dc_dev_);                                                                                                 \
+        const unsigned long long dc_bit_ = 1ull << (dc_dev_ & 63);                                                                    \
+        if (!(dc_done_.load(std::memory_order_acquire) & dc_bit_)) {                                                                  \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes));        \
+            dc_done_.fetch_or(dc_bit_, std::memory_order_release);                                                                    \
+        }                                                                                                                             \
+    } while (0)
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();

@@ -142,11 +142,7 @@ extern "C" int dc_conv2d_wgrad_bf16(const dc_conv_wgrad_bf16_desc* d, void* work
     Epilogue ep{d->dw, N, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, d->accumulate, 1};
     BOperand dy{d->dy, d->Cout, M, nullptr, (unsigned)((size_t)K * d->Cout * 2)};
     BIm2col xc{d->x, d->H, d->W, d->Cin, d->Ho, d->Wo, d->stride, d->pad_t, d->pad_l, d->kw, K, (unsigned)((size_t)d->N * d->H * d->W * d->Cin * 2)};
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    DC_ENSURE_DYN_LDS(&bgemm_wgrad_kernel, 160 * 1024);
     const int tiles = ((M + BT - 1) / BT) * ((N + BT - 1) / BT);
     hipLaunchKernelGGL(bgemm_wgrad_kernel, dim3(tiles, 1, sp.split), dim3(256), bgemm_lds_bytes(), s, dy, xc, ep, M, N, K, sp.klen, partial);
     rc = check_launch("bgemm_wgrad_kernel");

@@ -402,12 +402,7 @@ int launch_igemm_bs2(const AL& al, const BL& bl, const Epilogue& ep, int M, int 
         partial = static_cast<float*>(workspace);
     }
     constexpr size_t lds = igemm_bs2_lds_bytes<BM, BN>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bs2_kernel<BM, BN, AL, BL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    DC_ENSURE_DYN_LDS((&igemm_bs2_kernel<BM, BN, AL, BL>), 160 * 1024);
     dim3 grid(tiles, 1, split_k);
     hipLaunchKernelGGL((igemm_bs2_kernel<BM, BN, AL, BL>), grid, dim3(bs2_shape<BM, BN>::THREADS), lds, stream, al, bl, ep, M, N, K, klen, partial);
     int rc = check_launch("igemm_bs2_kernel");
@@ -437,12 +432,7 @@ int launch_igemm_bs(const AL& al, const BL& bl, const Epilogue& ep, int M, int N
         partial = static_cast<float*>(workspace);
     }
     constexpr size_t lds = igemm_bs_lds_bytes<BM, BN, NP>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bs_kernel<BM, BN, AL, BL, NP>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    DC_ENSURE_DYN_LDS((&igemm_bs_kernel<BM, BN, AL, BL, NP>), 160 * 1024);
     dim3 grid(tiles, 1, split_k);
     hipLaunchKernelGGL((igemm_bs_kernel<BM, BN, AL, BL, NP>), grid, dim3(256), lds, stream, al, bl, ep, M, N, K, klen, partial);
     int rc = check_launch("igemm_bs_kernel");

@@ -951,21 +951,12 @@ int launch_igemm(const AL& al, const BL& bl, const Epilogue& ep, int M, int N, i
         partial = static_cast<float*>(workspace);
     }
     constexpr size_t lds = PC ? igemm_pc_lds_bytes<BM, BN, AL, BL>() : igemm_lds_bytes<BM, BN, AL, BL>();
-    static bool attr_set = false;
     dim3 grid(tiles, 1, split_k);
     if constexpr (PC) {
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pc_kernel<BM, BN, AL, BL>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
+        DC_ENSURE_DYN_LDS((&igemm_pc_kernel<BM, BN, AL, BL>), 160 * 1024);
         hipLaunchKernelGGL((igemm_pc_kernel<BM, BN, AL, BL>), grid, dim3(512), lds, stream, al, bl, ep, M, N, K, klen, partial);
     } else {
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, AL, BL>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
+        DC_ENSURE_DYN_LDS((&igemm_kernel<BM, BN, AL, BL>), 160 * 1024);
         hipLaunchKernelGGL((igemm_kernel<BM, BN, AL, BL>), grid, dim3(256), lds, stream, al, bl, ep, M, N, K, klen, partial);
     }
     int rc = check_launch("igemm_kernel");

@@ -472,11 +472,7 @@ static int topk_select(const float* scores, int B, int A_total, int k, TopkState
     int rc = check_launch("top-k select kernels");
     if (rc) return rc;
     if (P <= TK_LDS_MAX) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_sort_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TK_LDS_MAX * 8);
-            attr_set = true;
-        }
+        DC_ENSURE_DYN_LDS(&topk_sort_lds_kernel, TK_LDS_MAX * 8);
         hipLaunchKernelGGL(topk_sort_lds_kernel, dim3(B), dim3(1024), (size_t)P * 8, s, cand, (long)P, k, P, vals, keys, (long)A_total);
         return check_launch("topk_sort_lds_kernel");
     }

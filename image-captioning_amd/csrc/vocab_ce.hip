@@ -286,20 +286,12 @@ template <int MODE>
 static int ce_launch(const dc_vocab_ce_desc* d, const CeArgs& ce, const CePlan& p, hipStream_t s) {
     const int tiles = p.tiles_m * p.tiles_n;
     if (d->bf16) {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vocab_ce_bf16_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr = true;
-        }
+        DC_ENSURE_DYN_LDS((&vocab_ce_bf16_kernel<MODE>), 160 * 1024);
         BOperand a{static_cast<const unsigned short*>(d->X), d->ldx, d->M, nullptr, (unsigned)((size_t)d->M * d->ldx * 2)};
         BOperand b{static_cast<const unsigned short*>(d->W), d->ldw, d->V, nullptr, (unsigned)((size_t)d->K * d->ldw * 2)};
         hipLaunchKernelGGL((vocab_ce_bf16_kernel<MODE>), dim3(tiles), dim3(256), bgemm_lds_bytes(), s, a, b, ce, d->K);
     } else {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vocab_ce_f32_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr = true;
-        }
+        DC_ENSURE_DYN_LDS((&vocab_ce_f32_kernel<MODE>), 160 * 1024);
         CeA32 al{static_cast<const float*>(d->X), d->ldx, d->M, nullptr};
         CeB32 bl{static_cast<const float*>(d->W), d->ldw, d->V, nullptr};
         constexpr size_t lds = igemm_lds_bytes<128, 128, CeA32, CeB32>();
