@@ -508,3 +508,13 @@ def test_hdf5_reader_rejects_what_it_does_not_implement(tmp_path):
     bad[8] = 3                                                              # superblock version 3 (libver='latest')
     with pytest.raises(NotImplementedError):
         H.H5File(bytes(bad))
+
+
+def test_vgg16_layer_table_flops():
+    """The alternative backbone's 13-conv table: Keras-applications names, 641.43 GFLOP per 1024x1024 image."""
+    from image_captioning_amd.layers import vgg16_convs
+    L = vgg16_convs()
+    assert [s.name for s in L][:3] == ["block1_conv1", "block1_conv2", "block2_conv1"] and len(L) == 13
+    assert all(s.k == 3 and s.stride == 1 and s.padding == "same" and s.bn is None for s in L)
+    fl = sum(2.0 * (1024 // 2 ** (int(s.name[5]) - 1)) ** 2 * 9 * s.cin * s.cout for s in L)
+    assert abs(fl / 1e9 - 641.43) < 0.01
