@@ -535,6 +535,12 @@ def main():
             one = json.loads(r1.stdout.strip().splitlines()[-1])
             other["configs2_one_image"] = {"workload": "BASELINE configs[2] as defined: 1 image x %d RoI per step, same model" % R,
                                            "value": one["value"], "unit": "captions/s", "ms_per_step": one["ms_per_step"], "steps": one["steps"]}
+            # the same model at twice configs[3]'s per-GPU batch (4 images): what the fp32 kernels reach with fuller grids
+            cmd4 = [a if a != "1" or cmd1[i - 1] != "--images-per-gpu" else "4" for i, a in enumerate(cmd1)]
+            r4 = subprocess.run(cmd4, capture_output=True, text=True, timeout=300)
+            four = json.loads(r4.stdout.strip().splitlines()[-1])
+            other["four_images_per_gpu"] = {"workload": "the headline's model at 4 images x %d RoI per step and GPU (not a BASELINE config)" % R,
+                                            "value": four["value"], "unit": "captions/s", "ms_per_step": four["ms_per_step"], "steps": four["steps"]}
             other["configs1_gpu"] = gpu_configs1(dev)
             # configs[2]'s label taken literally: the VGG16 13-conv backbone (child process; its roofline leg gives the conv TFLOP/s)
             cmdv = [sys.executable, os.path.abspath(__file__), "--backbone", "vgg16", "--steps", str(max(5, args.steps // 2)), "--warmup", "2",
