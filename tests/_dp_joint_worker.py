@@ -1,0 +1,49 @@
+"""Worker of tests/test_gpu_multirank.py (joint model): one rank of a 2-rank data-parallel run of the REAL joint model
+(dense_img_cap/dense_model.py) under ParallelModel, one image per rank and step."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+S, V, T, BLOCKS = 128, 24, 5, 1
+
+
+def build():
+    import test_gpu_models as TM
+    model, cfg, Wt = TM.make_joint(S, V, T, BLOCKS)
+    model.compile(1e-3)
+    return model
+
+
+def global_inputs(world):
+    import test_gpu_models as TM
+    per = [TM.joint_inputs(S, V, T, seed=8 + r) for r in range(world)]
+    for r, p in enumerate(per):                         # different images too
+        from image_captioning_amd import synth
+        p[0] = synth.images(7 + r, 1, S, S)
+    return [np.concatenate([p[i] for p in per], axis=0) for i in range(6)], per
+
+
+def main():
+    out_dir, steps = sys.argv[1], int(sys.argv[2])
+    from image_captioning_amd.parallel_model import ParallelModel, init_process_group_from_env
+    import torch.distributed as dist
+    rank, world, _ = init_process_group_from_env()
+    model = build()
+    pm = ParallelModel(model, world)
+    inputs, _ = global_inputs(world)
+    losses = [pm.train_on_batch(inputs) for _ in range(steps)]
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, "joint_rank%d.npz" % rank), flat=model.store.flat.cpu().numpy(), losses=np.array(losses))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -51,3 +51,44 @@ def test_parallel_model_two_ranks_match_single_rank_on_the_concatenated_batch(tm
     np.testing.assert_allclose(r[0]["losses"], losses, rtol=2e-5)        # mean over towers of tower means == batch mean (equal shards)
     scale = np.abs(single).max()
     assert np.abs(r[0]["flat"] - single).max() < 2e-5 * scale
+
+
+def test_joint_model_two_ranks_average_the_tower_gradients(tmp_path):
+    """The joint model (configs[4]'s model at a small size) under ParallelModel, one image per rank: after a step every replica
+    holds the same weights, and they are the weights a single process gets from the MEAN of the two images' gradient buckets
+    (the reference's mean-of-tower-means, parallel_model.py:58-102) through the same clip + AMSGrad update."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    sys.path.insert(0, HERE)
+    import _dp_joint_worker as W
+    world, steps = 2, 1
+    backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   DCAP_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dp_joint_worker.py"), str(tmp_path), str(steps)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
+    r = [np.load(tmp_path / ("joint_rank%d.npz" % k)) for k in range(world)]
+    np.testing.assert_array_equal(r[0]["flat"], r[1]["flat"])            # replicas stay bit-identical
+    np.testing.assert_allclose(r[0]["losses"], r[1]["losses"], rtol=0, atol=0)
+    # single process: each image's gradient bucket from a fresh model (same weights, same sampling stream), averaged, one update
+    _, per = W.global_inputs(world)
+    grads, tower_losses = [], []
+    for k in range(world):
+        m = W.build()
+        losses = m._loss_list(m.forward_backward(per[k]))
+        grads.append(m.store.flat_grad.clone())
+        tower_losses.append([losses["loss"], losses["rpn_class_loss"], losses["rpn_bbox_loss"], losses["imgcap_loss"]])
+    ref = W.build()
+    ref.store.flat_grad.copy_((grads[0] + grads[1]) / 2)
+    ref.optimizer.apply(ref.store, grad_scale=1.0)
+    single = ref.store.flat.cpu().numpy()
+    np.testing.assert_allclose(r[0]["losses"][0], np.mean(tower_losses, axis=0), rtol=1e-5)
+    start = W.build().store.flat.cpu().numpy()
+    moved = np.abs(single - start).max()
+    assert moved > 0
+    assert np.abs(r[0]["flat"] - single).max() < 2e-3 * moved + 1e-7     # RoIAlign's backward scatters with float atomics
