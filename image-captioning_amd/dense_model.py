@@ -292,8 +292,11 @@ class DenseImageCapRCNN(object):
         extra.append(("rpn_head/bias", hb, True))
         self.caption_model = CaptionModelV1([cfg.POOL_SIZE, cfg.POOL_SIZE, 256], cfg, self.units, 'training', dev, seed,
                                             extra_params=extra, compute_dtype=self.compute_dtype)
-        # the L2 term and the trainable mask touch the whole gradient bucket after the decoder's backward: no early all-reduce
+        # data parallel: a decoder layer's gradient range gets its L2 term and trainable mask right when its backward is done, then
+        # its all-reduce starts (forward_backward installs the hook when a gradient exchange is attached); the single-GPU step keeps
+        # the one fused regulariser pass over the whole bucket
         self.caption_model.overlap_sync = False
+        self._reg_done = []
         self.caption_model.recurrent_dropout = float(getattr(cfg, "RECURRENT_DROPOUT", 0.0))    # opt-in: dense_model.py:769-770 uses 0.2
         self.store = self.caption_model.store
         self._plan = None
@@ -596,6 +599,19 @@ class DenseImageCapRCNN(object):
             return losses
 
         # ---- backward: decoder + head -> RoI features -> pyramid
+        overlap = self.grad_sync is not None and hasattr(self.grad_sync, "ready") and getattr(self.grad_sync, "world", 1) > 1
+        self._reg_done = []
+        if overlap:
+            coef_, mask_ = self._masks()
+
+            def early(lo, hi):                              # regulariser gradient + mask of one layer range, then it may travel
+                if mask_ is not None:
+                    st.flat_grad[lo:hi].mul_(mask_[lo:hi])
+                ops.l2_reg(st.flat[lo:hi], coef_[lo:hi], st.flat_grad[lo:hi])
+                self._reg_done.append((lo, hi))
+            cm.before_sync, cm.grad_sync, cm.overlap_sync = early, self.grad_sync, True
+        else:
+            cm.before_sync, cm.overlap_sync = None, False
         dX = cm._backward(want_dx=True)
         maps = list(p.P) + [p.P6]
         dP = [self._buf("dP%d" % i, tuple(m.shape)) for i, m in enumerate(maps)]
@@ -648,9 +664,19 @@ class DenseImageCapRCNN(object):
 
         # ---- regulariser (+ frozen subset when set_trainable narrowed the set)
         coef, mask = self._masks()
-        if mask is not None:
-            st.flat_grad.mul_(mask)
-        ops.l2_reg(st.flat, coef, st.flat_grad, loss=losses[3:4])
+        if self._reg_done:                                  # the ranges that did not go early (FPN / RPN, anything the decoder skipped)
+            n, pos = st.flat.numel(), 0
+            for lo, hi in sorted(self._reg_done) + [(n, n)]:
+                if lo > pos:
+                    if mask is not None:
+                        st.flat_grad[pos:lo].mul_(mask[pos:lo])
+                    ops.l2_reg(st.flat[pos:lo], coef[pos:lo], st.flat_grad[pos:lo])
+                pos = max(pos, hi)
+            ops.l2_reg(st.flat, coef, None, loss=losses[3:4])      # the loss term alone (weights only)
+        else:
+            if mask is not None:
+                st.flat_grad.mul_(mask)
+            ops.l2_reg(st.flat, coef, st.flat_grad, loss=losses[3:4])
         self._loss_scale = float(loss_rows.numel())
         return losses
 

@@ -163,6 +163,7 @@ class CaptionModelV1(KerasLikeModel):
     D1 = 1024
     HEAD = (("mrcnn_class_conv1", "mrcnn_class_bn1"), ("mrcnn_class_conv2", "mrcnn_class_bn2"))
     overlap_sync = True        # data parallel: all-reduce a layer group's gradients as soon as its backward is enqueued
+    before_sync = None         # optional hook(lo, hi): last touch of a gradient range before its all-reduce starts
     # Keras recurrent_dropout of imgcap_lstm1 / imgcap_lstm2 (:141-142).  0.0 (default) = the deterministic graph every parity
     # test and the benchmark run; 0.2 = the reference's training-phase behaviour: per train step four inverted-dropout masks
     # [B, units] per LSTM (one per gate i,f,c,o), fixed over the timesteps, drawn from a seeded generator.  One mask set per RoI
@@ -232,6 +233,8 @@ class CaptionModelV1(KerasLikeModel):
         if self.overlap_sync and self.grad_sync is not None and hasattr(self.grad_sync, 'ready'):
             for layer in layers:
                 lo, hi = self.store.layer_range(layer)
+                if self.before_sync is not None:        # the joint model adds its regulariser's gradient to the range first
+                    self.before_sync(lo, hi)
                 self.grad_sync.ready(self.store.flat_grad, lo, hi)
 
     # ---------------------------------------------------------------------------------- engine
