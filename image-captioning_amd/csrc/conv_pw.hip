@@ -27,7 +27,7 @@ constexpr size_t pw_lds_bytes() {
 
 template <int K, int RES>
 __global__ __launch_bounds__(256, 2) void pwconv_stream_kernel(const float* __restrict__ x, const float* __restrict__ w, Epilogue ep, int M,
-                                                              int N) {
+                                                              int N, int gx, int gy, int xcd_map) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NC = 16384 / K, LDW = K + 4, KH = K / 2;
     float* const Ws = smem;
@@ -35,7 +35,14 @@ __global__ __launch_bounds__(256, 2) void pwconv_stream_kernel(const float* __re
     float* const shs = scs + NC;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.x * NC;
+    // 1-D grid of gx * gy blocks, dealt round-robin over the 8 XCDs: the gx weight slices of one pixel group (which read the same
+    // strips in the same order) are given consecutive slots of ONE XCD, so the strips are fetched from HBM once and shared through
+    // that XCD's L2 (with slice = blockIdx.x on a 2-D grid the four slices of fpn_c2p2 sat on four XCDs: 554 MB fetched for 134 MB).
+    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+    const int slice = xcd_map ? slot % gx : bid % gx;
+    const int grp = xcd_map ? (slot / gx) * 8 + xcd : bid / gx;        // grp >= gy: a padding block of the last round
+    if (grp >= gy) return;
+    const int n0 = slice * NC;
     const int nc = min(NC, N - n0);                     // host-checked: a multiple of 64
     for (int idx = tid; idx < nc * (K / 4); idx += 256) {
         const int c = idx / (K / 4), k4 = idx - c * (K / 4);
@@ -47,7 +54,7 @@ __global__ __launch_bounds__(256, 2) void pwconv_stream_kernel(const float* __re
     }
     __syncthreads();
     const int strips = (M + 31) / 32;
-    for (int st = blockIdx.y * 4 + wave; st < strips; st += gridDim.y * 4) {
+    for (int st = grp * 4 + wave; st < strips; st += gy * 4) {
         const int prow = st * 32 + i;
         const bool pv = prow < M;
         const int p = min(prow, M - 1);
@@ -114,11 +121,13 @@ static int launch_pw(const dc_conv_desc* d, const Epilogue& ep, int M, int N, hi
     const int gx = (N + NC - 1) / NC;
     const int strips = (M + 31) / 32;
     const int gy = std::max(1, std::min((2 * kNumCU) / gx, (strips + 3) / 4));
-    const dim3 grid(gx, gy);
+    static int xcd_map = -1;                               // DCAP_PW_XCD=0: slices dealt over the XCDs (measurements only)
+    if (xcd_map < 0) { const char* e = getenv("DCAP_PW_XCD"); xcd_map = e ? atoi(e) : 1; }
+    const dim3 grid(gx * ((gy + 7) / 8) * 8);            // whole rounds of 8 XCDs; the kernel drops the padding blocks
 #define DCAP_PW_LAUNCH(RES_)                                                                                                          \
     do {                                                                                                                              \
         DC_ENSURE_DYN_LDS((&pwconv_stream_kernel<K, RES_>), 160 * 1024);                                                              \
-        hipLaunchKernelGGL((pwconv_stream_kernel<K, RES_>), grid, dim3(256), lds, s, d->x, d->w, ep, M, N);                           \
+        hipLaunchKernelGGL((pwconv_stream_kernel<K, RES_>), grid, dim3(256), lds, s, d->x, d->w, ep, M, N, gx, gy, xcd_map);                           \
     } while (0)
     if (ep.res_mode == 0) DCAP_PW_LAUNCH(0);
     else if (ep.res_mode == 1) DCAP_PW_LAUNCH(1);
