@@ -173,3 +173,37 @@ def test_full_size_joint_step_bf16_and_f32(ops):
         torch.cuda.empty_cache()
     for k in ('imgcap_loss', 'rpn_class_loss', 'rpn_bbox_loss', 'reg_loss'):
         assert abs(out['bf16'][k] - out['f32'][k]) < 2e-2 * max(1.0, abs(out['f32'][k])), (k, out)
+
+
+def test_full_size_vgg16_plan_and_bf16_storage_plan(ops):
+    """The two other plans at 1024x1024: the VGG16 alternative backbone (eager == hipGraph replay bit for bit, finite, 641.43 GF
+    per image, translation-invariant interior on a constant image) and the ResNet-FPN plan in bf16 storage (dc_conv2d_bf16),
+    whose pyramid maps must track the exact-fp32 plan's within the bf16 tolerance of a 100-convolution stack."""
+    from image_captioning_amd import synth
+    from image_captioning_amd.encoder import EncoderPlan, Vgg16Plan
+    img = torch.tensor(synth.images(5, 1), device="cuda")
+    vg = Vgg16Plan(synth.vgg16_weights(0), 1, 1024, 1024, "cuda")
+    outs = []
+    for rep in range(3):
+        vg.forward(img)
+        outs.append(vg.C[0].clone())
+    assert torch.equal(outs[0], outs[2]) and bool(torch.isfinite(outs[0]).all())
+    assert abs(vg.flops - 641.43e9) < 0.01e9
+    const = torch.full_like(img, 97)
+    vg.forward(const)
+    inner = vg.C[0][0, 24:40, 24:40]
+    assert float((inner - inner[0, 0]).abs().max()) < 1e-3 * float(inner.abs().max())
+    feats = vg.roi_features(synth.rois(3, 1, 32, 1024, 1024))
+    assert feats.shape == (1, 32, 7, 7, 512) and bool(torch.isfinite(feats).all())
+    del vg, outs
+    torch.cuda.empty_cache()
+    W = synth.encoder_weights(0, 22)
+    ref = [p.clone() for p in EncoderPlan(W, 1, 1024, 1024, "cuda").forward(img)]
+    fast = EncoderPlan(W, 1, 1024, 1024, "cuda", math="bf16")
+    assert fast.fast_bf16
+    for rep in range(3):
+        got = [p.clone() for p in fast.forward(img)]
+    for a, b in zip(got, ref):
+        assert bool(torch.isfinite(a).all())
+        rel = float((a - b).norm() / b.norm())
+        assert rel < 5e-2, rel
