@@ -611,3 +611,35 @@ def test_vgg16_plan_matches_oracle(gpu):
         got = plan.roi_features(rois).cpu().numpy()
         assert got.shape == (B, R, 7, 7, 512)
         assert rel_err(got, want) < 2e-4, rep
+
+
+def test_joint_model_inference_in_bf16(gpu):
+    """The inference graph with configs[4]'s arithmetic (bf16 storage between the convolutions, bf16 head / decoder): valid boxes,
+    probabilities that sum to one, and word distributions close to the exact-fp32 model's on the boxes both models keep."""
+    from image_captioning_amd import synth
+    from image_captioning_amd.dense_model import DenseImageCapRCNN
+    S, V, T, blocks = 128, 24, 5, 1
+    _, cfg, Wt = make_joint(S, V, T, blocks)
+    cfg.POST_NMS_ROIS_INFERENCE = 40
+    cfg.DETECTION_MAX_INSTANCES = 10
+    img = synth.images(7, 1, S, S)
+    out = {}
+    for name, kw in (("f32", {}), ("bf16", dict(compute_dtype="bf16", conv_math="bf16"))):
+        model = DenseImageCapRCNN("inference", cfg, "logs", stage4_blocks=blocks, **kw)
+        model.set_weights(Wt)
+        out[name] = model.generate_captions([img[0]])[0]
+        if name == "bf16":
+            assert model.plan().fast_bf16
+    res = out["bf16"]
+    K = res["rois"].shape[0]
+    assert 0 < K <= 10 and res["captions"].shape == (K, T, V) and np.isfinite(res["captions"]).all()
+    assert np.all(res["rois"][:, 2] > res["rois"][:, 0]) and res["rois"].min() >= 0 and res["rois"].max() <= S
+    np.testing.assert_allclose(res["captions"].sum(-1), 1.0, atol=1e-3)
+    common = 0
+    for k in range(K):                                     # boxes within a pixel of an fp32 box: same region, compare the words
+        d = np.abs(out["f32"]["rois"].astype(np.float64) - res["rois"][k]).max(1)
+        if d.size and d.min() <= 1:
+            j = int(d.argmin())
+            assert np.abs(out["f32"]["captions"][j] - res["captions"][k]).max() < 5e-2
+            common += 1
+    assert common >= max(1, K // 2)
