@@ -497,10 +497,19 @@ class DenseImageCapRCNN(object):
         return self._reg_coef, self._train_mask
 
     # ---- one training step ------------------------------------------------------------------
-    def _wgrad(self, x, dy, k, pad, out, accumulate=False, key=None):
+    def _cast_cached(self, t, key):
+        """bf16 copy of `t`; with a key, one cast per step (callers pass the same key only while `t` is unchanged)."""
+        if key is not None and key in self._bf16_cache:
+            return self._bf16_cache[key]
+        b = ops.to_bf16(t, out=self._buf(("castb", key or tuple(t.shape)), tuple(t.shape), torch.bfloat16))
+        if key is not None:
+            self._bf16_cache[key] = b
+        return b
+
+    def _wgrad(self, x, dy, k, pad, out, accumulate=False, key=None, dy_key=None):
         """Packed weight gradient of a k x k / stride 1 convolution.  bf16 model: operands cast to bf16, products on the bf16
         matrix pipe (fp32 accumulation) when the shapes allow; exact fp32 products otherwise.  key: cache slot of x's bf16 copy
-        (the shared RPN convolution reads every P level twice)."""
+        (the shared RPN convolution reads every P level twice); dy_key: cache slot of dy's (shared with the data gradient)."""
         if self.compute_dtype == "bf16" and ops.wgrad_bf16_supported(x.shape, dy.shape):
             xb = self._bf16_cache.get(key) if key is not None else None
             if xb is None:
@@ -509,11 +518,11 @@ class DenseImageCapRCNN(object):
                 xb = ops.to_bf16(x, out=self._buf(("xb", key or id(x), tuple(x.shape)), tuple(x.shape), torch.bfloat16))
                 if key is not None:
                     self._bf16_cache[key] = xb
-            dyb = ops.to_bf16(dy, out=self._buf(("dyb", tuple(dy.shape)), tuple(dy.shape), torch.bfloat16))
+            dyb = self._cast_cached(dy, dy_key)
             return ops.conv2d_wgrad_bf16(xb, dyb, k, k, 1, pad, pad, out=out, accumulate=accumulate)
         return ops.conv2d_wgrad(x, dy, k, k, 1, pad, pad, out=out, accumulate=accumulate)
 
-    def _dgrad(self, dy, wd, k, out, residual=None, key=None):
+    def _dgrad(self, dy, wd, k, out, residual=None, key=None, dy_key=None):
         """Data gradient of a k x k / stride-1 'same' convolution = the forward convolution of dy with the rotated, transposed
         kernel `wd` (packed [Cin, k*k*Cout] fp32).  bf16 model with bf16 storage: dy and wd are cast and the product runs on
         dc_conv2d_bf16; otherwise dc_conv2d_nhwc_f32 in the plan's conv arithmetic.  residual: added (the accumulation into a
@@ -523,8 +532,8 @@ class DenseImageCapRCNN(object):
         pad = (k - 1) // 2
         res_mode = 0 if residual is None else 1
         if p.fast_bf16 and ops.conv_bf16_supported(cout):
-            dyb = ops.to_bf16(dy, out=self._buf(("dgb", tuple(dy.shape)), tuple(dy.shape), torch.bfloat16))
-            wdb = ops.to_bf16(wd, out=self._buf(("wdb", key or tuple(wd.shape)), tuple(wd.shape), torch.bfloat16))
+            dyb = self._cast_cached(dy, dy_key)
+            wdb = self._cast_cached(wd, None if key is None else "wd_" + key)      # the RPN's rotated kernel serves five levels
             return ops.conv2d_bf16(dyb, wdb, k, k, 1, pad, pad, h_, w_, residual=residual, res_mode=res_mode, out=out)[0]
         return ops.conv2d(dy, wd, k, k, 1, pad, pad, h_, w_, residual=residual, res_mode=res_mode, out=out, math=p.math)
 
@@ -641,9 +650,9 @@ class DenseImageCapRCNN(object):
             dsh = self._buf("dsh%d" % i, tuple(sh.shape))          # 1x1 head: its data gradient is a K = 20 GEMM on the packed weights
             ops.gemm(dh.view(-1, HEAD_PAD), w["rpn_head/kernel"], out=dsh.view(-1, 512))
             ops.relu_bwd(dsh.view(-1, 512), sh.view(-1, 512), dsh.view(-1, 512))
-            self._wgrad(pm, dsh, 3, 1, g["rpn_conv_shared/kernel"], accumulate=acc, key="P%d" % i)
+            self._wgrad(pm, dsh, 3, 1, g["rpn_conv_shared/kernel"], accumulate=acc, key="P%d" % i, dy_key="dsh%d" % i)
             ops.colsum(dsh.view(-1, 512), out=g["rpn_conv_shared/bias"], accumulate=acc)
-            self._dgrad(dsh, wd_shared, 3, dP[i], residual=dP[i], key="rpn_shared")     # dP += dgrad
+            self._dgrad(dsh, wd_shared, 3, dP[i], residual=dP[i], key="rpn_shared", dy_key="dsh%d" % i)     # dP += dgrad
         ops.scatter2_add(dP[4], dP[3])                       # P6 = MaxPooling2D(1, strides=2)(P5)
 
         # ---- FPN backward
@@ -652,9 +661,9 @@ class DenseImageCapRCNN(object):
             name = "fpn_p%d" % (i + 2)
             wd = ops.conv_weight_dgrad_pack(w[name + "/kernel"], 3, 3, 256, out=self._buf("wd_" + name, (256, 9 * 256)))
             _, h_, w_, _ = dP[i].shape
-            self._wgrad(p.pre[i], dP[i], 3, 1, g[name + "/kernel"])
+            self._wgrad(p.pre[i], dP[i], 3, 1, g[name + "/kernel"], dy_key="dP%d" % i)
             ops.colsum(dP[i].view(-1, 256), out=g[name + "/bias"])
-            dpre.append(self._dgrad(dP[i], wd, 3, self._buf("dpre%d" % i, tuple(dP[i].shape)), key=name))
+            dpre.append(self._dgrad(dP[i], wd, 3, self._buf("dpre%d" % i, tuple(dP[i].shape)), key=name, dy_key="dP%d" % i))
         for i in range(3):                                   # pre[k] = upsample(pre[k+1]) + lateral(C_k)
             ops.downsample2x_sum(dpre[i], out=dpre[i + 1], accumulate=True)
         for i, cmap in enumerate(p.C):
