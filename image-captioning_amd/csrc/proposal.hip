@@ -127,6 +127,9 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
     return ((unsigned long long)hi << 32) | lo;
 }
 
+#ifndef NMS_ROWS
+#define NMS_ROWS 24        // kept rows whose suppression masks are fetched together: the scan is one dependent round trip per batch
+#endif
 __global__ __launch_bounds__(64) void nms_scan_wave_kernel(const float4* __restrict__ boxes, const unsigned long long* __restrict__ mask, int k,
                                                            int words, int count, float4* __restrict__ proposals, int* __restrict__ keep_out) {
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -160,10 +163,10 @@ __global__ __launch_bounds__(64) void nms_scan_wave_kernel(const float4* __restr
         }
         kept += __builtin_popcountll(keepmask);
         unsigned long long km = keepmask;
-        while (km != 0) {                                                      // uniform; 8 rows (16 loads per lane) in flight
-            unsigned long long v0[8], v1[8];
+        while (km != 0) {                                                      // uniform; NMS_ROWS rows (2 loads per lane each) in flight
+            unsigned long long v0[NMS_ROWS], v1[NMS_ROWS];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < NMS_ROWS; ++u) {
                 v0[u] = 0; v1[u] = 0;
                 if (km != 0) {
                     const int j = __builtin_ctzll(km);
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(64) void nms_scan_wave_kernel(const float4* __restr
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { rem0 |= v0[u]; rem1 |= v1[u]; }
+            for (int u = 0; u < NMS_ROWS; ++u) { rem0 |= v0[u]; rem1 |= v1[u]; }
         }
         self = self_next;
     }
