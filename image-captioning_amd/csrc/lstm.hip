@@ -12,6 +12,10 @@
 
 namespace dcap {
 
+#ifdef DCAP_LSTM_STAMPS      // diagnostic builds only (tools/build_variant.sh): workgroup lifetimes of the forward step kernel
+__device__ unsigned long long g_lstm_stamps[2];
+#endif
+
 __device__ __forceinline__ float hard_sigmoid(float z) { return fminf(fmaxf(0.2f * z + 0.5f, 0.f), 1.f); }
 __device__ __forceinline__ float hard_sigmoid_grad(float z) {
     const float y = 0.2f * z + 0.5f;
@@ -112,6 +116,9 @@ __global__ __launch_bounds__(NW * 64) void lstm_step_fused_kernel(float* __restr
                                                                   float* __restrict__ c_t, int B, int U) {
     constexpr int HALF = NW / 2, THREADS = NW * 64, ITEMS = RT * 256, IT = (ITEMS + THREADS - 1) / THREADS;
     __shared__ float part[HALF][RT * 32][33];
+#ifdef DCAP_LSTM_STAMPS
+    const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifndef DCAP_LSTM_NOPRIO
     // In the training pipeline these waves share their SIMDs with the encoder's convolution waves, which issue 64-clock fp32 MFMAs
     // back to back.  The recurrence is the decoder's serial chain and a step's MFMA work is tiny: ask for the issue slots first.
@@ -224,6 +231,13 @@ __global__ __launch_bounds__(NW * 64) void lstm_step_fused_kernel(float* __restr
         h_t[o] = gmk[q] ? hn : ghp[q];
         c_t[o] = gmk[q] ? cn : gcp[q];
     }
+#ifdef DCAP_LSTM_STAMPS
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&g_lstm_stamps[0], __builtin_amdgcn_s_memrealtime() - stamp0);      // 100 MHz ticks
+        atomicAdd(&g_lstm_stamps[1], 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -428,6 +442,13 @@ static dc_gemm_desc dU_desc(int B, int T, int U, const float* h_seq, const float
 }  // namespace dcap
 
 using namespace dcap;
+
+#ifdef DCAP_LSTM_STAMPS
+extern "C" void dc_lstm_stamps(unsigned long long* out, int reset) {
+    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(dcap::g_lstm_stamps), sizeof(unsigned long long) * 2);
+    if (reset) { unsigned long long z[2] = {0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(dcap::g_lstm_stamps), z, sizeof(z)); }
+}
+#endif
 
 extern "C" size_t dc_lstm_seq_workspace_bytes(int B, int T, int U) {
     if (B <= 0 || T <= 0 || U <= 0) return 0;
