@@ -9,7 +9,8 @@ Default workload (BASELINE.json configs[2], and configs[3] at --gpus 8): per GPU
 All arithmetic is fp32 (exact-f32 MFMA).  Inputs are resident in HBM before the timed region.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1: either under python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ..., or plainly:
+   without WORLD_SIZE in the environment this process starts the N ranks itself as child processes, see self_launch)
   python bench.py --config joint      BASELINE configs[4]: the joint model (bf16 decoder / head / vocabulary GEMMs), one
                                       1024x1024 image per GPU and step, 2000 proposals -> 200 RoIs, V = 50 000
 
@@ -63,6 +64,8 @@ def parse():
     ap.add_argument("--cpu-baseline-steps", type=int, default=5)
     ap.add_argument("--layer-table", default=None, help="write the per-layer conv timing table (TSV) to this path")
     ap.add_argument("--joint-dtype", default="bf16", choices=["bf16", "f32"], help="joint leg: decoder/head/vocabulary arithmetic")
+    ap.add_argument("--joint-dropout", type=float, default=0.0, help="joint leg: recurrent_dropout of the two LSTMs (the reference trains with "
+                    "0.2 = this package's default; the benchmark opts out so that runs are comparable: the masks cost one small kernel per LSTM)")
     ap.add_argument("--joint-host-images", action="store_true", help="joint leg: hand the image over as a host array every step")
     ap.add_argument("--joint-conv-math", default=None, help="joint leg: conv arithmetic (f32 | bf16x3 | bf16x2 | bf16); default bf16 with "
                     "--joint-dtype bf16 (forward convolutions and data gradients; weight gradients accumulate fp32 products)")
@@ -369,6 +372,7 @@ def build_joint(args, dev, rank=0, world=1):
         PADDING_SIZE = T
         VOCABULARY_SIZE = V
         EMBEDDING_SIZE = 300
+        RECURRENT_DROPOUT = args.joint_dropout
     cfg = Cfg()
     cfg.EMBEDDING_WEIGHTS = synth.embedding_matrix(3, V)
     model = DenseImageCapRCNN("training", cfg, "logs", device=dev, stage4_blocks=args.stage4_blocks, seed=0,
@@ -420,16 +424,72 @@ def run_joint(args, dev, rank, world, barrier):
     return dt, out, R, inner
 
 
+def self_launch(n, argv=None, script=None, timeout_s=None, extra_env=None):
+    """`python bench.py --gpus N` without an external launcher: this process touches no GPU; it starts the N ranks as CHILD
+    processes (never exec) with the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT on
+    127.0.0.1), relays rank 0's stdout (the JSON line) and every rank's stderr, and returns non-zero when a rank fails or the
+    job outlives `timeout_s` (the remaining ranks are then killed by PID).  With fewer GPUs than ranks (a one-GPU box) the ranks
+    share devices over the gloo backend -- a rehearsal of the multi-process path, flagged as such in the JSON line
+    (`dist_backend`)."""
+    import socket
+    import subprocess
+    script = script or os.path.abspath(__file__)
+    argv = list(sys.argv[1:] if argv is None else argv)
+    timeout_s = float(os.environ.get("DCAP_BENCH_TIMEOUT", 1500) if timeout_s is None else timeout_s)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env0 = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env0.update(extra_env or {})
+    if "DCAP_DIST_BACKEND" not in env0 and torch.cuda.device_count() < n:      # device_count() does not initialise the GPU
+        sys.stderr.write("bench.py: %d rank(s) on %d visible GPU(s): ranks share devices, gradient exchange over gloo (rehearsal)\n"
+                         % (n, torch.cuda.device_count()))
+        env0["DCAP_DIST_BACKEND"] = "gloo"
+    procs = []
+    for rank in range(n):
+        env = dict(env0, RANK=str(rank), LOCAL_RANK=str(rank))
+        procs.append(subprocess.Popen([sys.executable, script] + argv, env=env, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL,
+                                      text=True))
+    deadline = time.monotonic() + timeout_s
+    rc = 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            if any(c not in (None, 0) for c in codes):                # a rank died: the others would wait in a collective forever
+                rc = next(c for c in codes if c not in (None, 0))
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > deadline:
+                sys.stderr.write("bench.py: ranks still running after %.0f s -- killing them\n" % timeout_s)
+                rc = 124
+                break
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    out = procs[0].stdout.read() if procs[0].stdout else ""
+    for p in procs:
+        p.wait()
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # started plainly: be the launcher (before anything touches the GPU)
+        raise SystemExit(self_launch(args.gpus))
     if os.environ.get("DCAP_HANG_DUMP"):                 # diagnostics: dump every thread's Python stack after N seconds and exit
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["DCAP_HANG_DUMP"]), exit=True)
     from image_captioning_amd.parallel_model import init_process_group_from_env, GradAllReduce
     rank, world, local_rank = init_process_group_from_env()
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start it plainly (python bench.py --gpus %d starts its own ranks) or with "
+                         "torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -462,7 +522,7 @@ def main():
                                    "ProposalLayer(2000) + DetectionTargetLayer(200 RoIs) + RoIAlign + trainable RoI head + Model-3 decoder "
                                    "+ 4 losses + Adam(amsgrad, clipnorm 0.5); %dx%d synth image, 1 image/GPU, V=%d, %d-token captions"
                                    % (S, S, V, T), "images_per_gpu": 1, "rois_per_image": rois_per_step, "parallelism": "dp%d" % world,
-                       "decoder_dtype": args.joint_dtype, "conv_math": inner.conv_math_name, "losses": [float(v) for v in losses],
+                       "decoder_dtype": args.joint_dtype, "recurrent_dropout": args.joint_dropout, "conv_math": inner.conv_math_name, "losses": [float(v) for v in losses],
                        "rccl_ranks": ranks_seen, "dist_backend": backend},
         }
         if rank == 0:

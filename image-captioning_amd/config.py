@@ -53,6 +53,9 @@ DEFAULTS = (
     ("EMBEDDING_SIZE", 100, "word embedding width"),
     ("EMBEDDING_WEIGHTS", None, "embedding matrix [vocab, width]"),
     ("VOCABULARY_SIZE", 0, "softmax width"),
+    # not a field of the reference's Config: the reference hard-codes it in the model (dense_img_cap/dense_model.py:769-770,
+    # text_generation_model.py:141-142: KL.LSTM(..., recurrent_dropout=0.2)); a field here so that parity runs can switch it off
+    ("RECURRENT_DROPOUT", 0.2, "recurrent_dropout of imgcap_lstm1/2 in the training phase (the reference's hard-coded 0.2)"),
 )
 
 

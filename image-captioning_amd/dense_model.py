@@ -297,7 +297,7 @@ class DenseImageCapRCNN(object):
         # the one fused regulariser pass over the whole bucket
         self.caption_model.overlap_sync = False
         self._reg_done = []
-        self.caption_model.recurrent_dropout = float(getattr(cfg, "RECURRENT_DROPOUT", 0.0))    # opt-in: dense_model.py:769-770 uses 0.2
+        self.caption_model.recurrent_dropout = float(getattr(cfg, "RECURRENT_DROPOUT", 0.2))    # dense_img_cap/dense_model.py:769-770: recurrent_dropout=0.2
         self.store = self.caption_model.store
         self._plan = None
         self._reg_coef = None
@@ -364,8 +364,8 @@ class DenseImageCapRCNN(object):
             cur = self.get_weights_dict()
             full = {k: W.get(k, cur[k]) for k in ("rpn_class_raw/kernel", "rpn_class_raw/bias", "rpn_bbox_pred/kernel", "rpn_bbox_pred/bias")}
             hk, hb = fuse_rpn_head(full, HEAD_PAD)
-            st.assign("rpn_head/kernel", pack_conv_kernel(hk))
-            st.assign("rpn_head/bias", hb)
+            st.assign("rpn_head/kernel", pack_conv_kernel(hk), refresh=False)
+            st.assign("rpn_head/bias", hb, refresh=False)
         backbone_changed = False
         for k, v in W.items():
             layer = k.split("/")[0]
@@ -373,12 +373,13 @@ class DenseImageCapRCNN(object):
                 continue
             if k in st.w:
                 packed = k.endswith("/kernel") and layer.startswith(("fpn_", "rpn_"))
-                st.assign(k, pack_conv_kernel(np.asarray(v, np.float32)) if packed else v)
+                st.assign(k, pack_conv_kernel(np.asarray(v, np.float32)) if packed else v, refresh=False)
             elif k in self._backbone:
                 self._backbone[k] = np.asarray(v, np.float32)
                 backbone_changed = True
         if backbone_changed:
             self._plan = None
+        st.refresh_shadow()                  # the bf16 operand copies: once per call, not once per weight
 
     def load_weights(self, filepath, by_name=False, exclude=None):
         loaded = load_weight_file(filepath)
@@ -439,7 +440,8 @@ class DenseImageCapRCNN(object):
         return "\n".join(rows)
 
     def _weights_changed(self):
-        pass
+        """Master weights rewritten from outside the optimizer (ParallelModel.broadcast_weights): re-cast the bf16 mirror."""
+        self.store.refresh_shadow()
 
     @property
     def trainable_weights(self):
@@ -690,27 +692,38 @@ class DenseImageCapRCNN(object):
         return losses
 
     def _loss_list(self, losses):
-        v = losses.cpu().numpy().astype(np.float64)
+        """losses: the step's raw loss terms [rpn_class, rpn_bbox, imgcap (unscaled), reg], a device tensor or its host copy."""
+        v = (losses.cpu().numpy() if isinstance(losses, torch.Tensor) else np.asarray(losses)).astype(np.float64)
         out = dict(rpn_class_loss=v[0], rpn_bbox_loss=v[1], imgcap_loss=v[2] * self._loss_scale, reg_loss=v[3])
         out["loss"] = out["rpn_class_loss"] + out["rpn_bbox_loss"] + out["imgcap_loss"] + out["reg_loss"]
         return out
 
-    def train_on_batch(self, inputs, targets=None):
-        """One optimizer step; returns [loss, rpn_class_loss, rpn_bbox_loss, imgcap_loss] like the compiled Keras model
-        (metrics_names order, :1722-1730)."""
+    def _losses_to_api(self, v):
+        self.last_losses = d = self._loss_list(v)
+        return [d["loss"], d["rpn_class_loss"], d["rpn_bbox_loss"], d["imgcap_loss"]]
+
+    def train_on_batch_device(self, inputs, targets=None):
+        """One optimizer step; the raw loss terms as a float32 device tensor [4] (the loss all-reduce of ParallelModel and the
+        epoch sums of train() work on it; _losses_to_api makes the Keras return value from its host copy)."""
         assert self.mode == "training", "Create model in training mode."
         if self.optimizer is None:
             raise RuntimeError("compile(learning_rate) first")
         losses = self.forward_backward(inputs)
         scale = self.grad_sync(self.store.flat_grad) if self.grad_sync is not None else 1.0
         self.optimizer.apply(self.store, grad_scale=scale)
-        self.last_losses = d = self._loss_list(losses)
-        return [d["loss"], d["rpn_class_loss"], d["rpn_bbox_loss"], d["imgcap_loss"]]
+        return losses
+
+    def train_on_batch(self, inputs, targets=None):
+        """One optimizer step; returns [loss, rpn_class_loss, rpn_bbox_loss, imgcap_loss] like the compiled Keras model
+        (metrics_names order, :1722-1730)."""
+        return self._losses_to_api(self.train_on_batch_device(inputs, targets))
+
+    def test_on_batch_device(self, inputs, targets=None):
+        return self.forward_backward(inputs, backward=False)
 
     def test_on_batch(self, inputs, targets=None):
         """Forward only (Keras test_on_batch): losses of the batch, no gradient, no effect on the training state."""
-        self.last_losses = d = self._loss_list(self.forward_backward(inputs, backward=False))
-        return [d["loss"], d["rpn_class_loss"], d["rpn_bbox_loss"], d["imgcap_loss"]]
+        return self._losses_to_api(self.test_on_batch_device(inputs, targets))
 
     # ---- inference -------------------------------------------------------------------------
     def mold_inputs(self, images):
@@ -761,10 +774,11 @@ class DenseImageCapRCNN(object):
         names = ("loss",) + self.LOSS_NAMES
         history = []
         for epoch in range(self.epoch, epochs):
-            sums = np.zeros(4)
+            acc = None                                           # raw loss terms summed on the device: one host copy per epoch
             for _ in range(cfg.STEPS_PER_EPOCH):
-                sums += np.asarray(self._outer.train_on_batch(next(train_generator)[0]))
-            logs = {n: v / cfg.STEPS_PER_EPOCH for n, v in zip(names, sums)}
+                step = self._outer.train_on_batch_device(next(train_generator)[0])
+                acc = step.clone() if acc is None else acc.add_(step)
+            logs = dict(zip(names, self._losses_to_api((acc / cfg.STEPS_PER_EPOCH).cpu().numpy())))
             # the reference validates on ONE fixed batch too: validation_data=next(val_generator) (:1878)
             logs.update({"val_" + n: v for n, v in zip(names, self._outer.test_on_batch(val_batch))})
             history.append(logs)

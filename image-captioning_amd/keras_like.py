@@ -77,11 +77,13 @@ class KerasLikeModel(object):
                 if skip_mismatch:
                     continue
                 raise ValueError("shape mismatch for %s" % k)
-            self.store.assign(k, v)
+            self.store.assign(k, v, refresh=False)
         self._weights_changed()
 
     def _weights_changed(self):
-        pass
+        """Master weights were rewritten from outside the optimizer (load_weights, ParallelModel's broadcast): re-cast the bf16
+        operand copies the bf16 GEMMs read (compute_dtype='bf16'); sub-classes also re-derive what they fold from weights."""
+        self.store.refresh_shadow()
 
     def summary(self):
         lines = ["%-40s %-22s %s" % ("weight", "shape", "trainable")]
@@ -96,22 +98,105 @@ class KerasLikeModel(object):
         lines.append("Total params: %d  Trainable: %d  Non-trainable: %d" % (total, train, total - train))
         return "\n".join(lines)
 
+    # ---- losses without a host round trip --------------------------------------------------------------------------------
+    # train_on_batch / test_on_batch return Python floats like Keras and therefore wait for the step.  Training loops
+    # (fit_generator, ParallelModel) use the *_device forms instead: a float32 DEVICE tensor of the step's loss terms, nothing
+    # synchronised; _losses_to_api turns its host copy into what the Keras call returns.
+    def train_on_batch_device(self, inputs, targets):
+        raise NotImplementedError
+
+    @staticmethod
+    def _losses_to_api(v):
+        return float(v[0])
+
     def fit_generator(self, generator, epochs=1, steps_per_epoch=None, callbacks=None, validation_data=None,
                       verbose=1, max_queue_size=10, workers=1, use_multiprocessing=False, initial_epoch=0):
-        """Runs the generator on the calling thread (the reference lets Keras run it on one
-        background thread; the synthetic/benchmark path feeds device-resident batches instead)."""
+        """keras.Model.fit_generator as the reference calls it (text_generation_model_v2.py:300-313: workers=1,
+        max_queue_size=10; text_generation_model.py:458-472: max_queue_size=100).  Keras' GeneratorEnqueuer semantics:
+        workers >= 1 runs next(generator) on ONE background thread per worker filling a queue of at most max_queue_size batches
+        (threads, not processes: use_multiprocessing=True with a plain generator is refused like Keras warns against; more than
+        one worker needs a thread-safe generator exactly as in Keras); workers=0 runs the generator on the calling thread.
+        The loop itself never waits for the GPU: step losses stay on the device and are read once per epoch."""
+        if use_multiprocessing:
+            raise NotImplementedError("use_multiprocessing=True duplicates a plain generator in every process (Keras warns about it); "
+                                      "the reference uses threads (use_multiprocessing=False)")
+        if steps_per_epoch is None:
+            raise ValueError("steps_per_epoch is required for a generator")
+        outer = getattr(self, "_outer", None) or self          # under ParallelModel the loop feeds GLOBAL batches through the wrapper
+        enq = GeneratorEnqueuer(generator, workers, max_queue_size) if workers and workers > 0 else None
+        batches = enq.get() if enq is not None else generator
         history = []
-        for epoch in range(initial_epoch, epochs):
-            losses = []
-            for _ in range(steps_per_epoch):
-                inputs, targets = next(generator)
-                losses.append(self.train_on_batch(inputs, targets))
-            logs = {"loss": float(np.mean(losses))}
-            if validation_data is not None:
-                logs["val_loss"] = float(self.test_on_batch(validation_data[0], validation_data[1]))
-            if verbose:
-                print("Epoch %d/%d - " % (epoch + 1, epochs) + " - ".join("%s: %.4f" % kv for kv in sorted(logs.items())))
-            for cb in callbacks or []:
-                cb.on_epoch_end(self, epoch, logs)
-            history.append(logs)
+        try:
+            for epoch in range(initial_epoch, epochs):
+                acc = None
+                for _ in range(steps_per_epoch):
+                    inputs, targets = next(batches)
+                    step = outer.train_on_batch_device(inputs, targets)      # device tensor; its buffer is reused by the next step
+                    acc = step.clone() if acc is None else acc.add_(step)    # (bookkeeping on the step's stream, not model arithmetic)
+                logs = {"loss": self._losses_to_api((acc / steps_per_epoch).cpu().numpy())}       # the epoch's ONE host sync
+                if validation_data is not None:
+                    logs["val_loss"] = float(outer.test_on_batch(validation_data[0], validation_data[1]))
+                if verbose and getattr(self, "is_chief", True):
+                    print("Epoch %d/%d - " % (epoch + 1, epochs) + " - ".join("%s: %.4f" % kv for kv in sorted(logs.items())))
+                if getattr(self, "is_chief", True):
+                    for cb in callbacks or []:
+                        cb.on_epoch_end(self, epoch, logs)
+                history.append(logs)
+        finally:
+            if enq is not None:
+                enq.stop()
         return history
+
+
+class GeneratorEnqueuer(object):
+    """keras.utils.GeneratorEnqueuer(generator, use_multiprocessing=False): `workers` daemon threads call next(generator)
+    (under a lock: a Python generator is not re-entrant; with one worker -- the reference's setting -- the lock is free) and put
+    batches into a bounded queue; get() yields them in arrival order.  A generator that raises ends the stream with that error;
+    StopIteration ends it cleanly."""
+
+    _END = object()
+
+    def __init__(self, generator, workers=1, max_queue_size=10):
+        import queue
+        import threading
+        self._gen, self._q = generator, queue.Queue(maxsize=max(1, int(max_queue_size)))
+        self._stop, self._lock = threading.Event(), threading.Lock()
+        self._threads = [threading.Thread(target=self._work, daemon=True) for _ in range(max(1, int(workers)))]
+        for t in self._threads:
+            t.start()
+
+    def _put(self, item):
+        import queue
+        while not self._stop.is_set():
+            try:
+                self._q.put(item, timeout=0.05)
+                return
+            except queue.Full:
+                continue
+
+    def _work(self):
+        while not self._stop.is_set():
+            try:
+                with self._lock:
+                    item = next(self._gen)
+            except StopIteration:
+                self._put(self._END)
+                return
+            except BaseException as e:          # hand the error to the consumer
+                self._put(e)
+                return
+            self._put(item)
+
+    def get(self):
+        while True:
+            item = self._q.get()
+            if item is self._END:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+
+    def stop(self):
+        self._stop.set()
+        for t in self._threads:
+            t.join(timeout=5)

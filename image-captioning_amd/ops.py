@@ -652,6 +652,14 @@ def mean(x, out=None):
     return out
 
 
+def dropout_mask(out, rate, seed, offset):
+    """K.dropout(ones, rate): out filled with 1/(1-rate) (kept) or 0, element i a pure function of (i, seed, offset)."""
+    lib = _lib.load()
+    check(lib.dc_dropout_mask_f32(_ptr(_chk(out, name="out")), out.numel(), float(rate), int(seed) & 0xFFFFFFFF, int(offset) & 0xFFFFFFFF, _stream()),
+          "dc_dropout_mask_f32")
+    return out
+
+
 def amsgrad_step(p, g, m, v, vhat, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, gnorm_sq=None, clipnorm=0.0, p_bf16=None):
     lib = _lib.load()
     d = AmsgradDesc()

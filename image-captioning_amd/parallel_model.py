@@ -127,20 +127,30 @@ class ParallelModel(object):
     def shard_inputs(self, inputs):
         return [shard(x, self.rank, self.gpu_count) for x in inputs]
 
-    def _run(self, fn, inputs, targets):
+    def mean_over_towers(self, raw):
+        """tf.reduce_mean over the towers' loss terms (parallel_model.py:88-102): all-reduce(sum) of a small float32 device
+        tensor, scaled by 1/gpu_count -- enqueued like the gradient exchange, the host does not wait (RCCL; the gloo rehearsal
+        backend stages through the host by nature).  Returns a new device tensor."""
+        if self.gpu_count == 1:
+            return raw
+        t = raw.to(torch.float32).clone()
+        dist.all_reduce(t)
+        return t.mul_(1.0 / self.gpu_count)
+
+    def _run_device(self, fn, inputs, targets):
         mine = None if targets is None or len(targets) == 0 else shard(targets, self.rank, self.gpu_count)
-        loss = fn(self.shard_inputs(inputs), mine)
-        if self.gpu_count > 1:
-            t = torch.tensor(loss if isinstance(loss, (list, tuple)) else [loss], dtype=torch.float64, device=self.inner_model.device)
-            dist.all_reduce(t)
-            vals = (t / self.gpu_count).tolist()
-            loss = vals if isinstance(loss, (list, tuple)) else vals[0]
-        return loss
+        return self.mean_over_towers(fn(self.shard_inputs(inputs), mine))
+
+    def train_on_batch_device(self, inputs, targets=None):
+        """Global batch in, split like tf.split; the mean over towers of the towers' loss terms as a DEVICE tensor -- no host
+        synchronisation anywhere in the step, so a training loop (fit_generator, train()) keeps enqueueing and the two-stream
+        overlap survives; inner_model._losses_to_api(host copy) gives what train_on_batch returns."""
+        return self._run_device(self.inner_model.train_on_batch_device, inputs, targets)
 
     def train_on_batch(self, inputs, targets=None):
-        """Global batch in, split like tf.split; returns the mean over towers of the tower losses (a scalar, or the
-        joint model's [loss, rpn_class_loss, rpn_bbox_loss, imgcap_loss] list)."""
-        return self._run(self.inner_model.train_on_batch, inputs, targets)
+        """Keras return value (a float, or the joint model's [loss, rpn_class_loss, rpn_bbox_loss, imgcap_loss] list): ONE
+        device->host copy at the end of the step, as on a single GPU."""
+        return self.inner_model._losses_to_api(self.train_on_batch_device(inputs, targets).cpu().numpy())
 
     def test_on_batch(self, inputs, targets=None):
-        return self._run(self.inner_model.test_on_batch, inputs, targets)
+        return self.inner_model._losses_to_api(self._run_device(self.inner_model.test_on_batch_device, inputs, targets).cpu().numpy())

@@ -82,13 +82,14 @@ class ParamStore:
     def to_numpy(self):
         return {k: v.detach().cpu().numpy() for k, v in self.w.items()}
 
-    def assign(self, name, array):
+    def assign(self, name, array, refresh=True):
+        """refresh=False: the caller assigns many weights and calls refresh_shadow() once afterwards (load_weights)."""
         t = self.w[name]
         a = np.asarray(array, np.float32)
         if tuple(a.shape) != tuple(t.shape):
             raise ValueError("shape mismatch for %s: %s vs %s" % (name, a.shape, tuple(t.shape)))
         t.copy_(torch.tensor(a, device=self.device))
-        if self.flat_bf16 is not None and name in self.wb:
+        if refresh and self.flat_bf16 is not None and name in self.wb:
             self.refresh_shadow()
 
 

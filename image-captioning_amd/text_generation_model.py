@@ -164,13 +164,15 @@ class CaptionModelV1(KerasLikeModel):
     HEAD = (("mrcnn_class_conv1", "mrcnn_class_bn1"), ("mrcnn_class_conv2", "mrcnn_class_bn2"))
     overlap_sync = True        # data parallel: all-reduce a layer group's gradients as soon as its backward is enqueued
     before_sync = None         # optional hook(lo, hi): last touch of a gradient range before its all-reduce starts
-    # Keras recurrent_dropout of imgcap_lstm1 / imgcap_lstm2 (:141-142).  0.0 (default) = the deterministic graph every parity
-    # test and the benchmark run; 0.2 = the reference's training-phase behaviour: per train step four inverted-dropout masks
-    # [B, units] per LSTM (one per gate i,f,c,o), fixed over the timesteps, drawn from a seeded generator.  One mask set per RoI
-    # serves all T prefixes of its caption (Keras draws one per (RoI, prefix) row of the TimeDistributed batch -- the same
-    # marginal distribution; per-RoI masks are what keeps the T-prefix graph equal to a single pass).  Never applied in
-    # predict / test_on_batch / generate (Keras' learning phase 0).
-    recurrent_dropout = 0.0
+    # Keras recurrent_dropout of imgcap_lstm1 / imgcap_lstm2 (:141-142; dense_img_cap/dense_model.py:769-770).  Default = the
+    # reference's 0.2: every train step (train_on_batch / fit_generator / train()) draws four inverted-dropout masks [B, units]
+    # per LSTM (one per gate i,f,c,o), fixed over the timesteps, from a seeded counter-based generator ON THE DEVICE
+    # (dc_dropout_mask_f32; stream = (seed, step, lstm)).  Parity tests and bench.py set 0.0 explicitly (the deterministic graph
+    # the oracle restates).  One mask set per RoI serves all T prefixes of its caption: Keras draws one per (RoI, prefix) row of
+    # the TimeDistributed batch -- the same marginal distribution per row, but rows of one RoI are correlated here; per-RoI
+    # masks are what keeps the T-prefix graph equal to the single masked pass ("recurrent dropout").  Never
+    # applied in predict / test_on_batch / generate (Keras' learning phase 0).
+    recurrent_dropout = 0.2
 
     def __init__(self, features_input, config, units, mode, device=None, seed=0, extra_params=(), compute_dtype="f32"):
         """extra_params: (name, array, trainable) entries that share this model's flat parameter bucket (the joint
@@ -204,9 +206,15 @@ class CaptionModelV1(KerasLikeModel):
             st.enable_bf16_shadow(own)                    # GEMM kernels only: biases, BN parameters and the recurrences stay fp32
         self.grad_sync = None
         self._bufs = {}
-        self._drop_rng = np.random.default_rng(seed + 77)
+        self._drop_seed, self._drop_step = (seed + 77) & 0xFFFFFFFF, 0
         self._rec_masks = (None, None)           # device masks of the current train step (lstm1, lstm2) or None
-        self.last_rec_masks = None               # their host copies (tests feed them to the oracle)
+
+    @property
+    def last_rec_masks(self):
+        """Host copies of the current train step's masks ([4, B, units] per LSTM; tests feed them to the oracle) or None."""
+        if self._rec_masks[0] is None:
+            return None
+        return [m.cpu().numpy() for m in self._rec_masks]
 
     def compile(self, optimizer, loss=None):
         self.optimizer, self.loss = optimizer, loss
@@ -215,11 +223,11 @@ class CaptionModelV1(KerasLikeModel):
         """Keras LSTMCell._generate_recurrent_dropout_mask for both LSTMs: K.dropout(ones, rate) x 4 in the training phase."""
         rate = float(self.recurrent_dropout or 0.0)
         if not training or rate <= 0.0:
-            self._rec_masks, self.last_rec_masks = (None, None), None
+            self._rec_masks = (None, None)
             return
-        host = [(self._drop_rng.random((4, B, self.units)) >= rate).astype(np.float32) / np.float32(1.0 - rate) for _ in range(2)]
-        self.last_rec_masks = host
-        self._rec_masks = tuple(torch.tensor(m, device=self.device) for m in host)
+        self._drop_step += 1
+        self._rec_masks = tuple(ops.dropout_mask(self._buf('rec_mask%d' % l, (4, B, self.units)), rate, self._drop_seed, 2 * self._drop_step + l)
+                                for l in range(2))
 
     def _buf(self, key, shape, dtype=torch.float32):
         b = self._bufs.get(key)
@@ -457,14 +465,21 @@ class CaptionModelV1(KerasLikeModel):
         B, T = np.asarray(caps).shape
         return self._unpack(probs, B, T)
 
-    def train_on_batch(self, inputs, targets):
+    def train_on_batch_device(self, inputs, targets):
+        """train_on_batch without the host round trip: the loss as a float32 device tensor [1] (see keras_like)."""
         feat, caps = inputs
-        return float(self.train_step(self._dev_feat(feat), caps, self._target_ids(targets)).item())
+        return self.train_step(self._dev_feat(feat), caps, self._target_ids(targets))
 
-    def test_on_batch(self, inputs, targets):
+    def train_on_batch(self, inputs, targets):
+        return float(self.train_on_batch_device(inputs, targets).item())
+
+    def test_on_batch_device(self, inputs, targets):
         feat, caps = inputs
         loss_rows, _ = self._forward_train(self._dev_feat(feat), caps, self._target_ids(targets))
-        return float(ops.mean(loss_rows).item())
+        return ops.mean(loss_rows)
+
+    def test_on_batch(self, inputs, targets):
+        return float(self.test_on_batch_device(inputs, targets).item())
 
     def generate(self, feat, return_probabilities=None):
         """ROICaptionInferenceLayer (:192-232): start token 1; step j feeds [prev..., 0...] through the word

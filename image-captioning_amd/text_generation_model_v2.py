@@ -232,6 +232,7 @@ class CaptionModelV2(KerasLikeModel):
 
     # frozen head: fold BN once (float64 on the host)
     def _weights_changed(self):
+        self.store.refresh_shadow()
         w = {k: v.detach().cpu().numpy() for k, v in self.store.w.items() if k.startswith('mrcnn_class')}
         dev = self.device
         self._head = []
@@ -359,16 +360,23 @@ class CaptionModelV2(KerasLikeModel):
         _, probs = self._forward(self._dev_feat(feat), tb, want_probs=True)
         return probs.cpu().numpy()
 
-    def train_on_batch(self, inputs, targets):
+    def train_on_batch_device(self, inputs, targets):
+        """train_on_batch without the host round trip: the loss as a float32 device tensor [1] (see keras_like)."""
         feat, words = inputs
         tb = SampleTables.from_samples(words, self._target_ids(targets), self.device)
-        return float(self.train_step(self._dev_feat(feat), tb).item())
+        return self.train_step(self._dev_feat(feat), tb)
 
-    def test_on_batch(self, inputs, targets):
+    def train_on_batch(self, inputs, targets):
+        return float(self.train_on_batch_device(inputs, targets).item())
+
+    def test_on_batch_device(self, inputs, targets):
         feat, words = inputs
         tb = SampleTables.from_samples(words, self._target_ids(targets), self.device)
         loss_rows, _ = self._forward(self._dev_feat(feat), tb)
-        return float(ops.mean(loss_rows).item())
+        return ops.mean(loss_rows)
+
+    def test_on_batch(self, inputs, targets):
+        return float(self.test_on_batch_device(inputs, targets).item())
 
     def train_on_captions(self, feat, captions_or_tables):
         """Algorithmic (single teacher-forced pass) train step over R RoIs and their captions."""

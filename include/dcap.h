@@ -465,6 +465,12 @@ int dc_colsum_f32(const float* x, int M, int N, int ld, float* out, int accumula
 size_t dc_sumsq_workspace_bytes(size_t n);
 int dc_sumsq_f32(const float* x, size_t n, float* out, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Inverted-dropout mask of ones: out[i] = 1/(1-rate) with probability 1-rate, else 0 -- K.dropout(K.ones_like(h), rate), the
+ * per-gate recurrent_dropout masks Keras' LSTMCell draws in the training phase (recurrent.py _generate_recurrent_dropout_mask;
+ * used by text_generation_model.py:141-142 and dense_img_cap/dense_model.py:769-770 with rate 0.2).  Counter-based
+ * (Philox-2x32-10): element i of stream (seed, offset) is a pure function of (i, seed, offset). */
+int dc_dropout_mask_f32(float* out, size_t n, float rate, uint32_t seed, uint32_t offset, void* stream);
+
 /* mean of loss rows: out[0] = sum(x)/n. */
 int dc_mean_f32(const float* x, size_t n, float* out, void* stream);
 

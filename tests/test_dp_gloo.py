@@ -96,16 +96,23 @@ def _worker_parallel_model(rank, world, port, out_dir):
         def _weights_changed(self):
             self.changed += 1
 
-        def train_on_batch(self, inputs, targets=None):
+        def train_on_batch_device(self, inputs, targets=None):       # the surface ParallelModel drives: loss terms as a tensor
             assert targets is None
             x = inputs[0]                                             # this rank's shard of the global batch
             self.store.flat_grad[:] = float(x.sum())
             scale = self.grad_sync(self.store.flat_grad)
             self.store.flat -= 0.5 * scale * self.store.flat_grad
-            return [float(x.sum()), float(x.min()), float(x.max()), 1.0]
+            return torch.tensor([float(x.sum()), float(x.min()), float(x.max()), 1.0])
+
+        @staticmethod
+        def _losses_to_api(v):
+            return [float(t) for t in v]
     pm = ParallelModel(Toy(), world)
     assert torch.all(pm.store.flat == 1.0) and torch.all(pm.store.w["emb"] == 10.0) and pm.inner_model.changed == 1
     batch = np.arange(8, dtype=np.float64).reshape(4, 2)             # rank 0 gets rows 0-1, rank 1 rows 2-3
+    dev = pm.train_on_batch_device([batch], [])                       # the loop form: a tensor, mean over towers, nothing synchronised
+    assert isinstance(dev, torch.Tensor) and np.allclose(dev.numpy(), [14.0, 2.0, 5.0, 1.0])
+    pm.store.flat[:] = 1.0                                            # undo that step: the Keras form below takes the same one
     losses = pm.train_on_batch([batch], [])
     want = [(1 + 5 + 9 + 13) / 2.0, (0 + 4) / 2.0, (3 + 7) / 2.0, 1.0]      # mean over towers of each entry
     np.save(os.path.join(out_dir, "pm_%d.npy" % rank), np.array(list(losses) + pm.store.flat.tolist()))

@@ -670,3 +670,22 @@ def test_maxpool2x2s2_matches_numpy(ops):
     from image_captioning_amd._lib import DcapError
     with pytest.raises(DcapError):
         ops.maxpool2x2s2(dev(x[:, :5]))                 # odd height
+
+
+def test_dropout_mask_is_keras_inverted_dropout_of_ones(ops):
+    """dc_dropout_mask_f32 = K.dropout(ones, rate): values 0 or 1/(1-rate), keep fraction 1-rate, a pure function of
+    (element, seed, offset) -- the same stream twice is identical, another offset or seed is a different mask."""
+    n, rate = 4 * 200 * 512, 0.2
+    a = ops.dropout_mask(torch.empty(n, device="cuda"), rate, seed=77, offset=2).cpu().numpy()
+    assert set(np.unique(a)) == {0.0, np.float32(1.25)}
+    assert abs((a > 0).mean() - 0.8) < 5e-3 and abs(a.mean() - 1.0) < 6e-3
+    again = ops.dropout_mask(torch.empty(n, device="cuda"), rate, seed=77, offset=2).cpu().numpy()
+    np.testing.assert_array_equal(a, again)
+    head = ops.dropout_mask(torch.empty(1000, device="cuda"), rate, seed=77, offset=2).cpu().numpy()
+    np.testing.assert_array_equal(head, a[:1000])                       # independent of the launch geometry
+    for seed, off in ((77, 3), (78, 2)):
+        b = ops.dropout_mask(torch.empty(n, device="cuda"), rate, seed=seed, offset=off).cpu().numpy()
+        assert 0.6 < ((a > 0) == (b > 0)).mean() < 0.76                  # independent masks agree on 0.8^2 + 0.2^2 = 0.68
+    k = (a.reshape(4, 200, 512) > 0)
+    assert abs(np.corrcoef(k[0].ravel(), k[1].ravel())[0, 1]) < 0.02    # the four gate masks are uncorrelated
+    assert np.all(ops.dropout_mask(torch.empty(64, device="cuda"), 0.0, 1, 1).cpu().numpy() == 1.0)

@@ -163,6 +163,8 @@ def make_v1(V, T, B, seed=0):
     cfg = DenseCapConfig(V, synth.embedding_matrix(seed + 3, V), B)
     cfg.PADDING_SIZE = T
     model = build_lstm_model([7, 7, 256], cfg, 512, 'training', seed=seed)
+    assert model.recurrent_dropout == 0.2         # the reference's training default (text_generation_model.py:141-142)
+    model.recurrent_dropout = 0.0                 # parity against the deterministic oracle graph
     model.compile(optimizer=Adam(amsgrad=True), loss=roi_caption_loss)
     Wt = {k: v.astype(np.float64) for k, v in model.get_weights_dict().items()}
     return model, Wt, cfg
@@ -198,8 +200,8 @@ def test_v1_training_graph_matches_as_written_oracle(gpu):
             assert np.abs(model.store.w[k].cpu().numpy() - Wt[k]).max() < 2e-5, (k, step)
 
 
-def test_v1_recurrent_dropout_is_opt_in_seeded_and_matches_the_oracle_given_its_masks(gpu):
-    """recurrent_dropout=0.2 (text_generation_model.py:141-142): off by default; when switched on, a train step draws seeded
+def test_v1_recurrent_dropout_default_is_seeded_and_matches_the_oracle_given_its_masks(gpu):
+    """recurrent_dropout=0.2 (text_generation_model.py:141-142) is the training default; a train step draws seeded
     per-gate masks for both LSTMs, and loss + every gradient equal the oracle's T-prefix graph run with those masks;
     test_on_batch / predict (learning phase 0) never apply them."""
     from image_captioning_amd import synth
@@ -209,7 +211,8 @@ def test_v1_recurrent_dropout_is_opt_in_seeded_and_matches_the_oracle_given_its_
     cfg.PADDING_SIZE = T
     model = build_lstm_model([7, 7, 256], cfg, 512, 'training', seed=0)
     model.compile(optimizer=Adam(amsgrad=True), loss="roi_caption_loss")
-    assert model.recurrent_dropout == 0.0
+    assert model.recurrent_dropout == 0.2
+    model.recurrent_dropout = 0.0
     Wt = {k: v.astype(np.float64) for k, v in model.get_weights_dict().items()}
     rng = np.random.default_rng(1)
     feat = rng.standard_normal((B, 7, 7, 256)).astype(np.float32)
@@ -227,8 +230,7 @@ def test_v1_recurrent_dropout_is_opt_in_seeded_and_matches_the_oracle_given_its_
     assert abs(got_loss - want_loss) < 1e-5 * max(1.0, abs(want_loss)) and abs(got_loss - plain) > 2e-6            # dropout did change the forward pass
     for k, g in G.items():
         assert rel_err(model.store.grad[k].cpu().numpy(), g) < 3e-4, k
-    again = build_lstm_model([7, 7, 256], cfg, 512, 'training', seed=0)                          # same seed: same masks
-    again.recurrent_dropout = 0.2
+    again = build_lstm_model([7, 7, 256], cfg, 512, 'training', seed=0)                          # same seed: same masks (the default rate)
     again._forward_train(again._dev_feat(feat), caps, tg, want_grad=True)
     assert all(np.array_equal(a, b) for a, b in zip(again.last_rec_masks, model.last_rec_masks))
 
@@ -299,6 +301,7 @@ def make_joint(S=128, V=24, T=5, blocks=1, rois=12, compute_dtype="f32"):
         PADDING_SIZE = T
         VOCABULARY_SIZE = V
         EMBEDDING_SIZE = 300
+        RECURRENT_DROPOUT = 0.0          # parity against the deterministic oracle graph (the training default is the reference's 0.2)
     cfg = Cfg()
     Wt = dict(synth.encoder_weights(0, blocks), **synth.rpn_weights(4))
     Wt['rpn_conv_shared/kernel'] = Wt['rpn_conv_shared/kernel'] * np.float32(0.05)
@@ -425,6 +428,35 @@ def test_joint_model_training_reduces_loss_and_round_trips_weights(gpu, tmp_path
     c = other.get_weights_dict()
     assert np.array_equal(b['fpn_p3/kernel'], c['fpn_p3/kernel']) and np.array_equal(b['mrcnn_class_conv1/kernel'], c['mrcnn_class_conv1/kernel'])
     assert not np.array_equal(b['imgcap_lstm_d2/kernel'], c['imgcap_lstm_d2/kernel'])
+
+
+def test_joint_model_trains_with_the_reference_recurrent_dropout_by_default(gpu):
+    """dense_img_cap/dense_model.py:769-770 builds both LSTMs with recurrent_dropout=0.2: without an explicit opt-out the joint
+    model's train steps draw fresh masks every step (seeded: two models with one seed agree), validation never does."""
+    S, V, T, blocks = 128, 24, 5, 1
+    _, cfg, Wt = make_joint(S, V, T, blocks)
+    del type(cfg).RECURRENT_DROPOUT                      # back to Config's default
+    assert cfg.RECURRENT_DROPOUT == 0.2
+    from image_captioning_amd.dense_model import DenseImageCapRCNN
+    inputs = joint_inputs(S, V, T)
+    runs = []
+    for _ in range(2):
+        model = DenseImageCapRCNN("training", cfg, "logs", stage4_blocks=blocks)
+        model.set_weights(Wt)
+        model.compile(1e-5)
+        assert model.caption_model.recurrent_dropout == 0.2
+        v0 = model.test_on_batch(inputs)
+        assert model.caption_model.last_rec_masks is None and v0 == model.test_on_batch(inputs)          # learning phase 0
+        l1 = model.train_on_batch(inputs)
+        m1 = model.caption_model.last_rec_masks
+        l2 = model.train_on_batch(inputs)
+        m2 = model.caption_model.last_rec_masks
+        assert np.isfinite(l1).all() and np.isfinite(l2).all()
+        assert m1[0].shape == (4, cfg.TRAIN_ROIS_PER_IMAGE, 512) and set(np.unique(m1[0])) <= {0.0, np.float32(1.25)}
+        assert not np.array_equal(m1[0], m2[0]) and not np.array_equal(m1[0], m1[1])                    # per step, per LSTM
+        runs.append((l1, l2, m2))
+    assert np.allclose(runs[0][0], runs[1][0], rtol=1e-5) and np.allclose(runs[0][1], runs[1][1], rtol=1e-4)      # (RPN loss sums are float atomics)
+    assert np.array_equal(runs[0][2][1], runs[1][2][1])                                                           # same seed, same step: same masks
 
 
 def test_joint_model_validation_is_forward_only(gpu):

@@ -518,3 +518,54 @@ def test_vgg16_layer_table_flops():
     assert all(s.k == 3 and s.stride == 1 and s.padding == "same" and s.bn is None for s in L)
     fl = sum(2.0 * (1024 // 2 ** (int(s.name[5]) - 1)) ** 2 * 9 * s.cin * s.cout for s in L)
     assert abs(fl / 1e9 - 641.43) < 0.01
+
+
+def test_fit_generator_runs_the_generator_on_a_background_thread_like_keras():
+    """keras fit_generator(workers=1, max_queue_size=q) as the reference calls it (text_generation_model_v2.py:300-313): batches
+    are produced on ONE background thread ahead of the training loop, never more than q (+ the one in hand) ahead; order is the
+    generator's; workers=0 runs it inline; a generator error reaches the caller; losses are averaged per epoch."""
+    import threading
+    import time
+    import torch
+    from image_captioning_amd.keras_like import KerasLikeModel, GeneratorEnqueuer
+
+    main = threading.get_ident()
+    produced, consumed, threads = [], [], set()
+
+    def gen(n=10 ** 6, fail_at=None):
+        for i in range(n):
+            if fail_at is not None and i == fail_at:
+                raise RuntimeError("bad batch %d" % i)
+            threads.add(threading.get_ident())
+            produced.append(i)
+            yield [np.full((2, 3), i, np.float32)], np.array([i])
+
+    class Toy(KerasLikeModel):
+        def train_on_batch_device(self, inputs, targets):
+            consumed.append(int(targets[0]))
+            assert len(produced) - len(consumed) <= self.q + 2          # bounded run-ahead: queue + one in each hand
+            time.sleep(0.002)
+            return torch.tensor([float(inputs[0][0, 0])])
+
+        def test_on_batch(self, inputs, targets):
+            return 7.0
+
+    m = Toy()
+    m.q = 3
+    hist = m.fit_generator(gen(), epochs=2, steps_per_epoch=5, max_queue_size=3, workers=1, verbose=0, validation_data=([0], [0]))
+    assert consumed == list(range(10)) and threads and main not in threads
+    assert [h["loss"] for h in hist] == [2.0, 7.0] and hist[0]["val_loss"] == 7.0
+    time.sleep(0.1)
+    assert len(produced) <= 10 + 3 + 2                                   # the worker stopped with the loop (bounded queue)
+    produced.clear(); consumed.clear(); threads.clear()
+    m.q = 0
+    m.fit_generator(gen(), epochs=1, steps_per_epoch=4, workers=0, verbose=0)
+    assert threads == {main} and produced == consumed == [0, 1, 2, 3]   # inline: exactly one batch per step
+    with pytest.raises(RuntimeError, match="bad batch 2"):
+        m.q = 10
+        m.fit_generator(gen(fail_at=2), epochs=1, steps_per_epoch=5, workers=1, verbose=0)
+    with pytest.raises(NotImplementedError):
+        m.fit_generator(gen(), epochs=1, steps_per_epoch=1, use_multiprocessing=True)
+    e = GeneratorEnqueuer(iter([1, 2, 3]), workers=1, max_queue_size=2)
+    assert list(e.get()) == [1, 2, 3]                                    # a finite generator ends the stream cleanly
+    e.stop()

@@ -33,6 +33,7 @@ def main():
         PADDING_SIZE = T
         VOCABULARY_SIZE = V
         EMBEDDING_SIZE = 300
+        RECURRENT_DROPOUT = 0.0
     cfg = Cfg()
     cfg.EMBEDDING_WEIGHTS = synth.embedding_matrix(3, V)
     model = DenseImageCapRCNN("training", cfg, "logs", conv_math=a.conv_math)
