@@ -1,8 +1,9 @@
 // gemm_bf16.hip -- dc_gemm_bf16: dense GEMM with bf16 operands in memory and fp32 accumulation on
 // v_mfma_f32_32x32x16_bf16 (bgemm_core.h), all three layouts of a training step (NN / NT / TN), the fused epilogue of
 // dc_gemm_f32 plus an optional bf16 copy of the output; and the fp32 -> bf16 cast that feeds it.
-#include "bgemm_core.h"
+#include "bgemm256_core.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace dcap {
 
@@ -88,10 +89,21 @@ __global__ __launch_bounds__(256) void cast_bf16_2d_kernel(const float* __restri
 
 using namespace dcap;
 
+// the 256-square kernel (bgemm256_core.h) where its grid fills the chip; the K-major gather (embedding-side weight gradient) stays
+// on the 128-square loop
+static bool use_b256(const dc_gemm_bf16_desc* d) { return !(d->a_gather && d->a_trans) && b256::prefer(d->M, d->N, d->K, d->split_k, bgemm_epilogue(d).vec4 != 0); }
+
 extern "C" size_t dc_gemm_bf16_workspace_bytes(const dc_gemm_bf16_desc* d) {
     if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
-    const BSplit sp = bgemm_split(d->M, d->N, d->K, d->split_k);
+    const BSplit sp = use_b256(d) ? b256::split(d->M, d->N, d->K, d->split_k) : bgemm_split(d->M, d->N, d->K, d->split_k);
     return sp.split > 1 ? (size_t)sp.split * d->M * d->N * sizeof(float) : 0;
+}
+
+extern "C" int dc_gemm_bf16_tile(const dc_gemm_bf16_desc* d, int* split_k) {
+    if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+    const bool big = use_b256(d);
+    if (split_k) *split_k = (big ? b256::split(d->M, d->N, d->K, d->split_k) : bgemm_split(d->M, d->N, d->K, d->split_k)).split;
+    return big ? 256 : 128;
 }
 
 extern "C" int dc_gemm_bf16(const dc_gemm_bf16_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
@@ -101,6 +113,12 @@ extern "C" int dc_gemm_bf16(const dc_gemm_bf16_desc* d, void* workspace, size_t 
     const Epilogue ep = bgemm_epilogue(d);
     BOperand a, b;
     bgemm_operands(d, a, b);
+    if (use_b256(d)) {
+        if (!d->a_trans && !d->b_trans) return b256::launch<true, false>(a, b, ep, d->M, d->N, d->K, d->split_k, workspace, workspace_bytes, s);
+        if (!d->a_trans && d->b_trans) return b256::launch<true, true>(a, b, ep, d->M, d->N, d->K, d->split_k, workspace, workspace_bytes, s);
+        if (d->a_trans && !d->b_trans) return b256::launch<false, false>(a, b, ep, d->M, d->N, d->K, d->split_k, workspace, workspace_bytes, s);
+        return b256::launch<false, true>(a, b, ep, d->M, d->N, d->K, d->split_k, workspace, workspace_bytes, s);
+    }
     if (!d->a_trans && !d->b_trans) return launch_bgemm<true, false>(a, b, ep, d->M, d->N, d->K, d->split_k, workspace, workspace_bytes, s);
     if (!d->a_trans && d->b_trans) return launch_bgemm<true, true>(a, b, ep, d->M, d->N, d->K, d->split_k, workspace, workspace_bytes, s);
     if (d->a_trans && !d->b_trans) return launch_bgemm<false, false>(a, b, ep, d->M, d->N, d->K, d->split_k, workspace, workspace_bytes, s);

@@ -17,7 +17,7 @@
 //               data gradient GEMMs) plus per-tile column sums (the bias gradient, combined in a fixed order).
 // The recomputation costs one extra GEMM pass (two for keras_sparse); in exchange nothing of size rows x V is written
 // but the gradient itself.  All reductions are wavefront shuffles over the 32 lanes that share a row of the tile.
-#include "bgemm_core.h"
+#include "bgemm256_core.h"
 #include <algorithm>
 
 namespace dcap {
@@ -184,6 +184,163 @@ __global__ __launch_bounds__(256, 2) void vocab_ce_bf16_kernel(BOperand a, BOper
     ce_epilogue<MODE>(acc, smem, ce, m0, n0, wm, wn, tile_m, tile_n);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same three passes on the 256 x 256 bf16 tile (bgemm256_core.h).  The accumulators are never transposed through LDS:
+// lane l of wave (group g, column c) holds, for mt = 0..7 and nt = 0..3, the four consecutive logits
+//   row  m0 + 128 g + 64 (mt >> 2) + 16 (mt & 3) + (l & 15),   columns  n0 + 64 c + 32 (nt >> 1) + 16 (nt & 1) + 4 (l >> 4) .. + 3,
+// so a row reduction over the tile's 256 columns is 16 in-lane terms, two shuffles (lanes l ^ 16, l ^ 32 hold the other column
+// quads of the same row) and a 4-entry combine across the wave columns through LDS; column sums (the bias gradient) are 8 in-lane
+// rows, four shuffles over the 16 row lanes and a 2-entry combine across the wave groups -- all in a fixed order.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float quad_max(float v) { return fmaxf(fmaxf(v, __shfl_xor(v, 16, 64)), fmaxf(__shfl_xor(v, 32, 64), __shfl_xor(v, 48, 64))); }
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+template <int MODE>
+__device__ __forceinline__ void ce_epilogue256(b256::f32x4 (&acc)[8][4], float* lds, const CeArgs& ce, int m0, int n0, int tile_m, int tile_n) {
+    using b256::f32x4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int group = wave >> 2, wcol = wave & 3, i = lane & 15, q = lane >> 4;
+    const int cbase = n0 + 64 * wcol + 4 * q;
+    f32x4 bias[4];
+    bool cv[4];
+    int col[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        col[nt] = cbase + 32 * (nt >> 1) + 16 * (nt & 1);
+        cv[nt] = col[nt] < ce.V;                                  // V % 4 == 0: a lane's four columns are all inside or all outside
+        bias[nt] = (ce.bias && cv[nt]) ? *reinterpret_cast<const f32x4*>(ce.bias + col[nt]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float2* part = reinterpret_cast<float2*>(lds);               // [4 wave columns][256 tile rows]
+    f32x4 cs[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) cs[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        const int lr = 128 * group + 64 * (mt >> 2) + 16 * (mt & 3) + i, row = m0 + lr;
+        const bool rv = row < ce.M;
+        const int t = rv ? ce.targets[row] : -1;
+        f32x4 z[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) z[nt] = acc[mt][nt] + bias[nt];
+        if constexpr (MODE == CE_STATS) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                if (cv[nt]) mx = fmaxf(mx, fmaxf(fmaxf(z[nt][0], z[nt][1]), fmaxf(z[nt][2], z[nt][3])));
+            mx = quad_max(mx);
+            float sm = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                if (cv[nt]) sm += __expf(z[nt][0] - mx) + __expf(z[nt][1] - mx) + __expf(z[nt][2] - mx) + __expf(z[nt][3] - mx);
+            sm = quad_sum(sm);
+            if (q == 0) part[wcol * 256 + lr] = make_float2(mx, sm);       // mx = -inf, sm = 0 when the wave's 64 columns lie past V
+            if (rv && t < ce.V)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int d = t - col[nt];
+                    if (d >= 0 && d < 4) ce.zt[row] = d == 0 ? z[nt][0] : (d == 1 ? z[nt][1] : (d == 2 ? z[nt][2] : z[nt][3]));
+                }
+        } else {
+            const float* ri = ce.rowinfo + (long)min(row, ce.M - 1) * CE_RI;
+            const float m = ri[0], inv_s = ri[1];
+            auto unclipped = [](float p) { return p >= 1e-7f && p <= 1.f - 1e-7f; };
+            auto clip = [](float p) { return fminf(fmaxf(p, 1e-7f), 1.f - 1e-7f); };
+            f32x4 p[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) p[nt][j] = __expf(z[nt][j] - m) * inv_s;
+            if constexpr (MODE == CE_CLIP) {
+                float S = 0.f, U = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    if (cv[nt])
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            S += clip(p[nt][j]);
+                            U += unclipped(p[nt][j]) ? p[nt][j] : 0.f;
+                        }
+                S = quad_sum(S);
+                U = quad_sum(U);
+                if (q == 0) part[wcol * 256 + lr] = make_float2(S, U);
+            } else {
+                const float gs = ri[2], invS = ri[3], c = ri[4], tq = ri[5];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    f32x4 g;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool hit = t == col[nt] + j;
+                        g[j] = ce.keras_sparse ? gs * p[nt][j] * ((unclipped(p[nt][j]) ? invS : 0.f) - (hit ? tq : 0.f) - c) : gs * (p[nt][j] - (hit ? 1.f : 0.f));
+                        if (!cv[nt]) g[j] = 0.f;               // columns V .. lddl-1 of the gradient are the zero K padding of the GEMMs that read it
+                    }
+                    if (rv) {
+                        cs[nt] += g;
+                        if (col[nt] < ce.lddl) {                   // lddl % 4 == 0
+                            if (ce.dl_f32) {
+                                *reinterpret_cast<f32x4*>(ce.dl_f32 + (long)row * ce.lddl + col[nt]) = g;
+                            } else {
+                                typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+                                *reinterpret_cast<us4*>(ce.dl_bf16 + (long)row * ce.lddl + col[nt]) =
+                                    us4{Epilogue::bf16_bits(g[0]), Epilogue::bf16_bits(g[1]), Epilogue::bf16_bits(g[2]), Epilogue::bf16_bits(g[3])};
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (MODE != CE_DL) {
+        __syncthreads();
+        if (tid < 256 && m0 + tid < ce.M) {                          // one thread per tile row: combine the four wave columns in order
+            const float2 a0 = part[tid], a1 = part[256 + tid], a2 = part[512 + tid], a3 = part[768 + tid];
+            float2 r;
+            if constexpr (MODE == CE_STATS) {
+                const float m = fmaxf(fmaxf(a0.x, a1.x), fmaxf(a2.x, a3.x));            // finite: column 0 of every tile is a real word
+                r = make_float2(m, a0.y * __expf(a0.x - m) + a1.y * __expf(a1.x - m) + a2.y * __expf(a2.x - m) + a3.y * __expf(a3.x - m));
+            } else {
+                r = make_float2(a0.x + a1.x + a2.x + a3.x, a0.y + a1.y + a2.y + a3.y);
+            }
+            *reinterpret_cast<float2*>(ce.stats + ((long)(m0 + tid) * ce.tiles_n + tile_n) * 2) = r;
+        }
+    } else if (ce.dbias_part) {
+        float* red = lds;                                            // [2 wave groups][256 tile columns]
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = cs[nt][j];
+                v += __shfl_xor(v, 1, 64);
+                v += __shfl_xor(v, 2, 64);
+                v += __shfl_xor(v, 4, 64);
+                v += __shfl_xor(v, 8, 64);
+                if (i == 0) red[group * 256 + 64 * wcol + 32 * (nt >> 1) + 16 * (nt & 1) + 4 * q + j] = v;
+            }
+        __syncthreads();
+        if (tid < 256 && n0 + tid < ce.V) ce.dbias_part[(long)tile_m * ce.V + n0 + tid] = red[tid] + red[256 + tid];
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(b256::NTHREADS, 2) void vocab_ce_bf16_256_kernel(BOperand a, BOperand b, CeArgs ce, int K, int tiles_m) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tile_m, tile_n;
+    b256::tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, ce.tiles_n, tile_m, tile_n);
+    const int m0 = tile_m * b256::BM, n0 = tile_n * b256::BN;
+    b256::Load<true, true> la;
+    b256::Load<false, false> lb;
+    la.init(a, m0, lane, wave);
+    lb.init(b, n0, lane, wave);
+    b256::f32x4 acc[8][4];
+    b256::mainloop(la, lb, reinterpret_cast<char*>(smem), 0, K, acc);
+    ce_epilogue256<MODE>(acc, smem, ce, m0, n0, tile_m, tile_n);
+}
+
 // One wave per row: combines the per-tile partials.
 //   phase 0 (after STATS): m = max m_j, s = sum s_j exp(m_j - m), p_t = exp(z_t - m)/s.
 //       categorical: loss = rw * -log(clip(p_t)); gs = grad_scale * rw when p_t is inside the clip range, else 0
@@ -245,10 +402,13 @@ struct CePlan {
     int tiles_m, tiles_n;
     size_t off_stats, off_zt, off_ri, off_db, total;
 };
+// bf16 problems whose 256-square grid covers the chip run on the large tile (bgemm256_core.h)
+static bool ce_big(const dc_vocab_ce_desc* d) { return d->bf16 && b256::prefer(d->M, d->V, d->K, 1); }
 static CePlan ce_plan(const dc_vocab_ce_desc* d) {
     CePlan p;
-    p.tiles_m = (d->M + 127) / 128;
-    p.tiles_n = (d->V + 127) / 128;
+    const int T = ce_big(d) ? 256 : 128;
+    p.tiles_m = (d->M + T - 1) / T;
+    p.tiles_n = (d->V + T - 1) / T;
     p.off_stats = 0;
     p.off_zt = align256((size_t)d->M * p.tiles_n * 2 * sizeof(float));
     p.off_ri = p.off_zt + align256((size_t)d->M * sizeof(float));
@@ -285,7 +445,12 @@ static int ce_validate(const dc_vocab_ce_desc* d) {
 template <int MODE>
 static int ce_launch(const dc_vocab_ce_desc* d, const CeArgs& ce, const CePlan& p, hipStream_t s) {
     const int tiles = p.tiles_m * p.tiles_n;
-    if (d->bf16) {
+    if (ce_big(d)) {
+        DC_ENSURE_DYN_LDS((&vocab_ce_bf16_256_kernel<MODE>), 160 * 1024);
+        BOperand a{static_cast<const unsigned short*>(d->X), d->ldx, d->M, nullptr, (unsigned)((size_t)d->M * d->ldx * 2)};
+        BOperand b{static_cast<const unsigned short*>(d->W), d->ldw, d->V, nullptr, (unsigned)((size_t)d->K * d->ldw * 2)};
+        hipLaunchKernelGGL((vocab_ce_bf16_256_kernel<MODE>), dim3(tiles), dim3(b256::NTHREADS), b256::LDS_BYTES, s, a, b, ce, d->K, p.tiles_m);
+    } else if (d->bf16) {
         DC_ENSURE_DYN_LDS((&vocab_ce_bf16_kernel<MODE>), 160 * 1024);
         BOperand a{static_cast<const unsigned short*>(d->X), d->ldx, d->M, nullptr, (unsigned)((size_t)d->M * d->ldx * 2)};
         BOperand b{static_cast<const unsigned short*>(d->W), d->ldw, d->V, nullptr, (unsigned)((size_t)d->K * d->ldw * 2)};

@@ -112,7 +112,7 @@ def to_bf16(x, out=None, pad_cols=None):
 
 
 def gemm_bf16(A, B, out=None, out_bf16=None, a_trans=False, b_trans=False, gather=None, scale=None, shift=None,
-              residual=None, res_rows=0, relu=False, accumulate=False, split_k=0):
+              residual=None, res_rows=0, relu=False, accumulate=False, split_k=0, info=None):
     """op(A) @ op(B) with bf16 operands, fp32 accumulate (dc_gemm_bf16).  out: fp32 [M,N] result (allocated when neither
     out nor out_bf16 is given); out_bf16: optional bf16 [M,N] copy of the result.  Returns out if present else out_bf16."""
     lib = _lib.load()
@@ -148,6 +148,10 @@ def gemm_bf16(A, B, out=None, out_bf16=None, a_trans=False, b_trans=False, gathe
         _chk(residual, name="residual")
         d.residual, d.ldr, d.res_rows = residual.data_ptr(), residual.stride(0), int(res_rows)
     d.relu, d.accumulate, d.split_k = int(relu), int(accumulate), int(split_k)
+    if info is not None:                      # tests / benches: which kernel runs this problem
+        sk = C.c_int(0)
+        info["tile"] = int(lib.dc_gemm_bf16_tile(C.byref(d), C.byref(sk)))
+        info["split_k"] = int(sk.value)
     ws, wsb = WORKSPACE.get(lib.dc_gemm_bf16_workspace_bytes(C.byref(d)), A.device)
     check(lib.dc_gemm_bf16(C.byref(d), _ptr(ws), wsb, _stream()), "dc_gemm_bf16")
     return out if out is not None else out_bf16

@@ -94,6 +94,10 @@ typedef struct {
 
 size_t dc_gemm_bf16_workspace_bytes(const dc_gemm_bf16_desc* d);
 int    dc_gemm_bf16(const dc_gemm_bf16_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+/* Profiling / test aid: the block tile dc_gemm_bf16 runs `d` on -- 256 (bgemm256_kernel: 256 x 256 x 64, 8 waves, one block per CU,
+ * v_mfma_f32_16x16x32_bf16) or 128 (bgemm_kernel: 128 x 128 x 64, 4 waves, two blocks per CU); *split_k (may be NULL) receives the
+ * number of split-K slices.  Returns 0 for an invalid descriptor. */
+int    dc_gemm_bf16_tile(const dc_gemm_bf16_desc* d, int* split_k);
 
 /* conv2d weight gradient on the bf16 matrix pipe (configs[4]: the joint model's trainable FPN / RPN convolutions,
  * dense_img_cap/dense_model.py:1829-1831): dw[cout][(ky,kx,ci)] (+)= sum over output pixels of dy[p][cout] * x[p*stride + tap - pad][ci],

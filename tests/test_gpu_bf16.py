@@ -57,6 +57,59 @@ def test_gemm_bf16_layouts(ops, M, N, K, ta, tb):
     close(ops.gemm_bf16(a, b, a_trans=bool(ta), b_trans=bool(tb)), O.to_bf16(A) @ O.to_bf16(B))
 
 
+@pytest.mark.parametrize("M,N,K,split", [(3000, 4104, 200, 1), (1024, 1024, 8192, 16), (3072, 4096, 512, 1), (4096, 3072, 72, 1)])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_bf16_256_tile_layouts(ops, M, N, K, split, ta, tb):
+    """The 256 x 256 x 64 kernel (csrc/bgemm256_core.h): all four layouts, ragged edges in M and N, a K tail (200 = 3 x 64 + 8), a
+    single short K-tile pair (72), exact tiling, automatic split-K; the library reports which tile ran."""
+    rng = np.random.default_rng(M * 7 + N * 3 + K + ta * 2 + tb)
+    A = rng.standard_normal((M, K))
+    B = rng.standard_normal((K, N))
+    a = ops.to_bf16(dev(A.T if ta else A))
+    b = ops.to_bf16(dev(B.T if tb else B))
+    info = {}
+    got = ops.gemm_bf16(a, b, a_trans=bool(ta), b_trans=bool(tb), info=info)
+    assert info == {"tile": 256, "split_k": split}
+    close(got, O.to_bf16(A) @ O.to_bf16(B))
+
+
+def test_gemm_bf16_256_tile_epilogue_gather_and_bf16_output(ops):
+    """Fused epilogue of the 256-square kernel straight from the accumulators: scale / shift / residual / ReLU / accumulate, the
+    per-RoI (row-modulo) residual, the bf16 copy, a bf16-only output, and the row gather on A."""
+    rng = np.random.default_rng(21)
+    M, N, K = 3000, 4096, 512
+    A = rng.standard_normal((M, K))
+    B = rng.standard_normal((K, N)) / np.sqrt(K)
+    sc, sh = rng.uniform(0.5, 1.5, N), rng.standard_normal(N)
+    R = rng.standard_normal((M, N))
+    C0 = rng.standard_normal((M, N))
+    ab, bb = ops.to_bf16(dev(A)), ops.to_bf16(dev(B))
+    prod = O.to_bf16(A) @ O.to_bf16(B)
+    want = np.maximum(prod * sc + sh + R, 0) + C0
+    out = dev(C0)
+    outb = torch.empty((M, N), dtype=BF, device="cuda")
+    info = {}
+    ops.gemm_bf16(ab, bb, out=out, out_bf16=outb, scale=dev(sc), shift=dev(sh), residual=dev(R), relu=True, accumulate=True, info=info)
+    assert info["tile"] == 256
+    close(out, want)
+    assert np.abs(outb.float().cpu().numpy() - want).max() <= 2.0 ** -8 * np.abs(want).max() + 1e-6
+    only_b = torch.empty((M, N), dtype=BF, device="cuda")
+    ops.gemm_bf16(ab, bb, out_bf16=only_b, shift=dev(sh), info=info)
+    assert info["tile"] == 256
+    assert np.abs(only_b.float().cpu().numpy() - (prod + sh)).max() <= 2.0 ** -8 * np.abs(prod + sh).max() + 1e-6
+    Bn = 200                                                           # per-RoI term broadcast over the 15 timesteps
+    r = rng.standard_normal((Bn, N))
+    close(ops.gemm_bf16(ab, bb, residual=dev(r), res_rows=Bn, info=info), prod + np.tile(r, (M // Bn, 1)))
+    assert info["tile"] == 256
+    ids = rng.integers(0, M, 2600)
+    close(ops.gemm_bf16(ab, bb, gather=dev(ids, torch.int32), info=info), prod[ids])
+    assert info["tile"] == 256
+    # rows that are not 16-byte addressable go to the 128-square kernel (scalar epilogue)
+    bt = ops.to_bf16(dev(B.T))
+    close(ops.gemm_bf16(ab, bt[:4094], b_trans=True, info=info), prod[:, :4094])
+    assert info["tile"] == 128
+
+
 @pytest.mark.parametrize("split", [0, 1, 3, 7])
 def test_gemm_bf16_epilogue_splitk_and_bf16_output(ops, split):
     rng = np.random.default_rng(11 + split)
@@ -199,6 +252,42 @@ def test_vocab_ce_masked_keras_sparse(ops, bf16, M, V, K):
     only_loss = torch.empty(M, device="cuda")
     ops.vocab_ce(Xd, Wd, dev(b), dev(t, torch.int32), loss_rows=only_loss, row_weights=dev(w), keras_sparse=True)      # forward only
     assert torch.equal(only_loss, loss)
+
+
+@pytest.mark.parametrize("M,V,K,sparse", [(3000, 4104, 256, False), (2900, 5000, 200, False), (1500, 8200, 512, True), (3000, 50000, 1024, True)])
+def test_vocab_ce_bf16_on_the_256_tile(ops, M, V, K, sparse):
+    """Problems whose 256 x 256 grid covers the chip run the three passes on the large tile (csrc/bgemm256_core.h), reductions
+    straight from the accumulators: ragged M and V, a K tail, both loss flavours, fp32 and bf16 gradient, the bias gradient.
+    The last case is BASELINE configs[4]'s own shape (200 RoIs x 15 tokens, 50 000 words)."""
+    rng = np.random.default_rng(V + K + M)
+    X, W, b, t, _ = _ce_case(rng, M, V, K, True)
+    if sparse:
+        b[t[0]] -= 80.0
+    X[1] = 0
+    w = rng.random(M)
+    w[2] = 0.0
+    Xd, Wd = ops.to_bf16(dev(X)), ops.to_bf16(dev(W))
+    p = O.softmax(O.to_bf16(X) @ O.to_bf16(W) + b)
+    if sparse:
+        want_loss, want_d = O.sparse_cce_keras_with_grad(t, p, w)
+        kw = dict(grad_scale=1.0, row_weights=dev(w), keras_sparse=True)
+        scale = 1.0
+    else:
+        want_loss, want_d = O.categorical_crossentropy(t, p), O.softmax_ce_grad_logits(t, p, np.full(M, 1.0 / M)) * M
+        kw = dict(grad_scale=1.0 / M)
+        scale = float(M)
+    loss = torch.empty(M, device="cuda")
+    dl = torch.full((M, V), 7.0, device="cuda")
+    db = torch.empty(V, device="cuda")
+    ops.vocab_ce(Xd, Wd, dev(b), dev(t, torch.int32), loss_rows=loss, dlogits=dl, dbias=db, **kw)
+    close(loss, want_loss, 3e-5)
+    close(dl * scale, want_d, 3e-5)
+    close(db * scale, want_d.sum(0), 2e-4)
+    Vp = V + 8
+    dlb = torch.full((M, Vp), 7.0, dtype=BF, device="cuda")              # bf16 gradient output, K-padded with zeros
+    ops.vocab_ce(Xd, Wd, dev(b), dev(t, torch.int32), dlogits=dlb, **kw)
+    got = dlb.float().cpu().numpy().astype(np.float64) * scale
+    assert np.abs(got[:, :V] - want_d).max() <= 2.0 ** -8 * np.abs(want_d).max() + 1e-6 and not got[:, V:].any()
 
 
 @pytest.mark.parametrize("case", [

@@ -1,0 +1,52 @@
+"""Micro-benchmark of dc_vocab_ce at BASELINE configs[4]'s shape (200 RoIs x 15 tokens = 3000 rows, K = 1024, V = 50 000, bf16):
+the whole call (keras_sparse: STATS + CLIP + DL passes, 3 x 307 GFLOP) and the forward-only call (2 passes), random data.
+Usage: python tools/vocab_ce_bench.py [M V K]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from image_captioning_amd import ops
+
+
+def timed(fn, reps=5, inner=5):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(inner):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / inner)
+    return best
+
+
+def main():
+    M, V, K = (int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (3000, 50000, 1024)
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(0)
+    X = torch.randn((M, K), device=dev, generator=g).to(torch.bfloat16)
+    W = (torch.randn((K, V), device=dev, generator=g) * (2.0 / K ** 0.5)).to(torch.bfloat16)
+    b = torch.randn(V, device=dev, generator=g)
+    t = torch.randint(0, V, (M,), device=dev, generator=g, dtype=torch.int32)
+    w = torch.rand(M, device=dev, generator=g)
+    loss = torch.empty(M, device=dev)
+    dl = torch.empty((M, V), dtype=torch.bfloat16, device=dev)
+    db = torch.empty(V, device=dev)
+    gf = 2.0 * M * V * K / 1e9
+    for name, sparse in (("categorical (2 passes)", False), ("keras_sparse (3 passes)", True)):
+        passes = 3 if sparse else 2
+        kw = dict(row_weights=w, keras_sparse=True) if sparse else {}
+        ms = timed(lambda: ops.vocab_ce(X, W, b, t, loss_rows=loss, dlogits=dl, dbias=db, grad_scale=1.0, **kw))
+        fwd = timed(lambda: ops.vocab_ce(X, W, b, t, loss_rows=loss, **kw))
+        print("%-24s train call %7.1f us = %6.1f us/pass, %6.1f TFLOP/s per pass incl. row kernels; forward-only call %7.1f us"
+              % (name, ms * 1e3, ms * 1e3 / passes, passes * gf / ms, fwd * 1e3), flush=True)
+
+
+if __name__ == "__main__":
+    main()
