@@ -28,6 +28,7 @@ Rank 0 prints ONE JSON line (see the driver contract) with extra objects:
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -432,7 +433,6 @@ def self_launch(n, argv=None, script=None, timeout_s=None, extra_env=None):
     share devices over the gloo backend -- a rehearsal of the multi-process path, flagged as such in the JSON line
     (`dist_backend`)."""
     import socket
-    import subprocess
     script = script or os.path.abspath(__file__)
     argv = list(sys.argv[1:] if argv is None else argv)
     timeout_s = float(os.environ.get("DCAP_BENCH_TIMEOUT", 1500) if timeout_s is None else timeout_s)
@@ -476,6 +476,62 @@ def self_launch(n, argv=None, script=None, timeout_s=None, extra_env=None):
     sys.stdout.write(out)
     sys.stdout.flush()
     return rc
+
+
+def joint_roofline(args, dev, inner):
+    """Roofline block of the joint leg (rank 0, after the timed region), against the dense bf16 MFMA peak:
+    the bf16 convolutions of the forward plan, timed per launch with HIP events on the launch stream and grouped by kernel
+    (bconv256_kernel: the 256 x 256 x 64 tile; bconv_kernel: the 128 x 128 tile incl. its split-K slab reductions) -- `achieved`
+    is the group with the largest time share; and the fused vocabulary softmax / cross-entropy at the step's own shape
+    (TRAIN_ROIS_PER_IMAGE x T rows, K = 1024, V words; keras_sparse: three GEMM passes), timed as whole calls."""
+    from image_captioning_amd import ops
+    plan = inner.plan()
+    rows = plan.time_bconvs(reps=3)
+    groups = {}
+    for name, fl, ms, tile, sk in rows:
+        g = groups.setdefault("bconv256_kernel" if tile == 256 else "bconv_kernel", {"flops": 0.0, "ms": 0.0, "launches": 0, "split_k_layers": 0})
+        g["flops"] += fl
+        g["ms"] += ms
+        g["launches"] += 1
+        g["split_k_layers"] += int(sk > 1)
+    dom = max(groups, key=lambda k: groups[k]["ms"])
+    g = groups[dom]
+    ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
+    tot_fl, tot_ms = sum(v["flops"] for v in groups.values()), sum(v["ms"] for v in groups.values())
+    out = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS,
+           "traffic": None, "measured": "HIP events around every dc_conv2d_bf16 launch of the forward plan (eager replay, alone on the chip)",
+           "launches_per_step": g["launches"], "gflop_per_launch": g["flops"] / g["launches"] / 1e9, "avg_launch_us": 1e3 * g["ms"] / g["launches"],
+           "forward_bf16_convs": {"gflop_per_step": tot_fl / 1e9, "ms_per_step": tot_ms, "tflops": tot_fl / (tot_ms * 1e-3) / 1e12},
+           "kernels": {k: {"launches": v["launches"], "split_k_layers": v["split_k_layers"], "ms": round(v["ms"], 4),
+                           "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in groups.items()}}
+    # the vocabulary layer at the step's shape
+    M, V, K = inner.config.TRAIN_ROIS_PER_IMAGE * args.tokens, args.vocab, 1024
+    gen = torch.Generator(device=dev).manual_seed(0)
+    X = torch.randn((M, K), device=dev, generator=gen).to(torch.bfloat16)
+    W = (torch.randn((K, V), device=dev, generator=gen) * (2.0 / K ** 0.5)).to(torch.bfloat16)
+    b = torch.randn(V, device=dev, generator=gen)
+    t = torch.randint(0, V, (M,), device=dev, generator=gen, dtype=torch.int32)
+    w = torch.rand(M, device=dev, generator=gen)
+    loss, dl, db = torch.empty(M, device=dev), torch.empty((M, V), dtype=torch.bfloat16, device=dev), torch.empty(V, device=dev)
+
+    def call():
+        ops.vocab_ce(X, W, b, t, loss_rows=loss, dlogits=dl, dbias=db, grad_scale=1.0, row_weights=w, keras_sparse=True)
+    for _ in range(3):
+        call()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / 5)
+    gf = 3 * 2.0 * M * V * K / 1e9
+    out["vocab_ce"] = {"rows": M, "vocab": V, "k": K, "passes": 3, "ms_per_call": best, "ms_per_pass": best / 3, "tflops": gf / best,
+                       "frac": gf / best / PEAK_BF16_MFMA_TFLOPS, "gflop_per_call": gf}
+    return out
 
 
 def main():
@@ -525,6 +581,9 @@ def main():
                        "decoder_dtype": args.joint_dtype, "recurrent_dropout": args.joint_dropout, "conv_math": inner.conv_math_name, "losses": [float(v) for v in losses],
                        "rccl_ranks": ranks_seen, "dist_backend": backend},
         }
+        if rank == 0 and not args.no_roofline and args.joint_dtype == "bf16" and inner.conv_math_name == "bf16":
+            inner.grad_sync = None
+            out["roofline"] = joint_roofline(args, dev, inner)
         if rank == 0:
             print(json.dumps(out))
         if world > 1:
@@ -565,7 +624,6 @@ def main():
         # Same workload with the encoder's convolutions on the bf16 matrix pipe (operands split into bf16 pieces on the fly,
         # fp32 accumulate; csrc/igemm_bf16s.h), each mode timed by a child process of this one after the headline run.
         # Reported beside the headline, which stays on exact fp32 products.
-        import subprocess
         torch.cuda.synchronize()
         labels = {"bf16x3": "3-piece bf16 split of both operands, 6 MFMA products, fp32 accumulate (fp32-grade: same test tolerances)",
                   "bf16x2": "2-piece bf16 split, 3 MFMA products, fp32 accumulate (2^-16 products; features within 1e-3 of the oracle)"}
@@ -585,7 +643,6 @@ def main():
         other = {}
         try:
             # configs[2] proper: ONE image per step, timed by a child process (a fresh context, like the alt_math legs)
-            import subprocess
             del e2e
             torch.cuda.empty_cache()
             cmd1 = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-alt-math",
@@ -612,6 +669,18 @@ def main():
                                        "all_conv": vg.get("roofline", {}).get("all_conv")}
         except Exception as e:
             other["error_gpu"] = repr(e)[:300]
+        try:
+            # BASELINE configs[4]: the joint model's train step in bf16 (child process; carries its own roofline block against the
+            # dense bf16 MFMA peak)
+            cmdj = [sys.executable, os.path.abspath(__file__), "--config", "joint", "--steps", str(max(5, args.steps // 2)), "--warmup", "3",
+                    "--image-size", str(S), "--tokens", str(T), "--stage4-blocks", str(args.stage4_blocks)]
+            rj = subprocess.run(cmdj, capture_output=True, text=True, timeout=400)
+            jt = json.loads(rj.stdout.strip().splitlines()[-1])
+            other["configs4_joint"] = {"workload": jt["config"]["workload"], "value": jt["value"], "unit": "captions/s", "ms_per_step": jt["ms_per_step"],
+                                       "steps": jt["steps"], "dtype": jt["dtype"], "positive_rois": jt["config"]["positive_rois"],
+                                       "rois_per_image": jt["config"]["rois_per_image"], "roofline": jt.get("roofline")}
+        except Exception as e:
+            other["error_joint"] = repr(e)[:300]
         if not args.no_cpu_baseline:
             try:
                 other.update(cpu_companions())

@@ -8,7 +8,7 @@
 // padding load hardware zeros (the lane's offset is replaced by an out-of-range one).  No im2col buffer, no staging
 // registers, no conversion: the split-bf16 loop this replaces (igemm_bf16s.h with one product) loaded fp32, rounded on the
 // way to LDS and synchronised every 32 k -- 250 TFLOP/s on the joint model's layers.
-#include "bgemm_core.h"
+#include "bgemm256_core.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -79,6 +79,65 @@ __global__ __launch_bounds__(256, 2) void bconv_kernel(BConvA a, BOperand b, Epi
     store_tile<BT, BT>(acc, smem_f, ep, partial, M, N, m0, n0, wm, wn);
 }
 
+// The same A operand for the 256 x 256 tile (bgemm256_core.h): two 128-row sub-images per K-tile, two 1-KiB pieces per wave each.
+struct BLoadConvA256 {
+    static constexpr bool KC = true;
+    __amdgpu_buffer_rsrc_t rsrc;
+    BConvA c;
+    unsigned base[2][2];           // [half][piece]: byte offset of (image n, row 0, col 0, this lane's channel chunk)
+    int iy0[2][2], ix0[2][2];      // input row / column of tap (0, 0) for this lane's output pixel
+    int kpt;                       // K-tiles per tap = Cin / 64
+    __device__ __forceinline__ void init(const BConvA& cc, int m0, int lane, int wave) {
+        c = cc;
+        kpt = c.Cin / BKB;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(c.x), 0, (int)c.bytes, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int rp = 8 * (2 * wave + jj) + (lane >> 3);         // sub-image row of this lane's chunk
+                const int ch = (lane & 7) ^ ((rp >> 1) & 7);
+                const int p = min(m0 + b256::tile_index<true>(u, rp), c.M - 1);   // pixels past the end feed rows that are never stored
+                const int n = p / (c.Ho * c.Wo), rem = p - n * (c.Ho * c.Wo);
+                const int oy = rem / c.Wo, ox = rem - oy * c.Wo;
+                iy0[u][jj] = oy * c.stride - c.pad_t;
+                ix0[u][jj] = ox * c.stride - c.pad_l;
+                base[u][jj] = (unsigned)(((long)n * c.H * c.W * c.Cin + 8 * ch) * 2);
+            }
+    }
+    __device__ __forceinline__ void issue(int u, char* sub, int k0, int kend, int wave) const {
+        const int t = k0 / BKB;                                        // block-uniform: K-tile -> (tap, channel chunk)
+        const int tap = t / kpt, c0 = (t - tap * kpt) * BKB;
+        const int ky = tap / c.kw, kx = tap - ky * c.kw;
+        const bool live = k0 < kend;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int iy = iy0[u][jj] + ky, ix = ix0[u][jj] + kx;
+            const bool in = live && (unsigned)iy < (unsigned)c.H && (unsigned)ix < (unsigned)c.W;
+            const unsigned off = base[u][jj] + (unsigned)(((iy * c.W + ix) * c.Cin + c0) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (DC_LDS void*)(sub + (2 * wave + jj) * 1024), 16, (int)(in ? off : kOobOffset), 0, 0, 0);
+        }
+    }
+};
+
+__global__ __launch_bounds__(b256::NTHREADS, 2) void bconv256_kernel(BConvA a, BOperand b, Epilogue ep, int M, int N, int K, int klen, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tiles_m = (M + b256::BM - 1) / b256::BM, tiles_n = (N + b256::BN - 1) / b256::BN;
+    int tm, tn;
+    b256::tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * b256::BM, n0 = tn * b256::BN;
+    const int kbeg = blockIdx.z * klen, kend = min(K, kbeg + klen);
+    BLoadConvA256 la;
+    b256::Load<true, false> lb;
+    la.init(a, m0, lane, wave);
+    lb.init(b, n0, lane, wave);
+    b256::f32x4 acc[8][4];
+    b256::mainloop(la, lb, reinterpret_cast<char*>(smem_f), kbeg, kend, acc);
+    b256::store_tile(acc, ep, partial, M, N, m0, n0);
+}
+
 static int conv_bf16_validate(const dc_conv_bf16_desc* d) {
     DC_REQUIRE(d && d->x && d->w && (d->y || d->y_bf16), DC_EINVAL, "dc_conv2d_bf16: x, w and at least one of y / y_bf16 must be non-null");
     DC_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->kh >= 1 && d->kw >= 1 && d->stride >= 1 && d->Cout > 0, DC_EINVAL,
@@ -114,11 +173,25 @@ static BSplit bconv_split(int M, int N, int K, int user_split) {
 
 using namespace dcap;
 
+// the 256-square tile where its grid covers the chip (the P2 / P3-level FPN and RPN layers and their data gradients)
+static bool bconv_big(const dc_conv_bf16_desc* d, int M, int N, int K) {
+    const bool vec4 = (d->Cout & 3) == 0 && (!d->residual || aligned16(d->residual)) && (!d->scale || aligned16(d->scale)) && (!d->shift || aligned16(d->shift));
+    return b256::prefer(M, N, K, d->split_k, vec4);
+}
+
 extern "C" size_t dc_conv2d_bf16_workspace_bytes(const dc_conv_bf16_desc* d) {
     if (!d || conv_bf16_validate(d)) return 0;
     const int M = d->N * d->Ho * d->Wo, N = d->Cout, K = d->kh * d->kw * d->Cin;
-    const BSplit sp = bconv_split(M, N, K, d->split_k);
+    const BSplit sp = bconv_big(d, M, N, K) ? b256::split(M, N, K, d->split_k) : bconv_split(M, N, K, d->split_k);
     return sp.split > 1 ? (size_t)sp.split * M * N * sizeof(float) : 0;
+}
+
+extern "C" int dc_conv2d_bf16_tile(const dc_conv_bf16_desc* d, int* split_k) {
+    if (!d || conv_bf16_validate(d)) return 0;
+    const int M = d->N * d->Ho * d->Wo, N = d->Cout, K = d->kh * d->kw * d->Cin;
+    const bool big = bconv_big(d, M, N, K);
+    if (split_k) *split_k = (big ? b256::split(M, N, K, d->split_k) : bconv_split(M, N, K, d->split_k)).split;
+    return big ? 256 : 128;
 }
 
 extern "C" int dc_conv2d_bf16(const dc_conv_bf16_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
@@ -126,7 +199,8 @@ extern "C" int dc_conv2d_bf16(const dc_conv_bf16_desc* d, void* workspace, size_
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int M = d->N * d->Ho * d->Wo, N = d->Cout, K = d->kh * d->kw * d->Cin;
-    const BSplit sp = bconv_split(M, N, K, d->split_k);
+    const bool big = bconv_big(d, M, N, K);
+    const BSplit sp = big ? b256::split(M, N, K, d->split_k) : bconv_split(M, N, K, d->split_k);
     float* partial = nullptr;
     if (sp.split > 1) {
         const size_t need = (size_t)sp.split * M * N * sizeof(float);
@@ -140,10 +214,17 @@ extern "C" int dc_conv2d_bf16(const dc_conv_bf16_desc* d, void* workspace, size_
     ep.ldcb = d->Cout;
     BConvA a{d->x, d->H, d->W, d->Cin, d->Ho, d->Wo, d->stride, d->pad_t, d->pad_l, d->kw, M, (unsigned)((size_t)d->N * d->H * d->W * d->Cin * 2)};
     BOperand b{d->w, K, N, nullptr, (unsigned)((size_t)N * K * 2)};
-    DC_ENSURE_DYN_LDS(&bconv_kernel, 160 * 1024);
-    const int tiles = ((M + BT - 1) / BT) * ((N + BT - 1) / BT);
-    hipLaunchKernelGGL(bconv_kernel, dim3(tiles, 1, sp.split), dim3(256), bgemm_lds_bytes(), s, a, b, ep, M, N, K, sp.klen, partial);
-    rc = check_launch("bconv_kernel");
+    if (big) {
+        DC_ENSURE_DYN_LDS(&bconv256_kernel, 160 * 1024);
+        const int tiles = ((M + b256::BM - 1) / b256::BM) * ((N + b256::BN - 1) / b256::BN);
+        hipLaunchKernelGGL(bconv256_kernel, dim3(tiles, 1, sp.split), dim3(b256::NTHREADS), b256::LDS_BYTES, s, a, b, ep, M, N, K, sp.klen, partial);
+        rc = check_launch("bconv256_kernel");
+    } else {
+        DC_ENSURE_DYN_LDS(&bconv_kernel, 160 * 1024);
+        const int tiles = ((M + BT - 1) / BT) * ((N + BT - 1) / BT);
+        hipLaunchKernelGGL(bconv_kernel, dim3(tiles, 1, sp.split), dim3(256), bgemm_lds_bytes(), s, a, b, ep, M, N, K, sp.klen, partial);
+        rc = check_launch("bconv_kernel");
+    }
     if (rc || sp.split <= 1) return rc;
     const long total = (long)M * N;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(splitk_reduce_blocks(total)), dim3(256), 0, s, partial, sp.split, M, N, ep);

@@ -342,6 +342,37 @@ class EncoderPlan:
                 acc[i] += e0.elapsed_time(e1)
         return [(op[2], a / reps) for op, a in zip(convs, acc)]
 
+    def time_bconvs(self, reps=3):
+        """bf16-storage mode (configs[4]): eager replay with a HIP event pair around every dc_conv2d_bf16 launch on the launch
+        stream; returns [(layer, flops, mean milliseconds, block tile (256 | 128), split-K slices)] in launch order -- the
+        roofline leg of `bench.py --config joint` (a split-K layer's time includes its slab reduction)."""
+        lib = self.lib
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        wsp, wsb = C.c_void_p(self._ws.data_ptr()), self._ws.numel()
+        convs = [op for op in self._ops if op[0] == "bconv"]
+        acc = [0.0] * len(convs)
+        for _ in range(reps):
+            self._run_ops()
+            torch.cuda.synchronize()
+            evs = []
+            for op in convs:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = lib.dc_conv2d_bf16(C.byref(op[1]), wsp, wsb, stream)
+                e1.record()
+                if rc:
+                    check(rc, "dc_conv2d_bf16(%s)" % op[2])
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            for i, (e0, e1) in enumerate(evs):
+                acc[i] += e0.elapsed_time(e1)
+        rows = []
+        for op, a in zip(convs, acc):
+            d, sk = op[1], C.c_int(0)
+            tile = int(lib.dc_conv2d_bf16_tile(C.byref(d), C.byref(sk)))
+            rows.append((op[2], 2.0 * d.N * d.Ho * d.Wo * d.Cout * d.kh * d.kw * d.Cin, a / reps, tile, int(sk.value)))
+        return rows
+
     def forward(self, images_u8=None):
         """images_u8: [B,H,W,3] uint8 torch tensor (any device) or None to reuse self.images.
         Returns (P2, P3, P4, P5), plan-owned buffers valid until the next forward()."""

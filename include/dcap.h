@@ -139,6 +139,8 @@ typedef struct {
 } dc_conv_bf16_desc;
 size_t dc_conv2d_bf16_workspace_bytes(const dc_conv_bf16_desc* d);
 int    dc_conv2d_bf16(const dc_conv_bf16_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+/* Test / profiling aid: 256 when `d` runs on the 256 x 256 x 64 tile (bconv256_kernel), 128 otherwise; *split_k (may be NULL) = slices. */
+int    dc_conv2d_bf16_tile(const dc_conv_bf16_desc* d, int* split_k);
 
 /* fp32 -> bf16 (round to nearest even): the bf16 shadow of weights / activations that feed dc_gemm_bf16.
  * _2d: rows x cols with row strides, output columns cols..cols_out-1 zero-filled (pads K to a multiple of 8). */

@@ -330,10 +330,15 @@ BCONV_CASES = [
     (2, 9, 7, 128, 20, 1, 1, 'valid', 0, False),            # the padded RPN head: Cout = 20
     (1, 40, 40, 64, 192, 3, 1, 'same', 1, True),            # two column tiles, the second partial
 ]
+BCONV_BIG = [   # the 256 x 256 tile (bconv256_kernel: grids of >= 192 tiles)
+    (1, 128, 135, 64, 768, 3, 1, 'same', 1, True),          # 68 x 3 tiles, ragged pixel count, borders, residual
+    (2, 96, 128, 128, 712, 1, 1, 'valid', 2, False),        # 96 x 3 tiles (the third 200 columns wide), upsample-add residual
+    (1, 64, 64, 1024, 256, 3, 1, 'same', 0, True),          # 16 tiles, K = 9216: split-K on the large tile
+]
 
 
 @pytest.mark.parametrize("outs", ["f32", "bf16", "both"])
-@pytest.mark.parametrize("case", BCONV_CASES)
+@pytest.mark.parametrize("case", BCONV_CASES + BCONV_BIG)
 def test_conv2d_bf16_matches_oracle(ops, case, outs):
     """dc_conv2d_bf16 (bf16 activations and weights in memory, LDS-DMA im2col) against the float64 oracle on the same
     bf16-rounded operands: only fp32 accumulation order separates them.  fp32 output, bf16 output (one more rounding) or both."""
@@ -358,9 +363,11 @@ def test_conv2d_bf16_matches_oracle(ops, case, outs):
     pad = (k - 1) // 2 if padding == 'same' else 0
     xb = ops.to_bf16(dev(x))
     wb = ops.to_bf16(dev(pack_conv_kernel(w.astype(np.float32))))
+    info = {}
     got, gotb = ops.conv2d_bf16(xb, wb, k, k, stride, pad, pad, Ho, Wo, scale=dev(scale), shift=dev(shift),
                                 residual=None if res is None else dev(res), res_mode=res_mode, relu=relu,
-                                want_f32=outs != "bf16", want_bf16=outs != "f32")
+                                want_f32=outs != "bf16", want_bf16=outs != "f32", info=info)
+    assert info["tile"] == (256 if case in BCONV_BIG else 128), info
     if outs != "bf16":
         close(got, y, 3e-5)
     else:
