@@ -360,7 +360,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void bgemm256_kernel(BOperand a, BOper
     store_tile(acc, ep, partial, M, N, m0, n0);
 }
 
-// split-K so that a small grid still covers the chip (one block per CU); slices are multiples of the 64-deep K-tile
+// split-K so that a small grid still covers the chip in ONE round of blocks (one block per CU: a grid of 1.1 rounds takes as long as
+// one of 2); slices are multiples of the 64-deep K-tile
 inline BSplit split(int M, int N, int K, int user_split) {
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const int ktiles = (K + BK - 1) / BK;
@@ -368,7 +369,7 @@ inline BSplit split(int M, int N, int K, int user_split) {
     if (s <= 0) {
         s = 1;
         if (tiles < (3 * kNumCU) / 4 && ktiles >= 16) {
-            s = (kNumCU + tiles - 1) / tiles;
+            s = kNumCU / tiles;                           // floor: tiles * s <= 256
             if (s > ktiles / 8) s = ktiles / 8;           // >= 8 K-tiles (512 deep) per slice
             if (s > 32) s = 32;
             if (s < 1) s = 1;
@@ -379,16 +380,30 @@ inline BSplit split(int M, int N, int K, int user_split) {
     return BSplit{(K + klen - 1) / klen, klen};
 }
 
-// Is the 256-square kernel the better grid for this problem?  (DCAP_BGEMM_TILE = 128 | 256 forces a choice.)
+// Which block tile is faster for this problem?  A small cost model fitted to measurements on MI355X (profiles/r03_bgemm_bench.txt,
+// r03_bconv_bench.txt): rounds of blocks x (K-tiles per slice x time per K-tile + fixed cost per block) + the split-K slab traffic.
+//   256 x 256 tile, one block per CU:    1.55 us per 64-deep K-tile (8.4 MFLOP), 4 us per block (prologue, epilogue)
+//   128 x 128 tile, two blocks per CU:   1.13 us per K-tile and block (2.1 MFLOP, two co-resident), 3 us per block
+//   split-K: (slices + 1) x M x N x 4 bytes at 4 TB/s + one more launch (3 us)
+// (DCAP_BGEMM_TILE = 128 | 256 forces a choice.)
+inline double tile_cost_us(int M, int N, int K, int tile, const BSplit& sp) {
+    const long tiles = (long)((M + tile - 1) / tile) * ((N + tile - 1) / tile);
+    const long blocks = tiles * sp.split, slots = tile == 256 ? kNumCU : 2 * kNumCU;
+    const double rounds = (double)((blocks + slots - 1) / slots);
+    const double kt = (double)(sp.klen / 64);
+    double t = rounds * (tile == 256 ? kt * 1.55 + 4.0 : kt * 1.13 + 3.0);
+    if (sp.split > 1) t += (sp.split + 1.0) * (double)M * N * 4.0 / 4e6 + 3.0;
+    return t;
+}
+
 inline bool prefer(int M, int N, int K, int user_split, bool vec4 = true) {
     if (!vec4 || (N & 3) || M < 4 || N < 4) return false;       // the epilogue is 16-byte accesses only
     static const int forced = [] { const char* e = getenv("DCAP_BGEMM_TILE"); return e ? atoi(e) : 0; }();
     if (forced == 128) return false;
     if (forced == 256) return true;
     const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    const double waste = (double)tiles * BM * BN / ((double)M * N);                 // padded / useful outputs
-    const BSplit sp = split(M, N, K, user_split);
-    return waste <= 1.25 && tiles * sp.split >= (3 * kNumCU) / 4;
+    if ((double)tiles * BM * BN > 1.25 * (double)M * N) return false;              // padded / useful outputs
+    return tile_cost_us(M, N, K, 256, split(M, N, K, user_split)) < tile_cost_us(M, N, K, 128, bgemm_split(M, N, K, user_split));
 }
 
 template <bool AKC, bool BKC>
