@@ -481,7 +481,8 @@ def self_launch(n, argv=None, script=None, timeout_s=None, extra_env=None):
 def joint_roofline(args, dev, inner):
     """Roofline block of the joint leg (rank 0, after the timed region), against the dense bf16 MFMA peak:
     the bf16 convolutions of the forward plan, timed per launch with HIP events on the launch stream and grouped by kernel
-    (bconv256_kernel: the 256 x 256 x 64 tile; bconv_kernel: the 128 x 128 tile incl. its split-K slab reductions) -- `achieved`
+    (bconv256_kernel: the 256 x 256 x 64 tile; bconv64_kernel: the 64 x 64 tile with the whole K loop per block; bconv_kernel: the
+    128 x 128 tile incl. its split-K slab reductions) -- `achieved`
     is the group with the largest time share; and the fused vocabulary softmax / cross-entropy at the step's own shape
     (TRAIN_ROIS_PER_IMAGE x T rows, K = 1024, V words; keras_sparse: three GEMM passes), timed as whole calls."""
     from image_captioning_amd import ops
@@ -489,7 +490,7 @@ def joint_roofline(args, dev, inner):
     rows = plan.time_bconvs(reps=3)
     groups = {}
     for name, fl, ms, tile, sk in rows:
-        g = groups.setdefault("bconv256_kernel" if tile == 256 else "bconv_kernel", {"flops": 0.0, "ms": 0.0, "launches": 0, "split_k_layers": 0})
+        g = groups.setdefault({256: "bconv256_kernel", 64: "bconv64_kernel"}.get(tile, "bconv_kernel"), {"flops": 0.0, "ms": 0.0, "launches": 0, "split_k_layers": 0})
         g["flops"] += fl
         g["ms"] += ms
         g["launches"] += 1

@@ -60,7 +60,7 @@ class ConvBf16Desc(C.Structure):
                 ("pad_t", C.c_int), ("pad_l", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
                 ("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p), ("y_bf16", C.c_void_p),
                 ("scale", C.c_void_p), ("shift", C.c_void_p), ("residual", C.c_void_p), ("res_mode", C.c_int),
-                ("relu", C.c_int), ("split_k", C.c_int)]
+                ("relu", C.c_int), ("split_k", C.c_int), ("tile", C.c_int)]
 
 
 MATH_F32, MATH_BF16X3, MATH_BF16X2, MATH_BF16 = 0, 1, 2, 3

@@ -8,7 +8,7 @@
 // padding load hardware zeros (the lane's offset is replaced by an out-of-range one).  No im2col buffer, no staging
 // registers, no conversion: the split-bf16 loop this replaces (igemm_bf16s.h with one product) loaded fp32, rounded on the
 // way to LDS and synchronised every 32 k -- 250 TFLOP/s on the joint model's layers.
-#include "bgemm256_core.h"
+#include "bgemm64_core.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -138,6 +138,65 @@ __global__ __launch_bounds__(b256::NTHREADS, 2) void bconv256_kernel(BConvA a, B
     b256::store_tile(acc, ep, partial, M, N, m0, n0);
 }
 
+// ... and for the 64 x 64 tile (bgemm64_core.h): one 64-row image per K-tile, two pieces per wave.
+struct BLoadConvA64 {
+    static constexpr bool KC = true;
+    __amdgpu_buffer_rsrc_t rsrc;
+    BConvA c;
+    unsigned base[2];
+    int iy0[2], ix0[2];
+    int ky, kx, c0;                // (tap, channel chunk) of the NEXT K-tile: the main loop issues K-tiles in order, 64 channels at a time
+    __device__ __forceinline__ void init(const BConvA& cc, int m0, int lane, int wave) {
+        c = cc;
+        ky = kx = c0 = 0;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(c.x), 0, (int)c.bytes, 0x00020000);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int rp = 8 * (2 * wave + jj) + (lane >> 3);
+            const int ch = (lane & 7) ^ ((rp >> 1) & 7);
+            const int p = min(m0 + rp, c.M - 1);
+            const int n = p / (c.Ho * c.Wo), rem = p - n * (c.Ho * c.Wo);
+            const int oy = rem / c.Wo, ox = rem - oy * c.Wo;
+            iy0[jj] = oy * c.stride - c.pad_t;
+            ix0[jj] = ox * c.stride - c.pad_l;
+            base[jj] = (unsigned)(((long)n * c.H * c.W * c.Cin + 8 * ch) * 2);
+        }
+    }
+    // K-tiles arrive in order starting at k = 0 (bgemm64_core.h: no split-K), so the tap walk is an add and two compares
+    __device__ __forceinline__ void issue(char* img, int k0, int kend, int wave) {
+        const bool live = k0 < kend;
+        const int tapoff = ((ky * c.W + kx) * c.Cin + c0) * 2;             // block-uniform
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int iy = iy0[jj] + ky, ix = ix0[jj] + kx;
+            const bool in = live && (unsigned)iy < (unsigned)c.H && (unsigned)ix < (unsigned)c.W;
+            const unsigned off = base[jj] + (unsigned)((iy0[jj] * c.W + ix0[jj]) * c.Cin * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (DC_LDS void*)(img + (2 * wave + jj) * 1024), 16, (int)(in ? off + (unsigned)tapoff : kOobOffset), 0, 0, 0);
+        }
+        c0 += BKB;
+        if (c0 >= c.Cin) {
+            c0 = 0;
+            if (++kx >= c.kw) { kx = 0; ++ky; }
+        }
+    }
+};
+
+__global__ __launch_bounds__(b64::NTHREADS, 2) void bconv64_kernel(BConvA a, BOperand b, Epilogue ep, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tiles_n = (N + b64::BN - 1) / b64::BN;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (lid / tiles_n) * b64::BM, n0 = (lid % tiles_n) * b64::BN;
+    BLoadConvA64 la;
+    b64::Load lb;
+    la.init(a, m0, lane, wave);
+    lb.init(b, n0, lane, wave);
+    b64::f32x4 acc[2][2];
+    b64::mainloop(la, lb, reinterpret_cast<char*>(smem_f), 0, K, acc);
+    b64::store_tile(acc, ep, M, N, m0, n0);
+}
+
 static int conv_bf16_validate(const dc_conv_bf16_desc* d) {
     DC_REQUIRE(d && d->x && d->w && (d->y || d->y_bf16), DC_EINVAL, "dc_conv2d_bf16: x, w and at least one of y / y_bf16 must be non-null");
     DC_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->kh >= 1 && d->kw >= 1 && d->stride >= 1 && d->Cout > 0, DC_EINVAL,
@@ -173,25 +232,42 @@ static BSplit bconv_split(int M, int N, int K, int user_split) {
 
 using namespace dcap;
 
-// the 256-square tile where its grid covers the chip (the P2 / P3-level FPN and RPN layers and their data gradients)
-static bool bconv_big(const dc_conv_bf16_desc* d, int M, int N, int K) {
+// Which tile runs this layer: 256 (the P2 / P3-level FPN and RPN layers and their data gradients), 64 (the one-image trunk layers:
+// whole K loop in one block, no split-K slabs) or 128, by the cost model of bgemm256_core.h / bgemm64_core.h.
+// DCAP_BCONV_TILE = 64 | 128 | 256 forces a choice where the shape allows it.
+static int bconv_tile(const dc_conv_bf16_desc* d, int M, int N, int K) {
     const bool vec4 = (d->Cout & 3) == 0 && (!d->residual || aligned16(d->residual)) && (!d->scale || aligned16(d->scale)) && (!d->shift || aligned16(d->shift));
-    return b256::prefer(M, N, K, d->split_k, vec4);
+    static const int env_forced = [] { const char* e = getenv("DCAP_BCONV_TILE"); return e ? atoi(e) : 0; }();
+    const int forced = d->tile ? d->tile : env_forced;
+    if (!vec4 || M < 4 || N < 4) return 128;
+    if (forced == 128) return 128;
+    if (forced == 64 && d->split_k <= 1) return 64;
+    if (forced == 256) return ((long)((M + 255) / 256) * ((N + 255) / 256) * 65536 <= 4L * M * N) ? 256 : 128;     // (not for slivers of a tile)
+    const bool can256 = (double)((M + 255) / 256) * ((N + 255) / 256) * 65536.0 <= 1.25 * (double)M * N;
+    const double c256 = can256 ? b256::tile_cost_us(M, N, K, 256, b256::split(M, N, K, d->split_k)) : 1e30;
+    const double c128 = b256::tile_cost_us(M, N, K, 128, bconv_split(M, N, K, d->split_k));
+    const double c64 = d->split_k > 1 ? 1e30 : b64::cost_us(M, N, K);           // (a caller that asks for slabs gets a split-K tile)
+    return (c256 <= c128 && c256 <= c64) ? 256 : (c64 < c128 ? 64 : 128);
+}
+static BSplit bconv_split_for(int tile, int M, int N, int K, int user_split) {
+    if (tile == 256) return b256::split(M, N, K, user_split);
+    if (tile == 64) return BSplit{1, ((K + BKB - 1) / BKB) * BKB};
+    return bconv_split(M, N, K, user_split);
 }
 
 extern "C" size_t dc_conv2d_bf16_workspace_bytes(const dc_conv_bf16_desc* d) {
     if (!d || conv_bf16_validate(d)) return 0;
     const int M = d->N * d->Ho * d->Wo, N = d->Cout, K = d->kh * d->kw * d->Cin;
-    const BSplit sp = bconv_big(d, M, N, K) ? b256::split(M, N, K, d->split_k) : bconv_split(M, N, K, d->split_k);
+    const BSplit sp = bconv_split_for(bconv_tile(d, M, N, K), M, N, K, d->split_k);
     return sp.split > 1 ? (size_t)sp.split * M * N * sizeof(float) : 0;
 }
 
 extern "C" int dc_conv2d_bf16_tile(const dc_conv_bf16_desc* d, int* split_k) {
     if (!d || conv_bf16_validate(d)) return 0;
     const int M = d->N * d->Ho * d->Wo, N = d->Cout, K = d->kh * d->kw * d->Cin;
-    const bool big = bconv_big(d, M, N, K);
-    if (split_k) *split_k = (big ? b256::split(M, N, K, d->split_k) : bconv_split(M, N, K, d->split_k)).split;
-    return big ? 256 : 128;
+    const int tile = bconv_tile(d, M, N, K);
+    if (split_k) *split_k = bconv_split_for(tile, M, N, K, d->split_k).split;
+    return tile;
 }
 
 extern "C" int dc_conv2d_bf16(const dc_conv_bf16_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
@@ -199,8 +275,9 @@ extern "C" int dc_conv2d_bf16(const dc_conv_bf16_desc* d, void* workspace, size_
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int M = d->N * d->Ho * d->Wo, N = d->Cout, K = d->kh * d->kw * d->Cin;
-    const bool big = bconv_big(d, M, N, K);
-    const BSplit sp = big ? b256::split(M, N, K, d->split_k) : bconv_split(M, N, K, d->split_k);
+    const int tile = bconv_tile(d, M, N, K);
+    const bool big = tile == 256;
+    const BSplit sp = bconv_split_for(tile, M, N, K, d->split_k);
     float* partial = nullptr;
     if (sp.split > 1) {
         const size_t need = (size_t)sp.split * M * N * sizeof(float);
@@ -214,6 +291,12 @@ extern "C" int dc_conv2d_bf16(const dc_conv_bf16_desc* d, void* workspace, size_
     ep.ldcb = d->Cout;
     BConvA a{d->x, d->H, d->W, d->Cin, d->Ho, d->Wo, d->stride, d->pad_t, d->pad_l, d->kw, M, (unsigned)((size_t)d->N * d->H * d->W * d->Cin * 2)};
     BOperand b{d->w, K, N, nullptr, (unsigned)((size_t)N * K * 2)};
+    if (tile == 64) {
+        DC_ENSURE_DYN_LDS(&bconv64_kernel, 160 * 1024);
+        const int tiles = ((M + b64::BM - 1) / b64::BM) * ((N + b64::BN - 1) / b64::BN);
+        hipLaunchKernelGGL(bconv64_kernel, dim3(tiles), dim3(b64::NTHREADS), b64::LDS_BYTES, s, a, b, ep, M, N, K);
+        return check_launch("bconv64_kernel");
+    }
     if (big) {
         DC_ENSURE_DYN_LDS(&bconv256_kernel, 160 * 1024);
         const int tiles = ((M + b256::BM - 1) / b256::BM) * ((N + b256::BN - 1) / b256::BN);

@@ -235,7 +235,7 @@ def conv2d_wgrad_bf16(x, dy, kh, kw, stride, pad_t, pad_l, out=None, split_k=0, 
 
 
 def conv2d_bf16(x, w, kh, kw, stride, pad_t, pad_l, Ho, Wo, scale=None, shift=None, residual=None, res_mode=0, relu=False,
-                out=None, out_bf16=None, want_f32=True, want_bf16=False, split_k=0, info=None):
+                out=None, out_bf16=None, want_f32=True, want_bf16=False, split_k=0, info=None, tile=0):
     """conv2d with bf16 storage (dc_conv2d_bf16): x [N,H,W,Cin] bf16 (Cin % 64 == 0), w packed [Cout, kh*kw*Cin] bf16; the fp32
     epilogue operands as in conv2d.  Returns (fp32 output or None, bf16 output or None)."""
     lib = _lib.load()
@@ -257,7 +257,7 @@ def conv2d_bf16(x, w, kh, kw, stride, pad_t, pad_l, Ho, Wo, scale=None, shift=No
     d.scale = None if scale is None else _chk(scale, name="scale").data_ptr()
     d.shift = None if shift is None else _chk(shift, name="shift").data_ptr()
     d.residual = None if residual is None else _chk(residual, name="residual").data_ptr()
-    d.res_mode, d.relu, d.split_k = int(res_mode), int(relu), int(split_k)
+    d.res_mode, d.relu, d.split_k, d.tile = int(res_mode), int(relu), int(split_k), int(tile)
     if info is not None:                      # tests / benches: which kernel runs this layer
         sk = C.c_int(0)
         info["tile"] = int(lib.dc_conv2d_bf16_tile(C.byref(d), C.byref(sk)))

@@ -136,10 +136,13 @@ typedef struct {
     const float* residual;  int res_mode;
     int relu;
     int split_k;
+    int tile;                 /* 0 = the library's cost model picks the block tile; 64 | 128 | 256 = run on that tile where the shape allows it
+                               * (tests and benchmarks; dc_conv2d_bf16_tile reports what will run) */
 } dc_conv_bf16_desc;
 size_t dc_conv2d_bf16_workspace_bytes(const dc_conv_bf16_desc* d);
 int    dc_conv2d_bf16(const dc_conv_bf16_desc* d, void* workspace, size_t workspace_bytes, void* stream);
-/* Test / profiling aid: 256 when `d` runs on the 256 x 256 x 64 tile (bconv256_kernel), 128 otherwise; *split_k (may be NULL) = slices. */
+/* Test / profiling aid: the block tile `d` runs on -- 256 (bconv256_kernel, 256 x 256 x 64), 128 (bconv_kernel) or 64 (bconv64_kernel: whole K
+ * loop per block, no split-K); *split_k (may be NULL) = slices. */
 int    dc_conv2d_bf16_tile(const dc_conv_bf16_desc* d, int* split_k);
 
 /* fp32 -> bf16 (round to nearest even): the bf16 shadow of weights / activations that feed dc_gemm_bf16.

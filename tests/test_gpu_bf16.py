@@ -338,9 +338,17 @@ BCONV_BIG = [   # the 256 x 256 tile (bconv256_kernel: grids of >= 192 tiles)
 ]
 
 
+BCONV_SMALL = [  # the 64 x 64 tile (bconv64_kernel: whole K loop per block): the one-image trunk layers of configs[4]
+    (1, 64, 64, 256, 256, 3, 1, 'same', 0, True),           # res4*_2b at one image: 36 K-tiles through the four-stage ring
+    (1, 64, 64, 1024, 256, 1, 1, 'valid', 1, True),         # res4*_2a
+    (1, 32, 32, 512, 320, 3, 1, 'same', 0, False),          # 72 K-tiles, ragged columns (the cost model itself prefers split-K slabs here)
+]
+
+
+@pytest.mark.parametrize("tile", [0, 64, 128, 256])
 @pytest.mark.parametrize("outs", ["f32", "bf16", "both"])
-@pytest.mark.parametrize("case", BCONV_CASES + BCONV_BIG)
-def test_conv2d_bf16_matches_oracle(ops, case, outs):
+@pytest.mark.parametrize("case", BCONV_CASES + BCONV_BIG + BCONV_SMALL)
+def test_conv2d_bf16_matches_oracle(ops, case, outs, tile):
     """dc_conv2d_bf16 (bf16 activations and weights in memory, LDS-DMA im2col) against the float64 oracle on the same
     bf16-rounded operands: only fp32 accumulation order separates them.  fp32 output, bf16 output (one more rounding) or both."""
     from image_captioning_amd.packing import pack_conv_kernel
@@ -367,9 +375,14 @@ def test_conv2d_bf16_matches_oracle(ops, case, outs):
     info = {}
     got, gotb = ops.conv2d_bf16(xb, wb, k, k, stride, pad, pad, Ho, Wo, scale=dev(scale), shift=dev(shift),
                                 residual=None if res is None else dev(res), res_mode=res_mode, relu=relu,
-                                want_f32=outs != "bf16", want_bf16=outs != "f32", info=info,
-                                split_k=16 if Cin == 1024 else 0)        # (requested slices: the cost model would keep that shape on the 128 tile)
-    assert info["tile"] == (256 if case in BCONV_BIG else 128), info
+                                want_f32=outs != "bf16", want_bf16=outs != "f32", info=info, tile=tile,
+                                split_k=16 if Cin == 1024 and k == 3 and tile != 64 else 0)   # (slabs on request: the cost model would not split that shape)
+    if tile == 0:                                                  # the library's own choice
+        assert info["tile"] == (256 if case in BCONV_BIG[:2] else 64 if case in BCONV_SMALL[:2] else info["tile"]), info
+    elif tile == 256 and N * Ho * Wo * Cout * 4 < -(-N * Ho * Wo // 256) * -(-Cout // 256) * 65536:
+        assert info["tile"] == 128                                 # a sliver of one 256-square tile is refused
+    else:
+        assert info["tile"] == tile, info
     if outs != "bf16":
         close(got, y, 3e-5)
     else:

@@ -16,6 +16,8 @@ SHAPES = [
     ("res4_2b 3x3 256", 64, 256, 256, 3, 1), ("res4_2c 1x1 256>1024", 64, 256, 1024, 1, 1), ("res4_2a 1x1 1024>256", 64, 1024, 256, 1, 1),
     ("res5_2b 3x3 512", 32, 512, 512, 3, 1), ("fpn_p2 3x3 256", 256, 256, 256, 3, 1), ("fpn_p3 3x3 256", 128, 256, 256, 3, 1),
     ("rpn_shared P2 3x3 256>512", 256, 256, 512, 3, 1), ("rpn dgrad P2 3x3 512>256", 256, 512, 256, 3, 1),
+    ("res5_2a 1x1 2048>512", 32, 2048, 512, 1, 1), ("res5_2c 1x1 512>2048", 32, 512, 2048, 1, 1), ("res3_2a 1x1 512>128", 128, 512, 128, 1, 1),
+    ("rpn_shared P4 3x3 256>512", 64, 256, 512, 3, 1), ("rpn dgrad P4 3x3 512>256", 64, 512, 256, 3, 1), ("fpn_p4 3x3 256", 64, 256, 256, 3, 1),
 ]
 
 
@@ -23,6 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--tile", type=int, default=0, help="0 = the library's choice; 64 | 128 | 256 forces a block tile")
     a = ap.parse_args()
     dev = torch.device("cuda")
     for name, H, Cin, Cout, k, stride in SHAPES:
@@ -34,7 +37,8 @@ def main():
         yf = torch.empty(a.batch, Ho, Ho, Cout, device=dev)
         res = []
         for out, outb in ((None, yb), (yf, yb)):
-            f = lambda: ops.conv2d_bf16(x, w, k, k, stride, pad, pad, Ho, Ho, relu=True, out=out, out_bf16=outb, want_f32=False)
+            info = {}
+            f = lambda: ops.conv2d_bf16(x, w, k, k, stride, pad, pad, Ho, Ho, relu=True, out=out, out_bf16=outb, want_f32=False, tile=a.tile, info=info)
             for _ in range(3):
                 f()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -45,7 +49,8 @@ def main():
             torch.cuda.synchronize()
             res.append(e0.elapsed_time(e1) * 1e3 / a.reps)
         fl = 2.0 * a.batch * Ho * Ho * Cout * k * k * Cin
-        print("%-28s bf16 out %7.1f us %6.1f TF/s   f32+bf16 out %7.1f us %6.1f TF/s" % (name, res[0], fl / res[0] / 1e6, res[1], fl / res[1] / 1e6), flush=True)
+        print("%-28s tile %3d split %2d  bf16 out %7.1f us %6.1f TF/s   f32+bf16 out %7.1f us %6.1f TF/s"
+              % (name, info["tile"], info["split_k"], res[0], fl / res[0] / 1e6, res[1], fl / res[1] / 1e6), flush=True)
 
 
 if __name__ == "__main__":
