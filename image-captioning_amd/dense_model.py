@@ -560,6 +560,53 @@ class DenseImageCapRCNN(object):
         level = np.searchsorted(bounds, idx, side="right") - 1
         return level.astype(np.int32), (idx - bounds[level]).astype(np.int32), m[idx].astype(np.int32)
 
+    def _pinned(self, key, shape, dtype=torch.float32):
+        """A page-locked host buffer owned by the model (asynchronous device -> host copies land here)."""
+        b = self._pins.get(key) if hasattr(self, "_pins") else None
+        if b is None or tuple(b.shape) != tuple(shape) or b.dtype != dtype:
+            if not hasattr(self, "_pins"):
+                self._pins = {}
+            b = torch.empty(shape, dtype=dtype, pin_memory=True)
+            self._pins[key] = b
+        return b
+
+    def _rpn_backward(self, p, rpn_match, rpn_bbox, losses, up):
+        """RPN losses (dense_model.py:1008-1075) and the backward of the RPN branch: gradients of the fused head and of the shared
+        3x3 convolution (accumulated over the five pyramid levels) and the data gradients into dP2..dP6, which this call creates
+        (zeroed) and returns together with the pyramid maps.  Independent of the detection targets."""
+        st = self.store
+        w, g = st.w, st.grad
+        maps = list(p.P) + [p.P6]
+        dP = [self._buf("dP%d" % i, tuple(m.shape)) for i, m in enumerate(maps)]
+        for t in dP:
+            t.zero_()
+        # ---- RPN losses and their gradients w.r.t. the fused head outputs
+        lvl, idx, mt = self._rpn_selection(rpn_match[0])
+        n_pos = int((mt == 1).sum())
+        dheads = [self._buf("dhead%d" % i, tuple(h.shape)) for i, h in enumerate(p.rpn_heads)]
+        for t in dheads:
+            t.zero_()
+        tdl = np.asarray(rpn_bbox[0], np.float32)
+        if n_pos > tdl.shape[0]:
+            raise ValueError("%d positive anchors but only %d target rows" % (n_pos, tdl.shape[0]))
+        ops.rpn_loss_grad(p.rpn_heads, dheads, up(lvl, torch.int32), up(idx, torch.int32), up(mt, torch.int32),
+                          up(tdl if tdl.size else np.zeros((1, 4), np.float32)), n_pos, losses[0:2], anchors_per_loc=self.A)
+
+        # ---- RPN backward (shared weights over the five levels: gradients accumulate)
+        wd_shared = ops.conv_weight_dgrad_pack(w["rpn_conv_shared/kernel"], 3, 3, 256, out=self._buf("wd_shared", (256, 9 * 512)))
+        for i, (pm, sh, dh) in enumerate(zip(maps, p.rpn_shared, dheads)):
+            _, h_, w_, _ = pm.shape
+            acc = i > 0
+            ops.conv2d_wgrad(sh, dh, 1, 1, 1, 0, 0, out=g["rpn_head/kernel"], accumulate=acc)          # 20 output channels: fp32
+            ops.colsum(dh.view(-1, HEAD_PAD), out=g["rpn_head/bias"], accumulate=acc)
+            dsh = self._buf("dsh%d" % i, tuple(sh.shape))          # 1x1 head: its data gradient is a K = 20 GEMM on the packed weights
+            ops.gemm(dh.view(-1, HEAD_PAD), w["rpn_head/kernel"], out=dsh.view(-1, 512))
+            ops.relu_bwd(dsh.view(-1, 512), sh.view(-1, 512), dsh.view(-1, 512))
+            self._wgrad(pm, dsh, 3, 1, g["rpn_conv_shared/kernel"], accumulate=acc, key="P%d" % i, dy_key="dsh%d" % i)
+            ops.colsum(dsh.view(-1, 512), out=g["rpn_conv_shared/bias"], accumulate=acc)
+            self._dgrad(dsh, wd_shared, 3, dP[i], residual=dP[i], key="rpn_shared", dy_key="dsh%d" % i)     # dP += dgrad
+        return maps, dP
+
     def forward_backward(self, inputs, shuffle="rng", backward=True):
         """Losses and gradients of one image into the flat gradient bucket (no optimizer step).
         Returns the device tensor [rpn_class_loss, rpn_bbox_loss, imgcap_loss, reg_loss].
@@ -583,7 +630,21 @@ class DenseImageCapRCNN(object):
         gt_norm = (np.asarray(gt_boxes[0], np.float32) / np.array([H, W, H, W], np.float32)).astype(np.float32)
         rng = self._rng if backward else self._val_rng
         mix = None if shuffle is None else (rng.permutation if shuffle == "rng" else shuffle)
-        rois, caps, npos, nneg = detection_targets(proposals[0].cpu().numpy(), gt_caps[0], gt_norm, cfg, mix)
+        losses = self._buf("losses", (4,))
+        if backward:
+            # The detection-target sample is drawn on the host (the step's one round trip).  The proposals start their way to
+            # the host first; the RPN branch's backward -- which needs only the plan's outputs and the step's RPN targets --
+            # is enqueued behind that copy, so the GPU works through it while the host samples the RoIs.
+            host_props = self._pinned("props", tuple(proposals[0].shape))
+            host_props.copy_(proposals[0], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            maps, dP = self._rpn_backward(p, rpn_match, rpn_bbox, losses, up)
+            ev.synchronize()
+            props_np = host_props.numpy()
+        else:
+            props_np = proposals[0].cpu().numpy()
+        rois, caps, npos, nneg = detection_targets(props_np, gt_caps[0], gt_norm, cfg, mix)
         self.last_targets = dict(rois=rois, caps=caps, npos=npos, nneg=nneg)
         boxes = up(rois[None])
         R = rois.shape[0]
@@ -592,7 +653,6 @@ class DenseImageCapRCNN(object):
         live = (tg > 0).astype(np.float32)
         count = float(live.sum())
         loss_rows, _ = cm._forward_train(feats[0], caps, tg, want_grad=backward, row_weights=live / max(count, 1.0), keras_sparse=True)
-        losses = self._buf("losses", (4,))
         ops.mean(loss_rows, out=losses[2:3])                 # x rows below: the weights already carry 1/count
         self._loss_scale = float(loss_rows.numel())
         if not backward:
@@ -623,41 +683,22 @@ class DenseImageCapRCNN(object):
             cm.before_sync, cm.grad_sync, cm.overlap_sync = early, self.grad_sync, True
         else:
             cm.before_sync, cm.overlap_sync = None, False
+        if overlap:                                          # the RPN's gradients are final (computed beside the host's RoI sampling): they travel first
+            for layer in ("rpn_conv_shared", "rpn_head"):
+                lo, hi = st.layer_range(layer)
+                early(lo, hi)
+                self.grad_sync.ready(st.flat_grad, lo, hi)
         dX = cm._backward(want_dx=True)
-        maps = list(p.P) + [p.P6]
-        dP = [self._buf("dP%d" % i, tuple(m.shape)) for i, m in enumerate(maps)]
-        for t in dP:
-            t.zero_()
+        # dP already holds the RPN branch's data gradients; the RoI features' gradient is scattered on top (atomic adds)
         ops.roi_align_pyramid_bwd(dP[:4], boxes, float(H * W), dX.view(1, R, cfg.POOL_SIZE, cfg.POOL_SIZE, 256), cfg.POOL_SIZE)
-
-        # ---- RPN losses and their gradients w.r.t. the fused head outputs
-        lvl, idx, mt = self._rpn_selection(rpn_match[0])
-        n_pos = int((mt == 1).sum())
-        dheads = [self._buf("dhead%d" % i, tuple(h.shape)) for i, h in enumerate(p.rpn_heads)]
-        for t in dheads:
-            t.zero_()
-        tdl = np.asarray(rpn_bbox[0], np.float32)
-        if n_pos > tdl.shape[0]:
-            raise ValueError("%d positive anchors but only %d target rows" % (n_pos, tdl.shape[0]))
-        ops.rpn_loss_grad(p.rpn_heads, dheads, up(lvl, torch.int32), up(idx, torch.int32), up(mt, torch.int32),
-                          up(tdl if tdl.size else np.zeros((1, 4), np.float32)), n_pos, losses[0:2], anchors_per_loc=self.A)
-
-        # ---- RPN backward (shared weights over the five levels: gradients accumulate)
-        wd_shared = ops.conv_weight_dgrad_pack(w["rpn_conv_shared/kernel"], 3, 3, 256, out=self._buf("wd_shared", (256, 9 * 512)))
-        for i, (pm, sh, dh) in enumerate(zip(maps, p.rpn_shared, dheads)):
-            _, h_, w_, _ = pm.shape
-            acc = i > 0
-            ops.conv2d_wgrad(sh, dh, 1, 1, 1, 0, 0, out=g["rpn_head/kernel"], accumulate=acc)          # 20 output channels: fp32
-            ops.colsum(dh.view(-1, HEAD_PAD), out=g["rpn_head/bias"], accumulate=acc)
-            dsh = self._buf("dsh%d" % i, tuple(sh.shape))          # 1x1 head: its data gradient is a K = 20 GEMM on the packed weights
-            ops.gemm(dh.view(-1, HEAD_PAD), w["rpn_head/kernel"], out=dsh.view(-1, 512))
-            ops.relu_bwd(dsh.view(-1, 512), sh.view(-1, 512), dsh.view(-1, 512))
-            self._wgrad(pm, dsh, 3, 1, g["rpn_conv_shared/kernel"], accumulate=acc, key="P%d" % i, dy_key="dsh%d" % i)
-            ops.colsum(dsh.view(-1, 512), out=g["rpn_conv_shared/bias"], accumulate=acc)
-            self._dgrad(dsh, wd_shared, 3, dP[i], residual=dP[i], key="rpn_shared", dy_key="dsh%d" % i)     # dP += dgrad
         ops.scatter2_add(dP[4], dP[3])                       # P6 = MaxPooling2D(1, strides=2)(P5)
 
-        # ---- FPN backward
+        # ---- FPN backward (data parallel: every layer's gradient range starts its all-reduce as soon as it is complete)
+        def announce(layer):
+            if overlap:
+                lo, hi = st.layer_range(layer)
+                early(lo, hi)
+                self.grad_sync.ready(st.flat_grad, lo, hi)
         dpre = []
         for i in range(4):
             name = "fpn_p%d" % (i + 2)
@@ -665,6 +706,7 @@ class DenseImageCapRCNN(object):
             _, h_, w_, _ = dP[i].shape
             self._wgrad(p.pre[i], dP[i], 3, 1, g[name + "/kernel"], dy_key="dP%d" % i)
             ops.colsum(dP[i].view(-1, 256), out=g[name + "/bias"])
+            announce(name)
             dpre.append(self._dgrad(dP[i], wd, 3, self._buf("dpre%d" % i, tuple(dP[i].shape)), key=name, dy_key="dP%d" % i))
         for i in range(3):                                   # pre[k] = upsample(pre[k+1]) + lateral(C_k)
             ops.downsample2x_sum(dpre[i], out=dpre[i + 1], accumulate=True)
@@ -672,6 +714,7 @@ class DenseImageCapRCNN(object):
             name = "fpn_c%dp%d" % (i + 2, i + 2)
             self._wgrad(cmap, dpre[i], 1, 0, g[name + "/kernel"])
             ops.colsum(dpre[i].view(-1, 256), out=g[name + "/bias"])
+            announce(name)
 
         # ---- regulariser (+ frozen subset when set_trainable narrowed the set)
         coef, mask = self._masks()
