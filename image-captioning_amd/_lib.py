@@ -162,6 +162,7 @@ SYMBOLS = {
     "dc_downsample2x_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dc_maxpool2x2s2_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dc_maxpool3x3s2_same_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dc_mold_image_padded_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "dc_mold_image_rgbx_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "dc_roi_align_pyramid_f32": (C.c_int, [C.POINTER(RoiAlignDesc), C.c_void_p]),

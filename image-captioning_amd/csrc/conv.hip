@@ -171,6 +171,21 @@ __global__ void mold_rgbx_kernel(const uint8_t* __restrict__ img, float4* __rest
     }
 }
 
+// ---- the same with the pixel zero-padded to CP channels (CP % 4 == 0): one thread per 16-byte channel quad
+__global__ void mold_padded_kernel(const uint8_t* __restrict__ img, float4* __restrict__ out, long npix, int cq, float mr, float mg, float mb) {
+    const long total = npix * cq;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / cq;
+        const int q = (int)(i - pix * cq);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q == 0) {
+            const uint8_t* p = img + 3 * pix;
+            v = make_float4((float)p[0] - mr, (float)p[1] - mg, (float)p[2] - mb, 0.f);
+        }
+        out[i] = v;
+    }
+}
+
 }  // namespace dcap
 
 using namespace dcap;
@@ -405,4 +420,15 @@ extern "C" int dc_mold_image_rgbx_f32(const uint8_t* img, float* out, int N, int
     hipLaunchKernelGGL(mold_rgbx_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), img,
                        reinterpret_cast<float4*>(out), npix, mean_r, mean_g, mean_b);
     return check_launch("mold_rgbx_kernel");
+}
+
+extern "C" int dc_mold_image_padded_f32(const uint8_t* img, float* out, int N, int H, int W, int channels, float mean_r, float mean_g, float mean_b,
+                                        void* stream) {
+    DC_REQUIRE(img && out && N > 0 && H > 0 && W > 0 && channels >= 4 && (channels & 3) == 0, DC_EINVAL, "dc_mold_image_padded: bad arguments (channels % 4 == 0)");
+    DC_REQUIRE(aligned16(out), DC_EALIGN, "dc_mold_image_padded: out must be 16-byte aligned");
+    const long npix = (long)N * H * W, total = npix * (channels / 4);
+    const int blocks = (int)std::min<long>((total + 255) / 256, (long)kNumCU * 8);
+    hipLaunchKernelGGL(mold_padded_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), img, reinterpret_cast<float4*>(out), npix,
+                       channels / 4, mean_r, mean_g, mean_b);
+    return check_launch("mold_padded_kernel");
 }

@@ -6,6 +6,7 @@
 // contraction) so the in-range test and floor/ceil decisions match the reference's CPU path.
 #include "dcap_internal.h"
 #include <math.h>
+#include <algorithm>
 
 namespace dcap {
 
@@ -64,38 +65,109 @@ __global__ __launch_bounds__(256) void roi_align_kernel(dc_roialign_desc d) {
     }
 }
 
-// backward: one wave per output bin scatters its gradient row into the four corner pixels of the routed level
-__global__ __launch_bounds__(256) void roi_align_bwd_kernel(dc_roialign_desc d) {
-    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    const int bins = d.pool * d.pool;
-    if (wave >= d.B * d.R * bins) return;
-    const int box = wave / bins, bin = wave - box * bins;
-    const int py = bin / d.pool, px = bin - py * d.pool;
-    const float4 bx = reinterpret_cast<const float4*>(d.boxes)[box];
-    const int li = roi_level(bx.x, bx.y, bx.z, bx.w, d.image_area) - 2;
-    const int H = d.Hs[li], W = d.Ws[li];
-    float* gm = const_cast<float*>(d.maps[li]) + (long)(box / d.R) * H * W * d.C;
-    const float* go = d.out + (long)wave * d.C;
-    const float hs = (d.pool > 1) ? __fdiv_rn(__fmul_rn(__fsub_rn(bx.z, bx.x), (float)(H - 1)), (float)(d.pool - 1)) : 0.f;
-    const float ws = (d.pool > 1) ? __fdiv_rn(__fmul_rn(__fsub_rn(bx.w, bx.y), (float)(W - 1)), (float)(d.pool - 1)) : 0.f;
-    const float in_y = (d.pool > 1) ? __fadd_rn(__fmul_rn(bx.x, (float)(H - 1)), __fmul_rn((float)py, hs))
-                                    : __fmul_rn(__fmul_rn(0.5f, __fadd_rn(bx.x, bx.z)), (float)(H - 1));
-    const float in_x = (d.pool > 1) ? __fadd_rn(__fmul_rn(bx.y, (float)(W - 1)), __fmul_rn((float)px, ws))
-                                    : __fmul_rn(__fmul_rn(0.5f, __fadd_rn(bx.y, bx.w)), (float)(W - 1));
-    if (!((in_y >= 0.f) && (in_y <= (float)(H - 1)) && (in_x >= 0.f) && (in_x <= (float)(W - 1)))) return;
-    const int top = (int)floorf(in_y), bot = (int)ceilf(in_y), left = (int)floorf(in_x), right = (int)ceilf(in_x);
-    const float ly = in_y - (float)top, lx = in_x - (float)left;
-    float* tl = gm + ((long)top * W + left) * d.C;
-    float* tr = gm + ((long)top * W + right) * d.C;
-    float* bl = gm + ((long)bot * W + left) * d.C;
-    float* br = gm + ((long)bot * W + right) * d.C;
-    for (int c = lane; c < d.C; c += 64) {
-        const float g = go[c];
-        atomicAdd(tl + c, g * (1.f - ly) * (1.f - lx));
-        atomicAdd(tr + c, g * (1.f - ly) * lx);
-        atomicAdd(bl + c, g * ly * (1.f - lx));
-        atomicAdd(br + c, g * ly * lx);
+// Sample coordinates of bin row / column `p` of a box on a map of extent n (TF's operation order, as in the forward kernel).
+__device__ __forceinline__ float roi_sample(float lo, float hi, int p, int n, int pool) {
+    if (pool > 1) {
+        const float step = __fdiv_rn(__fmul_rn(__fsub_rn(hi, lo), (float)(n - 1)), (float)(pool - 1));
+        return __fadd_rn(__fmul_rn(lo, (float)(n - 1)), __fmul_rn((float)p, step));
     }
+    return __fmul_rn(__fmul_rn(0.5f, __fadd_rn(lo, hi)), (float)(n - 1));
+}
+
+// backward, DETERMINISTIC (round 3): gather per destination pixel instead of an atomic scatter per bin.  One wave per pixel of
+// a pyramid level: the lanes test 64 RoIs at a time (routed to this level? does its sampling grid come within one pixel of
+// this one?), the hits are then visited in ascending (RoI, bin row, bin column) order -- the same order on every run and on
+// every rank -- and each contributing bin adds  weight x its 256-channel gradient row  (four channels per lane) to a register
+// accumulator that is added to the map with ONE plain read-modify-write.  weight = the bilinear corner weight the forward used:
+//   wy = [y == floor(in_y)] (1 - ly) + [y == ceil(in_y)] ly,  wx likewise  (both terms when in_y is integral: 1).
+// No float atomics: the joint model's FPN / RPN gradients become bit-reproducible (they were the only ones that were not).
+constexpr int RA_MAX_POOL = 16;
+
+__global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(dc_roialign_desc d, int li, long wave0) {
+    const int lane = threadIdx.x & 63;
+    const long wv = wave0 + (((long)blockIdx.x * 256 + threadIdx.x) >> 6);
+    const int H = d.Hs[li], W = d.Ws[li];
+    const long per_img = (long)H * W;
+    if (wv >= (long)d.B * per_img) return;
+    const int img = (int)(wv / per_img);
+    const int pix = (int)(wv - (long)img * per_img);
+    const int y = pix / W, x = pix - y * W;
+    const float4* boxes = reinterpret_cast<const float4*>(d.boxes) + (long)img * d.R;
+    const int bins = d.pool * d.pool;
+    float4 acc[4];                                   // channels 4 lane .. 4 lane + 3 (+ 256 k): C <= 1024
+    const int C4 = d.C >> 2, nchunk = (C4 + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool any = false;
+    for (int b0 = 0; b0 < d.R; b0 += 64) {
+        const int bi = b0 + lane;
+        bool hit = false;
+        if (bi < d.R) {
+            const float4 bx = boxes[bi];
+            if (roi_level(bx.x, bx.y, bx.z, bx.w, d.image_area) - 2 == li) {
+                // the sampling grid spans [in(0), in(pool - 1)] (either order for a flipped box): can it touch row y / column x?
+                const float ya = roi_sample(bx.x, bx.z, 0, H, d.pool), yb = roi_sample(bx.x, bx.z, d.pool - 1, H, d.pool);
+                const float xa = roi_sample(bx.y, bx.w, 0, W, d.pool), xb = roi_sample(bx.y, bx.w, d.pool - 1, W, d.pool);
+                hit = fminf(ya, yb) < (float)y + 1.f && fmaxf(ya, yb) > (float)y - 1.f && fminf(xa, xb) < (float)x + 1.f && fmaxf(xa, xb) > (float)x - 1.f;
+            }
+        }
+        unsigned long long m = __ballot(hit);
+        while (m) {                                  // wave-uniform: ascending RoI index
+            const int j = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int box = b0 + j;
+            const float4 bx = boxes[box];            // same address in every lane: one broadcast load
+            float wys[RA_MAX_POOL], wxs[RA_MAX_POOL];
+#pragma unroll 1
+            for (int p = 0; p < d.pool; ++p) {
+                const float iy = roi_sample(bx.x, bx.z, p, H, d.pool), ix = roi_sample(bx.y, bx.w, p, W, d.pool);
+                float wy = 0.f, wx = 0.f;
+                if (iy >= 0.f && iy <= (float)(H - 1)) {
+                    const float ly = iy - floorf(iy);
+                    if ((int)floorf(iy) == y) wy += 1.f - ly;
+                    if ((int)ceilf(iy) == y) wy += ly;
+                } else {
+                    wy = -1.f;                       // this bin row is outside the map: the forward wrote zeros, no gradient
+                }
+                if (ix >= 0.f && ix <= (float)(W - 1)) {
+                    const float lx = ix - floorf(ix);
+                    if ((int)floorf(ix) == x) wx += 1.f - lx;
+                    if ((int)ceilf(ix) == x) wx += lx;
+                } else {
+                    wx = -1.f;
+                }
+                wys[p] = wy;
+                wxs[p] = wx;
+            }
+            const float* go = d.out + ((long)(img * d.R + box) * bins) * d.C;
+#pragma unroll 1
+            for (int py = 0; py < d.pool; ++py) {
+                if (!(wys[py] > 0.f)) continue;
+#pragma unroll 1
+                for (int px = 0; px < d.pool; ++px) {
+                    if (!(wxs[px] > 0.f)) continue;
+                    const float wgt = wys[py] * wxs[px];
+                    const float4* row = reinterpret_cast<const float4*>(go + (long)(py * d.pool + px) * d.C);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < nchunk && lane + 64 * k < C4) {
+                            const float4 g = row[lane + 64 * k];
+                            acc[k].x += g.x * wgt; acc[k].y += g.y * wgt; acc[k].z += g.z * wgt; acc[k].w += g.w * wgt;
+                        }
+                    any = true;
+                }
+            }
+        }
+    }
+    if (!any) return;
+    float4* dst = reinterpret_cast<float4*>(const_cast<float*>(d.maps[li]) + ((long)img * per_img + pix) * d.C);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < nchunk && lane + 64 * k < C4) {
+            float4 v = dst[lane + 64 * k];
+            v.x += acc[k].x; v.y += acc[k].y; v.z += acc[k].z; v.w += acc[k].w;
+            dst[lane + 64 * k] = v;
+        }
 }
 
 }  // namespace dcap
@@ -104,12 +176,23 @@ using namespace dcap;
 
 extern "C" int dc_roi_align_pyramid_bwd_f32(const dc_roialign_desc* d, void* stream) {
     DC_REQUIRE(d && d->boxes && d->out, DC_EINVAL, "dc_roi_align_pyramid_bwd: null pointer");
-    DC_REQUIRE(d->B > 0 && d->R > 0 && d->pool > 0 && d->C > 0, DC_EINVAL, "dc_roi_align_pyramid_bwd: bad B/R/pool/C");
-    for (int l = 0; l < 4; ++l) DC_REQUIRE(d->maps[l] && d->Hs[l] > 0 && d->Ws[l] > 0, DC_EINVAL, "dc_roi_align_pyramid_bwd: bad map %d", l);
-    DC_REQUIRE(aligned16(d->boxes), DC_EALIGN, "dc_roi_align_pyramid_bwd: boxes not 16-byte aligned");
-    const long waves = (long)d->B * d->R * d->pool * d->pool;
-    hipLaunchKernelGGL(roi_align_bwd_kernel, dim3((int)((waves + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), *d);
-    return check_launch("roi_align_bwd_kernel");
+    DC_REQUIRE(d->B > 0 && d->R > 0 && d->pool > 0 && d->pool <= RA_MAX_POOL && d->C > 0 && (d->C & 3) == 0 && d->C <= 1024, DC_EINVAL,
+               "dc_roi_align_pyramid_bwd: bad B/R/pool/C (pool <= 16, C a multiple of 4 and <= 1024)");
+    for (int l = 0; l < 4; ++l) {
+        DC_REQUIRE(d->maps[l] && d->Hs[l] > 0 && d->Ws[l] > 0, DC_EINVAL, "dc_roi_align_pyramid_bwd: bad map %d", l);
+        DC_REQUIRE(aligned16(d->maps[l]), DC_EALIGN, "dc_roi_align_pyramid_bwd: gradient map %d not 16-byte aligned", l);
+    }
+    DC_REQUIRE(aligned16(d->boxes) && aligned16(d->out), DC_EALIGN, "dc_roi_align_pyramid_bwd: boxes / dout not 16-byte aligned");
+    for (int l = 0; l < 4; ++l) {
+        const long waves = (long)d->B * d->Hs[l] * d->Ws[l];
+        for (long w0 = 0; w0 < waves; w0 += 4L * 0x40000000) {       // (grids stay below 2^31 blocks)
+            const long n = std::min(waves - w0, 4L * 0x40000000);
+            hipLaunchKernelGGL(roi_align_bwd_gather_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), *d, l, w0);
+        }
+        int rc = check_launch("roi_align_bwd_gather_kernel");
+        if (rc) return rc;
+    }
+    return DC_OK;
 }
 
 extern "C" int dc_roi_align_pyramid_f32(const dc_roialign_desc* d, void* stream) {

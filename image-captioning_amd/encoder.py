@@ -467,11 +467,9 @@ class Vgg16Plan(EncoderPlan):
         B, H, W = self.B, self.H, self.W
         self._ops, self._ws_bytes, self.flops, self._bufs = [], 0, 0.0, []
         self.images = torch.empty((B, H, W, 3), dtype=torch.uint8, device=self.device)
-        rgbx = torch.empty((B, H, W, 4), dtype=torch.float32, device=self.device)
-        x32 = torch.zeros((B, H, W, 32), dtype=torch.float32, device=self.device)
-        self._bufs += [rgbx, x32]
-        self._ops.append(("mold", self.images, rgbx))
-        self._ops.append(("pad32", rgbx, x32))
+        x32 = torch.empty((B, H, W, 32), dtype=torch.float32, device=self.device)
+        self._bufs += [x32]
+        self._ops.append(("mold32", self.images, x32))       # mean-subtracted RGB + 29 zero channels, one kernel (dc_mold_image_padded_f32)
         x, h, w = x32, H, W
         for b, (n, cout) in enumerate(((2, 64), (2, 128), (3, 256), (3, 512), (3, 512)), 1):
             for i in range(1, n + 1):
@@ -498,10 +496,8 @@ class Vgg16Plan(EncoderPlan):
                 rc = lib.dc_conv2d_nhwc_f32(C.byref(op[1]), wsp, wsb, stream)
                 if rc:
                     check(rc, "dc_conv2d_nhwc_f32(%s)" % op[2])
-            elif kind == "mold":
-                ops.mold_image_rgbx(op[1], self.mean_pixel, out=op[2])
-            elif kind == "pad32":
-                op[2][..., :4].copy_(op[1])
+            elif kind == "mold32":
+                ops.mold_image_padded(op[1], self.mean_pixel, out=op[2])
             else:
                 ops.maxpool2x2s2(op[1], out=op[2])
 

@@ -336,6 +336,18 @@ def mold_image_rgbx(img_u8, mean_pixel, out=None):
     return out
 
 
+def mold_image_padded(img_u8, mean_pixel, out):
+    """mold_image into pixels zero-padded to out.shape[-1] channels (a multiple of 4)."""
+    lib = _lib.load()
+    _chk(img_u8, torch.uint8, "images"), _chk(out, name="out")
+    N, H, W, c = img_u8.shape
+    if c != 3 or not img_u8.is_contiguous() or not out.is_contiguous() or tuple(out.shape[:3]) != (N, H, W):
+        raise _lib.DcapError("mold_image_padded: images contiguous [N,H,W,3] uint8, out contiguous [N,H,W,C]")
+    check(lib.dc_mold_image_padded_f32(_ptr(img_u8), _ptr(out), N, H, W, out.shape[3], float(mean_pixel[0]), float(mean_pixel[1]),
+                                       float(mean_pixel[2]), _stream()), "dc_mold_image_padded_f32")
+    return out
+
+
 def roi_align_pyramid(maps, boxes, image_area, pool=7, out=None, levels_out=None):
     """maps: [P2,P3,P4,P5] each [B,H,W,C]; boxes [B,R,4] normalised float32 -> [B,R,pool,pool,C]."""
     lib = _lib.load()

@@ -225,6 +225,10 @@ int dc_maxpool2x2s2_f32(const float* x, float* y, int N, int H, int W, int C, vo
  * out[n,h,w,0..2] = float(img_u8) - mean[c], out[...,3] = 0. */
 int dc_mold_image_rgbx_f32(const uint8_t* img, float* out, int N, int H, int W,
                            float mean_r, float mean_g, float mean_b, void* stream);
+/* The same with the pixel zero-padded to `channels` floats (channels % 4 == 0): the first convolution of the VGG16 alternative
+ * backbone reads 32-channel pixels (the implicit-GEMM loader wants Cin % 32 == 0). */
+int dc_mold_image_padded_f32(const uint8_t* img, float* out, int N, int H, int W, int channels,
+                             float mean_r, float mean_g, float mean_b, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * PyramidROIAlign forward (feature_generation/dense_model.py:317-418): level routing

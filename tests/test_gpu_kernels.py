@@ -479,6 +479,36 @@ def test_roi_align_backward_is_the_adjoint_of_forward(ops):
         close(d, w, 2e-5)
 
 
+def test_roi_align_backward_is_deterministic_and_accumulates(ops):
+    """The backward gathers per destination pixel in a fixed (RoI, bin) order -- no float atomics: two runs are bit-identical even
+    with hundreds of overlapping RoIs (incl. boxes that leave the image, degenerate and duplicate boxes, two images), and it ADDS to
+    what the maps already hold (the joint model puts the RPN branch's data gradients there first)."""
+    from image_captioning_amd import synth
+    rng = np.random.default_rng(11)
+    B, R, C, S = 2, 200, 256, 256
+    shapes = [(B, S // s, S // s, C) for s in (4, 8, 16, 32)]
+    rois = synth.rois(3, B, R, S, S, lo=8, hi=256).astype(np.float64)
+    rois[:, :8] = rois[:, 8:16]                                        # duplicates: several RoIs hit the same pixels
+    rois[0, 16] = [-40, -30, 90, 120]                                  # sampling points outside the map (zero rows in the forward)
+    rois[1, 17] = [200, 180, 300, 320]
+    rois[0, 18] = [50, 60, 50, 60]                                     # zero area
+    nb = O.normalize_boxes(rois, S, S)
+    boxes = dev(nb)
+    g = rng.standard_normal((B, R, 7, 7, C))
+    gd = dev(g)
+    base = [rng.standard_normal(sh) for sh in shapes]
+    runs = []
+    for _ in range(2):
+        dm = [dev(b) for b in base]
+        ops.roi_align_pyramid_bwd(dm, boxes, S * S, gd, 7)
+        runs.append([d.cpu().numpy() for d in dm])
+    for a, b in zip(*runs):
+        np.testing.assert_array_equal(a, b)
+    want = O.pyramid_roi_align_backward(nb, shapes, (S, S), g)
+    for got, w, b in zip(runs[0], want, base):
+        close(got, w + b, 3e-5)
+
+
 def test_downsample2x_sum_is_upsample_adjoint(ops):
     rng = np.random.default_rng(6)
     fine = rng.standard_normal((2, 8, 12, 8))

@@ -91,4 +91,6 @@ def test_joint_model_two_ranks_average_the_tower_gradients(tmp_path):
     start = W.build().store.flat.cpu().numpy()
     moved = np.abs(single - start).max()
     assert moved > 0
-    assert np.abs(r[0]["flat"] - single).max() < 2e-3 * moved + 1e-7     # RoIAlign's backward scatters with float atomics
+    diff = np.abs(r[0]["flat"] - single).max()
+    print("joint 2-rank vs averaged single process: max |dw| = %.3e of a %.3e update" % (diff, moved))
+    assert diff < 1e-5 * moved + 1e-9     # (round 2: 2e-3 -- RoIAlign's backward was an atomic scatter; it is a fixed-order gather now)
