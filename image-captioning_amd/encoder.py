@@ -381,7 +381,10 @@ class EncoderPlan:
             # on the compute queue).  A pinned staging buffer + one DMA was tried and measured SLOWER inside the joint step (35 vs
             # 12.9 ms: the DMA and the CPU-side refill of the buffer stall each other on this box); callers that care hand over a
             # device-resident uint8 tensor (bench.py does, the data generator can prefetch one).
-            self.images.copy_(images_u8, non_blocking=True)
+            # (pageable memory: the copy must be complete when this call returns -- on this runtime a non_blocking copy from unpinned
+            # memory really is asynchronous, and the caller's array may be freed or refilled right away: round 3 found the training
+            # pipeline reading half-overwritten images that way.  Device tensors and pinned buffers stay asynchronous.)
+            self.images.copy_(images_u8, non_blocking=bool(images_u8.is_cuda or images_u8.is_pinned()))
         if not self.use_graph:
             self._run_ops()
         elif self._graph is not None:

@@ -33,10 +33,12 @@ def load_model(weights=None, model_path=None, **kw):
     return model
 
 
-def generate_features(dataset, image_id, model):
-    """[N,7,7,256] features of the image's ground-truth regions (one batch of one image)."""
+def generate_features(dataset, image_id, model, device_features=False):
+    """[N,7,7,256] features of the image's ground-truth regions (one batch of one image); device_features=True: a torch
+    tensor that stays on the GPU (text_generation_model_v2.data_generator(device_resident=True))."""
     boxes = dataset.load_captions_and_rois(image_id)[0]
-    out = model.generate_captions([dataset.load_image(image_id)], boxes[np.newaxis], verbose=0)
+    kw = {"device_features": True} if device_features else {}          # (feature models with the reference's plain signature keep working)
+    out = model.generate_captions([dataset.load_image(image_id)], boxes[np.newaxis], verbose=0, **kw)
     return out[0]['features']
 
 

@@ -140,15 +140,18 @@ class DenseImageCapRCNN(object):
             windows.append(window)
         return np.stack(molded), np.stack(metas), np.stack(windows)
 
-    def generate_captions(self, images, rois=None, verbose=0):
+    def generate_captions(self, images, rois=None, verbose=0, device_features=False):
         """images: list of [H,W,3] uint8; rois: [len(images), N, 4] (y1,x1,y2,x2) pixels.
         Returns [{'features': float32 [N,7,7,256]}] like the reference (whose slice
-        features[i][1000*i:1000*(i+1)] only works for BATCH_SIZE == 1; image i > 0 gets its own RoIs here)."""
+        features[i][1000*i:1000*(i+1)] only works for BATCH_SIZE == 1; image i > 0 gets its own RoIs here).
+        device_features=True keeps the features on the GPU (torch tensors, a copy the caller owns): a training generator that
+        feeds them back to the decoder then never moves [N,7,7,256] floats through host memory."""
         assert self.mode == "inference", "Create model in inference mode."
         assert len(images) == self.config.BATCH_SIZE, "len(images) must be equal to BATCH_SIZE"
         molded, metas, windows = self.mold_inputs(images)
         rois = None if self.use_generated_rois else np.asarray(rois, np.float32)
-        feats = self.extract_features(molded, rois).cpu().numpy()
+        feats = self.extract_features(molded, rois)
+        feats = feats.clone() if device_features else feats.cpu().numpy()
         n = self.config.POST_NMS_ROIS_INFERENCE
         return [{"features": feats[i][:n]} for i in range(len(images))]
 

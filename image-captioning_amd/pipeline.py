@@ -24,6 +24,8 @@ class CaptionTrainPipeline(object):
         self.ev_free = [torch.cuda.Event() for _ in range(2)]       # decoder done reading slot
         self.pending = None                                          # (slot, tables) awaiting its decoder pass
         self.n = 0
+        self._hold = []        # inputs of the last steps: their memory must not go back to the allocator (and be handed to the next
+                               # step's uploads, made on another stream) while kernels that read them are still queued
         cur = torch.cuda.current_stream(dev)
         self.s_enc.wait_stream(cur)
         self.s_dec.wait_stream(cur)
@@ -49,6 +51,7 @@ class CaptionTrainPipeline(object):
         device tensor or None (already in plan.images); boxes: normalised [B,R,4]; tables: SampleTables.
         Returns the previous batch's loss (device scalar) or None on the first call."""
         slot = self.n & 1
+        self._hold = (self._hold + [(images, boxes, tables)])[-3:]
         self._encode(slot, images, boxes)
         loss = None
         if self.pending is not None:

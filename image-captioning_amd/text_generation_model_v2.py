@@ -90,6 +90,19 @@ class VisualGenomeDataset(Dataset):
                 caps.append(cap)
         return np.array(rois), np.array(caps, dtype=object) if len({c.shape for c in caps}) > 1 else np.array(caps)
 
+    def load_caption_ids_and_rois(self, image_id):
+        """The regions of load_captions_and_rois with their captions as word-id lists (the argmax of the one-hot rows, without
+        building them: [L, V] float64 per caption is 1.2 MB at V = 10 000); train_on_dataset reads this form when a dataset has it."""
+        from .preprocess import encode_caption
+        info = self.image_info[image_id]
+        rois, caps = [], []
+        for roi, caption in zip(info['rois'], info['captions']):
+            ids = encode_caption(caption[0], self.word_to_id)
+            if ids.size != 0:
+                rois.append(roi)
+                caps.append([int(i) for i in ids])
+        return np.array(rois), caps
+
     def load_original_captions_and_rois(self, image_id):
         info = self.image_info[image_id]
         return np.array(info['rois']), info['captions']
@@ -112,8 +125,15 @@ def load_sequences(dataset):
     return sequences
 
 
-def data_generator(dataset, features_model, config, batch_size, shuffle=False):
-    """Infinite generator of ([feat f32[B,7,7,256], words int32[B,T]], onehot f64[B,V]) batches."""
+def data_generator(dataset, features_model, config, batch_size, shuffle=False, device_resident=False):
+    """Infinite generator of ([feat f32[B,7,7,256], words int32[B,T]], onehot f64[B,V]) batches -- the reference's layout
+    (text_generation_model_v2.py:169-205).  device_resident=True yields the SAME samples in the form the device wants: the RoI
+    features as a torch tensor that never left the GPU (rows gathered from the feature model's output) and the next-word
+    targets as int32 ids [B] instead of float64 one-hot rows (B x V x 8 bytes per batch: 5 MB at V = 10 000); train_on_batch /
+    fit_generator take both forms."""
+    if device_resident:
+        for batch in _data_generator_device(dataset, features_model, config, batch_size, shuffle):
+            yield batch
     from .generate_one_roi_features import generate_features
     b = 0
     sequence_index = -1
@@ -146,6 +166,113 @@ def data_generator(dataset, features_model, config, batch_size, shuffle=False):
         if b >= batch_size:
             yield [batch_image_features, batch_prev_words], batch_next_word
             b = 0
+
+
+def _data_generator_device(dataset, features_model, config, batch_size, shuffle):
+    """data_generator(device_resident=True): same sequence order, same shuffling stream, same batches."""
+    from .generate_one_roi_features import generate_features
+    sequence_index = -1
+    sequence_ids = np.arange(len(dataset.sequences))
+    prev_im_id, prev_img_features = -1, None
+    rows, words, targets = [], [], []
+    while True:
+        sequence_index = (sequence_index + 1) % len(sequence_ids)
+        if shuffle and sequence_index == 0:
+            np.random.shuffle(sequence_ids)
+        sequence_id = sequence_ids[sequence_index]
+        image_id, roi_id, prev_words, next_word = dataset.sequences[sequence_id]
+        if prev_im_id != image_id:
+            prev_img_features = generate_features(dataset, image_id, features_model, device_features=True)
+        prev_im_id = image_id
+        rows.append(prev_img_features[roi_id])
+        words.append(pad_sequences([prev_words], config.PADDING_SIZE)[0])
+        targets.append(next_word)
+        if len(rows) >= batch_size:
+            yield [torch.stack(rows), np.stack(words)], np.asarray(targets, np.int32)
+            rows, words, targets = [], [], []
+
+
+def train_on_dataset(model, features_model, dataset, images_per_step, rois_per_image, epochs=1, steps_per_epoch=None, shuffle=False,
+                     max_queue_size=4, callbacks=None, verbose=1):
+    """The measured pipeline (bench.py) behind the training script's objects: trains `model` (build_model(...), compiled) on
+    `dataset` (a VisualGenomeDataset-like utils.Dataset: load_image, load_captions_and_rois) with the feature model's encoder
+    plan and the decoder on TWO HIP streams (pipeline.CaptionTrainPipeline): the encoder of step i + 1 runs while the decoder
+    of step i trains, RoI features never leave the GPU, every caption goes through the word LSTM once
+    (train_on_captions: the same loss and gradients as the reference's (prefix -> next word) samples of those captions).
+    One step = `images_per_step` images x their first `rois_per_image` regions (images with fewer regions are skipped);
+    images are resized like the feature model does (mold_inputs) on a background thread, `max_queue_size` steps ahead.
+    Differences to fit_generator(data_generator(...)): a batch is whole captions of whole images instead of 64 consecutive
+    prefix samples, so batch boundaries fall differently unless images_per_step x rois_per_image x caption length equals the
+    batch size (tests/test_gpu_models.py::test_train_on_dataset_equals_fit_generator builds exactly that case).
+    Returns the per-epoch logs like fit_generator."""
+    from .keras_like import GeneratorEnqueuer
+    from .pipeline import CaptionTrainPipeline
+    cfg = features_model.config
+    H = W = cfg.IMAGE_MAX_DIM
+    plan = features_model.plan(images_per_step, H, W)
+    inner = getattr(model, "inner_model", model)
+    pipe = CaptionTrainPipeline(plan, inner, rois_per_image)
+    if steps_per_epoch is None:
+        steps_per_epoch = max(1, len(dataset.image_ids) // images_per_step)
+
+    dev = inner.device
+    s_copy = torch.cuda.Stream(device=dev)          # uploads run on the producer thread's own stream, beside both compute streams
+
+    def batches():
+        ids = np.array(dataset.image_ids)
+        pos = 0
+        while True:
+            imgs, boxes, caps = [], [], []
+            while len(imgs) < images_per_step:
+                if pos == 0 and shuffle:
+                    np.random.shuffle(ids)
+                image_id = ids[pos]
+                pos = (pos + 1) % len(ids)
+                if hasattr(dataset, "load_caption_ids_and_rois"):
+                    rois, ids = dataset.load_caption_ids_and_rois(image_id)
+                else:                                            # the reference's form: one-hot rows per word
+                    rois, captions = dataset.load_captions_and_rois(image_id)
+                    ids = [[int(np.argmax(w)) for w in c] for c in captions[:rois_per_image]]
+                if len(rois) < rois_per_image:
+                    continue
+                molded, _, _ = features_model.mold_inputs([dataset.load_image(image_id)])
+                imgs.append(molded[0])
+                boxes.append(np.asarray(rois[:rois_per_image], np.float32))
+                caps += [list(c) for c in ids[:rois_per_image]]
+            # everything the step needs goes to the GPU here, on the producer thread (blocking copies on its stream: complete when
+            # the batch is queued), so the training loop below only enqueues kernels
+            with torch.cuda.stream(s_copy):
+                images_dev = torch.as_tensor(np.stack(imgs)).to(dev)
+                boxes_dev = plan.normalize_boxes(np.stack(boxes))
+                tables = SampleTables.from_captions(caps, dev)
+                s_copy.synchronize()
+            yield images_dev, boxes_dev, tables
+
+    enq = GeneratorEnqueuer(batches(), workers=1, max_queue_size=max_queue_size)
+    feed = enq.get()
+    history = []
+    keep = []                                        # the last few batches stay referenced until their kernels have certainly run
+    try:
+        for epoch in range(epochs):
+            acc, n = None, 0
+            for _ in range(steps_per_epoch):
+                batch = next(feed)
+                keep = (keep + [batch])[-4:]
+                loss = pipe.step(*batch)
+                if loss is not None:
+                    with torch.cuda.stream(pipe.s_dec):          # the loss buffer belongs to the decoder's stream (and is reused by the next step)
+                        acc, n = (loss.clone() if acc is None else acc.add_(loss)), n + 1
+            last = pipe.flush()                                  # the epoch's last decoder pass; joins both streams
+            acc, n = (last.clone() if acc is None else acc.add_(last)), n + 1
+            logs = {"loss": float((acc / n).item())}             # the epoch's one host synchronisation
+            if verbose:
+                print("Epoch %d/%d - loss: %.4f" % (epoch + 1, epochs, logs["loss"]))
+            for cb in callbacks or []:
+                cb.on_epoch_end(inner, epoch, logs)
+            history.append(logs)
+    finally:
+        enq.stop()
+    return history
 
 
 # --------------------------------------------------------------------------------------------------

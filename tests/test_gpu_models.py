@@ -675,3 +675,109 @@ def test_joint_model_inference_in_bf16(gpu):
             assert np.abs(out["f32"]["captions"][j] - res["captions"][k]).max() < 5e-2
             common += 1
     assert common >= max(1, K // 2)
+
+
+# ---------------------------------------------------------------------------------------------
+# the v2 training script's flow on the device (text_generation_model_v2.py:224-346) and the pipeline route behind it
+# ---------------------------------------------------------------------------------------------
+
+def _toy_vg(S, n_images, R, L, V):
+    """A VisualGenomeDataset with in-memory pixels: n_images images, R regions each, captions of exactly L in-vocabulary words."""
+    from image_captioning_amd.text_generation_model_v2 import VisualGenomeDataset
+    w2i = {"<unk>": 0, "<start>": 1, "<end>": 2}
+    w2i.update({"w%d" % i: i for i in range(3, V)})
+    ds = VisualGenomeDataset(w2i, L + 2)
+    rng = np.random.RandomState(5)
+    for i in range(n_images):
+        y, x = rng.randint(0, S - 40, R), rng.randint(0, S - 40, R)
+        rois = [[int(a), int(b), int(a + rng.randint(24, 40)), int(b + rng.randint(24, 40))] for a, b in zip(y, x)]
+        caps = [[" ".join("w%d" % rng.randint(3, V) for _ in range(L))] for _ in range(R)]
+        ds.add_image("VisualGenome", image_id=1000 + i, path="none", width=S, height=S, rois=rois, captions=caps,
+                     pixels=rng.randint(0, 255, (S, S, 3)).astype(np.uint8))
+    ds.prepare()
+    return ds
+
+
+def test_v2_script_flow_device_resident_generator_and_train_on_dataset(gpu, tmp_path):
+    """The reference's training script flow on a toy Visual Genome: feature model -> load_sequences -> data_generator ->
+    fit_generator (background enqueuer, ModelCheckpoint + CSVLogger per epoch) -> load_weights -> greedy decode.  Then the same
+    training (a) from the device-resident generator (features stay on the GPU, sparse targets): bit-identical weights; (b) through
+    train_on_dataset (two-stream pipeline, every caption once through the word LSTM): the same weights up to fp32 summation order,
+    because here a batch of the as-written generator is exactly the captions of whole images."""
+    from image_captioning_amd import synth
+    from image_captioning_amd.config import Config
+    from image_captioning_amd.keras_like import ModelCheckpoint, CSVLogger
+    from image_captioning_amd.modified_dense_model import DenseImageCapRCNN
+    from image_captioning_amd.text_generation_model_v2 import (DenseCapConfig, build_model, Adam, data_generator, load_sequences,
+                                                                train_on_dataset)
+    S, V, R, L, n_img, k, blocks = 128, 40, 4, 3, 4, 2, 1
+
+    class FCfg(Config):
+        NAME = "toy"
+        IMAGES_PER_GPU = 1
+        IMAGE_MIN_DIM = S
+        IMAGE_MAX_DIM = S
+    feats = DenseImageCapRCNN("inference", FCfg(), str(tmp_path / "logs"), stage4_blocks=blocks)
+    feats.set_weights(synth.encoder_weights(0, blocks))
+    ds = _toy_vg(S, n_img, R, L, V)
+    ds.add_sequences(load_sequences(ds))
+    assert len(ds.sequences) == n_img * R * L
+    cfg = DenseCapConfig(V, synth.embedding_matrix(3, V))
+    cfg.PADDING_SIZE = L + 2
+    batch, steps, epochs = k * R * L, n_img // k, 2
+
+    def fresh():
+        m = build_model((7, 7, 256), (cfg.PADDING_SIZE,), cfg, 256, inject=True, seed=7)
+        m.compile(optimizer=Adam(amsgrad=True), loss="categorical_crossentropy")
+        return m
+    # ---- as written
+    ref = fresh()
+    ckpt = str(tmp_path / "ck" / "weights-{epoch:02d}.npz")
+    hist = ref.fit_generator(data_generator(ds, feats, cfg, batch), epochs=epochs, steps_per_epoch=steps, verbose=0, workers=1, max_queue_size=10,
+                             callbacks=[ModelCheckpoint(ckpt, verbose=0, save_weights_only=True, mode='min'), CSVLogger(str(tmp_path / "log.csv"))])
+    assert len(hist) == epochs and hist[1]["loss"] < hist[0]["loss"]
+    assert open(str(tmp_path / "log.csv")).read().splitlines()[0] == "epoch,loss" and os.path.exists(ckpt.format(epoch=2))
+    want = ref.get_weights_dict()
+    again = fresh()
+    again.load_weights(ckpt.format(epoch=2))
+    assert all(np.array_equal(want[n], v) for n, v in again.get_weights_dict().items())
+    f0 = feats.generate_captions([ds.load_image(0)], ds.load_captions_and_rois(0)[0][None])[0]["features"]
+    ids, probs = again.greedy_decode(f0[0])
+    assert len(ids) == cfg.PADDING_SIZE - 1 and np.isfinite(probs).all()
+    # ---- (a) device-resident generator: the same samples, features never on the host, sparse targets
+    g = data_generator(ds, feats, cfg, batch, device_resident=True)
+    (fd, wd), td = next(g)
+    (fh, wh), th = next(data_generator(ds, feats, cfg, batch))
+    assert isinstance(fd, torch.Tensor) and fd.is_cuda and np.array_equal(fd.cpu().numpy(), fh) and np.array_equal(wd, wh)
+    assert td.dtype == np.int32 and np.array_equal(td, th.argmax(1))
+    a = fresh()
+    a.fit_generator(data_generator(ds, feats, cfg, batch, device_resident=True), epochs=epochs, steps_per_epoch=steps, verbose=0)
+    assert all(np.array_equal(want[n], v) for n, v in a.get_weights_dict().items())
+    # ---- (b) the measured pipeline behind the same objects
+    b = fresh()
+    hb = train_on_dataset(b, feats, ds, images_per_step=k, rois_per_image=R, epochs=epochs, steps_per_epoch=steps, verbose=0)
+    got = b.get_weights_dict()
+    # (b1) against the same single-pass steps run one after the other on one stream: the two-stream pipeline (encoder of step
+    # i + 1 beside the decoder of step i, double-buffered features, events) changes NOTHING -- bit-identical weights and losses
+    c = fresh()
+    hc = []
+    for _ in range(epochs):
+        losses = []
+        for st in range(steps):
+            imgs = np.stack([feats.mold_inputs([ds.load_image(i)])[0][0] for i in range(st * k, (st + 1) * k)])
+            boxes = np.stack([ds.load_captions_and_rois(i)[0][:R] for i in range(st * k, (st + 1) * k)])
+            caps = [[int(np.argmax(w)) for w in cap] for i in range(st * k, (st + 1) * k) for cap in ds.load_captions_and_rois(i)[1][:R]]
+            f = feats.extract_features(imgs, boxes)
+            losses.append(float(c.train_on_captions(f.reshape(-1, 7, 7, 256), caps).item()))
+        hc.append(float(np.mean(np.float32(losses))))
+    assert all(np.array_equal(got[n], v) for n, v in c.get_weights_dict().items())
+    assert [abs(h["loss"] - l) < 1e-6 * l for h, l in zip(hb, hc)] == [True] * epochs
+    # (b2) against the as-written path: the first epoch's loss (one update in) agrees to fp32 summation order.  Later weights
+    # are the same training run but not the same bits: the single pass and the expanded batch sum the same gradient in
+    # different orders (test_v2_single_pass_equals_expanded_batch: 2e-4), and AMSGrad's first steps are +-lr whatever |g| is.
+    assert abs(hb[0]["loss"] - hist[0]["loss"]) < 1e-4 * abs(hist[0]["loss"]), (hb, hist)
+    assert abs(hb[1]["loss"] - hist[1]["loss"]) < 0.05 * abs(hist[1]["loss"]) and hb[1]["loss"] < hb[0]["loss"], (hb, hist)
+    start = fresh().get_weights_dict()
+    for n in want:
+        d = np.abs(got[n] - want[n])
+        assert d.max() <= 1e-3 * epochs * steps + 1e-6 and d.mean() < 0.25 * np.abs(want[n] - start[n]).mean() + 1e-7, (n, d.mean(), d.max())
