@@ -229,16 +229,16 @@ def train_on_dataset(model, features_model, dataset, images_per_step, rois_per_i
                 image_id = ids[pos]
                 pos = (pos + 1) % len(ids)
                 if hasattr(dataset, "load_caption_ids_and_rois"):
-                    rois, ids = dataset.load_caption_ids_and_rois(image_id)
+                    rois, words = dataset.load_caption_ids_and_rois(image_id)
                 else:                                            # the reference's form: one-hot rows per word
                     rois, captions = dataset.load_captions_and_rois(image_id)
-                    ids = [[int(np.argmax(w)) for w in c] for c in captions[:rois_per_image]]
+                    words = [[int(np.argmax(w)) for w in c] for c in captions[:rois_per_image]]
                 if len(rois) < rois_per_image:
                     continue
                 molded, _, _ = features_model.mold_inputs([dataset.load_image(image_id)])
                 imgs.append(molded[0])
                 boxes.append(np.asarray(rois[:rois_per_image], np.float32))
-                caps += [list(c) for c in ids[:rois_per_image]]
+                caps += [[int(t) for t in c] for c in words[:rois_per_image]]
             # everything the step needs goes to the GPU here, on the producer thread (blocking copies on its stream: complete when
             # the batch is queued), so the training loop below only enqueues kernels
             with torch.cuda.stream(s_copy):
