@@ -32,16 +32,28 @@ def batch(V, T, B, seed=11):
     return feat, words, onehot
 
 
+def caption_shard(V, T, R, rank):
+    """One rank's shard of the configs[3] step: R RoI features and their full-length captions (bench.py's per-rank seeds)."""
+    from image_captioning_amd import synth
+    rng = np.random.default_rng(1234 + rank)
+    return rng.standard_normal((R, 7, 7, 256)).astype(np.float32), synth.captions_v2(1234 + rank + 2, R, T, V, full=True)
+
+
 def main():
     out_dir, V, T, B, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    mode = sys.argv[6] if len(sys.argv) > 6 else "samples"
     from image_captioning_amd.parallel_model import ParallelModel, init_process_group_from_env
     import torch.distributed as dist
     rank, world, _ = init_process_group_from_env()
     model = build(V, T, seed=rank)                      # rank-dependent initial weights: the broadcast must make them rank 0's
     pm = ParallelModel(model, world)
     seen = model.grad_sync.check_ranks(model.device)
-    feat, words, onehot = batch(V, T, B)
-    losses = [pm.train_on_batch([feat, words], onehot) for _ in range(steps)]       # GLOBAL batch in, tf.split inside
+    if mode == "captions":                              # bench.py's form: every rank steps its own shard of whole captions (B = RoIs per rank)
+        feat, caps = caption_shard(V, T, B, rank)
+        losses = [float(model.train_on_captions(feat, caps).item()) for _ in range(steps)]
+    else:
+        feat, words, onehot = batch(V, T, B)
+        losses = [pm.train_on_batch([feat, words], onehot) for _ in range(steps)]   # GLOBAL batch in, tf.split inside
     torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), flat=model.store.flat.cpu().numpy(), losses=np.array(losses),
              seen=np.array([seen]), backend=np.array([dist.get_backend()]))

@@ -53,6 +53,38 @@ def test_parallel_model_two_ranks_match_single_rank_on_the_concatenated_batch(tm
     assert np.abs(r[0]["flat"] - single).max() < 2e-5 * scale
 
 
+def test_configs3_shaped_step_two_ranks_at_the_full_per_rank_size(tmp_path):
+    """BASELINE configs[3]'s per-rank shard (2 images x 32 RoIs = 64 captions x 15 tokens, V = 10 000) on two ranks, the way
+    bench.py steps it (every rank its own shard, per-layer-group gradient all-reduce, mean over towers in the AMSGrad kernel):
+    the replicas stay bit-identical over the steps and equal ONE process training on the 128 captions of both shards."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    sys.path.insert(0, HERE)
+    import _dp_worker as W
+    V, T, R, steps, world = 10000, 15, 64, 3, 2
+    backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   DCAP_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dp_worker.py"), str(tmp_path), str(V), str(T), str(R), str(steps), "captions"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
+    r = [np.load(tmp_path / ("rank%d.npz" % k)) for k in range(world)]
+    assert int(r[0]["seen"][0]) == world
+    np.testing.assert_array_equal(r[0]["flat"], r[1]["flat"])            # replicas bit-identical after 3 steps at full size
+    model = W.build(V, T, seed=0)
+    shards = [W.caption_shard(V, T, R, k) for k in range(world)]
+    feat = np.concatenate([s[0] for s in shards])
+    caps = [c for s in shards for c in s[1]]
+    losses = [float(model.train_on_captions(feat, caps).item()) for _ in range(steps)]
+    np.testing.assert_allclose((r[0]["losses"] + r[1]["losses"]) / 2, losses, rtol=2e-5)       # equal shards: mean of tower means == batch mean
+    single = model.store.flat.cpu().numpy()
+    assert np.abs(r[0]["flat"] - single).max() < 2e-5 * np.abs(single).max()
+
+
 def test_joint_model_two_ranks_average_the_tower_gradients(tmp_path):
     """The joint model (configs[4]'s model at a small size) under ParallelModel, one image per rank: after a step every replica
     holds the same weights, and they are the weights a single process gets from the MEAN of the two images' gradient buckets

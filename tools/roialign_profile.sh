@@ -32,4 +32,6 @@ with open(os.path.join(os.path.dirname(out), "roialign_profile.txt"), "w") as f:
         f.write("%-11s %7.2f us   fetch %8.2f MB  write %7.2f MB   %6.2f TB/s HBM\n" % (label, d, fb / 1e6, wb / 1e6, (fb + wb) / d / 1e6))
 print(open(os.path.join(os.path.dirname(out), "roialign_profile.txt")).read())
 PY
+(echo; echo "== row / embedding gathers of the decoder (tools/gather_bench.py, HIP events)"; python3 $root/tools/gather_bench.py 2>&1 | grep -v amdgpu.ids) >> $root/gpurun_out/roialign_profile.txt
+tail -6 $root/gpurun_out/roialign_profile.txt
 rm -rf $out
