@@ -213,8 +213,7 @@ static int conv_bf16_validate(const dc_conv_bf16_desc* d) {
 
 // split-K for the convolution: `target` blocks on the chip (DCAP_BCONV_BLOCKS, default 2 per CU), >= 4 K-tiles per slice
 static BSplit bconv_split(int M, int N, int K, int user_split) {
-    static int target = -1;
-    if (target < 0) { const char* e = getenv("DCAP_BCONV_BLOCKS"); target = e ? atoi(e) : 2 * kNumCU; }
+    static const int target = env_int("DCAP_BCONV_BLOCKS", 2 * kNumCU);
     if (user_split > 0) return bgemm_split(M, N, K, user_split);
     const int tiles = ((M + BT - 1) / BT) * ((N + BT - 1) / BT);
     const int ktiles = (K + BKB - 1) / BKB;

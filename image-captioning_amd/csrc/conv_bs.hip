@@ -10,8 +10,7 @@ using WeightKCb = DenseKCT<true>;
 // v1 (single-role waves, two blocks per CU) is the default: it wins on 1x1 and small layers; v2 (producer / consumer waves,
 // pre-split weights) is ~2 % ahead on the large 3x3 layers only.  DCAP_BS_VER=2 selects it (experiments).
 static int bs_version() {
-    static int ver = -1;
-    if (ver < 0) { const char* e = getenv("DCAP_BS_VER"); ver = e ? atoi(e) : 1; }
+    static const int ver = env_int("DCAP_BS_VER", 1);
     return ver;
 }
 

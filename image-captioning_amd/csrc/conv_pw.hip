@@ -121,8 +121,7 @@ static int launch_pw(const dc_conv_desc* d, const Epilogue& ep, int M, int N, hi
     const int gx = (N + NC - 1) / NC;
     const int strips = (M + 31) / 32;
     const int gy = std::max(1, std::min((2 * kNumCU) / gx, (strips + 3) / 4));
-    static int xcd_map = -1;                               // DCAP_PW_XCD=0: slices dealt over the XCDs (measurements only)
-    if (xcd_map < 0) { const char* e = getenv("DCAP_PW_XCD"); xcd_map = e ? atoi(e) : 1; }
+    static const int xcd_map = env_int("DCAP_PW_XCD", 1);                               // DCAP_PW_XCD=0: slices dealt over the XCDs (measurements only)
     const dim3 grid(gx * ((gy + 7) / 8) * 8);            // whole rounds of 8 XCDs; the kernel drops the padding blocks
 #define DCAP_PW_LAUNCH(RES_)                                                                                                          \
     do {                                                                                                                              \
@@ -138,8 +137,7 @@ static int launch_pw(const dc_conv_desc* d, const Epilogue& ep, int M, int N, hi
 
 // true when the streaming kernel takes this (already validated, f32-math, pointwise) convolution
 bool conv_pw_stream_supported(const dc_conv_desc* d, const Epilogue& ep) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("DCAP_PW_STREAM"); on = e ? atoi(e) : 1; }
+    static const int on = env_int("DCAP_PW_STREAM", 1);
     if (!on) return false;
     if (d->Cin != 64 && d->Cin != 128 && d->Cin != 256) return false;
     if (d->Cout < 64 || (d->Cout & 63) != 0 || !ep.vec4) return false;

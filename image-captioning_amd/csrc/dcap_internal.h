@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <atomic>
 #include "../../include/dcap.h"
 
@@ -33,6 +34,13 @@ inline int check_launch(const char* what) {
         return DC_ELAUNCH;
     }
     return DC_OK;
+}
+
+// An integer tuning knob from the environment.  Call as  static const int v = env_int("NAME", default);  -- a function-local
+// static with a dynamic initialiser is initialised exactly once, thread-safely (host threads may call the C-ABI concurrently).
+inline int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -984,8 +984,7 @@ struct TileChoice {
 inline TileChoice choose_tile(int M, int N, int K, int user_split, bool allow_128 = true) {
     auto nb = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     TileChoice t{64, 64, 1};
-    static int force = -1;
-    if (force < 0) { const char* e = getenv("DCAP_TILE"); force = e ? atoi(e) : 0; }
+    static const int force = env_int("DCAP_TILE", 0);
     const int ktiles = (K + BK - 1) / BK;
     bool priced = false;
     if (force == 64 || !allow_128) t = {64, 64, 1};

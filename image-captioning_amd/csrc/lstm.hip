@@ -396,11 +396,6 @@ __global__ __launch_bounds__(256) void lstm_masked_acc_kernel(float* __restrict_
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // DCAP_LSTM_BWD=steps selects the three-launch form of the backward timestep (measurements only).
-static int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
 static bool lstm_bwd_fused_enabled() {
     static const bool on = [] {
         const char* e = getenv("DCAP_LSTM_BWD");

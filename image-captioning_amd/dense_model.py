@@ -399,7 +399,10 @@ class DenseImageCapRCNN(object):
     def save_weights(self, path):
         """Atomic: written beside the target and renamed, so a reader (or a second rank) never sees a torn file."""
         tmp = path + (".tmp.h5" if path.endswith((".h5", ".hdf5")) else ".tmp.npz")
-        save_weight_file(tmp, self.get_weights_dict())
+        # the reference keeps the caption decoder inside TimeDistributed(caption_model, name='imgcap_caption_td'): a Keras-layout
+        # file stores those layers under that group, where its load_weights(by_name=True) finds them
+        nested = {l: "imgcap_caption_td" for l in ("imgcap_embedding_layer", "imgcap_lstm1", "imgcap_lstm2", "imgcap_lstm_d1", "imgcap_lstm_d2")}
+        save_weight_file(tmp, self.get_weights_dict(), layer_groups=nested)
         os.replace(tmp, path)
 
     def set_log_dir(self, model_path=None):

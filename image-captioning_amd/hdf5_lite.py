@@ -484,24 +484,40 @@ def _chunked_attrs(name, values, limit=64512):
     return {"%s%d" % (name, i): c for i, c in enumerate(np.array_split(arr, parts))}
 
 
-def save_keras_weights(path, weights, layer_order=None):
+def save_keras_weights(path, weights, layer_order=None, layer_groups=None):
     """Write {'<layer>/<weight>': ndarray} as a Keras weights file: /<layer>/<layer>/<weight>:0 datasets, weight_names and
     layer_names attributes (fixed-length byte strings), float32 data.  layer_order: Keras lists layers in model order; default
-    is first-seen order of `weights`."""
+    is first-seen order of `weights`.
+    layer_groups: {inner layer: outer layer} for layers that live inside a wrapper or nested model -- Keras stores those under the
+    OUTER layer's group with the inner names (the joint model's decoder: TimeDistributed(caption_model, name='imgcap_caption_td'),
+    dense_img_cap/dense_model.py:1554-1560: /imgcap_caption_td/imgcap_lstm1/kernel:0 with weight_names 'imgcap_lstm1/kernel:0'),
+    which is where the reference's load_weights(by_name=True) looks for them."""
     w = _Writer()
     layers = {}
     for key, arr in weights.items():
         layer, name = key.split("/", 1)
         layers.setdefault(layer, []).append((name, np.asarray(arr, np.float32)))
     order = list(layer_order) if layer_order is not None else list(layers)
+    groups = dict(layer_groups or {})
+    outer_order, members = [], {}
+    for layer in order:                                   # outer groups in first-seen order of their members
+        g = groups.get(layer, layer)
+        if g not in members:
+            members[g] = []
+            outer_order.append(g)
+        members[g].append(layer)
     top = {}
-    for layer in order:
-        items = layers.get(layer, [])
-        inner = {("%s:0" % n): w.dataset(a) for n, a in items}
-        inner_addr, _, _ = w.group(inner, {})
-        wn = _chunked_attrs("weight_names", [("%s/%s:0" % (layer, n)).encode("utf-8") for n, _ in items])
-        top[layer], _, _ = w.group({layer: inner_addr} if items else {}, wn)
-    attrs = _chunked_attrs("layer_names", [l.encode("utf-8") for l in order])
+    for g in outer_order:
+        inner_groups, names = {}, []
+        for layer in members[g]:
+            items = layers.get(layer, [])
+            if not items:
+                continue
+            inner = {("%s:0" % n): w.dataset(a) for n, a in items}
+            inner_groups[layer], _, _ = w.group(inner, {})
+            names += [("%s/%s:0" % (layer, n)).encode("utf-8") for n, _ in items]
+        top[g], _, _ = w.group(inner_groups, _chunked_attrs("weight_names", names))
+    attrs = _chunked_attrs("layer_names", [l.encode("utf-8") for l in outer_order])
     attrs.update({"backend": np.array(b"tensorflow"), "keras_version": np.array(b"2.1.6")})
     root, tree, heap = w.group(top, attrs)
     data = w.finish(root, tree, heap)

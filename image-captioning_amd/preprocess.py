@@ -1,7 +1,9 @@
 """Vocabulary / caption encoding helpers (dense_img_cap_separate_models/preprocess.py:8-114).
-The reference tokenises with nltk.word_tokenize (not installable here): treebank.py restates its Penn Treebank rules
-(contractions, punctuation, quotes, brackets), so "man's" -> man + 's and "isn't" -> is + n't exactly as the reference's
-vocabulary and caption ids assume."""
+The reference tokenises with nltk.word_tokenize (not installable here): treebank.py restates its Penn Treebank word rules
+(contractions, punctuation, quotes, brackets: "man's" -> man + 's, "isn't" -> is + n't, held to NLTK's documented examples) and
+APPROXIMATES the Punkt sentence splitter in front of them (trained parameters unavailable: a fixed abbreviation list).  Single-
+phrase region captions tokenise identically; a caption with an interior period-final token that Punkt knows as an abbreviation
+and treebank.py does not (or vice versa) gets an extra / a missing '.' token there, i.e. different ids for that caption."""
 import numpy as np
 
 from .treebank import word_tokenize  # noqa: F401  (re-exported: the reference imports it into this module's namespace)

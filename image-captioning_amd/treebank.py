@@ -64,7 +64,14 @@ def treebank_tokenize(text, word_tokenize_rules=True):
     return text.split()
 
 
-_ABBREVIATIONS = frozenset("mr mrs ms dr st vs etc jr sr inc co corp ltd no mt ft e.g i.e u.s a.m p.m prof gen col sgt ave blvd dept".split())
+# Punkt's English model carries a learned list of abbreviation types (period-final tokens that do NOT end a sentence).  The pickle is
+# not available here; this list restates the common ones (titles, company forms, months, U.S. state forms of its Wall Street Journal
+# training text, clock / measure forms).  A period-final token outside the list ends the sentence, as in Punkt's first pass.
+_ABBREVIATIONS = frozenset((
+    "mr mrs ms messrs dr prof gen col lt maj sgt capt adm cmdr rep reps sen sens gov rev hon st vs etc jr sr inc co cos corp ltd bros "
+    "no nos mt ft approx dept univ ave blvd rd e.g i.e u.s u.k u.n a.m p.m ph.d m.d b.a m.a d.c n.y n.j n.h n.c s.c n.m w.va "
+    "jan feb mar apr jun jul aug sep sept oct nov dec mon tue tues wed thu thur thurs fri sat sun "
+    "calif mass conn fla pa va ga ill mich minn tenn wash wis colo ariz ala okla ore kan ky la nev neb mo miss ind del tex").split())
 _SENT_END = re.compile(r'(\S+?[.?!]+["\'\)\]]*)(\s+)')
 
 

@@ -344,6 +344,11 @@ def test_treebank_tokenizer_known_answers():
     assert word_tokenize("the dog (brown) cannot jump -- i'm sure we've seen they're gonna") == \
         ['the', 'dog', '(', 'brown', ')', 'can', 'not', 'jump', '--', 'i', "'m", 'sure', 'we', "'ve", 'seen', 'they', "'re", 'gon', 'na']
     assert word_tokenize('the sign says "stop"') == ['the', 'sign', 'says', '``', 'stop', "''"]
+    # interior periods (the Punkt approximation: listed abbreviations and initials do not end a sentence, anything else does)
+    assert word_tokenize("sign says no. 5 on it") == ['sign', 'says', 'no.', '5', 'on', 'it']
+    assert word_tokenize("open until 5 p.m. sign on st. marks ave.") == ['open', 'until', '5', 'p.m.', 'sign', 'on', 'st.', 'marks', 'ave', '.']
+    assert word_tokenize("approx. ten birds. one flies away") == ['approx.', 'ten', 'birds', '.', 'one', 'flies', 'away']
+    assert word_tokenize("j. smith's cafe") == ['j.', 'smith', "'s", 'cafe']
     assert word_tokenize("clock reads 10:30, price is 1,000 dollars") == ['clock', 'reads', '10:30', ',', 'price', 'is', '1,000', 'dollars']
     assert word_tokenize("") == [] and word_tokenize("   ") == []
     assert word_tokenize("dr. who's tardis") == ['dr.', 'who', "'s", 'tardis']          # abbreviation: no sentence break
@@ -497,6 +502,27 @@ def test_hdf5_writer_round_trip_and_libhdf5_tools_read_it(tmp_path):
     assert dump.returncode == 0 and "H5T_IEEE_F32LE" in dump.stdout and "( 8, 32 )" in dump.stdout
     first = float(dump.stdout.split("(0,0):")[1].split(",")[0])
     assert abs(first - float(W["imgcap_lstm1/recurrent_kernel"][0, 0])) < 1e-4 * max(1.0, abs(first))
+
+
+def test_hdf5_writer_nests_wrapped_layers_like_keras(tmp_path):
+    """Layers inside a wrapper (the joint model's decoder under TimeDistributed 'imgcap_caption_td') go under the wrapper's group
+    with their inner names -- /imgcap_caption_td/imgcap_lstm1/kernel:0, weight_names 'imgcap_lstm1/kernel:0' -- and read back
+    by name; plain layers keep /<layer>/<layer>/<weight>:0."""
+    from image_captioning_amd import hdf5_lite as H
+    rng = np.random.default_rng(1)
+    W = {"fpn_p2/kernel": rng.standard_normal((3, 3, 4, 4)).astype(np.float32), "fpn_p2/bias": rng.standard_normal(4).astype(np.float32),
+         "imgcap_lstm1/kernel": rng.standard_normal((6, 8)).astype(np.float32), "imgcap_lstm1/recurrent_kernel": rng.standard_normal((2, 8)).astype(np.float32),
+         "imgcap_lstm_d2/kernel": rng.standard_normal((4, 5)).astype(np.float32), "rpn_conv_shared/bias": rng.standard_normal(3).astype(np.float32)}
+    path = str(tmp_path / "nested.h5")
+    H.save_keras_weights(path, W, layer_groups={"imgcap_lstm1": "imgcap_caption_td", "imgcap_lstm_d2": "imgcap_caption_td"})
+    f = H.H5File(path)
+    assert H._attr_list(f, "layer_names") == ["fpn_p2", "imgcap_caption_td", "rpn_conv_shared"]
+    td = f["imgcap_caption_td"]
+    assert H._attr_list(td, "weight_names") == ["imgcap_lstm1/kernel:0", "imgcap_lstm1/recurrent_kernel:0", "imgcap_lstm_d2/kernel:0"]
+    assert np.array_equal(td["imgcap_lstm1/recurrent_kernel:0"].read(), W["imgcap_lstm1/recurrent_kernel"])
+    assert np.array_equal(f["fpn_p2"]["fpn_p2/kernel:0"].read(), W["fpn_p2/kernel"])
+    back = H.load_keras_weights(path)
+    assert set(back) == set(W) and all(np.array_equal(back[k], W[k]) for k in W)
 
 
 def test_hdf5_reader_rejects_what_it_does_not_implement(tmp_path):
