@@ -144,6 +144,7 @@ SYMBOLS = {
     "dc_gemm_bf16_tile": (C.c_int, [C.POINTER(GemmBf16Desc), C.POINTER(C.c_int)]),
     "dc_gemm_bf16": (C.c_int, [C.POINTER(GemmBf16Desc), C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_conv2d_wgrad_bf16_workspace_bytes": (C.c_size_t, [C.POINTER(ConvWgradBf16Desc)]),
+    "dc_conv2d_wgrad_bf16_tile": (C.c_int, [C.POINTER(ConvWgradBf16Desc), C.POINTER(C.c_int)]),
     "dc_conv2d_wgrad_bf16": (C.c_int, [C.POINTER(ConvWgradBf16Desc), C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_conv2d_bf16_workspace_bytes": (C.c_size_t, [C.POINTER(ConvBf16Desc)]),
     "dc_conv2d_bf16_tile": (C.c_int, [C.POINTER(ConvBf16Desc), C.POINTER(C.c_int)]),

@@ -273,6 +273,7 @@ struct BIm2col {
     const unsigned short* x;       // bf16 [N, H, W, Cin]
     int H, W, Cin, Ho, Wo, stride, pad_t, pad_l, kw, P;      // P = N*Ho*Wo output pixels (the K extent)
     unsigned bytes;
+    int ncols;                     // kh * kw * Cin: columns of the im2col matrix (the 256-tile loader clamps against it)
 };
 
 struct BLoadIm2col {

@@ -28,6 +28,76 @@ __global__ __launch_bounds__(256, 2) void bgemm_wgrad_kernel(BOperand dy, BIm2co
     store_tile<BT, BT>(acc, smem_f, ep, partial, M, N, m0, n0, wm, wn);
 }
 
+// The same weight gradient on the 256 x 256 tile (bgemm256_core.h): the K-major im2col operand as two 128-column sub-images.
+// A 256-column tile may span several taps (Cin = 128: two), so the tap offset is per lane (fixed over the K loop: a lane's columns
+// never change); the pixel walk advances once per K-tile, after the second half has been issued (the main loop always issues
+// half 0, then half 1 of a K-tile).
+struct BLoadIm2col256 {
+    static constexpr bool KC = false;
+    __amdgpu_buffer_rsrc_t rsrc;
+    BIm2col c;
+    int n[2], oy[2], ox[2];        // [piece]: output pixel of this lane's K row in the NEXT K-tile to issue
+    int dy[2][2], dx[2][2];        // [half][piece]: tap offset of this lane's 8-column chunk
+    unsigned cio[2][2];            // byte offset of its first channel inside the pixel
+    int krow[2];
+    __device__ __forceinline__ void init(const BIm2col& cc, int col0, int kbeg, int lane, int wave) {
+        c = cc;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(c.x), 0, (int)c.bytes, 0x00020000);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int k = 4 * (2 * wave + jj) + (lane >> 4);               // K row inside the tile
+            krow[jj] = k;
+            const int p = kbeg + k;
+            const int nn = p / (c.Ho * c.Wo), rem = p - nn * (c.Ho * c.Wo);
+            n[jj] = nn;
+            oy[jj] = rem / c.Wo;
+            ox[jj] = rem - oy[jj] * c.Wo;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ch = (lane & 15) ^ (((k & 3) << 2) | ((k >> 2) & 3));
+                const int col = min(col0 + b256::tile_index<false>(u, 8 * ch), c.ncols - 8);   // columns past the edge: clamped, never stored
+                const int tap = col / c.Cin, ci = col - tap * c.Cin;
+                const int ky = tap / c.kw, kx = tap - ky * c.kw;
+                dy[u][jj] = ky - c.pad_t;
+                dx[u][jj] = kx - c.pad_l;
+                cio[u][jj] = (unsigned)(ci * 2);
+            }
+        }
+    }
+    __device__ __forceinline__ void issue(int u, char* sub, int k0, int kend, int wave) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int iy = oy[jj] * c.stride + dy[u][jj], ix = ox[jj] * c.stride + dx[u][jj];
+            const bool in = (unsigned)iy < (unsigned)c.H && (unsigned)ix < (unsigned)c.W && k0 + krow[jj] < min(c.P, kend);
+            const unsigned off = (unsigned)((((long)n[jj] * c.H + iy) * c.W + ix) * c.Cin * 2) + cio[u][jj];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (DC_LDS void*)(sub + (2 * wave + jj) * 1024), 16, (int)(in ? off : kOobOffset), 0, 0, 0);
+            if (u == 1) {                                                       // both halves of this K-tile are out: 64 pixels on
+                ox[jj] += b256::BK;
+                while (ox[jj] >= c.Wo) { ox[jj] -= c.Wo; ++oy[jj]; }
+                while (oy[jj] >= c.Ho) { oy[jj] -= c.Ho; ++n[jj]; }
+            }
+        }
+    }
+};
+
+__global__ __launch_bounds__(b256::NTHREADS, 2) void bgemm256_wgrad_kernel(BOperand dy, BIm2col xc, Epilogue ep, int M, int N, int K, int klen, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tiles_m = (M + b256::BM - 1) / b256::BM, tiles_n = (N + b256::BN - 1) / b256::BN;
+    int tm, tn;
+    b256::tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * b256::BM, n0 = tn * b256::BN;
+    const int kbeg = blockIdx.z * klen, kend = min(K, kbeg + klen);
+    b256::Load<false, true> la;
+    BLoadIm2col256 lb;
+    la.init(dy, m0, lane, wave);
+    lb.init(xc, n0, kbeg, lane, wave);
+    b256::f32x4 acc[8][4];
+    b256::mainloop(la, lb, reinterpret_cast<char*>(smem_f), kbeg, kend, acc);
+    b256::store_tile(acc, ep, partial, M, N, m0, n0);
+}
+
 static int bgemm_validate(const dc_gemm_bf16_desc* d) {
     DC_REQUIRE(d != nullptr, DC_EINVAL, "dc_gemm_bf16: null descriptor");
     DC_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, DC_EINVAL, "dc_gemm_bf16: M,N,K must be positive (got %d,%d,%d)", d->M, d->N, d->K);
@@ -137,11 +207,21 @@ static int wgrad_bf16_validate(const dc_conv_wgrad_bf16_desc* d) {
     return DC_OK;
 }
 
+static bool wgrad_big(const dc_conv_wgrad_bf16_desc* d, int M, int N, int K) { return (d->Cout & 7) == 0 && b256::prefer(M, N, K, d->split_k, true); }
+
 extern "C" size_t dc_conv2d_wgrad_bf16_workspace_bytes(const dc_conv_wgrad_bf16_desc* d) {
     if (!d || wgrad_bf16_validate(d)) return 0;
     const int M = d->Cout, N = d->kh * d->kw * d->Cin, K = d->N * d->Ho * d->Wo;
-    const BSplit sp = bgemm_split(M, N, K, d->split_k);
+    const BSplit sp = wgrad_big(d, M, N, K) ? b256::split(M, N, K, d->split_k) : bgemm_split(M, N, K, d->split_k);
     return sp.split > 1 ? (size_t)sp.split * M * N * sizeof(float) : 0;
+}
+
+extern "C" int dc_conv2d_wgrad_bf16_tile(const dc_conv_wgrad_bf16_desc* d, int* split_k) {
+    if (!d || wgrad_bf16_validate(d)) return 0;
+    const int M = d->Cout, N = d->kh * d->kw * d->Cin, K = d->N * d->Ho * d->Wo;
+    const bool big = wgrad_big(d, M, N, K);
+    if (split_k) *split_k = (big ? b256::split(M, N, K, d->split_k) : bgemm_split(M, N, K, d->split_k)).split;
+    return big ? 256 : 128;
 }
 
 extern "C" int dc_conv2d_wgrad_bf16(const dc_conv_wgrad_bf16_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
@@ -149,7 +229,8 @@ extern "C" int dc_conv2d_wgrad_bf16(const dc_conv_wgrad_bf16_desc* d, void* work
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int M = d->Cout, N = d->kh * d->kw * d->Cin, K = d->N * d->Ho * d->Wo;
-    const BSplit sp = bgemm_split(M, N, K, d->split_k);
+    const bool big = wgrad_big(d, M, N, K);
+    const BSplit sp = big ? b256::split(M, N, K, d->split_k) : bgemm_split(M, N, K, d->split_k);
     float* partial = nullptr;
     if (sp.split > 1) {
         const size_t need = (size_t)sp.split * M * N * sizeof(float);
@@ -159,11 +240,19 @@ extern "C" int dc_conv2d_wgrad_bf16(const dc_conv_wgrad_bf16_desc* d, void* work
     }
     Epilogue ep{d->dw, N, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, d->accumulate, 1};
     BOperand dy{d->dy, d->Cout, M, nullptr, (unsigned)((size_t)K * d->Cout * 2)};
-    BIm2col xc{d->x, d->H, d->W, d->Cin, d->Ho, d->Wo, d->stride, d->pad_t, d->pad_l, d->kw, K, (unsigned)((size_t)d->N * d->H * d->W * d->Cin * 2)};
-    DC_ENSURE_DYN_LDS(&bgemm_wgrad_kernel, 160 * 1024);
-    const int tiles = ((M + BT - 1) / BT) * ((N + BT - 1) / BT);
-    hipLaunchKernelGGL(bgemm_wgrad_kernel, dim3(tiles, 1, sp.split), dim3(256), bgemm_lds_bytes(), s, dy, xc, ep, M, N, K, sp.klen, partial);
-    rc = check_launch("bgemm_wgrad_kernel");
+    BIm2col xc{d->x, d->H, d->W, d->Cin, d->Ho, d->Wo, d->stride, d->pad_t, d->pad_l, d->kw, K, (unsigned)((size_t)d->N * d->H * d->W * d->Cin * 2), N};
+    if (big) {
+        ep.vec4 = 1;                                           // dw rows are k*k*Cin floats (Cin % 128 == 0), 16-byte aligned base
+        DC_ENSURE_DYN_LDS(&bgemm256_wgrad_kernel, 160 * 1024);
+        const int tiles = ((M + b256::BM - 1) / b256::BM) * ((N + b256::BN - 1) / b256::BN);
+        hipLaunchKernelGGL(bgemm256_wgrad_kernel, dim3(tiles, 1, sp.split), dim3(b256::NTHREADS), b256::LDS_BYTES, s, dy, xc, ep, M, N, K, sp.klen, partial);
+        rc = check_launch("bgemm256_wgrad_kernel");
+    } else {
+        DC_ENSURE_DYN_LDS(&bgemm_wgrad_kernel, 160 * 1024);
+        const int tiles = ((M + BT - 1) / BT) * ((N + BT - 1) / BT);
+        hipLaunchKernelGGL(bgemm_wgrad_kernel, dim3(tiles, 1, sp.split), dim3(256), bgemm_lds_bytes(), s, dy, xc, ep, M, N, K, sp.klen, partial);
+        rc = check_launch("bgemm_wgrad_kernel");
+    }
     if (rc || sp.split <= 1) return rc;
     const long total = (long)M * N;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(splitk_reduce_blocks(total)), dim3(256), 0, s, partial, sp.split, M, N, ep);

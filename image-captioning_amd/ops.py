@@ -214,7 +214,7 @@ def conv2d_wgrad(x, dy, kh, kw, stride, pad_t, pad_l, out=None, split_k=0, accum
     return out
 
 
-def conv2d_wgrad_bf16(x, dy, kh, kw, stride, pad_t, pad_l, out=None, split_k=0, accumulate=False):
+def conv2d_wgrad_bf16(x, dy, kh, kw, stride, pad_t, pad_l, out=None, split_k=0, accumulate=False, info=None):
     """conv2d_wgrad on the bf16 pipe: x [N,H,W,Cin] and dy [N,Ho,Wo,Cout] contiguous bf16; dw fp32 packed [Cout][kh*kw*Cin]."""
     lib = _lib.load()
     _chk(x, BF16, "x"), _chk(dy, BF16, "dy")
@@ -229,6 +229,10 @@ def conv2d_wgrad_bf16(x, dy, kh, kw, stride, pad_t, pad_l, out=None, split_k=0, 
     d.Cout, d.kh, d.kw, d.stride, d.pad_t, d.pad_l, d.Ho, d.Wo = Cout, kh, kw, stride, pad_t, pad_l, Ho, Wo
     d.x, d.dy, d.dw = x.data_ptr(), dy.data_ptr(), _chk(out, name="dw").data_ptr()
     d.accumulate, d.split_k = int(accumulate), int(split_k)
+    if info is not None:
+        sk = C.c_int(0)
+        info["tile"] = int(lib.dc_conv2d_wgrad_bf16_tile(C.byref(d), C.byref(sk)))
+        info["split_k"] = int(sk.value)
     ws, wsb = WORKSPACE.get(lib.dc_conv2d_wgrad_bf16_workspace_bytes(C.byref(d)), x.device)
     check(lib.dc_conv2d_wgrad_bf16(C.byref(d), _ptr(ws), wsb, _stream()), "dc_conv2d_wgrad_bf16")
     return out

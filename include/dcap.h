@@ -115,6 +115,8 @@ typedef struct {
 } dc_conv_wgrad_bf16_desc;
 size_t dc_conv2d_wgrad_bf16_workspace_bytes(const dc_conv_wgrad_bf16_desc* d);
 int    dc_conv2d_wgrad_bf16(const dc_conv_wgrad_bf16_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+/* Test / profiling aid: the block tile (256 | 128) and split-K slices dc_conv2d_wgrad_bf16 runs `d` with. */
+int    dc_conv2d_wgrad_bf16_tile(const dc_conv_wgrad_bf16_desc* d, int* split_k);
 
 /* conv2d forward with bf16 STORAGE (configs[4]: "bf16"): bf16 NHWC activations and bf16 packed weights in HBM, fp32 accumulation,
  * the same fused epilogue as dc_conv2d_nhwc_f32 (frozen-BN scale / shift, residual (fp32), ReLU), output in fp32 (y), bf16 (y_bf16: the

@@ -298,6 +298,9 @@ def test_vocab_ce_bf16_on_the_256_tile(ops, M, V, K, sparse):
     (1, 32, 32, 256, 512, 3, 1, 'same'),       # automatic split-K over the pixels
     (2, 8, 8, 1024, 256, 1, 1, 'valid'),       # an FPN lateral
     (1, 2, 2, 256, 256, 3, 1, 'same'),         # a P6-sized level: every tap partly outside
+    (1, 128, 128, 256, 512, 3, 1, 'same'),     # the 256-square tile: rpn_conv_shared on a P3-sized level (one tap per column tile)
+    (1, 96, 100, 128, 512, 3, 1, 'same'),      # the 256-square tile: two taps per column tile, ragged pixel count, partial last tile
+    (2, 64, 64, 512, 256, 1, 1, 'valid'),      # a lateral (1x1) over two images: long K, small output
 ])
 def test_conv2d_wgrad_bf16_matches_oracle(ops, case):
     """Weight gradient on the bf16 pipe (K-major dy^T x K-major im2col, both through transposing LDS reads) against the oracle's
@@ -313,7 +316,9 @@ def test_conv2d_wgrad_bf16_matches_oracle(ops, case):
     pt, pl = (O.same_pad(H, k, stride)[0], O.same_pad(W, k, stride)[0]) if padding == 'same' else (0, 0)
     xb, dyb = ops.to_bf16(dev(x)), ops.to_bf16(dev(dy))
     assert ops.wgrad_bf16_supported(xb.shape, dyb.shape)
-    got = ops.conv2d_wgrad_bf16(xb, dyb, k, k, stride, pt, pl)
+    info = {}
+    got = ops.conv2d_wgrad_bf16(xb, dyb, k, k, stride, pt, pl, info=info)
+    assert info["tile"] == (256 if H >= 96 else 128), info          # (the lateral's 256 x 512 output stays on the 128-square tile)
     close(got, want, 5e-5)
     ops.conv2d_wgrad_bf16(xb, dyb, k, k, stride, pt, pl, out=got, accumulate=True)
     close(got, 2 * want, 5e-5)
