@@ -192,6 +192,10 @@ SYMBOLS = {
     "dc_sumsq_workspace_bytes": (C.c_size_t, [C.c_size_t]),
     "dc_sumsq_f32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_mean_f32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "dc_bn_fold_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "dc_bn_bwd_f32": (C.c_int, [C.c_void_p] * 8 + [C.c_long, C.c_int, C.c_void_p]),
+    "dc_mul_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dc_maxpool3x3s2_same_bwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
     "dc_dropout_mask_f32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p]),
     "dc_amsgrad_step_f32": (C.c_int, [C.POINTER(AmsgradDesc), C.c_void_p]),
 }

@@ -142,6 +142,44 @@ __global__ void maxpool3x3s2_kernel(const float4* __restrict__ x, float4* __rest
     }
 }
 
+// ---- its backward (training the stem: layers = "all"): gather per input pixel.  The gradient of a window goes to the FIRST
+// element (row-major) that equals the window's maximum, as TF's MaxPoolGrad routes it; a pixel sits in up to four windows.
+__global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx,
+                                        int N, int H, int W, int C, int Ho, int Wo, int pt, int pl) {
+    const long total = (long)N * H * W * C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        long p = idx / C;
+        const int ix = (int)(p % W);
+        p /= W;
+        const int iy = (int)(p % H);
+        const int n = (int)(p / H);
+        const float v = x[idx];
+        float g = 0.f;
+        for (int oy = max(0, (iy + pt - 1) / 2); oy <= min(Ho - 1, (iy + pt) / 2); ++oy) {           // windows with oy*2 - pt <= iy <= oy*2 - pt + 2
+            if (iy < oy * 2 - pt || iy > oy * 2 - pt + 2) continue;
+            for (int ox = max(0, (ix + pl - 1) / 2); ox <= min(Wo - 1, (ix + pl) / 2); ++ox) {
+                if (ix < ox * 2 - pl || ix > ox * 2 - pl + 2) continue;
+                const long o = (((long)n * Ho + oy) * Wo + ox) * C + c;
+                if (y[o] != v) continue;
+                bool first = true;                                   // is there an equal element earlier in the window?
+                for (int ky = 0; ky < 3 && first; ++ky) {
+                    const int jy = oy * 2 - pt + ky;
+                    if ((unsigned)jy >= (unsigned)H) continue;
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int jx = ox * 2 - pl + kx;
+                        if ((unsigned)jx >= (unsigned)W) continue;
+                        if (jy == iy && jx == ix) { ky = 3; break; }
+                        if (x[(((long)n * H + jy) * W + jx) * C + c] == v) { first = false; break; }
+                    }
+                }
+                if (first) g += dy[o];
+            }
+        }
+        dx[idx] = g;
+    }
+}
+
 // ---- maxpool 2x2 / stride 2 / valid (VGG16's block pools; H and W even)
 __global__ void maxpool2x2s2_kernel(const float4* __restrict__ x, float4* __restrict__ y, int N, int H, int W, int C4) {
     const int Ho = H / 2, Wo = W / 2;
@@ -429,4 +467,14 @@ extern "C" int dc_mold_image_padded_f32(const uint8_t* img, float* out, int N, i
     hipLaunchKernelGGL(mold_padded_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), img, reinterpret_cast<float4*>(out), npix,
                        channels / 4, mean_r, mean_g, mean_b);
     return check_launch("mold_padded_kernel");
+}
+
+extern "C" int dc_maxpool3x3s2_same_bwd_f32(const float* x, const float* y, const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
+    DC_REQUIRE(x && y && dy && dx && N > 0 && H > 0 && W > 0 && C > 0, DC_EINVAL, "dc_maxpool3x3s2_same_bwd: bad arguments");
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const int pad_h = std::max((Ho - 1) * 2 + 3 - H, 0), pad_w = std::max((Wo - 1) * 2 + 3 - W, 0);
+    const long total = (long)N * H * W * C;
+    const int blocks = (int)std::min<long>((total + 255) / 256, (long)kNumCU * 16);
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, dy, dx, N, H, W, C, Ho, Wo, pad_h / 2, pad_w / 2);
+    return check_launch("maxpool3x3s2_bwd_kernel");
 }

@@ -553,6 +553,73 @@ extern "C" int dc_dropout_mask_f32(float* out, size_t n, float rate, uint32_t se
     return check_launch("dropout_mask_kernel");
 }
 
+// ---- training ResNet stages (dense_img_cap/dense_model.py:1829-1845, layers = "3+" | "4+" | "5+" | "all"): BatchNorm layers
+// run with training=False (frozen statistics, :51-61) while gamma / beta -- and the convolution in front -- are trained.
+// The forward keeps the fused form  y = act(scale * conv(x) + shift [+ residual])  with
+//   scale = gamma / sqrt(var + eps),  shift = beta + (bias - mean) * scale
+// refreshed from the trained parameters by bn_fold before every pass; the backward recovers the normalised activation from the
+// stored BN output  n = (bn_out - beta) / gamma  (bn_out = y where the ReLU passed, = out - shortcut for the block's last
+// convolution; only needed where the upstream gradient is non-zero, which is exactly where it is recoverable).
+__global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ bias,
+                                                      const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                                      float* __restrict__ scale, float* __restrict__ shift, int n) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    const float sc = gamma[c] / sqrtf(var[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] + (bias[c] - mean[c]) * sc;
+}
+
+// dacc = dz * scale (gradient w.r.t. the convolution's output);  dzn = dz * n,  n = (a - b - beta) / gamma  (b may be null)
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const float4* __restrict__ dz, const float4* __restrict__ a, const float4* __restrict__ b,
+                                                     const float4* __restrict__ gamma, const float4* __restrict__ beta, const float4* __restrict__ scale,
+                                                     float4* __restrict__ dacc, float4* __restrict__ dzn, long rows, int c4) {
+    const long total = rows * c4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % c4);
+        const float4 g = dz[i], va = a[i], ga = gamma[c], be = beta[c], sc = scale[c];
+        float4 vb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b) vb = b[i];
+        dacc[i] = make_float4(g.x * sc.x, g.y * sc.y, g.z * sc.z, g.w * sc.w);
+        // where dz == 0 the recovered n is meaningless (and may be inf for gamma == 0): the product is defined as 0 there
+        dzn[i] = make_float4(g.x != 0.f ? g.x * ((va.x - vb.x - be.x) / ga.x) : 0.f, g.y != 0.f ? g.y * ((va.y - vb.y - be.y) / ga.y) : 0.f,
+                             g.z != 0.f ? g.z * ((va.z - vb.z - be.z) / ga.z) : 0.f, g.w != 0.f ? g.w * ((va.w - vb.w - be.w) / ga.w) : 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = a[i] * b[i];
+}
+
+extern "C" int dc_bn_fold_f32(const float* gamma, const float* beta, const float* bias, const float* mean, const float* var, float eps, float* scale,
+                              float* shift, int n, void* stream) {
+    DC_REQUIRE(gamma && beta && bias && mean && var && scale && shift && n > 0, DC_EINVAL, "dc_bn_fold: bad arguments");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), gamma, beta, bias, mean, var, eps, scale, shift, n);
+    return check_launch("bn_fold_kernel");
+}
+
+extern "C" int dc_bn_bwd_f32(const float* dz, const float* a, const float* b, const float* gamma, const float* beta, const float* scale, float* dacc,
+                             float* dzn, long rows, int channels, void* stream) {
+    DC_REQUIRE(dz && a && gamma && beta && scale && dacc && dzn && rows > 0 && channels > 0 && (channels & 3) == 0, DC_EINVAL,
+               "dc_bn_bwd: bad arguments (channels %% 4 == 0)");
+    DC_REQUIRE(aligned16(dz) && aligned16(a) && (!b || aligned16(b)) && aligned16(gamma) && aligned16(beta) && aligned16(scale) && aligned16(dacc) && aligned16(dzn),
+               DC_EALIGN, "dc_bn_bwd: pointers must be 16-byte aligned");
+    const long total = rows * (channels / 4);
+    const int blocks = (int)std::min<long>((total + 255) / 256, (long)kNumCU * 8);
+    hipLaunchKernelGGL(bn_bwd_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<const float4*>(dz),
+                       reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(b), reinterpret_cast<const float4*>(gamma),
+                       reinterpret_cast<const float4*>(beta), reinterpret_cast<const float4*>(scale), reinterpret_cast<float4*>(dacc),
+                       reinterpret_cast<float4*>(dzn), rows, channels / 4);
+    return check_launch("bn_bwd_kernel");
+}
+
+extern "C" int dc_mul_f32(const float* a, const float* b, float* out, size_t n, void* stream) {
+    DC_REQUIRE(a && b && out && n > 0, DC_EINVAL, "dc_mul: bad arguments");
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, (size_t)kNumCU * 8);
+    hipLaunchKernelGGL(mul_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, out, n);
+    return check_launch("mul_kernel");
+}
+
 extern "C" int dc_mean_f32(const float* x, size_t n, float* out, void* stream) {
     DC_REQUIRE(x && out && n > 0, DC_EINVAL, "dc_mean: bad arguments");
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), x, n, out);

@@ -28,7 +28,7 @@ from . import ops, synth, utils
 from .encoder import EncoderPlan, fuse_rpn_head
 from .layers import resnet_fpn_convs
 from .modified_dense_model import load_weight_file, save_weight_file
-from .packing import pack_conv_kernel
+from .packing import pack_conv_kernel, pack_stem_kernel
 from .params import Adam
 from .text_generation_model import CaptionModelV1, caption_targets
 
@@ -239,13 +239,17 @@ def data_generator(dataset, config, shuffle=True, augment=True, batch_size=1, rn
 
 class DenseImageCapRCNN(object):
     LOSS_NAMES = ("rpn_class_loss", "rpn_bbox_loss", "imgcap_loss")
-    LAYER_REGEX = {
+    LAYER_REGEX = {                       # dense_img_cap/dense_model.py:1829-1845
         "no_backbone": r"(imgcap\_.*)|(rpn\_.*)|(fpn\_.*)|(mrcnn\_.*)",
+        "3+": r"(res3.*)|(bn3.*)|(res4.*)|(bn4.*)|(res5.*)|(bn5.*)|(imgcap\_.*)|(rpn\_.*)|(fpn\_.*)|(mrcnn\_.*)",
+        "4+": r"(res4.*)|(bn4.*)|(res5.*)|(bn5.*)|(imgcap\_.*)|(rpn\_.*)|(fpn\_.*)|(mrcnn\_.*)",
+        "5+": r"(res5.*)|(bn5.*)|(imgcap\_.*)|(rpn\_.*)|(fpn\_.*)|(mrcnn\_.*)",
+        "all": ".*",
         "caption_only": r"imgcap\_.*",
     }
 
     def __init__(self, mode, config, model_dir, device=None, stage4_blocks=22, seed=0, lstm_units=512, conv_math=None,
-                 compute_dtype="f32"):
+                 compute_dtype="f32", backbone_from=None):
         """compute_dtype: 'f32', or 'bf16' = BASELINE configs[4]'s arithmetic for the RoI head, the caption decoder and the
         vocabulary layers (bf16 copies of weights / activations on the bf16 matrix pipe, fp32 master weights and
         accumulation; text_generation_model.CaptionModelV1).  conv_math selects the convolutions' arithmetic separately."""
@@ -272,16 +276,49 @@ class DenseImageCapRCNN(object):
         self._outer = self                 # ParallelModel points it at the wrapper: train() then feeds GLOBAL batches through
                                            # the wrapper's train_on_batch (tf.split over towers, losses averaged over towers)
         self._trainable_regex = self.LAYER_REGEX["no_backbone"]
+        # backbone_from: the lowest ResNet stage (5, 4, 3, 2; 1 = the stem) whose convolutions and BatchNorm gamma / beta are
+        # trainable parameters of this model (train(layers="5+" | "4+" | "3+" | "all") sets it, rebuilding the parameter
+        # bucket when needed); None = the backbone is frozen and folded (layers="no_backbone", the reference's training script)
+        self.backbone_from = backbone_from
+        self._seed = seed
         self.set_log_dir()
         self._build(seed)
 
     # ---- construction -----------------------------------------------------------------------
-    def _build(self, seed):
+    @staticmethod
+    def _stage_of(layer):
+        """ResNet stage of a trunk layer name (conv1 / bn_conv1 -> 1, res4b_branch2a / bn4b_branch2a -> 4), else None."""
+        if layer in ("conv1", "bn_conv1"):
+            return 1
+        m = re.match(r"(?:res|bn)(\d)[a-z]+_branch", layer)
+        return int(m.group(1)) if m else None
+
+    def _trunk_specs(self):
+        """ConvSpecs of the trainable ResNet stages (empty while the backbone is frozen)."""
+        if self.backbone_from is None:
+            return []
+        return [s for s in resnet_fpn_convs(self.stage4_blocks) if (self._stage_of(s.name) or 0) >= self.backbone_from]
+
+    def _build(self, seed, weights=None):
         cfg, dev = self.config, self.device
         W = dict(synth.encoder_weights(seed, self.stage4_blocks))
         W.update(synth.rpn_weights(seed + 4, self.A))
-        self._backbone = {k: v for k, v in W.items() if not k.startswith(("fpn_", "rpn_"))}
+        if weights is not None:                          # a rebuild (train(layers=...) moved stages into the bucket): keep every weight
+            W.update({k: v for k, v in weights.items() if k in W})
+        trunk = self._trunk_specs()
+        moved = set()
+        for sp in trunk:
+            moved.update({sp.name + "/kernel", sp.name + "/bias", sp.bn + "/gamma", sp.bn + "/beta", sp.bn + "/moving_mean", sp.bn + "/moving_variance"})
+        self._backbone = {k: v for k, v in W.items() if not k.startswith(("fpn_", "rpn_")) and k not in moved}
         extra = []
+        for sp in trunk:                                 # trainable ResNet layers: packed kernel, bias, gamma, beta in the bucket; statistics frozen
+            kern = W[sp.name + "/kernel"]
+            extra.append((sp.name + "/kernel", pack_stem_kernel(kern) if sp.name == "conv1" else pack_conv_kernel(kern), True))
+            extra.append((sp.name + "/bias", W[sp.name + "/bias"], True))
+            extra.append((sp.bn + "/gamma", W[sp.bn + "/gamma"], True))
+            extra.append((sp.bn + "/beta", W[sp.bn + "/beta"], True))
+            extra.append((sp.bn + "/moving_mean", W[sp.bn + "/moving_mean"], False))
+            extra.append((sp.bn + "/moving_variance", W[sp.bn + "/moving_variance"], False))
         for name, k, cin in FPN_CONVS:
             extra.append((name + "/kernel", pack_conv_kernel(W[name + "/kernel"]), True))
             extra.append((name + "/bias", W[name + "/bias"], True))
@@ -303,6 +340,8 @@ class DenseImageCapRCNN(object):
         self._reg_coef = None
         self._bufs = {}
         self._bf16_cache = {}
+        if weights is not None:
+            self.set_weights({k: v for k, v in weights.items() if k not in self._backbone})
 
     def _buf(self, key, shape, dtype=torch.float32, zero=False):
         b = self._bufs.get(key)
@@ -327,15 +366,24 @@ class DenseImageCapRCNN(object):
                        anchor_stride=cfg.RPN_ANCHOR_STRIDE, bbox_std=[float(v) for v in cfg.RPN_BBOX_STD_DEV],
                        nms_threshold=cfg.RPN_NMS_THRESHOLD, proposal_count=count, head_channels=HEAD_PAD)
             h, wd = [int(v) for v in cfg.IMAGE_SHAPE[:2]]
+            ext_bn = {}
+            for sp in self._trunk_specs():             # trainable ResNet layers: kernel in place, BN folded on the device every forward
+                ext[sp.name] = (w[sp.name + "/kernel"], None, None)
+                ext_bn[sp.name] = dict(gamma=w[sp.bn + "/gamma"], beta=w[sp.bn + "/beta"], bias=w[sp.name + "/bias"],
+                                       mean=w[sp.bn + "/moving_mean"], var=w[sp.bn + "/moving_variance"])
+            stages = () if self.backbone_from is None else tuple(range(max(self.backbone_from, 2), 6))
             # the FPN/RPN weights change every step: the plan reads them in place from the parameter bucket
             self._plan = EncoderPlan(self._backbone, 1, h, wd, self.device, self.stage4_blocks, cfg.MEAN_PIXEL, rpn=rpn, external=ext,
-                                     math=self.conv_math)
+                                     math=self.conv_math, external_bn=ext_bn, train_stages=stages)
         return self._plan
 
     # ---- weights ----------------------------------------------------------------------------
     def _unpacked(self, name, packed):
-        k = dict((n, kk) for n, kk, _ in FPN_CONVS).get(name, 3 if name == "rpn_conv_shared" else 1)
         cout = packed.shape[0]
+        if name == "conv1":                              # the stem's [cout][7][8][4] layout (packing.pack_stem_kernel)
+            return np.ascontiguousarray(packed.reshape(cout, 7, 8, 4)[:, :, :7, :3].transpose(1, 2, 3, 0))
+        trunk = {sp.name: sp.k for sp in self._trunk_specs()}
+        k = trunk.get(name) or dict((n, kk) for n, kk, _ in FPN_CONVS).get(name, 3 if name == "rpn_conv_shared" else 1)
         return np.ascontiguousarray(packed.reshape(cout, k, k, -1).transpose(1, 2, 3, 0))
 
     def get_weights_dict(self):
@@ -350,7 +398,7 @@ class DenseImageCapRCNN(object):
                     out["rpn_class_raw/kernel"], out["rpn_bbox_pred/kernel"] = hwio[..., :a2], hwio[..., a2:a6]
                 else:
                     out["rpn_class_raw/bias"], out["rpn_bbox_pred/bias"] = v[:a2], v[a2:a6]
-            elif wname == "kernel" and layer.startswith(("fpn_", "rpn_")):
+            elif wname == "kernel" and (layer.startswith(("fpn_", "rpn_")) or self._stage_of(layer) is not None):
                 out[k] = self._unpacked(layer, v)
             else:
                 out[k] = v
@@ -372,8 +420,11 @@ class DenseImageCapRCNN(object):
             if layer in ("rpn_class_raw", "rpn_bbox_pred"):
                 continue
             if k in st.w:
-                packed = k.endswith("/kernel") and layer.startswith(("fpn_", "rpn_"))
-                st.assign(k, pack_conv_kernel(np.asarray(v, np.float32)) if packed else v, refresh=False)
+                if k == "conv1/kernel":
+                    v = pack_stem_kernel(np.asarray(v, np.float32))
+                elif k.endswith("/kernel") and (layer.startswith(("fpn_", "rpn_")) or self._stage_of(layer) is not None):
+                    v = pack_conv_kernel(np.asarray(v, np.float32))
+                st.assign(k, v, refresh=False)
             elif k in self._backbone:
                 self._backbone[k] = np.asarray(v, np.float32)
                 backbone_changed = True
@@ -455,8 +506,17 @@ class DenseImageCapRCNN(object):
         """Only the regexes that leave the backbone frozen are available (the reference trains "no_backbone",
         train_dense_captions.py:199-203); a frozen subset is realised by masking its gradient."""
         rx = re.compile(layer_regex)
-        if any(rx.fullmatch(s.name) for s in resnet_fpn_convs(self.stage4_blocks) if not s.name.startswith("fpn_")):
-            raise NotImplementedError("training ResNet stages is not on this path: use layers='no_backbone'")
+        stages = [self._stage_of(n) for sp in resnet_fpn_convs(self.stage4_blocks) if sp.bn for n in (sp.name, sp.bn) if rx.fullmatch(n)]
+        need = min(stages) if stages else None
+        if need is not None and (self.backbone_from is None or need < self.backbone_from):
+            # ResNet stages join the trainable set: their weights move from the folded, frozen backbone into the parameter
+            # bucket (kernels, biases, BN gamma / beta; moving statistics stay frozen), the encoder plan is rebuilt around them
+            if self.conv_math_name == "bf16":
+                raise NotImplementedError("training ResNet stages runs the exact-fp32 (or split-bf16) convolutions: build the model with "
+                                          "conv_math='f32' (compute_dtype='bf16' for the decoder is fine)")
+            self.backbone_from = need
+            self._build(self._seed, weights=self.get_weights_dict())
+            self.optimizer = None
         self._trainable_regex = layer_regex
         self._reg_coef = None
 
@@ -494,7 +554,7 @@ class DenseImageCapRCNN(object):
                 elif rx.fullmatch(layer):
                     mask[off:off + n] = 1.0
                     if wname not in ("gamma", "beta"):
-                        coef[off:off + n] = wd / n
+                        coef[off:off + n] = wd / (7 * 7 * 3 * 64 if name == "conv1/kernel" else n)     # (the stem's packed layout carries zero padding)
                 else:
                     frozen = True
             self._reg_coef = torch.tensor(coef, device=self.device)
@@ -610,6 +670,94 @@ class DenseImageCapRCNN(object):
             self._dgrad(dsh, wd_shared, 3, dP[i], residual=dP[i], key="rpn_shared", dy_key="dsh%d" % i)     # dP += dgrad
         return maps, dP
 
+    # ---- backward through trainable ResNet stages (train(layers = "5+" | "4+" | "3+" | "all")) ------------------------
+    def _bn_conv_backward(self, conv, bn, dz, bn_out, bn_sub, x, k, stride, key):
+        """Backward of y_bn = BN_frozen_stats(conv(x)) given dz = d(loss)/d(y_bn) and y_bn = bn_out - bn_sub (bn_sub may be None):
+        writes the gradients of kernel, bias, gamma, beta into the bucket and returns dacc = d(loss)/d(conv output)."""
+        p, w, g = self.plan(), self.store.w, self.store.grad
+        scale = p._w[conv][1]                                # gamma / sqrt(var + eps), folded by this step's forward
+        cout = dz.shape[-1]
+        dacc = self._buf(("tb_dacc", key, tuple(dz.shape)), tuple(dz.shape))
+        dzn = self._buf(("tb_dzn", tuple(dz.shape)), tuple(dz.shape))
+        ops.bn_bwd(dz, bn_out, bn_sub, w[bn + "/gamma"], w[bn + "/beta"], scale, dacc, dzn)
+        ops.colsum(dz.view(-1, cout), out=g[bn + "/beta"])
+        ops.colsum(dzn.view(-1, cout), out=g[bn + "/gamma"])
+        ops.mul(scale, g[bn + "/beta"], g[conv + "/bias"])   # sum(dz * scale) over the pixels = scale * dbeta
+        pad = (k - 1) // 2
+        if stride == 1:
+            self._wgrad(x, dacc, k, pad, g[conv + "/kernel"])
+        else:                                                # the strided 1x1 convolutions at a stage's entry
+            ops.conv2d_wgrad(x, dacc, k, k, stride, pad, pad, out=g[conv + "/kernel"])
+        return dacc
+
+    def _stage_backward(self, p, s, d_out):
+        """d_out: gradient w.r.t. the stage's output; returns the gradient w.r.t. its input.  Blocks in reverse order; per block
+        out = relu(bn2c(conv2c(m2)) + shortcut), m2 = relu(bn2b(conv2b(m1))), m1 = relu(bn2a(conv2a(x))), shortcut = x or bn1(conv1(x))."""
+        w = self.store.w
+        for bi in range(len(p.saved[s]) - 1, -1, -1):
+            b = p.saved[s][bi]
+            cn, bn = b["name"], b["name"].replace("res", "bn", 1)
+            x, m1, m2, sc, out, st = b["x"], b["m1"], b["m2"], b["sc"], b["out"], b["stride"]
+            mid, cout, cin = m1.shape[-1], out.shape[-1], x.shape[-1]
+            ds = ops.relu_bwd(d_out.view(-1, cout), out.view(-1, cout), self._buf(("tb_ds", tuple(out.shape)), tuple(out.shape)).view(-1, cout)).view(out.shape)
+            # branch 2c (no activation of its own: its BN output is out - shortcut wherever ds != 0)
+            dacc = self._bn_conv_backward(cn + "2c", bn + "2c", ds, out, sc if sc is not None else x, m2, 1, 1, "2c")
+            dm2 = ops.gemm(dacc.view(-1, cout), w[cn + "2c/kernel"], out=self._buf(("tb_dm", tuple(m2.shape)), tuple(m2.shape)).view(-1, mid))
+            dz = ops.relu_bwd(dm2, m2.view(-1, mid), dm2).view(m2.shape)
+            dacc = self._bn_conv_backward(cn + "2b", bn + "2b", dz, m2, None, m1, 3, 1, "2b")
+            wd = ops.conv_weight_dgrad_pack(w[cn + "2b/kernel"], 3, 3, mid, out=self._buf(("tb_wd", mid), (mid, 9 * mid)))
+            dm1 = self._dgrad(dacc, wd, 3, self._buf(("tb_dm1", tuple(m1.shape)), tuple(m1.shape)))
+            dz = ops.relu_bwd(dm1.view(-1, mid), m1.view(-1, mid), dm1.view(-1, mid)).view(m1.shape)
+            dacc = self._bn_conv_backward(cn + "2a", bn + "2a", dz, m1, None, x, 1, st, "2a")
+            # gradient w.r.t. the block input at the block's OUTPUT resolution: branch 2a + the shortcut
+            dxc = self._buf(("tb_dxc", tuple(m1.shape[:3]) + (cin,)), tuple(m1.shape[:3]) + (cin,))
+            if sc is None:                                   # identity shortcut (stride 1): dx = W2a^T dacc + ds
+                ops.gemm(dacc.view(-1, mid), w[cn + "2a/kernel"], out=dxc.view(-1, cin), residual=ds.view(-1, cout))
+            else:
+                ops.gemm(dacc.view(-1, mid), w[cn + "2a/kernel"], out=dxc.view(-1, cin))
+                dacc1 = self._bn_conv_backward(cn + "1", bn + "1", ds, sc, None, x, 1, st, "1")
+                ops.gemm(dacc1.view(-1, cout), w[cn + "1/kernel"], out=dxc.view(-1, cin), accumulate=True)
+            if st == 1:
+                d_out = dxc
+            else:                                            # the 1x1 / stride-2 entry convolutions read every other pixel of x
+                d_out = self._buf(("tb_dx", tuple(x.shape)), tuple(x.shape))
+                d_out.zero_()
+                ops.scatter2_add(dxc, d_out)
+            # (the next, earlier block turns d_out into its ds before it writes its own dxc, which may be this very buffer)
+        return d_out
+
+    def _trunk_backward(self, p, dpre):
+        """Gradients of the trainable ResNet stages: C_s receives the data gradient of its FPN lateral plus what the stage above
+        passes down; stages are walked top-down (5 -> backbone_from), then the stem when layers = "all"."""
+        w, g = self.store.w, self.store.grad
+        low = max(self.backbone_from, 2)
+        d_c = None
+        for s in (5, 4, 3, 2):
+            if s < low:
+                break
+            cmap, name = p.C[s - 2], "fpn_c%dp%d" % (s, s)
+            cin = cmap.shape[-1]
+            dlat = self._buf(("tb_dC", s), tuple(cmap.shape))          # dC_s = lateral^T dpre_s (+ the gradient from stage s + 1)
+            ops.gemm(dpre[s - 2].view(-1, 256), w[name + "/kernel"], out=dlat.view(-1, cin), residual=None if d_c is None else d_c.view(-1, cin))
+            d_c = self._stage_backward(p, s, dlat)
+        if self.backbone_from == 1:                              # the stem: maxpool 3x3/2 <- relu <- bn_conv1 <- conv1 7x7/2 (ZeroPadding 3)
+            sv = p.saved[1]
+            c1, pooled = sv["c1"], sv["pooled"]
+            dc1 = ops.maxpool3x3s2_same_bwd(c1, pooled, d_c, out=self._buf("tb_dc1", tuple(c1.shape)))
+            dz = ops.relu_bwd(dc1.view(-1, 64), c1.view(-1, 64), dc1.view(-1, 64)).view(c1.shape)
+            scale = p._w["conv1"][1]
+            dacc = self._buf("tb_dacc_stem", tuple(c1.shape))
+            dzn = self._buf("tb_dzn_stem", tuple(c1.shape))
+            ops.bn_bwd(dz, c1, None, w["bn_conv1/gamma"], w["bn_conv1/beta"], scale, dacc, dzn)
+            ops.colsum(dz.view(-1, 64), out=g["bn_conv1/beta"])
+            ops.colsum(dzn.view(-1, 64), out=g["bn_conv1/gamma"])
+            ops.mul(scale, g["bn_conv1/beta"], g["conv1/bias"])
+            x64 = ops.mold_image_padded(p.images, p.mean_pixel, self._buf("tb_x64", tuple(p.images.shape[:3]) + (64,)))   # Cin % 64 == 0 for the wgrad kernel
+            gw = ops.conv2d_wgrad(x64, dacc, 7, 7, 2, 3, 3, out=self._buf("tb_gw_stem", (64, 49 * 64)))
+            gk = g["conv1/kernel"].view(64, 7, 8, 4)                       # the stem's packed layout (pads stay zero)
+            gk.zero_()
+            gk[:, :, :7, :3].copy_(gw.view(64, 7, 7, 64)[..., :3])
+
     def forward_backward(self, inputs, shuffle="rng", backward=True):
         """Losses and gradients of one image into the flat gradient bucket (no optimizer step).
         Returns the device tensor [rpn_class_loss, rpn_bbox_loss, imgcap_loss, reg_loss].
@@ -718,6 +866,8 @@ class DenseImageCapRCNN(object):
             self._wgrad(cmap, dpre[i], 1, 0, g[name + "/kernel"])
             ops.colsum(dpre[i].view(-1, 256), out=g[name + "/bias"])
             announce(name)
+        if self.backbone_from is not None:
+            self._trunk_backward(p, dpre)
 
         # ---- regulariser (+ frozen subset when set_trainable narrowed the set)
         coef, mask = self._masks()
@@ -809,8 +959,6 @@ class DenseImageCapRCNN(object):
         """fit_generator over data_generator with a checkpoint per epoch (:1810-1888)."""
         assert self.mode == "training", "Create model in training mode."
         layers = self.LAYER_REGEX.get(layers, layers)
-        if layers in ("all", "3+", "4+", "5+"):
-            raise NotImplementedError("training ResNet stages is not on this path: use layers='no_backbone'")
         cfg = self.config
         train_generator = data_generator(train_dataset, cfg, shuffle=True, batch_size=cfg.BATCH_SIZE)
         val_generator = data_generator(val_dataset, cfg, shuffle=True, batch_size=cfg.BATCH_SIZE, augment=False)

@@ -53,12 +53,17 @@ class EncoderPlan:
     fast_bf16 = False                # bf16 STORAGE between the convolutions (math = 'bf16' only; see __init__)
 
     def __init__(self, weights, batch, height, width, device, stage4_blocks=22,
-                 mean_pixel=(123.7, 116.8, 103.9), use_graph=True, rpn=None, external=None, math=None):
+                 mean_pixel=(123.7, 116.8, 103.9), use_graph=True, rpn=None, external=None, math=None, external_bn=None, train_stages=()):
         """rpn: None (GT-RoI variant: the RPN is never evaluated) or a dict with the config values the
         proposal path needs: scales, ratios, strides, anchor_stride, bbox_std, nms_threshold, proposal_count and
         optionally head_channels (the fused class+bbox head padded to a multiple of 4 channels for the wgrad kernel).
         external: {conv name: (packed kernel, scale or None, shift)} device tensors owned by the caller (the joint
-        model's trainable FPN/RPN weights live in its flat parameter bucket; the plan reads them in place)."""
+        model's trainable FPN/RPN weights live in its flat parameter bucket; the plan reads them in place).
+        external_bn: {conv name: dict(gamma, beta, bias, mean, var)} device tensors for TRAINABLE ResNet layers (train(layers=
+        "3+" ...), dense_img_cap/dense_model.py:1829-1845): the plan owns scale / shift vectors for them and refreshes both
+        from the trained parameters at the start of every forward (dc_bn_fold_f32); their packed kernels come through `external`
+        with scale = shift = None.  train_stages: the ResNet stages (2..5; 1 = the stem) whose activations must survive the
+        forward for the backward pass: they get buffers of their own instead of the recycled ones (self.saved)."""
         if height % 64 or width % 64:
             raise ValueError("Image size must be dividable by 2 at least 6 times (got %dx%d)" % (height, width))
         self.lib = _lib.load()
@@ -83,6 +88,14 @@ class EncoderPlan:
         self._specs = {s.name: s for s in resnet_fpn_convs(stage4_blocks)}
         self.rpn = rpn
         self._external = dict(external or {})
+        self._external_bn = dict(external_bn or {})
+        self.train_stages = tuple(sorted(train_stages))
+        self.saved = {}
+        for name, bnp in self._external_bn.items():         # plan-owned epilogue vectors of the trainable BatchNorm layers
+            n = bnp["gamma"].numel()
+            sc, sh = torch.empty(n, dtype=torch.float32, device=self.device), torch.empty(n, dtype=torch.float32, device=self.device)
+            kern = self._external[name][0]
+            self._external[name] = (kern, sc, sh)
         if rpn is not None:
             a = len(rpn["ratios"])
             self.head_channels = hc = int(rpn.get("head_channels", 6 * a))
@@ -203,6 +216,9 @@ class EncoderPlan:
         self._twin, self._wb = {}, {}
         self.images = torch.empty((B, H, W, 3), dtype=torch.uint8, device=self.device)
         rgbx = torch.empty((B, H, W, 4), dtype=torch.float32, device=self.device)
+        for name, bnp in self._external_bn.items():
+            _, sc, sh = self._external[name]
+            self._ops.append(("bnfold", bnp, sc, sh))
         self._ops.append(("mold", self.images, rgbx))
         c1 = self._buf(H // 2, W // 2, 64)
         self._conv("conv1", rgbx, c1)
@@ -210,17 +226,27 @@ class EncoderPlan:
         self._ops.append(("pool", c1, x))
         if self.fast_bf16:
             self._ops.append(("cast", x, self._bf(x)))
+        self.saved[1] = dict(rgbx=rgbx, c1=c1, pooled=x)
 
         def stage(s, blocks, mid, cout, stride, x):
             h, w = x.shape[1] // stride, x.shape[2] // stride
-            m1, m2, sc = self._buf(h, w, mid), self._buf(h, w, mid), self._buf(h, w, cout)
-            pp = [self._buf(h, w, cout), self._buf(h, w, cout)]
+            keep = s in self.train_stages              # a trainable stage: every activation survives for the backward (fp32 copies too)
+            if not keep:
+                m1, m2, sc = self._buf(h, w, mid), self._buf(h, w, mid), self._buf(h, w, cout)
+                pp = [self._buf(h, w, cout), self._buf(h, w, cout)]
             final = self._buf(h, w, cout)
+            self.saved[s] = []
             for i, blk in enumerate(blocks):
                 cn = "res%d%s_branch" % (s, blk)
-                out = final if i == len(blocks) - 1 else pp[i & 1]
-                self._conv(cn + "2a", x, m1, f32=False, bf16=True)               # read by the next convolution only
-                self._conv(cn + "2b", m1, m2, f32=False, bf16=True)
+                if keep:
+                    m1, m2 = self._buf(h, w, mid), self._buf(h, w, mid)
+                    sc = self._buf(h, w, cout) if i == 0 else None
+                    out = final if i == len(blocks) - 1 else self._buf(h, w, cout)
+                    self.saved[s].append(dict(name=cn, x=x, m1=m1, m2=m2, sc=sc, out=out, stride=stride if i == 0 else 1))
+                else:
+                    out = final if i == len(blocks) - 1 else pp[i & 1]
+                self._conv(cn + "2a", x, m1, f32=keep, bf16=True)                # read by the next convolution only (and by a backward pass)
+                self._conv(cn + "2b", m1, m2, f32=keep, bf16=True)
                 if i == 0:
                     self._conv(cn + "1", x, sc, relu=False)                        # read as a residual only
                     self._conv(cn + "2c", m2, out, residual=sc, res_mode=1, bf16=True)
@@ -290,6 +316,9 @@ class EncoderPlan:
                     check(rc, "dc_conv2d_bf16(%s)" % op[2])
             elif kind == "cast":
                 ops.to_bf16(op[1], out=op[2])
+            elif kind == "bnfold":
+                b = op[1]
+                ops.bn_fold(b["gamma"], b["beta"], b["bias"], b["mean"], b["var"], op[2], op[3])
             elif kind == "mold":
                 ops.mold_image_rgbx(op[1], self.mean_pixel, out=op[2])
             elif kind == "sub2":

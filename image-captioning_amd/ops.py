@@ -684,6 +684,43 @@ def dropout_mask(out, rate, seed, offset):
     return out
 
 
+def bn_fold(gamma, beta, bias, mean, var, scale, shift, eps=1e-3):
+    """Fused-epilogue operands of a convolution followed by a frozen-statistics BatchNorm (dc_bn_fold_f32)."""
+    lib = _lib.load()
+    for t in (gamma, beta, bias, mean, var, scale, shift):
+        _chk(t, name="bn_fold operand")
+    check(lib.dc_bn_fold_f32(_ptr(gamma), _ptr(beta), _ptr(bias), _ptr(mean), _ptr(var), float(eps), _ptr(scale), _ptr(shift), gamma.numel(), _stream()),
+          "dc_bn_fold_f32")
+
+
+def bn_bwd(dz, a, b, gamma, beta, scale, dacc, dzn):
+    """dacc = dz * scale, dzn = dz * (a - b - beta) / gamma over [..., C] tensors (dc_bn_bwd_f32); b may be None."""
+    lib = _lib.load()
+    for t in (dz, a, gamma, beta, scale, dacc, dzn):
+        if not _chk(t, name="bn_bwd operand").is_contiguous():
+            raise _lib.DcapError("bn_bwd: operands must be contiguous")
+    Cc = dz.shape[-1]
+    check(lib.dc_bn_bwd_f32(_ptr(dz), _ptr(a), _ptr(b), _ptr(gamma), _ptr(beta), _ptr(scale), _ptr(dacc), _ptr(dzn), dz.numel() // Cc, Cc, _stream()),
+          "dc_bn_bwd_f32")
+    return dacc, dzn
+
+
+def mul(a, b, out):
+    lib = _lib.load()
+    check(lib.dc_mul_f32(_ptr(_chk(a, name="a")), _ptr(_chk(b, name="b")), _ptr(_chk(out, name="out")), out.numel(), _stream()), "dc_mul_f32")
+    return out
+
+
+def maxpool3x3s2_same_bwd(x, y, dy, out=None):
+    lib = _lib.load()
+    _chk(x, name="x"), _chk(y, name="y"), _chk(dy, name="dy")
+    N, H, W, Cc = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.dc_maxpool3x3s2_same_bwd_f32(_ptr(x), _ptr(y), _ptr(dy), _ptr(out), N, H, W, Cc, _stream()), "dc_maxpool3x3s2_same_bwd_f32")
+    return out
+
+
 def amsgrad_step(p, g, m, v, vhat, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, gnorm_sq=None, clipnorm=0.0, p_bf16=None):
     lib = _lib.load()
     d = AmsgradDesc()

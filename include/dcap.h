@@ -486,6 +486,23 @@ int dc_sumsq_f32(const float* x, size_t n, float* out, int accumulate, void* wor
  * (Philox-2x32-10): element i of stream (seed, offset) is a pure function of (i, seed, offset). */
 int dc_dropout_mask_f32(float* out, size_t n, float rate, uint32_t seed, uint32_t offset, void* stream);
 
+/* Training ResNet stages (dense_img_cap/dense_model.py:1829-1845: layers "3+" | "4+" | "5+" | "all"; BatchNorm with frozen
+ * statistics :51-61, trainable gamma / beta and convolution).
+ *   dc_bn_fold_f32: scale[c] = gamma[c] / sqrt(var[c] + eps), shift[c] = beta[c] + (bias[c] - mean[c]) * scale[c] -- the fused
+ *     epilogue operands of the forward convolution, refreshed from the trained parameters before every pass.
+ *   dc_bn_bwd_f32: given dz [rows][channels] = d(loss)/d(BN output) and the BN output itself as a - b (b may be NULL):
+ *     dacc = dz * scale (gradient w.r.t. the convolution output, also the summand of the conv-bias gradient) and
+ *     dzn = dz * (a - b - beta) / gamma (0 where dz == 0); column sums of dzn / dz are dgamma / dbeta, dbias = scale * dbeta.
+ *   dc_mul_f32: out = a * b elementwise. */
+int dc_bn_fold_f32(const float* gamma, const float* beta, const float* bias, const float* mean, const float* var, float eps,
+                   float* scale, float* shift, int n, void* stream);
+int dc_bn_bwd_f32(const float* dz, const float* a, const float* b, const float* gamma, const float* beta, const float* scale,
+                  float* dacc, float* dzn, long rows, int channels, void* stream);
+int dc_mul_f32(const float* a, const float* b, float* out, size_t n, void* stream);
+/* Backward of dc_maxpool3x3s2_same_f32 (the stem's pool, trained with layers = "all"): dx[pixel] = sum of dy over the windows whose
+ * first maximum (row-major, as TF's MaxPoolGrad) is this pixel.  x [N,H,W,C], y / dy [N,ceil(H/2),ceil(W/2),C]. */
+int dc_maxpool3x3s2_same_bwd_f32(const float* x, const float* y, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+
 /* mean of loss rows: out[0] = sum(x)/n. */
 int dc_mean_f32(const float* x, size_t n, float* out, void* stream);
 

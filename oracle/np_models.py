@@ -37,6 +37,122 @@ def _bottleneck(x, Wt, stage, block, stride, shortcut_conv):
     return O.relu(y + sc)
 
 
+def _conv_bn_cached(x, Wt, conv, bn, stride=1, padding='valid'):
+    """conv + frozen-statistics BN (no activation) with what the backward needs."""
+    a = O.conv2d_nhwc(x, Wt[conv + '/kernel'], Wt[conv + '/bias'], stride, padding)
+    rstd = 1.0 / np.sqrt(np.asarray(Wt[bn + '/moving_variance'], F64) + O.BN_EPS)
+    xhat = (a - np.asarray(Wt[bn + '/moving_mean'], F64)) * rstd
+    y = np.asarray(Wt[bn + '/gamma'], F64) * xhat + np.asarray(Wt[bn + '/beta'], F64)
+    return y, dict(x=x, xhat=xhat, rstd=rstd, conv=conv, bn=bn, stride=stride, padding=padding)
+
+
+def _conv_bn_backward(dy, c, Wt, G):
+    """dy = d(loss)/d(BN output).  Adds the gradients of kernel / bias / gamma / beta to G, returns d(loss)/d(conv input)."""
+    G[c['bn'] + '/gamma'] = (dy * c['xhat']).sum(axis=(0, 1, 2))
+    G[c['bn'] + '/beta'] = dy.sum(axis=(0, 1, 2))
+    da = dy * (np.asarray(Wt[c['bn'] + '/gamma'], F64) * c['rstd'])
+    dx, dw, db = O.conv2d_nhwc_backward(c['x'], Wt[c['conv'] + '/kernel'], da, c['stride'], c['padding'])
+    G[c['conv'] + '/kernel'], G[c['conv'] + '/bias'] = dw, db
+    return dx
+
+
+def _bottleneck_cached(x, Wt, stage, block, stride, shortcut_conv):
+    cn, bn = 'res%d%s_branch' % (stage, block), 'bn%d%s_branch' % (stage, block)
+    ya, ca = _conv_bn_cached(x, Wt, cn + '2a', bn + '2a', stride)
+    m1 = O.relu(ya)
+    yb, cb = _conv_bn_cached(m1, Wt, cn + '2b', bn + '2b', 1, 'same')
+    m2 = O.relu(yb)
+    yc, cc = _conv_bn_cached(m2, Wt, cn + '2c', bn + '2c')
+    c1 = None
+    if shortcut_conv:
+        sc, c1 = _conv_bn_cached(x, Wt, cn + '1', bn + '1', stride)
+    else:
+        sc = x
+    out = O.relu(yc + sc)
+    return out, dict(a=ca, b=cb, c=cc, s=c1, m1=m1, m2=m2, out=out)
+
+
+def _bottleneck_backward(d_out, k, Wt, G):
+    ds = d_out * (k['out'] > 0)
+    dm2 = _conv_bn_backward(ds, k['c'], Wt, G)
+    dm1 = _conv_bn_backward(dm2 * (k['m2'] > 0), k['b'], Wt, G)
+    dx = _conv_bn_backward(dm1 * (k['m1'] > 0), k['a'], Wt, G)
+    return dx + (ds if k['s'] is None else _conv_bn_backward(ds, k['s'], Wt, G))
+
+
+def resnet_graph_cached(image, Wt, stage4_blocks=22):
+    """resnet_graph with the per-block caches the backward of trainable stages needs (train(layers="3+" ...))."""
+    x = np.pad(np.asarray(image, F64), ((0, 0), (3, 3), (3, 3), (0, 0)))
+    y1, c_stem = _conv_bn_cached(x, Wt, 'conv1', 'bn_conv1', 2)
+    r1 = O.relu(y1)
+    x = C1 = O.maxpool3x3s2_same(r1)
+    caches = {1: dict(stem=c_stem, r1=r1, pooled=C1), 2: [], 3: [], 4: [], 5: []}
+    plan = [(2, 'abc', 1), (3, 'abcd', 2), (4, ['a'] + [chr(98 + i) for i in range(stage4_blocks)], 2), (5, 'abc', 2)]
+    Cs = {1: C1}
+    for stage, blocks, stride in plan:
+        for i, blk in enumerate(blocks):
+            x, k = _bottleneck_cached(x, Wt, stage, blk, stride if i == 0 else 1, i == 0)
+            caches[stage].append(k)
+        Cs[stage] = x
+    return Cs, caches
+
+
+def maxpool3x3s2_same_backward(x, y, dy):
+    """Gradient of MaxPooling2D((3,3), strides 2, 'same'): each window's dy goes to its first (row-major) maximum."""
+    x, y, dy = np.asarray(x, F64), np.asarray(y, F64), np.asarray(dy, F64)
+    N, H, W, C = x.shape
+    Ho, Wo = y.shape[1:3]
+    pt, pl = O.same_pad(H, 3, 2)[0], O.same_pad(W, 3, 2)[0]
+    dx = np.zeros_like(x)
+    taken = np.zeros(y.shape, bool)
+    for ky in range(3):
+        for kx in range(3):
+            for oy in range(Ho):
+                iy = oy * 2 - pt + ky
+                if not 0 <= iy < H:
+                    continue
+                ox = np.arange(Wo)
+                ix = ox * 2 - pl + kx
+                ok = (ix >= 0) & (ix < W)
+                ox, ix = ox[ok], ix[ok]
+                hit = (x[:, iy, ix, :] == y[:, oy, ox, :]) & ~taken[:, oy, ox, :]
+                dx[:, iy, ix, :] += np.where(hit, dy[:, oy, ox, :], 0.0)
+                taken[:, oy, ox, :] |= hit
+    return dx
+
+
+def resnet_backward(dC, caches, Wt, backbone_from):
+    """dC: {stage: gradient w.r.t. that stage's output C_stage} (the FPN laterals' data gradients).  Walks the trainable stages
+    top-down; returns the gradients of their kernels, biases, gammas and betas."""
+    G = {}
+    d = None
+    for stage in (5, 4, 3, 2):
+        if stage < max(backbone_from, 2):
+            break
+        d = dC[stage] if d is None else dC[stage] + d
+        for k in reversed(caches[stage]):
+            d = _bottleneck_backward(d, k, Wt, G)
+    if backbone_from == 1:
+        st = caches[1]
+        d1 = maxpool3x3s2_same_backward(st['r1'], st['pooled'], d)
+        _conv_bn_backward(d1 * (st['r1'] > 0), st['stem'], Wt, G)
+    return G
+
+
+def backbone_trainable(Wt, backbone_from, stage4_blocks=22):
+    """Trunk weights train(layers="<backbone_from>+") adds to joint_trainable: kernels, biases, BN gammas and betas of the
+    ResNet stages >= backbone_from (1 = 'all': the stem too); moving statistics stay frozen."""
+    import re
+    keys = []
+    for k in Wt:
+        layer, wname = k.split('/')
+        m = re.match(r'(?:res|bn)(\d)[a-z]+_branch', layer)
+        stage = 1 if layer in ('conv1', 'bn_conv1') else (int(m.group(1)) if m else None)
+        if stage is not None and stage >= backbone_from and wname in ('kernel', 'bias', 'gamma', 'beta'):
+            keys.append(k)
+    return keys
+
+
 def resnet_graph(image, Wt, stage4_blocks=22):
     """resnet_graph(input_image, 'resnet101', stage5=True) (dense_model.py:143-173).
     stage4_blocks=22 is ResNet-101 (5 = the file's 'resnet50' option, used for fast tests)."""
@@ -433,7 +549,7 @@ def joint_trainable(Wt):
 
 
 def joint_loss_and_grads(Wt, image_u8, rpn_match, rpn_bbox_target, gt_captions, gt_boxes_px, cfg, shuffle=None, stage4_blocks=22,
-                         targets_override=None):
+                         targets_override=None, backbone_from=None):
     """One training step's losses and gradients for ONE image (IMAGES_PER_GPU = 1, train_dense_captions.py:27).
     cfg: dict(mean_pixel, scales, ratios, strides, proposal_count, nms, train_rois, positive_ratio, weight_decay, T).
     targets_override = (rois [R,4] normalised, caps [R,T]) replaces the DetectionTargetLayer's sample (which carries no
@@ -441,9 +557,13 @@ def joint_loss_and_grads(Wt, image_u8, rpn_match, rpn_bbox_target, gt_captions, 
     Returns (losses dict, grads dict over joint_trainable(Wt), aux dict)."""
     x = O.mold_image(image_u8[None], cfg['mean_pixel'])
     _, H, W, _ = x.shape
-    _, C2, C3, C4, C5 = resnet_graph(x, Wt, stage4_blocks)
-    Cs = {2: C2, 3: C3, 4: C4, 5: C5}
+    if backbone_from is None:
+        _, C2, C3, C4, C5 = resnet_graph(x, Wt, stage4_blocks)
+        Cs = {2: C2, 3: C3, 4: C4, 5: C5}
+    else:                                                           # train(layers="3+" | "4+" | "5+" | "all"): ResNet stages train too
+        Cs, trunk_caches = resnet_graph_cached(x, Wt, stage4_blocks)
     conv = lambda t, n, pad='valid': O.conv2d_nhwc(t, Wt[n + '/kernel'], Wt[n + '/bias'], 1, pad)
+    C5 = Cs[5]
     pre = {5: conv(C5, 'fpn_c5p5')}
     for k in (4, 3, 2):
         pre[k] = O.upsample2x(pre[k + 1]) + conv(Cs[k], 'fpn_c%dp%d' % (k, k))
@@ -476,7 +596,7 @@ def joint_loss_and_grads(Wt, image_u8, rpn_match, rpn_bbox_target, gt_captions, 
     l_cls, dlogits = O.rpn_class_loss(rpn_match, logits)
     l_box, dbbox = O.rpn_bbox_loss(rpn_bbox_target, rpn_match, bbox)
     losses['rpn_class_loss'], losses['rpn_bbox_loss'] = l_cls, l_box
-    train = joint_trainable(Wt)
+    train = joint_trainable(Wt) + (backbone_trainable(Wt, backbone_from, stage4_blocks) if backbone_from is not None else [])
     reg_keys = [k for k in train if 'gamma' not in k and 'beta' not in k]
     losses['reg_loss'] = float(sum(cfg['weight_decay'] * (np.asarray(Wt[k], F64) ** 2).sum() / np.asarray(Wt[k]).size for k in reg_keys))
     losses['loss'] = sum(losses[k] for k in ('imgcap_loss', 'rpn_class_loss', 'rpn_bbox_loss', 'reg_loss'))
@@ -511,9 +631,12 @@ def joint_loss_and_grads(Wt, image_u8, rpn_match, rpn_bbox_target, gt_captions, 
         g = dpre[k]
         N_, h_, w_, c_ = g.shape
         dpre[k + 1] = dpre[k + 1] + g.reshape(N_, h_ // 2, 2, w_ // 2, 2, c_).sum(axis=(2, 4))
+    dC = {}
     for k in (2, 3, 4, 5):
-        _, dw, db = O.conv2d_nhwc_backward(Cs[k], Wt['fpn_c%dp%d/kernel' % (k, k)], dpre[k])
+        dC[k], dw, db = O.conv2d_nhwc_backward(Cs[k], Wt['fpn_c%dp%d/kernel' % (k, k)], dpre[k])
         G['fpn_c%dp%d/kernel' % (k, k)], G['fpn_c%dp%d/bias' % (k, k)] = dw, db
+    if backbone_from is not None:
+        G.update(resnet_backward(dC, trunk_caches, Wt, backbone_from))
     for k in reg_keys:
         G[k] = G[k] + 2.0 * cfg['weight_decay'] * np.asarray(Wt[k], F64) / np.asarray(Wt[k]).size
     aux = dict(proposals=proposals, rois=rois, caps=caps, npos=npos, nneg=nneg, count=cnt, cap_probs=cap_probs, anchors=anchors)

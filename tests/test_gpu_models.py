@@ -331,13 +331,13 @@ def joint_inputs(S, V, T, seed=8):
     return [img, np.zeros((1, 12)), match, tdelta, gt_caps, gt_boxes]
 
 
-def joint_oracle(Wt, cfg, inputs, targets, blocks):
+def joint_oracle(Wt, cfg, inputs, targets, blocks, backbone_from=None):
     img, _, match, tdelta, gt_caps, gt_boxes = inputs
     oc = dict(mean_pixel=MEAN, scales=cfg.RPN_ANCHOR_SCALES, ratios=cfg.RPN_ANCHOR_RATIOS, strides=cfg.BACKBONE_STRIDES,
               proposal_count=cfg.POST_NMS_ROIS_TRAINING, nms=cfg.RPN_NMS_THRESHOLD, train_rois=cfg.TRAIN_ROIS_PER_IMAGE,
               positive_ratio=cfg.ROI_POSITIVE_RATIO, weight_decay=cfg.WEIGHT_DECAY, T=cfg.PADDING_SIZE)
     return M.joint_loss_and_grads(Wt, img[0], match[0, :, 0], tdelta[0], gt_caps[0], gt_boxes[0], oc, stage4_blocks=blocks,
-                                  targets_override=targets)
+                                  targets_override=targets, backbone_from=backbone_from)
 
 
 def joint_grads_as_reference(model):
@@ -372,6 +372,48 @@ def test_joint_model_step_matches_oracle(gpu, conv_math):
     got = joint_grads_as_reference(model)
     for k in M.joint_trainable(Wt):
         assert rel_err(got[k], G[k]) < 2e-4, (k, rel_err(got[k], G[k]))
+
+
+@pytest.mark.parametrize("layers,stage", [("5+", 5), ("4+", 4), ("3+", 3), ("all", 1)])
+def test_joint_model_trains_resnet_stages(gpu, layers, stage):
+    """train(layers="5+" | "4+" | "3+" | "all") (dense_img_cap/dense_model.py:1829-1845): the ResNet stages' convolutions and BatchNorm
+    gammas / betas (frozen statistics) join the trainable set.  set_trainable moves them into the parameter bucket without changing
+    any weight; losses and the gradient of EVERY trainable weight -- through bottleneck blocks, strided stage entries, projection
+    shortcuts, the max pool and the stem for "all" -- equal the oracle's backward; an optimizer step then moves them, the moving
+    statistics stay put, and the weights round-trip through get_weights_dict / set_weights."""
+    S, V, T, blocks = 128, 24, 5, 1
+    model, cfg, Wt = make_joint(S, V, T, blocks)
+    inputs = joint_inputs(S, V, T)
+    base = model._loss_list(model.forward_backward(inputs, shuffle=None))
+    model.set_trainable(model.LAYER_REGEX[layers])
+    assert model.backbone_from == stage
+    back = model.get_weights_dict()
+    assert set(back) == set(Wt) and all(np.array_equal(back[k], np.asarray(Wt[k], np.float32)) for k in Wt)
+    for rep in range(2):                                   # eager plan, then captured graph
+        losses = model._loss_list(model.forward_backward(inputs, shuffle=None))
+    tg = model.last_targets
+    want, G, aux = joint_oracle(Wt, cfg, inputs, (tg['rois'], tg['caps']), blocks, backbone_from=stage)
+    trunk = M.backbone_trainable(Wt, stage, blocks)
+    assert trunk and set(trunk) <= set(model.trainable_weights) and len(trunk) == 4 * sum(1 for k in Wt if k.endswith('/gamma') and k in trunk)
+    for k in ('imgcap_loss', 'rpn_class_loss', 'rpn_bbox_loss', 'loss'):
+        assert abs(losses[k] - want[k]) < 1e-4 * max(1.0, abs(want[k])), (k, losses[k], want[k])
+        if k != 'loss':
+            assert abs(losses[k] - base[k]) < 1e-5 * max(1.0, abs(base[k]))         # moving weights into the bucket changed no arithmetic
+    assert losses['reg_loss'] > base['reg_loss'] and abs(losses['reg_loss'] - want['reg_loss']) < 1e-5 * want['reg_loss']
+    got = joint_grads_as_reference(model)
+    worst = {k: rel_err(got[k], G[k]) for k in M.joint_trainable(Wt) + trunk if np.abs(G[k]).max() > 1e-12}
+    assert max(worst.values()) < 5e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    for k in trunk:                                        # dead units: exactly zero on both sides
+        if np.abs(G[k]).max() <= 1e-12:
+            assert np.abs(got[k]).max() < 1e-9, k
+    model.compile(1e-4)
+    model.train_on_batch(inputs)
+    after = model.get_weights_dict()
+    moved = [k for k in trunk if not np.array_equal(after[k], back[k])]
+    assert len(moved) > 0.5 * len(trunk)
+    assert all(np.array_equal(after[k], back[k]) for k in Wt if 'moving_' in k)
+    frozen = [k for k in Wt if k.split('/')[0].startswith(('res', 'bn', 'conv1')) and k not in trunk and 'moving_' not in k]
+    assert all(np.array_equal(after[k], back[k]) for k in frozen)               # stages below the first trainable one stay frozen
 
 
 def test_joint_model_bf16_step_tracks_the_fp32_oracle(gpu):
@@ -612,6 +654,16 @@ def test_joint_model_train_loop_checkpoints_and_resumes(gpu, tmp_path):
     more = resumed.train(train, val, learning_rate=1e-5, epochs=3, layers="no_backbone")
     assert len(more) == 1 and resumed.epoch == 3
     assert set(os.listdir(folder)) - before == {"img_cap_%s_0003.npz" % name}
+    # the next call widens the trainable set to ResNet stage 5 (the reference's schedule: train_dense_captions.py trains the heads first):
+    # the bucket is rebuilt around the current weights, one more epoch runs, its checkpoint carries the trained stage-5 weights
+    w3 = resumed.get_weights_dict()
+    last5 = resumed.train(train, val, learning_rate=1e-5, epochs=4, layers="5+")
+    assert len(last5) == 1 and resumed.epoch == 4 and resumed.backbone_from == 5
+    w4 = load_ckpt = __import__("image_captioning_amd.modified_dense_model", fromlist=["load_weight_file"]).load_weight_file(
+        os.path.join(folder, "img_cap_%s_0004.npz" % name))
+    assert not np.array_equal(w4["res5c_branch2c/kernel"], w3["res5c_branch2c/kernel"]) and not np.array_equal(w4["bn5a_branch1/gamma"], w3["bn5a_branch1/gamma"])
+    assert np.array_equal(w4["res4a_branch2a/kernel"], w3["res4a_branch2a/kernel"]) and np.array_equal(w4["bn5a_branch1/moving_mean"], w3["bn5a_branch1/moving_mean"])
+    assert all(np.isfinite(v).all() for v in w4.values())
 
 
 def test_vgg16_plan_matches_oracle(gpu):
