@@ -247,3 +247,52 @@ def test_box_deltas_clip_and_nms():
     assert O.nms_tf(b, s, 10, 0.7).tolist() == [0, 2, 3, 4]        # IoU(0,1)=0.9 > 0.7 suppressed; 0.69 kept; zero area kept
     assert O.nms_tf(b, s, 2, 0.7).tolist() == [0, 2]
     assert O.nms_tf(b, np.array([0.5, 0.5, 0.5, 0.5, 0.5], np.float32), 1, 0.7).tolist() == [0]   # ties: lowest index first
+
+
+def test_resnet_trunk_backward_matches_finite_differences():
+    """The oracle's backward through trainable ResNet stages (train(layers="3+" | "4+" | "5+" | "all"), dense_img_cap/dense_model.py:
+    1829-1845): bottleneck blocks with identity and projection shortcuts, strided stage entries, frozen-statistics BatchNorm with
+    trainable gamma / beta, the 3x3/2 max pool and the stem -- against central differences of the float64 forward."""
+    from image_captioning_amd import synth
+    from oracle import np_models as M
+    Wt = {k: np.asarray(v, np.float64) for k, v in synth.encoder_weights(0, 1).items()}
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((1, 64, 64, 3))
+    Cs, caches = M.resnet_graph_cached(x, Wt, 1)
+    plain = M.resnet_graph(x, Wt, 1)
+    assert all(np.allclose(Cs[s], plain[s - 1], rtol=0, atol=1e-12) for s in (2, 3, 4, 5))
+    R = {s: rng.standard_normal(Cs[s].shape) for s in (2, 3, 4, 5)}
+    loss = lambda W: sum((M.resnet_graph_cached(x, W, 1)[0][s] * R[s]).sum() for s in (2, 3, 4, 5))
+    G = M.resnet_backward(R, caches, Wt, 1)
+    assert set(G) == set(M.backbone_trainable(Wt, 1, 1))
+    assert set(M.backbone_trainable(Wt, 4, 1)) == {k for k in G if k.split('/')[0][3 if k.startswith('res') else 2] in '45'}
+    checked = 0
+    for key in ('res4a_branch2a/bias', 'bn3b_branch2c/beta', 'res2a_branch1/kernel', 'conv1/kernel', 'bn_conv1/gamma', 'res5a_branch2b/kernel',
+                'bn4a_branch1/gamma', 'res3a_branch1/kernel', 'bn2c_branch2a/beta'):
+        w = Wt[key]
+        for _ in range(3):
+            idx = tuple(int(rng.integers(0, n)) for n in w.shape)
+            if abs(G[key][idx]) < 1e-9:
+                continue                                   # a dead unit (zero on both sides; finite differences agree trivially)
+            vals = []
+            for sgn in (1, -1):
+                Wp = dict(Wt)
+                a = w.copy()
+                a[idx] += sgn * 1e-6
+                Wp[key] = a
+                vals.append(loss(Wp))
+            fd = (vals[0] - vals[1]) / 2e-6
+            assert abs(fd - G[key][idx]) < 5e-3 * max(1.0, abs(fd)), (key, idx, fd, G[key][idx])     # (ReLU / max-pool kinks inside the step)
+            checked += 1
+    assert checked >= 12
+
+
+def test_maxpool_backward_routes_to_the_first_maximum():
+    from oracle import np_models as M
+    x = np.zeros((1, 4, 4, 1))
+    x[0, 1, 1, 0], x[0, 1, 2, 0] = 5.0, 5.0                # a tie inside window (0,0) of the SAME-padded 3x3/2 pool
+    y = O.maxpool3x3s2_same(x)
+    dy = np.arange(1.0, 5.0).reshape(1, 2, 2, 1)
+    dx = M.maxpool3x3s2_same_backward(x, y, dy)
+    assert dx.sum() == dy.sum()                             # every window's gradient lands on exactly one pixel
+    assert dx[0, 1, 1, 0] >= dy[0, 0, 0, 0] and (dx[0, 1, 2, 0] == 0 or dx[0, 1, 2, 0] == dy[0, 0, 1, 0])

@@ -4,7 +4,7 @@
 # kernel summary, the bf16 GEMM micro-benchmark and the 2-rank rehearsal.  Outputs under gpurun_out/profiles_<tag>/ ; copy what
 # should be judged into profiles/.
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 out=$PWD/gpurun_out/profiles_$tag
 mkdir -p $out
 root=$PWD
@@ -22,13 +22,17 @@ python3 $root/bench.py --config joint --steps 10 --joint-dtype f32 > $out/joint_
 tail -1 $out/joint_bench_f32.log > $out/joint_bench_f32.json
 rocprofv3 --kernel-trace --stats -d $out/joint -o joint -- python3 $root/bench.py --config joint --steps 10 > $out/joint.log 2>&1
 python3 $root/tools/prof_summary.py $out/joint/joint_results.db $out/joint_kernels.csv 13
-python3 $root/tools/bgemm_bench.py > $out/bgemm_bench.txt 2>&1
-python3 $root/tools/bconv_bench.py 2>&1 | grep -v amdgpu.ids > $out/bconv_bench.txt
+python3 $root/tools/bgemm_bench.py 2>&1 | grep -v amdgpu.ids > $out/bgemm_bench.txt
+(echo "== DCAP_BGEMM_TILE=128 (the round-2 128 x 128 loop on the same shapes)"; DCAP_BGEMM_TILE=128 python3 $root/tools/bgemm_bench.py 2>&1 | grep -v amdgpu.ids) >> $out/bgemm_bench.txt
+python3 $root/tools/vocab_ce_bench.py 2>&1 | grep -v amdgpu.ids > $out/vocab_ce_bench.txt
+(for t in 0 64 128; do echo "== tile $t (0 = the library's cost model)"; python3 $root/tools/bconv_bench.py --tile $t 2>&1 | grep -v amdgpu.ids; done) > $out/bconv_bench.txt
 (echo "== one launch per timestep (default)"; python3 $root/tools/lstm_bench.py 2>&1 | grep B=; echo "== DCAP_LSTM_BWD=steps (gate kernel + split-K GEMM + slab reduce per backward timestep)"; DCAP_LSTM_BWD=steps python3 $root/tools/lstm_bench.py 2>&1 | grep B=) > $out/lstm_bench.txt
 (echo "== default (128x64 producer/consumer rule + streaming short-K kernel)"; python3 $root/tools/conv_bench.py --reps 50 2>&1 | grep -v amdgpu.ids; echo "== DCAP_PW_RULE=0 DCAP_PW_STREAM=0 (round-1 tile rule, no streaming kernel)"; DCAP_PW_RULE=0 DCAP_PW_STREAM=0 python3 $root/tools/conv_bench.py --reps 50 2>&1 | grep -v amdgpu.ids) > $out/conv_bench.txt
 rocprofv3 --kernel-trace --stats -d $out/dec -o dec -- python3 $root/tools/decoder_bench.py --captions 64 --steps 50 > $out/dec.log 2>&1
 python3 $root/tools/prof_summary.py $out/dec/dec_results.db $out/decoder_kernels.csv 53
 cd $root
-DCAP_DIST_BACKEND=gloo timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 2 > $out/rehearsal_2rank_gloo.log 2>&1 || true
+timeout -k 10 300 python3 bench.py --gpus 2 --steps 5 --warmup 2 > $out/rehearsal_2rank_selflaunch.log 2>&1 || true
+timeout -k 10 300 python3 bench.py --config joint --gpus 2 --steps 5 --warmup 2 --no-roofline > $out/rehearsal_2rank_joint.log 2>&1 || true
+bash tools/roialign_profile.sh > /dev/null 2>&1 && cp gpurun_out/roialign_profile.txt $out/roialign_hbm.txt || true
 rm -rf $out/trace $out/joint $out/dec $out/pmc_fetch $out/pmc_write
 ls $out
