@@ -382,7 +382,7 @@ class E2E(object):
         achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
         conv_ms = sum(v["ms"] for v in groups.values())
         traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
-        for tname in (("r02_pmc_traffic.json", "r01_pmc_traffic.json") if args.backbone == "resnet101" else ()):
+        for tname in (("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json") if args.backbone == "resnet101" else ()):
             tpath = os.path.join(ROOT, "profiles", tname)
             if traffic is None and os.path.exists(tpath):
                 for name, rec in json.load(open(tpath)).items():
