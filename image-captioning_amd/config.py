@@ -56,6 +56,7 @@ DEFAULTS = (
     # not a field of the reference's Config: the reference hard-codes it in the model (dense_img_cap/dense_model.py:769-770,
     # text_generation_model.py:141-142: KL.LSTM(..., recurrent_dropout=0.2)); a field here so that parity runs can switch it off
     ("RECURRENT_DROPOUT", 0.2, "recurrent_dropout of imgcap_lstm1/2 in the training phase (the reference's hard-coded 0.2)"),
+    ("DROPOUT_ROWS", "roi", "'roi': one recurrent-dropout mask set per RoI (single masked pass); 'prefix': per (RoI, prefix) row as Keras draws them"),
 )
 
 

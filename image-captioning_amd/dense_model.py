@@ -335,6 +335,7 @@ class DenseImageCapRCNN(object):
         self.caption_model.overlap_sync = False
         self._reg_done = []
         self.caption_model.recurrent_dropout = float(getattr(cfg, "RECURRENT_DROPOUT", 0.2))    # dense_img_cap/dense_model.py:769-770: recurrent_dropout=0.2
+        self.caption_model.dropout_rows = str(getattr(cfg, "DROPOUT_ROWS", "roi"))
         self.store = self.caption_model.store
         self._plan = None
         self._reg_coef = None

@@ -9,8 +9,8 @@ each of them (T^2 LSTM steps per RoI).  With Keras' mask carry a post-padded pre
 state the full caption has after that prefix, so ONE masked pass over the caption yields all T outputs:
 predict / train_on_batch here take the reference's batch layout ([feat f32[B,7,7,256], caps f32[B,T]],
 one-hot f64[B,T,V]) and return what the T-prefix graph returns (parity: tests/test_gpu_models.py against
-the as-written oracle), at 1/T of the LSTM work.  recurrent_dropout=0.2 of the reference is a
-training-time stochastic regulariser and is not applied (parity runs are dropout-off).
+the as-written oracle), at 1/T of the LSTM work.  recurrent_dropout=0.2 of the reference is applied in the training
+phase (device-side masks; `recurrent_dropout`, `dropout_rows` below); parity runs set it to 0 or replay the masks in the oracle.
 """
 import json
 import os
@@ -173,6 +173,12 @@ class CaptionModelV1(KerasLikeModel):
     # masks are what keeps the T-prefix graph equal to the single masked pass ("recurrent dropout").  Never
     # applied in predict / test_on_batch / generate (Keras' learning phase 0).
     recurrent_dropout = 0.2
+    # Which rows get their own mask.  'roi' (default): one mask set per RoI, shared by its T prefixes -- the single masked pass.
+    # 'prefix': one per (RoI, prefix) row of the TimeDistributed batch, which is what the reference's graph draws
+    # (text_generation_model.py:179-187: TimeDistributed(word_model) over the T prefixes; every application of the LSTM cell
+    # makes its own K.dropout mask): the LSTMs then really run over the B*T padded prefixes (T x the LSTM work, as the
+    # reference does), everything above them is unchanged.  Only matters when training with recurrent_dropout > 0.
+    dropout_rows = "roi"
 
     def __init__(self, features_input, config, units, mode, device=None, seed=0, extra_params=(), compute_dtype="f32"):
         """extra_params: (name, array, trainable) entries that share this model's flat parameter bucket (the joint
@@ -219,8 +225,14 @@ class CaptionModelV1(KerasLikeModel):
     def compile(self, optimizer, loss=None):
         self.optimizer, self.loss = optimizer, loss
 
+    def _prefix_rows(self, training):
+        if self.dropout_rows not in ("roi", "prefix"):
+            raise ValueError("dropout_rows must be 'roi' or 'prefix'")
+        return bool(training) and self.dropout_rows == "prefix" and float(self.recurrent_dropout or 0.0) > 0.0
+
     def _draw_rec_masks(self, B, training):
-        """Keras LSTMCell._generate_recurrent_dropout_mask for both LSTMs: K.dropout(ones, rate) x 4 in the training phase."""
+        """Keras LSTMCell._generate_recurrent_dropout_mask for both LSTMs: K.dropout(ones, rate) x 4 in the training phase.
+        B = rows the LSTMs run over (RoIs, or RoIs x prefixes with dropout_rows='prefix': row j*B_roi + b = prefix j of RoI b)."""
         rate = float(self.recurrent_dropout or 0.0)
         if not training or rate <= 0.0:
             self._rec_masks = (None, None)
@@ -296,22 +308,26 @@ class CaptionModelV1(KerasLikeModel):
             x = self._act('hact%d' % li, y)
         return x
 
-    def _hidden(self, f, ids_tm, mask, B, T):
+    def _hidden(self, f, ids_tm, mask, B, T, Bl=None):
         """word_generation_model up to the Dense-1024 layer, over time-major token ids: a1 [T*B, 1024] (row t*B+b = the
-        state after step t, i.e. for the prefix c_0..c_t)."""
+        state after step t, i.e. for the prefix c_0..c_t).  Bl = rows the LSTMs run over: B (one masked pass per RoI serves
+        all its prefixes) or T*B (dropout_rows='prefix': row j*B+b = prefix j of RoI b, zero-padded; Keras' mask carry leaves
+        the state after the prefix in the LAST step's rows, which are laid out exactly like the single pass's [T*B] rows)."""
         w, u = self.store.w, self.units
+        Bl = B if Bl is None else Bl
         zf = self._mm(f, self._wview('imgcap_lstm1/kernel', (self.E, self.E + self.FEAT)), key='zf').f        # per-RoI half of x.W
         z1 = ops.gemm(w['imgcap_embedding_layer/embeddings'], w['imgcap_lstm1/kernel'][:self.E], gather=ids_tm, shift=w['imgcap_lstm1/bias'],
-                      residual=zf, res_rows=B, out=self._buf('z1', (T * B, 4 * u)))
-        h1, c1 = ops.lstm_seq_fwd(z1, w['imgcap_lstm1/recurrent_kernel'], mask, B, T, self._buf('h1', (T * B, u)),
-                                  self._buf('c1', (T * B, u)), rec_masks=self._rec_masks[0])
+                      residual=zf, res_rows=B, out=self._buf('z1', (T * Bl, 4 * u)))
+        h1, c1 = ops.lstm_seq_fwd(z1, w['imgcap_lstm1/recurrent_kernel'], mask, Bl, T, self._buf('h1', (T * Bl, u)),
+                                  self._buf('c1', (T * Bl, u)), rec_masks=self._rec_masks[0])
         self._h1 = self._act('h1', h1)
         z2 = self._mm(self._h1, self._wview('imgcap_lstm2/kernel'), key='z2', shift=w['imgcap_lstm2/bias']).f
-        h2, c2 = ops.lstm_seq_fwd(z2, w['imgcap_lstm2/recurrent_kernel'], mask, B, T, self._buf('h2', (T * B, u)),
-                                  self._buf('c2', (T * B, u)), rec_masks=self._rec_masks[1])
+        h2, c2 = ops.lstm_seq_fwd(z2, w['imgcap_lstm2/recurrent_kernel'], mask, Bl, T, self._buf('h2', (T * Bl, u)),
+                                  self._buf('c2', (T * Bl, u)), rec_masks=self._rec_masks[1])
         self._h2 = self._act('h2', h2)
+        self._h2_out = self._h2 if Bl == B else self._act('h2_out', h2[(T - 1) * Bl:])        # [T*B, u] either way
         zdf = self._mm(f, self._wview('imgcap_lstm_d1/kernel', (u, u + self.FEAT)), key='zdf').f
-        return self._mm(self._h2, self._wview('imgcap_lstm_d1/kernel', (0, u)), key='a1', shift=w['imgcap_lstm_d1/bias'], residual=zdf,
+        return self._mm(self._h2_out, self._wview('imgcap_lstm_d1/kernel', (0, u)), key='a1', shift=w['imgcap_lstm_d1/bias'], residual=zdf,
                         res_rows=B, relu=True, want_b=True)
 
     def _word_model(self, f, ids_tm, mask, B, T):
@@ -321,21 +337,27 @@ class CaptionModelV1(KerasLikeModel):
         Vp = (self.V + 3) // 4 * 4
         return ops.gemm(a1.f, w['imgcap_lstm_d2/kernel'], shift=w['imgcap_lstm_d2/bias'], out=self._buf('logits', (T * B, Vp))[:, :self.V])
 
-    def _tables(self, caps):
+    def _tables(self, caps, prefix_rows=False):
+        """Time-major token ids and Keras masks of the rows the LSTMs run over.  prefix_rows: the T zero-padded prefixes of
+        every caption (build_roi_caption_model_training's Lambda, :180-185), row j*B+b = [c_0..c_j, 0...] of RoI b."""
         caps = np.asarray(caps)
         B, T = caps.shape
         ids = caps.astype(np.int32)                        # Embedding casts float ids to int32
+        if prefix_rows:
+            ids = (ids[None, :, :] * (np.arange(T)[None, None, :] <= np.arange(T)[:, None, None])).reshape(T * B, T)
         up = lambda a, dt: torch.tensor(np.ascontiguousarray(a), dtype=dt, device=self.device)
         return up(ids.T.reshape(-1), torch.int32), up((ids != 0).T.reshape(-1), torch.uint8), B, T
 
     def _forward_train(self, feat, caps, targets=None, want_probs=False, want_grad=False, row_weights=None, keras_sparse=False):
         """row_weights [B,T] + keras_sparse: the joint model's masked K.sparse_categorical_crossentropy
         (dense_img_cap/dense_model.py:936-946); loss rows and dlogits are then weighted per row instead of 1/N."""
-        ids_tm, mask, B, T = self._tables(caps)
-        self._draw_rec_masks(B, training=want_grad)
+        pr = self._prefix_rows(want_grad)
+        ids_tm, mask, B, T = self._tables(caps, prefix_rows=pr)
+        Bl = T * B if pr else B
+        self._draw_rec_masks(Bl, training=want_grad)
         X = feat.reshape(B, -1)
         f = self._head_forward(X)
-        a1 = self._hidden(f, ids_tm, mask, B, T)
+        a1 = self._hidden(f, ids_tm, mask, B, T, Bl)
         w, g = self.store.w, self.store.grad
         N = T * B
         tg = loss_rows = None
@@ -367,17 +389,18 @@ class CaptionModelV1(KerasLikeModel):
             if want_grad:
                 dl = self._act('logits', logits)
                 ops.colsum(logits, out=g['imgcap_lstm_d2/bias'])
-        self._ctx = (X, f, a1, dl, ids_tm, mask, B, T)
+        self._ctx = (X, f, a1, dl, ids_tm, mask, B, T, Bl)
         return loss_rows, probs
 
     def _backward(self, want_dx=False):
         """Gradients of every trainable weight into the flat bucket; with want_dx also returns the gradient w.r.t.
         the flattened RoI features [B, pool*pool*C] (the joint model backpropagates it through RoIAlign)."""
         w, g, u = self.store.w, self.store.grad, self.units
-        X, f, a1, dl, ids_tm, mask, B, T = self._ctx
+        X, f, a1, dl, ids_tm, mask, B, T, Bl = self._ctx
         bf = self._bufs
-        h1, h2 = self._h1, self._h2
-        N = T * B
+        h1, h2 = self._h1, self._h2_out
+        N = T * B                                          # rows of the layers above the LSTMs
+        NL = T * Bl                                        # rows of the LSTM sequences (= N unless dropout_rows='prefix')
         if dl.f is None:                                   # bf16 gradient of the fused loss: both products on the bf16 pipe
             ops.gemm_bf16(a1.b, dl.b, a_trans=True, out=g['imgcap_lstm_d2/kernel'])
             da1 = ops.gemm_bf16(dl.b, self.store.wb['imgcap_lstm_d2/kernel'], b_trans=True, out=self._buf('da1', (N, self.D1)))
@@ -395,20 +418,22 @@ class CaptionModelV1(KerasLikeModel):
         df = self._mm(dzd_f, self._wview('imgcap_lstm_d1/kernel', (u, u + self.FEAT)), key='df', b_trans=True).f
         dh2 = self._mm(dz_d1, self._wview('imgcap_lstm_d1/kernel', (0, u)), key='dh2', b_trans=True).f
         # lstm2
-        dz2, _ = ops.lstm_seq_bwd(bf['z2'], w['imgcap_lstm2/recurrent_kernel'], mask, h2.f, bf['c2'], B, T, dh_seq=dh2,
-                                  dz=self._buf('dz2', (N, 4 * u)), dU=g['imgcap_lstm2/recurrent_kernel'], rec_masks=self._rec_masks[1])
+        # (prefix rows: only the last -- carried -- state of each padded prefix feeds the dense layers: Keras' lstm2 without return_sequences)
+        dz2, _ = ops.lstm_seq_bwd(bf['z2'], w['imgcap_lstm2/recurrent_kernel'], mask, self._h2.f, bf['c2'], Bl, T,
+                                  dh_seq=dh2 if Bl == B else None, dh_last=None if Bl == B else dh2,
+                                  dz=self._buf('dz2', (NL, 4 * u)), dU=g['imgcap_lstm2/recurrent_kernel'], rec_masks=self._rec_masks[1])
         dz2 = self._act('dz2', dz2)
         self._mm(h1, dz2, a_trans=True, out=g['imgcap_lstm2/kernel'])
         ops.colsum(dz2.f, out=g['imgcap_lstm2/bias'])
         self._grads_ready('imgcap_lstm2')
         dh1 = self._mm(dz2, self._wview('imgcap_lstm2/kernel'), key='dh1', b_trans=True).f
         # lstm1
-        dz1, _ = ops.lstm_seq_bwd(bf['z1'], w['imgcap_lstm1/recurrent_kernel'], mask, h1.f, bf['c1'], B, T, dh_seq=dh1,
-                                  dz=self._buf('dz1', (N, 4 * u)), dU=g['imgcap_lstm1/recurrent_kernel'], rec_masks=self._rec_masks[0])
+        dz1, _ = ops.lstm_seq_bwd(bf['z1'], w['imgcap_lstm1/recurrent_kernel'], mask, h1.f, bf['c1'], Bl, T, dh_seq=dh1,
+                                  dz=self._buf('dz1', (NL, 4 * u)), dU=g['imgcap_lstm1/recurrent_kernel'], rec_masks=self._rec_masks[0])
         gW1 = g['imgcap_lstm1/kernel']
         ops.gemm(w['imgcap_embedding_layer/embeddings'], dz1, a_trans=True, gather=ids_tm, out=gW1[:self.E])
         ops.colsum(dz1, out=g['imgcap_lstm1/bias'])
-        dzf = self._act('dzf', ops.fold_time(dz1, T, B, self._buf('dzf', (B, 4 * u))))
+        dzf = self._act('dzf', ops.fold_time(dz1, NL // B, B, self._buf('dzf', (B, 4 * u))))      # rows (t*Bl + j*B + b) -> RoI b
         self._mm(f, dzf, a_trans=True, out=gW1[self.E:])
         self._grads_ready('imgcap_lstm1')
         self._mm(dzf, self._wview('imgcap_lstm1/kernel', (self.E, self.E + self.FEAT)), out=df, b_trans=True, accumulate=True)

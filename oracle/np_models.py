@@ -403,15 +403,17 @@ def v1_targets(caps):
 
 
 def v1_training_forward(Wt, feat, caps, rec_masks=None):
-    """build_lstm_model(..., 'training').predict([feat, caps]) -> [B,T,V].  rec_masks: see v1_word_model_forward; the SAME
-    per-RoI masks are applied to every prefix of a RoI (Keras draws them per (RoI, prefix) row of the TimeDistributed batch:
-    same marginal distribution, but only per-RoI masks keep the T-prefix graph equal to one masked pass over the caption)."""
+    """build_lstm_model(..., 'training').predict([feat, caps]) -> [B,T,V].  rec_masks: see v1_word_model_forward.  Masks of
+    shape [4,B,512] are applied to every prefix of a RoI (the product's single-pass form); masks of shape [T,4,B,512] give prefix
+    j its own set rec_masks[.][j] -- what Keras draws: TimeDistributed(word_model) (text_generation_model.py:187) applies the
+    LSTM cells once per prefix and each application makes its own K.dropout masks."""
     f, hc = roi_head_forward(feat, Wt)
     P = v1_prefixes(caps)
     T = P.shape[1]
     outs, caches = [], []
     for j in range(T):
-        p, c = v1_word_model_forward(Wt, f, P[:, j], rec_masks)
+        rm = rec_masks if rec_masks is None or np.ndim(rec_masks[0]) == 3 else (rec_masks[0][j], rec_masks[1][j])
+        p, c = v1_word_model_forward(Wt, f, P[:, j], rm)
         outs.append(p)
         caches.append(c)
     return np.stack(outs, axis=1), dict(head=hc, f=f, caches=caches)

@@ -235,6 +235,46 @@ def test_v1_recurrent_dropout_default_is_seeded_and_matches_the_oracle_given_its
     assert all(np.array_equal(a, b) for a, b in zip(again.last_rec_masks, model.last_rec_masks))
 
 
+def test_v1_recurrent_dropout_per_prefix_rows_match_the_as_written_graph(gpu):
+    """dropout_rows='prefix': every (RoI, prefix) row of the TimeDistributed batch gets its own masks, as Keras draws them
+    (text_generation_model.py:179-187, :141-142); the LSTMs run over the B*T zero-padded prefixes.  Loss and every gradient equal
+    the oracle's T-prefix graph given those [T,4,B,512] masks; the weights after AMSGrad steps follow the oracle's; evaluation
+    and the dropout-free graph are untouched by the switch."""
+    from image_captioning_amd import synth
+    from image_captioning_amd.text_generation_model import DenseCapConfig, build_lstm_model, Adam, caption_targets
+    V, T, B = 40, 6, 4
+    cfg = DenseCapConfig(V, synth.embedding_matrix(3, V), B)
+    cfg.PADDING_SIZE = T
+    model = build_lstm_model([7, 7, 256], cfg, 512, 'training', seed=0)
+    model.compile(optimizer=Adam(amsgrad=True), loss="roi_caption_loss")
+    model.dropout_rows = "prefix"
+    Wt = {k: v.astype(np.float64) for k, v in model.get_weights_dict().items()}
+    rng = np.random.default_rng(1)
+    feat = rng.standard_normal((B, 7, 7, 256)).astype(np.float32)
+    caps = synth.captions_v1(2, B, T, V, lmin=1, lmax=3)
+    tg = caption_targets(caps)
+    model.recurrent_dropout = 0.0
+    plain = model.test_on_batch([feat, caps], tg)
+    model.recurrent_dropout = 0.2
+    assert model.test_on_batch([feat, caps], tg) == plain                      # learning phase 0: single pass, no masks
+    opt = M.AMSGrad()
+    for step in range(2):
+        loss = model.train_on_batch([feat, caps], np.eye(V)[tg])
+        masks = [m.astype(np.float64).reshape(4, T, B, 512).transpose(1, 0, 2, 3) for m in model.last_rec_masks]   # row j*B+b -> [j][:, b]
+        assert all(set(np.unique(m)) <= {0.0, 1.25} for m in masks)
+        assert not np.array_equal(masks[0][0], masks[0][1])                    # prefixes of a RoI do not share masks
+        want_loss, G, _ = M.v1_loss_and_grads(Wt, feat.astype(np.float64), caps, rec_masks=tuple(masks))
+        assert abs(loss - want_loss) < 1e-5 * max(1.0, abs(want_loss)), (step, loss, want_loss)
+        for k in G:
+            assert rel_err(model.store.grad[k].cpu().numpy(), G[k]) < 3e-4, (k, step)
+        opt.step(Wt, G)
+        for k in G:
+            assert np.abs(model.store.w[k].cpu().numpy() - Wt[k]).max() < 2e-5, (k, step)
+    with pytest.raises(ValueError):
+        model.dropout_rows = "rows"
+        model.train_on_batch([feat, caps], np.eye(V)[tg])
+
+
 def test_v1_greedy_inference_ids_bit_exact(gpu):
     from image_captioning_amd import synth
     from image_captioning_amd.text_generation_model import DenseCapConfig, build_lstm_model
@@ -499,6 +539,20 @@ def test_joint_model_trains_with_the_reference_recurrent_dropout_by_default(gpu)
         runs.append((l1, l2, m2))
     assert np.allclose(runs[0][0], runs[1][0], rtol=1e-5) and np.allclose(runs[0][1], runs[1][1], rtol=1e-4)      # (RPN loss sums are float atomics)
     assert np.array_equal(runs[0][2][1], runs[1][2][1])                                                           # same seed, same step: same masks
+    # DROPOUT_ROWS='prefix': masks per (RoI, prefix) row, the LSTMs over the padded prefixes (Keras' TimeDistributed graph)
+    type(cfg).DROPOUT_ROWS = "prefix"
+    try:
+        model = DenseImageCapRCNN("training", cfg, "logs", stage4_blocks=blocks)
+        model.set_weights(Wt)
+        model.compile(1e-5)
+        v1 = model.test_on_batch(inputs)
+        assert np.allclose(v1, v0, rtol=1e-5)                                   # evaluation does not depend on the switch
+        lp = model.train_on_batch(inputs)
+        mp = model.caption_model.last_rec_masks
+        assert np.isfinite(lp).all() and mp[0].shape == (4, T * cfg.TRAIN_ROIS_PER_IMAGE, 512)
+        assert np.allclose(lp[1:3], runs[0][0][1:3], rtol=1e-5)                 # the RPN losses do not see the decoder's masks
+    finally:
+        del type(cfg).DROPOUT_ROWS
 
 
 def test_joint_model_validation_is_forward_only(gpu):

@@ -202,6 +202,28 @@ def test_v2_sample_expansion_and_padding():
     assert M.pad_sequences_pre([[1, 2, 3, 4, 5, 6]], 4).tolist() == [[3, 4, 5, 6]]     # truncating='pre'
 
 
+def test_v1_per_prefix_dropout_masks_reduce_to_shared_masks():
+    """v1_training_forward with [T,4,B,512] masks (one set per prefix, Keras' TimeDistributed graph): T copies of one set are the
+    [4,B,512] form; distinct sets change the output of the prefixes they belong to and only those."""
+    from image_captioning_amd import synth
+    V, T, B = 16, 3, 2
+    Wt = dict(synth.head_weights(1, 7, 256, 1024))
+    Wt.update(synth.v1_weights(2, V, 300, 512, 1024))
+    Wt['imgcap_embedding_layer/embeddings'] = synth.embedding_matrix(3, V)
+    Wt = {k: np.asarray(v, np.float64) for k, v in Wt.items()}
+    rng = np.random.default_rng(0)
+    feat = rng.standard_normal((B, 7, 7, 256))
+    caps = np.array([[1, 5, 2], [1, 7, 9]], np.float64)
+    m = tuple(O.recurrent_dropout_masks(np.random.default_rng(10 + l), B, 512, 0.2) for l in range(2))
+    shared, _ = M.v1_training_forward(Wt, feat, caps, m)
+    tiled, _ = M.v1_training_forward(Wt, feat, caps, tuple(np.stack([x] * T) for x in m))
+    np.testing.assert_array_equal(shared, tiled)
+    other = tuple(np.stack([x] * (T - 1) + [O.recurrent_dropout_masks(np.random.default_rng(20 + l), B, 512, 0.2)]) for l, x in enumerate(m))
+    mixed, _ = M.v1_training_forward(Wt, feat, caps, other)
+    np.testing.assert_array_equal(mixed[:, :T - 1], shared[:, :T - 1])
+    assert np.abs(mixed[:, T - 1] - shared[:, T - 1]).max() > 1e-6
+
+
 def test_v1_prefixes_and_targets():
     caps = np.array([[1, 5, 2, 0]], np.float32)
     P = M.v1_prefixes(caps)
