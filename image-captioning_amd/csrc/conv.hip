@@ -231,6 +231,7 @@ extern "C" size_t dc_conv2d_workspace_bytes(const dc_conv_desc* d) {
     if (conv_validate(d, stem)) return 0;
     int M, N, K;
     conv_dims(d, stem, M, N, K);
+    if (!stem && conv_winograd_supported(d)) return 0;
     const TileChoice t = conv_tile(d, M, N, K);
     return t.split > 1 ? (size_t)t.split * M * N * sizeof(float) : 0;
 }
@@ -260,6 +261,10 @@ extern "C" int dc_conv2d_kernel_name(const dc_conv_desc* d, char* buf, size_t bu
         snprintf(buf, buf_bytes, "igemm_bs_kernel<%d, %d>", t.bm, t.bn);
         return DC_OK;
     }
+    if (!stem && conv_winograd_supported(d)) {
+        snprintf(buf, buf_bytes, "wino_conv_kernel<%d>", conv_winograd_slices(d));
+        return DC_OK;
+    }
     const bool pw = !stem && conv_is_pointwise(d);
     if (pw && t.split == 1 && conv_pw_stream_supported(d, conv_epilogue(d))) {
         snprintf(buf, buf_bytes, "pwconv_stream_kernel<%d, %d>", d->Cin, d->res_mode);
@@ -284,6 +289,7 @@ extern "C" int dc_conv2d_nhwc_f32(const dc_conv_desc* d, void* workspace, size_t
     DC_REQUIRE(d->math == DC_MATH_F32 || d->math == DC_MATH_BF16X3 || d->math == DC_MATH_BF16X2 || d->math == DC_MATH_BF16, DC_EINVAL,
                "dc_conv2d: unknown math mode %d", d->math);
     if (d->math != DC_MATH_F32) return conv2d_bf16x3(d, stem, ep, M, N, K, t.bm, t.bn, t.split, workspace, workspace_bytes, s);
+    if (!stem && conv_winograd_supported(d)) return conv2d_winograd(d, s);
     WeightKC bl{d->w, K, N, nullptr};
     if (stem) {
         StemKC al{d->x, d->H, d->W, d->Ho, d->Wo, M, (unsigned)((size_t)d->N * d->H * d->W * 4 * sizeof(float))};

@@ -53,7 +53,8 @@ class EncoderPlan:
     fast_bf16 = False                # bf16 STORAGE between the convolutions (math = 'bf16' only; see __init__)
 
     def __init__(self, weights, batch, height, width, device, stage4_blocks=22,
-                 mean_pixel=(123.7, 116.8, 103.9), use_graph=True, rpn=None, external=None, math=None, external_bn=None, train_stages=()):
+                 mean_pixel=(123.7, 116.8, 103.9), use_graph=True, rpn=None, external=None, math=None, external_bn=None, train_stages=(),
+                 winograd=None):
         """rpn: None (GT-RoI variant: the RPN is never evaluated) or a dict with the config values the
         proposal path needs: scales, ratios, strides, anchor_stride, bbox_std, nms_threshold, proposal_count and
         optionally head_channels (the fused class+bbox head padded to a multiple of 4 channels for the wgrad kernel).
@@ -76,6 +77,11 @@ class EncoderPlan:
         # split-bf16 loop with one product (the round-2 start; measurements only).
         import os
         self.fast_bf16 = self.math == _lib.MATH_BF16 and os.environ.get("DCAP_BF16_CONV", "1") != "0"
+        # math = 'f32': the 3x3 / stride 1 layers with FROZEN weights (ResNet 2b branches, FPN output convolutions) run in the Winograd
+        # F(2x2, 3x3) form -- fp32 transforms, fp32 MFMA, 16 products per 2x2 output tile instead of 36 (csrc/conv_wino.hip); their
+        # kernels are transformed once here.  winograd=False / DCAP_WINOGRAD=0: the direct implicit GEMM everywhere.
+        self.winograd = (os.environ.get("DCAP_WINOGRAD", "1") != "0") if winograd is None else bool(winograd)
+        self._wwino = {}
         self._twin = {}
         self._wb = {}
         self.B, self.H, self.W = batch, height, width
@@ -204,6 +210,11 @@ class EncoderPlan:
             if name not in self._wsplit:
                 self._wsplit[name] = ops.split_bf16x3(wp)
             d.w_split = self._wsplit[name].data_ptr()
+        if (self.winograd and self.math == _lib.MATH_F32 and s.k == 3 and s.stride == 1 and s.padding == "same" and residual is None and
+                name not in self._external and s.cin % 32 == 0 and Cout % 32 == 0):
+            if name not in self._wwino:
+                self._wwino[name] = ops.winograd_pack(wp, s.cin, Cout)
+            d.w_wino = self._wwino[name].data_ptr()
         self._ws_bytes = max(self._ws_bytes, self.lib.dc_conv2d_workspace_bytes(C.byref(d)))
         self._ops.append(("conv", d, name))
         if self.fast_bf16 and bf16:                    # a layer the bf16 kernel does not take (the stem): cast its output

@@ -158,8 +158,9 @@ def gemm_bf16(A, B, out=None, out_bf16=None, a_trans=False, b_trans=False, gathe
 
 
 def conv2d(x, w_packed, kh, kw, stride, pad_t, pad_l, Ho, Wo, scale=None, shift=None, residual=None,
-           res_mode=0, relu=False, out=None, split_k=0, math=0, w_split=None):
-    """NHWC conv forward with fused epilogue; see dc_conv2d_nhwc_f32.  x [N,H,W,Cin] contiguous."""
+           res_mode=0, relu=False, out=None, split_k=0, math=0, w_split=None, w_wino=None, _name_only=False):
+    """NHWC conv forward with fused epilogue; see dc_conv2d_nhwc_f32.  x [N,H,W,Cin] contiguous.  w_wino: winograd_pack(w_packed)
+    of a frozen 3x3 / stride 1 / pad 1 kernel -> the layer runs in the Winograd F(2x2, 3x3) form (fp32, math=0 only)."""
     lib = _lib.load()
     _chk(x, name="x"), _chk(w_packed, name="w")
     N, H, W, Cin = x.shape
@@ -177,8 +178,36 @@ def conv2d(x, w_packed, kh, kw, stride, pad_t, pad_l, Ho, Wo, scale=None, shift=
     d.residual = None if residual is None else _chk(residual, name="residual").data_ptr()
     d.res_mode, d.relu, d.split_k, d.math = int(res_mode), int(relu), int(split_k), int(math)
     d.w_split = None if w_split is None else _chk(w_split, torch.int16, "w_split").data_ptr()
+    if w_wino is not None:
+        if not w_wino.is_contiguous() or w_wino.numel() != 16 * Cin * Cout:
+            raise _lib.DcapError("conv2d: w_wino must be the contiguous winograd_pack() of this layer's kernel (16*Cin*Cout floats)")
+        d.w_wino = _chk(w_wino, name="w_wino").data_ptr()
+    if _name_only:
+        buf = C.create_string_buffer(128)
+        check(lib.dc_conv2d_kernel_name(C.byref(d), buf, 128), "dc_conv2d_kernel_name")
+        return buf.value.decode()
     ws, wsb = WORKSPACE.get(lib.dc_conv2d_workspace_bytes(C.byref(d)), x.device)
     check(lib.dc_conv2d_nhwc_f32(C.byref(d), _ptr(ws), wsb, _stream()), "dc_conv2d_nhwc_f32")
+    return out
+
+
+def conv2d_kernel_name(*args, **kw):
+    """The kernel template instantiation conv2d(*args, **kw) would launch (dc_conv2d_kernel_name); nothing is launched."""
+    return conv2d(*args, _name_only=True, **kw)
+
+
+def winograd_pack(w_packed, cin, cout, out=None):
+    """U = G g G^T of a packed 3x3 kernel [Cout, 9*Cin] in the fragment order the Winograd kernel reads: fp32 [16*Cin*Cout]."""
+    lib = _lib.load()
+    _chk(w_packed, name="w")
+    if not w_packed.is_contiguous() or w_packed.numel() != 9 * cin * cout:
+        raise _lib.DcapError("winograd_pack: w must be the contiguous packed 3x3 kernel [Cout, 9*Cin]")
+    nbytes = lib.dc_conv2d_winograd_weight_bytes(cin, cout)
+    if nbytes == 0:
+        raise _lib.DcapError("winograd_pack: Cin and Cout must be multiples of 32")
+    if out is None:
+        out = torch.empty((nbytes // 4,), dtype=torch.float32, device=w_packed.device)
+    check(lib.dc_conv2d_winograd_pack_f32(_ptr(w_packed), _ptr(out), cin, cout, _stream()), "dc_conv2d_winograd_pack_f32")
     return out
 
 

@@ -188,6 +188,11 @@ typedef struct {
                                  the arithmetic BASELINE configs[4] names (2^-9 relative per operand) */
     const uint16_t* w_split;  /* optional with DC_MATH_BF16X3: the weights already split by dc_split_bf16x3_f32 into three bf16
                                  planes [3][Cout][kh*kw*Cin] (same packing as w); NULL = split on the fly from w */
+    const float* w_wino;      /* optional with DC_MATH_F32, forward only: the weights of a 3x3 / stride 1 / pad 1 layer transformed by
+                                 dc_conv2d_winograd_pack_f32 (16 * Cin * Cout floats).  Non-NULL = run the layer in the Winograd
+                                 F(2x2, 3x3) form: fp32 throughout, 16 products per 2x2 output tile instead of 36 (the minimal-filtering
+                                 algorithm cuDNN picks for these layers under the reference's TF); needs Cin, Cout multiples of 32, no
+                                 residual.  Layers that do not qualify ignore the field */
 } dc_conv_desc;
 
 /* x = p0 + p1 + p2 with bf16 pieces rounded to nearest even: out[0..n) = p0, out[n..2n) = p1, out[2n..3n) = p2. */
@@ -203,6 +208,11 @@ int    dc_conv2d_tile_config(const dc_conv_desc* d, int* bm, int* bn, int* split
 int    dc_conv2d_kernel_name(const dc_conv_desc* d, char* buf, size_t buf_bytes);
 /* 1 when `d` runs on the dense (pointwise: 1x1, stride 1, unpadded) A-operand loader instead of the im2col one. */
 int    dc_conv2d_is_pointwise(const dc_conv_desc* d);
+/* Winograd F(2x2, 3x3) weight transform U = G g G^T of a packed 3x3 kernel w [Cout][9*Cin] into the fragment order the kernel
+ * reads (dc_conv_desc.w_wino); done once per frozen weight.  Replaces nothing in the reference: it is how the KL.Conv2D(3x3) layers of
+ * feature_generation/dense_model.py:85-100, :1417-1421 are evaluated. */
+size_t dc_conv2d_winograd_weight_bytes(int Cin, int Cout);
+int    dc_conv2d_winograd_pack_f32(const float* w, float* u, int Cin, int Cout, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * conv2d weight gradient (for the layers the joint model trains: fpn_*, rpn_*, dense_img_cap/dense_model.py

@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from image_captioning_amd._lib import DcapError
+
 from oracle import np_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -144,6 +146,63 @@ def test_conv2d_matches_oracle(ops, case, math):
         close(got, np.maximum(yb, 0) if relu else yb, 3e-5)
         return
     close(got, y, 2e-5 if math < 3 else 1e-4)          # bf16x2: 16-bit-mantissa products (2^-16), TF32 would need 2e-3
+
+
+WINO_CASES = [
+    # N,H,W,Cin,Cout,relu,affine
+    (1, 16, 16, 32, 32, True, True),          # one tile group per 8 x 16 pixels: 2 x 1 groups
+    (2, 12, 20, 64, 64, True, True),          # ragged groups (6 x 10 tiles), two images, two K-chunks, two channel slices
+    (1, 9, 7, 32, 96, False, True),           # odd sizes: half-empty edge tiles in both directions, three slices
+    (1, 16, 16, 128, 128, False, False),      # no scale / shift (plain Conv2D, the FPN output layers)
+    (2, 32, 32, 256, 64, True, True),         # eight K-chunks
+    (1, 5, 40, 64, 32, True, True),           # one tile row of three, several group columns
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv2d_winograd_matches_oracle_and_direct(ops, case):
+    """dc_conv_desc.w_wino: a 3x3 / stride 1 / 'same' layer in the Winograd F(2x2, 3x3) form (fp32 transforms, fp32 MFMA, 16 products
+    per 2x2 tile instead of 36) against the float64 oracle at the direct kernel's own tolerance, and against the direct kernel."""
+    from image_captioning_amd.packing import pack_conv_kernel
+    N, H, W, Cin, Cout, relu, affine = case
+    rng = np.random.default_rng(sum(int(v) * (i + 3) for i, v in enumerate(case)))
+    x = rng.standard_normal((N, H, W, Cin))
+    w = rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)
+    sc, sh = (rng.uniform(0.5, 1.5, Cout), rng.standard_normal(Cout)) if affine else (None, None)
+    y = O.conv2d_nhwc(x, w, None, 1, 'same')
+    if affine:
+        y = y * sc + sh
+    if relu:
+        y = np.maximum(y, 0)
+    wp = dev(pack_conv_kernel(w))
+    u = ops.winograd_pack(wp, Cin, Cout)
+    assert u.shape == (16 * Cin * Cout,)
+    args = (dev(x), wp, 3, 3, 1, 1, 1, H, W, None if sc is None else dev(sc), None if sh is None else dev(sh), None, 0, relu)
+    out = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+    got = ops.conv2d(*args, out=out, w_wino=u)
+    assert ops.conv2d_kernel_name(*args, w_wino=u).startswith("wino_conv_kernel")
+    close(got, y, 2e-5)
+    direct = ops.conv2d(*args)
+    assert not ops.conv2d_kernel_name(*args).startswith("wino")
+    close(got, direct.cpu().numpy().astype(np.float64), 2e-5)
+
+
+def test_conv2d_winograd_falls_back_where_the_form_does_not_apply(ops):
+    """w_wino on a layer the Winograd kernel does not cover (a residual, a stride, another arithmetic): the direct kernels run."""
+    from image_captioning_amd.packing import pack_conv_kernel
+    rng = np.random.default_rng(5)
+    x, w = rng.standard_normal((1, 8, 8, 32)), rng.standard_normal((3, 3, 32, 32)) / 17.0
+    wp = dev(pack_conv_kernel(w))
+    u = ops.winograd_pack(wp, 32, 32)
+    res = rng.standard_normal((1, 8, 8, 32))
+    got = ops.conv2d(dev(x), wp, 3, 3, 1, 1, 1, 8, 8, None, None, dev(res), 1, False, w_wino=u)
+    close(got, O.conv2d_nhwc(x, w, None, 1, 'same') + res, 2e-5)
+    assert not ops.conv2d_kernel_name(dev(x), wp, 3, 3, 1, 1, 1, 8, 8, None, None, dev(res), 1, False, w_wino=u).startswith("wino")
+    assert not ops.conv2d_kernel_name(dev(x), wp, 3, 3, 1, 1, 1, 8, 8, math=1, w_wino=u).startswith("wino")
+    with pytest.raises(DcapError):
+        ops.winograd_pack(wp, 32, 48)                      # not this kernel's size
+    with pytest.raises(DcapError):
+        ops.conv2d(dev(x), wp, 3, 3, 1, 1, 1, 8, 8, w_wino=u[:100])
 
 
 def test_split_bf16x3_pieces(ops):
