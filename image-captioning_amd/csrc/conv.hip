@@ -262,7 +262,7 @@ extern "C" int dc_conv2d_kernel_name(const dc_conv_desc* d, char* buf, size_t bu
         return DC_OK;
     }
     if (!stem && conv_winograd_supported(d)) {
-        snprintf(buf, buf_bytes, "wino_conv_kernel<%d>", conv_winograd_slices(d));
+        snprintf(buf, buf_bytes, "wino%d_kernel", conv_winograd_tiles(d));
         return DC_OK;
     }
     const bool pw = !stem && conv_is_pointwise(d);

@@ -8,29 +8,34 @@
 //   M[xi]  = V[xi] (tiles x cin) . U[xi] (cin x cout)        16 independent GEMMs on the matrix pipe
 //   Y      = A^T M A                       2 x 2 output pixels per tile, then scale / shift / ReLU (frozen BN + bias folded)
 //
-// One kernel does all of it (nothing of V or M ever reaches HBM).  Block = 256 threads = 4 waves, 32 tiles (4 x 8: 8 x 16 output
-// pixels) x NB = 32 NT output channels, K-chunks of 32 input channels:
-//   * input transform: thread (tile, channel quad) loads its 4 x 4 patch as 16 dwordx4 (out-of-image pixels carry an out-of-range
-//     buffer offset: hardware zeros = TF 'SAME' padding), 32 adds per channel, 16 ds_write_b128 into V[16][32 tiles][32 k]
-//     (64 KiB, 128-B rows, 16-B chunk c of row r at c ^ ((r >> 1) & 7): conflict-free for these writes and for the reads below);
-//     the loads of chunk k + 1 are issued before the MFMAs of chunk k;
-//   * MFMA phase: wave w owns xi = 4 w .. 4 w + 3 (no two waves share a weight): per xi 4 ds_read_b128 of V and 4 NT
-//     global_load_dwordx4 of U straight into registers -- U is packed in fragment order, 1 KiB contiguous per wave-instruction,
-//     and prefetched one xi ahead -- feed 16 NT MFMAs.  The MFMA takes U as its A operand (rows = output channels), so a lane
-//     ends up with four consecutive output channels of one tile per accumulator quad;
-//   * output transform: the 16 M[xi] tiles go through the same LDS image, thread (tile, channel quad) gathers its 16 values,
-//     applies A^T . A and the epilogue, and stores 16-byte pieces (128 contiguous bytes per pixel and block).
-// Two blocks per CU (64 KiB of LDS, <= 256 VGPRs each): one block's input transform runs beside the other's MFMAs.
-// Grid: block -> (output-channel slice, tile group), slice-major through the XCD remap, so an XCD's L2 keeps ONE slice of U
-// (16 x Cin x NB x 4 bytes) and streams the activations once.
+// One kernel does all of it (nothing of V or M ever reaches HBM).  Common to both kernels below: 256 threads = 4 waves, a block
+// = a group of tiles x 32 output channels x all 16 xi; wave w owns xi = 4 w .. 4 w + 3 (no two waves share a weight), so U goes
+// from L2 STRAIGHT INTO REGISTERS -- it is packed in fragment order, 1 KiB contiguous per wave-instruction; the MFMA takes U as
+// its A operand (rows = output channels), so a lane ends up with four consecutive output channels of one tile per accumulator
+// quad; the input transform is done by thread (tile, channel quad): 16 dwordx4 of its 4 x 4 patch (out-of-image pixels carry an
+// out-of-range buffer offset: hardware zeros = TF 'SAME' padding), 32 adds per channel, 16 ds_write_b128 into the V image
+// (swizzled 16-byte chunks, conflict-free for these writes and for the fragment reads); the output transform sends the 16 M[xi]
+// through the same LDS, thread (tile, channel quad) gathers its 16 values, applies A^T . A and the epilogue and stores 16-byte
+// pieces (128 contiguous bytes per pixel and block).  Grid: block -> (output-channel slice, tile group), slice-major through the
+// XCD remap, so an XCD's L2 keeps ONE slice of U (16 x Cin x 32 x 4 bytes) and streams the activations once.
+//
+// What bounds it is not the matrix pipe alone: per MFMA the form moves 2.25x the operand bytes of the direct one (U is 16/9 of
+// the kernel and is re-read by every tile group; 4 x 4 patches overlap), and a CU takes 66-73 GB/s from L2
+// (MI355X_MICROARCH.md).  First version (wino32_kernel: 32 tiles, 32-channel K-chunks, V single-buffered, two blocks per CU
+// to overlap one block's transform with the other's MFMAs): 128 KB requested per 1.05 MFLOP-chunk and block -- measured
+// 810 us on fpn_p2, where the MFMAs alone need 437 and everything but the MFMAs 395: the two did not overlap, both blocks
+// waited on memory.  wino64_kernel: 64 tiles (8 x 8: U bytes per MFMA halved), 16-channel K-chunks, V double-buffered
+// (2 x 64 KiB), ONE block per CU with the overlap inside each wave: U for the whole next chunk and the next chunk's
+// patch are in flight (<= 24 loads per lane) during a chunk's 64 MFMAs, the transform's VALU work and LDS writes are
+// interleaved with the second half of them, one barrier per chunk.  wino32_kernel stays for layers with too few tiles to
+// give every CU a 64-tile block.
 #include "igemm_core.h"
 #include <algorithm>
 
 namespace dcap {
 namespace wino {
 
-constexpr int TILES = 32, TGY = 4, TGX = 8, KCH = 32, NTHREADS = 256;
-constexpr int LDS_BYTES = 16 * TILES * KCH * 4;          // 64 KiB
+constexpr int NTHREADS = 256;
 
 struct Args {
     const float* x;
@@ -43,15 +48,11 @@ struct Args {
     unsigned x_bytes;
 };
 
-__device__ __forceinline__ unsigned img_addr(int xi, int tile, int chunk) {
-    return (unsigned)((((xi * TILES + tile) << 3) + (chunk ^ ((tile >> 1) & 7))) << 4);
-}
-
-// U in fragment order: f4 index ((((xi * NTG + ntg) * KC + kc) * 4 + j) * 64 + lane), lane = 32 h + i, component e
-//   <->  cout = 32 ntg + i, cin = 32 kc + 16 h + 4 j + e        (MFMA step 4 j + e contracts cin 16 h + 4 j + e of the chunk)
+// U in fragment order, K in chunks of 16: f4 index ((((xi * NTG + ntg) * KC16 + kc) * 2 + j) * 64 + lane), lane = 32 h + i,
+// component e   <->   cout = 32 ntg + i, cin = 16 kc + 8 h + 4 j + e     (MFMA step 4 j + e of a chunk contracts cin 8 h + 4 j + e)
 __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cin, int Cout) {
     const long total = (long)Cin * Cout;
-    const int NTG = Cout / 32, KC = Cin / 32;
+    const int NTG = Cout / 32, KC = Cin / 16;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int cin = (int)(idx % Cin), cout = (int)(idx / Cin);
         float g[3][3];
@@ -65,21 +66,92 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
             gg[2][c] = 0.5f * (g[0][c] - g[1][c] + g[2][c]);
             gg[3][c] = g[2][c];
         }
-        const int ntg = cout >> 5, i = cout & 31, kc = cin >> 5, kk = cin & 31, h = kk >> 4, j = (kk & 15) >> 2, e = kk & 3;
+        const int ntg = cout >> 5, i = cout & 31, kc = cin >> 4, kk = cin & 15, h = kk >> 3, j = (kk & 7) >> 2, e = kk & 3;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const float r[4] = {gg[a][0], 0.5f * (gg[a][0] + gg[a][1] + gg[a][2]), 0.5f * (gg[a][0] - gg[a][1] + gg[a][2]), gg[a][2]};
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const int xi = 4 * a + b;
-                u[((((long)(xi * NTG + ntg) * KC + kc) * 4 + j) * 64 + (h * 32 + i)) * 4 + e] = r[b];
+                u[((((long)(xi * NTG + ntg) * KC + kc) * 2 + j) * 64 + (h * 32 + i)) * 4 + e] = r[b];
             }
         }
     }
 }
 
-template <int NT>
-__global__ __launch_bounds__(NTHREADS, NT == 1 ? 2 : 1) void wino_conv_kernel(Args a) {
+// [16 xi][32 tiles][32 floats]: 128-byte rows, 16-byte chunk c of row r at c ^ ((r >> 1) & 7).  V image of wino32_kernel and the M
+// (output transform) image of both kernels.
+__device__ __forceinline__ unsigned img32_addr(int xi, int tile, int chunk) {
+    return (unsigned)((((xi * 32 + tile) << 3) + (chunk ^ ((tile >> 1) & 7))) << 4);
+}
+// [16 xi][64 tiles][16 floats]: 64-byte rows, chunk c of row r at c ^ ((r >> 2) & 3).  V image of wino64_kernel.
+__device__ __forceinline__ unsigned img64_addr(int xi, int tile, int chunk) {
+    return (unsigned)((((xi * 64 + tile) << 2) + (chunk ^ ((tile >> 2) & 3))) << 4);
+}
+
+// B^T d B, in place friendly: first the rows (t = B^T d), then the columns.
+__device__ __forceinline__ void bt_rows(const f4 (&d)[4][4], f4 (&t)[4][4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        t[0][c] = d[0][c] - d[2][c];
+        t[1][c] = d[1][c] + d[2][c];
+        t[2][c] = d[2][c] - d[1][c];
+        t[3][c] = d[1][c] - d[3][c];
+    }
+}
+__device__ __forceinline__ void bt_cols(const f4 (&t)[4], f4 (&v)[4]) {
+    v[0] = t[0] - t[2];
+    v[1] = t[1] + t[2];
+    v[2] = t[2] - t[1];
+    v[3] = t[1] - t[3];
+}
+
+// Output transform Y = A^T M A of one (tile, 4 output channels), epilogue and stores.  m[xi = 4 r + c].
+__device__ __forceinline__ void finish_tile(const Args& a, const f4 (&m)[4][4], int img, int ty, int tx, int cout) {
+    f4 sc = (f4)(1.f), sh = (f4)(0.f);
+    if (a.scale) sc = *reinterpret_cast<const f4*>(a.scale + cout);
+    if (a.shift) sh = *reinterpret_cast<const f4*>(a.shift + cout);
+    f4 s[2][4];                                            // A^T M
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        s[0][c] = m[0][c] + m[1][c] + m[2][c];
+        s[1][c] = m[1][c] - m[2][c] - m[3][c];
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const f4 o[2] = {s[p][0] + s[p][1] + s[p][2], s[p][1] - s[p][2] - s[p][3]};
+#pragma unroll
+        for (int qx = 0; qx < 2; ++qx) {
+            f4 val = o[qx] * sc + sh;
+            if (a.relu) val = f4{fmaxf(val[0], 0.f), fmaxf(val[1], 0.f), fmaxf(val[2], 0.f), fmaxf(val[3], 0.f)};
+            if (2 * ty + p < a.H && 2 * tx + qx < a.W)
+                *reinterpret_cast<f4*>(a.y + (((long)img * a.H + 2 * ty + p) * a.W + 2 * tx + qx) * a.Cout + cout) = val;
+        }
+    }
+}
+
+// byte offsets of this thread's 4 x 4 input patch (channel quad q of the chunk at soffset), kOobOffset outside the image
+__device__ __forceinline__ void patch_offsets(const Args& a, int img, int ty, int tx, int q, unsigned (&off)[4][4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int iy = 2 * ty - 1 + r, ix = 2 * tx - 1 + c;
+            const bool in = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            off[r][c] = in ? (unsigned)(((((long)img * a.H + iy) * a.W + ix) * a.Cin + 4 * q) * 4) : kOobOffset;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// wino32_kernel: 32 tiles (4 x 8: 8 x 16 output pixels), K-chunks of 32 channels, V single-buffered (64 KiB), two blocks per CU.
+// ------------------------------------------------------------------------------------------------------------------------
+namespace w32 {
+constexpr int TGY = 4, TGX = 8, KCH = 32;
+constexpr int LDS_BYTES = 16 * 32 * KCH * 4;             // 64 KiB
+}
+
+__global__ __launch_bounds__(NTHREADS, 2) void wino32_kernel(Args a) {
+    using namespace w32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -90,19 +162,11 @@ __global__ __launch_bounds__(NTHREADS, NT == 1 ? 2 : 1) void wino_conv_kernel(Ar
     const int gyi = gr / a.gx, gxi = gr - gyi * a.gx;
     const int NTG = a.Cout >> 5, KC = a.Cin >> 5;
 
-    // ---- this thread's tile and channel quad (input and output transforms)
-    const int ti = tid >> 3, q = tid & 7;
+    const int ti = tid >> 3, q = tid & 7;                  // this thread's tile and channel quad (input and output transforms)
     const int ty = gyi * TGY + (ti >> 3), tx = gxi * TGX + (ti & 7);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
     unsigned off[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int iy = 2 * ty - 1 + r, ix = 2 * tx - 1 + c;
-            const bool in = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            off[r][c] = in ? (unsigned)(((((long)img * a.H + iy) * a.W + ix) * a.Cin + 4 * q) * 4) : kOobOffset;
-        }
+    patch_offsets(a, img, ty, tx, q, off);
     f4 raw[4][4];
     auto load_raw = [&](int kc) {
 #pragma unroll
@@ -110,130 +174,284 @@ __global__ __launch_bounds__(NTHREADS, NT == 1 ? 2 : 1) void wino_conv_kernel(Ar
 #pragma unroll
             for (int c = 0; c < 4; ++c) raw[r][c] = buf_f4s(rsrc, off[r][c], (unsigned)(kc * KCH * 4));
     };
-#ifdef WINO_EXP_NORAW
-    auto load_raw_loop = [&](int) {};
-#else
-    auto load_raw_loop = load_raw;
-#endif
-
-    // ---- this wave's xi range and fragment addresses
     const int fi = lane & 31, fh = lane >> 5;
     const f4* ubase = a.u + lane;
-    auto load_u = [&](f4 (&dst)[NT][4], int kc, int xl) {
-        const int xi = 4 * wave + xl;
+    auto load_u = [&](f4 (&dst)[4], int kc, int xl) {      // fragment jj of 16-channel half s = dst[2 s + jj]
+        const f4* p = ubase + (((long)((4 * wave + xl) * NTG + nb) * (2 * KC) + 2 * kc) << 7);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const f4* p = ubase + (((long)(xi * NTG + nb * NT + n) * KC + kc) << 8);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dst[n][j] = p[j * 64];
-        }
+        for (int j = 0; j < 4; ++j) dst[j] = p[j * 64];
     };
-
-    f32x16 acc[4][NT];
+    f32x16 acc[4];
 #pragma unroll
     for (int xl = 0; xl < 4; ++xl)
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[xl][n][r] = 0.f;
-
-    f4 ub[2][NT][4];
+        for (int r = 0; r < 16; ++r) acc[xl][r] = 0.f;
+    f4 ub[2][4];
     load_raw(0);
     load_u(ub[0], 0, 0);
-#ifdef WINO_EXP_NOU
-    load_u(ub[1], 0, 1);
-#endif
-
     for (int kc = 0; kc < KC; ++kc) {
-        // input transform B^T d B of this thread's patch, four channels at a time
-        f4 v[4][4];
-        {
-            f4 t[4][4];
+        f4 t[4][4], v[4][4];
+        bt_rows(raw, t);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                t[0][c] = raw[0][c] - raw[2][c];
-                t[1][c] = raw[1][c] + raw[2][c];
-                t[2][c] = raw[2][c] - raw[1][c];
-                t[3][c] = raw[1][c] - raw[3][c];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r][0] = t[r][0] - t[r][2];
-                v[r][1] = t[r][1] + t[r][2];
-                v[r][2] = t[r][2] - t[r][1];
-                v[r][3] = t[r][1] - t[r][3];
-            }
-        }
+        for (int r = 0; r < 4; ++r) bt_cols(t[r], v[r]);
         __syncthreads();                                   // every wave is done reading the previous chunk's V
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) *reinterpret_cast<f4*>(smem + img_addr(4 * r + c, ti, q)) = v[r][c];
-        load_raw_loop(min(kc + 1, KC - 1));                // in flight during the MFMA phase (the last one re-reads: uniform counts)
+            for (int c = 0; c < 4; ++c) *reinterpret_cast<f4*>(smem + img32_addr(4 * r + c, ti, q)) = v[r][c];
+        load_raw(min(kc + 1, KC - 1));                     // in flight during the MFMA phase (the last one re-reads: uniform counts)
         __syncthreads();
 #pragma unroll
         for (int xl = 0; xl < 4; ++xl) {
             const int cur = xl & 1;
-#ifndef WINO_EXP_NOU
             if (xl < 3) load_u(ub[cur ^ 1], kc, xl + 1);
             else load_u(ub[cur ^ 1], min(kc + 1, KC - 1), 0);
-#endif
             f4 vb[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) vb[j] = *reinterpret_cast<const f4*>(smem + img_addr(4 * wave + xl, fi, 4 * fh + j));
+            for (int j = 0; j < 4; ++j)                    // channels 16 (j >> 1) + 8 h + 4 (j & 1) ..+3 of the chunk, like U's fragment j
+                vb[j] = *reinterpret_cast<const f4*>(smem + img32_addr(4 * wave + xl, fi, 4 * (j >> 1) + 2 * fh + (j & 1)));
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int n = 0; n < NT; ++n)
-#ifdef WINO_EXP_NOMFMA
-                        acc[xl][n][(4 * j + e) & 15] += ub[cur][n][j][e] * vb[j][e];
-#else
-                        acc[xl][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[cur][n][j][e], vb[j][e], acc[xl][n], 0, 0, 0);
-#endif
+                for (int e = 0; e < 4; ++e) acc[xl] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[cur][j][e], vb[j][e], acc[xl], 0, 0, 0);
         }
     }
+    __syncthreads();
+#pragma unroll
+    for (int xl = 0; xl < 4; ++xl)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const f4 m = {acc[xl][4 * gq], acc[xl][4 * gq + 1], acc[xl][4 * gq + 2], acc[xl][4 * gq + 3]};
+            *reinterpret_cast<f4*>(smem + img32_addr(4 * wave + xl, fi, 2 * gq + fh)) = m;          // couts 8 gq + 4 h .. + 3 of tile fi
+        }
+    __syncthreads();
+    f4 m[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) m[r][c] = *reinterpret_cast<const f4*>(smem + img32_addr(4 * r + c, ti, q));
+    finish_tile(a, m, img, ty, tx, nb * 32 + 4 * q);
+}
 
-    // ---- output transform and epilogue, one 32-channel slice at a time through the LDS image
-    const bool row_in[2] = {2 * ty < a.H, 2 * ty + 1 < a.H}, col_in[2] = {2 * tx < a.W, 2 * tx + 1 < a.W};
+// ------------------------------------------------------------------------------------------------------------------------
+// wino64_kernel: 64 tiles (8 x 8: 16 x 16 output pixels) x 32 output channels, 512 threads = 8 waves, one block per CU.
+//
+// No V image at all.  The block's 18 x 18-pixel input patch goes to LDS ONCE per 32 channels -- LDS-DMA, whole 128-byte lines,
+// every byte of the patch fetched once per block (the register-staged transform of wino32_kernel asks for every interior pixel
+// four times, and with 16-channel chunks for every line twice) -- double-buffered, the next 32 channels in flight for two chunks.
+// Wave (a, th) owns the transform row a (xi = 4 a + b, b = 0..3) of the 32-tile half th and makes ITS OWN MFMA operand fragments
+// straight from the patch: lane (tile, k-half) reads the two patch rows that B^T's row a combines (8 ds_read_b128 per 4 channels
+// x 2), forms t = d[r1] +- d[r2] (row a of B^T d: one FMA per value) and the four column combinations v[b] -- exactly the V[xi]
+// values its next 16 MFMAs take as B operands.  Nothing is transformed twice, nothing transformed is stored.
+// Per 16-channel chunk and wave: 16 ds_read_b128, 64 VALU, 8 global_load_dwordx4 of U (one chunk ahead), 32 MFMAs; two waves
+// per SIMD (the two tile halves of one row: the same U lines, the second finds them in L1), one barrier per 32 channels.
+// Patch image: pixel p = 128 bytes = eight 16-byte chunks, chunk c at c ^ ((p >> 1) & 7): the DMA permutes the SOURCE chunk per
+// lane (its LDS destination is lane-linear), the eight tiles of a row then read eight different chunks.
+// ------------------------------------------------------------------------------------------------------------------------
+namespace w64 {
+constexpr int NT64 = 512, TG = 8, PW = 2 * TG + 2, NPIX = PW * PW, SLOTS = NPIX * 8, NDMA = (SLOTS + NT64 - 1) / NT64;
+constexpr int BUF = 65536;                               // one patch buffer (41.5 KiB used); buffer 1 = buffer 0 ^ BUF
+constexpr int LDS_BYTES = 2 * BUF;
+static_assert(NDMA * NT64 * 16 <= BUF, "patch buffer");
+// Patch image: pixel (y, x) of the 18 x 18 patch is 128 bytes at index y * 18 + (x >> 1) + 9 (x & 1) (a row's even columns first,
+// so that horizontally neighbouring TILES alternate between the two halves of the 256-byte bank row), its 16-byte channel chunk c
+// at position c ^ swizzle(y, x).  A ds_read_b128 is served in 16-lane groups that hold four tile rows x four consecutive tile
+// columns (MI355X_MICROARCH.md, LDS: {0-3, 12-15, 20-27}, ...): per half of the bank row that is 4 rows x 2 columns two tiles
+// apart, which the swizzle's bits ((y >> 1) & 3, (x >> 2) & 1) tell apart whatever patch row / column (r, c) is being read:
+// conflict-free.  (First version: index y * 18 + x, swizzle (index >> 1) & 7: SQ_LDS_BANK_CONFLICT = 74 % of SQ_LDS_IDX_ACTIVE.)
+__device__ __forceinline__ int patch_index(int y, int x) { return y * PW + (x >> 1) + (PW / 2) * (x & 1); }
+__device__ __forceinline__ int patch_swizzle(int y, int x) { return ((x >> 2) & 1) | (((y >> 1) & 3) << 1); }
+}
+
+__global__ __launch_bounds__(w64::NT64, 1) void wino64_kernel(Args a) {
+    using namespace w64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wave & 3, th = wave >> 2;
+    const int gpi = a.gy * a.gx;
+    const int NTG = a.Cout >> 5, KC = a.Cin >> 4, KP = a.Cin >> 5;
+    const int total = a.groups * NTG;                      // work items (slice, tile group); this block takes blockIdx.x, + gridDim.x, ...
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+
+    // ---- per work item: coordinates, patch DMA sources (slot s = n * 512 + tid of the image <-> pixel s >> 3, image chunk
+    // s & 7 = source chunk ^ swizzle), U fragment base
+    int nb, img, gyi, gxi;
+    unsigned doff[NDMA];
+    const f4* ubase;
+    auto setup = [&](int item) {
+        const int bid = xcd_remap(item, total);            // gridDim.x % 8 == 0: item % 8 is this block's XCD for every item it takes
+        nb = bid / a.groups;
+        const int g = bid - nb * a.groups;
+        img = g / gpi;
+        const int gr = g - img * gpi;
+        gyi = gr / a.gx;
+        gxi = gr - gyi * a.gx;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        __syncthreads();
+        for (int n = 0; n < NDMA; ++n) {
+            const int s = n * NT64 + tid, pq = s >> 3, py = pq / PW, rem = pq - py * PW;
+            const int px = rem < PW / 2 ? 2 * rem : 2 * (rem - PW / 2) + 1;          // inverse of patch_index(): even columns first
+            const int iy = gyi * 2 * TG - 1 + py, ix = gxi * 2 * TG - 1 + px;
+            const bool in = s < SLOTS && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const int c8 = (s & 7) ^ patch_swizzle(py, px);
+            doff[n] = in ? (unsigned)(((((long)img * a.H + iy) * a.W + ix) * a.Cin + 4 * c8) * 4) : kOobOffset;
+        }
+        ubase = a.u + lane + (((long)(4 * wa) * NTG + nb) * KC << 7);
+    };
+    auto issue_dma = [&](int pair, int buf) {
 #pragma unroll
-        for (int xl = 0; xl < 4; ++xl)
+        for (int n = 0; n < NDMA; ++n)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem + buf * BUF + (n * NT64 + wave * 64) * 16), 16,
+                                                     (int)doff[n], pair * 128, 0, 0);
+    };
+    const long ustep = (long)NTG * KC << 7;                // xi -> xi + 1
+    auto load_u = [&](f4 (&dst)[4][2], int kc) {
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const f4 m = {acc[xl][n][4 * gq], acc[xl][n][4 * gq + 1], acc[xl][n][4 * gq + 2], acc[xl][n][4 * gq + 3]};
-                *reinterpret_cast<f4*>(smem + img_addr(4 * wave + xl, fi, 2 * gq + fh)) = m;      // couts 8 gq + 4 h .. + 3 of tile fi
-            }
-        __syncthreads();
-        f4 m[4][4];
+        for (int b = 0; b < 4; ++b) {
+            const f4* p = ubase + b * ustep + ((long)kc << 7);
+            dst[b][0] = p[0];
+            dst[b][1] = p[64];
+        }
+    };
+
+    // ---- fragment geometry: lane (tile i of this wave's half, k-half h); transform row wa combines patch rows r1, r2
+    const int fi = lane & 31, fh = lane >> 5;
+    const int tile = 32 * th + fi, tyl = tile >> 3, txl = tile & 7;
+    const int r1 = (wa == 0) ? 0 : (wa == 2 ? 2 : 1), r2 = (wa == 0 || wa == 1) ? 2 : (wa == 2 ? 1 : 3);
+    const float sgn = (wa == 1) ? 1.f : -1.f;
+    // byte address of patch pixel (row rr, column c) of this lane's tile, image chunk 2 h (step 0 of a pair), in the buffer being read:
+    // the chunk of step st = 2 half + j is 4 half + 2 h + j, i.e. this address ^ (j << 4) ^ (half << 6) -- the swizzle is an XOR too
+    unsigned paddr[2][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) m[r][c] = *reinterpret_cast<const f4*>(smem + img_addr(4 * r + c, ti, q));
-        const int cout = (nb * NT + n) * 32 + 4 * q;
-        f4 sc = (f4)(1.f), sh = (f4)(0.f);
-        if (a.scale) sc = *reinterpret_cast<const f4*>(a.scale + cout);
-        if (a.shift) sh = *reinterpret_cast<const f4*>(a.shift + cout);
-        f4 s[2][4];                                        // A^T M
+    for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            s[0][c] = m[0][c] + m[1][c] + m[2][c];
-            s[1][c] = m[1][c] - m[2][c] - m[3][c];
+            const int py = 2 * tyl + (rr ? r2 : r1), px = 2 * txl + c;
+            paddr[rr][c] = (unsigned)(patch_index(py, px) * 128 + (((2 * fh) ^ patch_swizzle(py, px)) << 4));
         }
+    // step st = 2 half + j of a pair: channels 16 half + 8 h + 4 j .. + 3 = image chunk 4 half + 2 h + j
+    auto read_d = [&](f4 (&d)[2][4], int st) {
+        const unsigned k = (unsigned)(((st & 1) << 4) ^ ((st >> 1) << 6));
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            f4 o[2] = {s[p][0] + s[p][1] + s[p][2], s[p][1] - s[p][2] - s[p][3]};
+        for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-            for (int qx = 0; qx < 2; ++qx) {
-                f4 val = o[qx] * sc + sh;
-                if (a.relu) val = f4{fmaxf(val[0], 0.f), fmaxf(val[1], 0.f), fmaxf(val[2], 0.f), fmaxf(val[3], 0.f)};
-                if (row_in[p] && col_in[qx])
-                    *reinterpret_cast<f4*>(a.y + (((long)img * a.H + 2 * ty + p) * a.W + 2 * tx + qx) * a.Cout + cout) = val;
+            for (int c = 0; c < 4; ++c) d[rr][c] = *reinterpret_cast<const f4*>(smem + (paddr[rr][c] ^ k));
+    };
+    auto transform = [&](const f4 (&d)[2][4], f4 (&v)[4]) {
+        f4 t[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t[c] = d[1][c] * sgn + d[0][c];         // row wa of B^T d
+        bt_cols(t, v);
+    };
+
+    int item = blockIdx.x;
+    if (item >= total) return;                             // (block-uniform; only when a tiny layer is forced onto this kernel)
+    setup(item);
+    issue_dma(0, 0);
+    f4 ub[2][4][2];
+    load_u(ub[0], 0);
+#ifdef WINO_EXP_NOU
+    load_u(ub[1], 1);
+#endif
+    for (;;) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+        for (int p = 0; p < KP; ++p) {
+#ifndef WINO_EXP_NOBAR
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the patch (and its U fragments) have landed
+            __syncthreads();                               // every wave's have; every wave is done with the other buffer
+#endif
+#ifndef WINO_EXP_NODMA
+            if (p + 1 < KP) issue_dma(p + 1, (p + 1) & 1);
+#endif
+            // four steps of 16 MFMAs; the patch reads of step st + 1 and its transform are issued beside the MFMAs of step st
+            f4 d[2][4], vcur[4], vnext[4];
+            read_d(d, 0);
+            transform(d, vcur);
+            read_d(d, 1);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int half = st >> 1, j = st & 1;
+#ifndef WINO_EXP_NOU
+                if (j == 0) load_u(ub[half ^ 1], min(2 * p + half + 1, KC - 1));          // (the last one re-reads: uniform counts)
+#endif
+#ifndef WINO_EXP_NOREAD
+                if (st < 3) transform(d, vnext);
+                if (st < 2) read_d(d, st + 2);
+#else
+                if (st < 3) { for (int b = 0; b < 4; ++b) vnext[b] = vcur[b]; }
+#endif
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[half][b][j][e], vcur[b][e], acc[b], 0, 0, 0);
+                if (st < 3) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) vcur[b] = vnext[b];
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) paddr[rr][c] ^= (unsigned)BUF;      // the other buffer
+        }
+        if (KP & 1) {                                      // every item starts in buffer 0
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) paddr[rr][c] ^= (unsigned)BUF;
+        }
+
+        // ---- this item is summed.  Start the next item's first patch and U loads, then finish this one beside them.
+        const int onb = nb, oimg = img, ogy = gyi, ogx = gxi;
+        const int next = item + (int)gridDim.x;
+        __syncthreads();                                   // every wave is done with both patch buffers
+        if (next < total) {
+            setup(next);
+            issue_dma(0, 0);
+            load_u(ub[0], 0);
+        }
+        // output transform.  In registers: the column half (A applied to this wave's row a): s[qx] from M[a][0..3]; through LDS (the
+        // SECOND buffer: the first is being filled): the row half across the four waves of a tile half.  Plane 2 a + qx of half th.
+        {
+            const f32x16 s0 = acc[0] + acc[1] + acc[2], s1 = acc[1] - acc[2] - acc[3];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const f4 m0 = {s0[4 * gq], s0[4 * gq + 1], s0[4 * gq + 2], s0[4 * gq + 3]};
+                const f4 m1 = {s1[4 * gq], s1[4 * gq + 1], s1[4 * gq + 2], s1[4 * gq + 3]};
+                *reinterpret_cast<f4*>(smem + BUF + th * 32768 + img32_addr(2 * wa, fi, 2 * gq + fh)) = m0;      // couts 8 gq + 4 h .. + 3 of tile fi
+                *reinterpret_cast<f4*>(smem + BUF + th * 32768 + img32_addr(2 * wa + 1, fi, 2 * gq + fh)) = m1;
             }
         }
+        __syncthreads();
+        {
+            const int oth = tid >> 8, ti = (tid >> 3) & 31, oq = tid & 7;
+            f4 sv[4][2];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int qx = 0; qx < 2; ++qx) sv[r][qx] = *reinterpret_cast<const f4*>(smem + BUF + oth * 32768 + img32_addr(2 * r + qx, ti, oq));
+            const int otile = 32 * oth + ti, ty = ogy * TG + (otile >> 3), tx = ogx * TG + (otile & 7), cout = onb * 32 + 4 * oq;
+            f4 sc = (f4)(1.f), sh = (f4)(0.f);
+            if (a.scale) sc = *reinterpret_cast<const f4*>(a.scale + cout);
+            if (a.shift) sh = *reinterpret_cast<const f4*>(a.shift + cout);
+#pragma unroll
+            for (int qx = 0; qx < 2; ++qx) {
+                const f4 o[2] = {sv[0][qx] + sv[1][qx] + sv[2][qx], sv[1][qx] - sv[2][qx] - sv[3][qx]};
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    f4 val = o[pr] * sc + sh;
+                    if (a.relu) val = f4{fmaxf(val[0], 0.f), fmaxf(val[1], 0.f), fmaxf(val[2], 0.f), fmaxf(val[3], 0.f)};
+                    if (2 * ty + pr < a.H && 2 * tx + qx < a.W)
+                        *reinterpret_cast<f4*>(a.y + (((long)oimg * a.H + 2 * ty + pr) * a.W + 2 * tx + qx) * a.Cout + cout) = val;
+                }
+            }
+        }
+        if (next >= total) break;
+        item = next;                                       // (the next pair loop opens with a barrier: the M image is read before buffer 1 is refilled)
     }
 }
 
@@ -245,11 +463,14 @@ bool conv_winograd_supported(const dc_conv_desc* d) {
            aligned16(d->w_wino) && (!d->scale || aligned16(d->scale)) && (!d->shift || aligned16(d->shift));
 }
 
-int conv_winograd_slices(const dc_conv_desc* d) {
-    // output channels per block: 64 where the grid still covers the chip twice over (half the V transforms and V reads per MFMA)
-    static const int force = env_int("DCAP_WINO_NT", 0);
-    if (force == 1 || force == 2) return (d->Cout % (32 * force) == 0) ? force : 1;
-    return 1;
+// tiles per block: 64 where every CU still gets a block (half the U bytes per MFMA, overlap inside the block), else 32.
+// DCAP_WINO_TILES = 32 / 64 forces one (measurements and tests).
+int conv_winograd_tiles(const dc_conv_desc* d) {
+    static const int force = env_int("DCAP_WINO_TILES", 0);
+    if (force == 32 || force == 64) return force;
+    const int th = (d->H + 1) / 2, tw = (d->W + 1) / 2;
+    const long blocks64 = (long)d->N * ((th + 7) / 8) * ((tw + 7) / 8) * (d->Cout / 32);
+    return blocks64 >= kNumCU ? 64 : 32;
 }
 
 int conv2d_winograd(const dc_conv_desc* d, hipStream_t s) {
@@ -261,19 +482,21 @@ int conv2d_winograd(const dc_conv_desc* d, hipStream_t s) {
     a.shift = d->shift;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.relu = d->relu;
     const int th = (d->H + 1) / 2, tw = (d->W + 1) / 2;
-    a.gy = (th + wino::TGY - 1) / wino::TGY;
-    a.gx = (tw + wino::TGX - 1) / wino::TGX;
-    a.groups = d->N * a.gy * a.gx;
     a.x_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->Cin * sizeof(float));
-    const int nt = conv_winograd_slices(d);
-    const long blocks = (long)a.groups * (d->Cout / (32 * nt));
+    const bool big = conv_winograd_tiles(d) == 64;
+    a.gy = big ? (th + 7) / 8 : (th + wino::w32::TGY - 1) / wino::w32::TGY;
+    a.gx = big ? (tw + 7) / 8 : (tw + wino::w32::TGX - 1) / wino::w32::TGX;
+    a.groups = d->N * a.gy * a.gx;
+    const long blocks = (long)a.groups * (d->Cout / 32);
     DC_REQUIRE(blocks < (1l << 31), DC_EINVAL, "dc_conv2d (winograd): grid too large");
-    if (nt == 2) {
-        DC_ENSURE_DYN_LDS(wino::wino_conv_kernel<2>, wino::LDS_BYTES);
-        hipLaunchKernelGGL(wino::wino_conv_kernel<2>, dim3((unsigned)blocks), dim3(wino::NTHREADS), wino::LDS_BYTES, s, a);
+    if (big) {
+        DC_ENSURE_DYN_LDS(wino::wino64_kernel, wino::w64::LDS_BYTES);
+        // persistent: one block per CU walks the work items (a multiple of 8 blocks, so that an item's XCD is fixed by item % 8)
+        const unsigned grid = blocks >= kNumCU ? (unsigned)kNumCU : (unsigned)std::max<long>(8, blocks / 8 * 8);
+        hipLaunchKernelGGL(wino::wino64_kernel, dim3(grid), dim3(wino::w64::NT64), wino::w64::LDS_BYTES, s, a);
     } else {
-        DC_ENSURE_DYN_LDS(wino::wino_conv_kernel<1>, wino::LDS_BYTES);
-        hipLaunchKernelGGL(wino::wino_conv_kernel<1>, dim3((unsigned)blocks), dim3(wino::NTHREADS), wino::LDS_BYTES, s, a);
+        DC_ENSURE_DYN_LDS(wino::wino32_kernel, wino::w32::LDS_BYTES);
+        hipLaunchKernelGGL(wino::wino32_kernel, dim3((unsigned)blocks), dim3(wino::NTHREADS), wino::w32::LDS_BYTES, s, a);
     }
     return check_launch("dc_conv2d (winograd)");
 }

@@ -156,6 +156,9 @@ WINO_CASES = [
     (1, 16, 16, 128, 128, False, False),      # no scale / shift (plain Conv2D, the FPN output layers)
     (2, 32, 32, 256, 64, True, True),         # eight K-chunks
     (1, 5, 40, 64, 32, True, True),           # one tile row of three, several group columns
+    (2, 64, 64, 64, 256, True, True),         # 256 blocks of 64 tiles: the large-group kernel (wino64), four K-chunks of 16
+    (1, 71, 119, 32, 288, False, True),       # wino64 with ragged 8 x 8 groups and half-empty edge tiles, two K-chunks, nine slices
+    (1, 128, 128, 96, 32, True, False),       # wino64, six K-chunks (odd number of 32-channel pairs), one slice
 ]
 
 
@@ -180,7 +183,9 @@ def test_conv2d_winograd_matches_oracle_and_direct(ops, case):
     args = (dev(x), wp, 3, 3, 1, 1, 1, H, W, None if sc is None else dev(sc), None if sh is None else dev(sh), None, 0, relu)
     out = torch.full((N, H, W, Cout), float("nan"), device="cuda")
     got = ops.conv2d(*args, out=out, w_wino=u)
-    assert ops.conv2d_kernel_name(*args, w_wino=u).startswith("wino_conv_kernel")
+    th, tw = (H + 1) // 2, (W + 1) // 2
+    big = N * ((th + 7) // 8) * ((tw + 7) // 8) * (Cout // 32) >= 256
+    assert ops.conv2d_kernel_name(*args, w_wino=u) == ("wino64_kernel" if big else "wino32_kernel")
     close(got, y, 2e-5)
     direct = ops.conv2d(*args)
     assert not ops.conv2d_kernel_name(*args).startswith("wino")
