@@ -367,11 +367,15 @@ __global__ __launch_bounds__(w64::NT64, 1) void wino64_kernel(Args a) {
 #ifndef WINO_EXP_NODMA
             if (p + 1 < KP) issue_dma(p + 1, (p + 1) & 1);
 #endif
-            // four steps of 16 MFMAs; the patch reads of step st + 1 and its transform are issued beside the MFMAs of step st
+#ifdef WINO_EXP_STAGGER
+            if (th) __builtin_amdgcn_s_sleep(WINO_EXP_STAGGER);
+#endif
+            // four steps of 16 MFMAs.  The patch reads of step st + 1 are issued at the top of step st, ahead of its first eight MFMAs;
+            // the transform of step st + 1 is VALU work placed beside the last eight.  The scheduling fences keep the compiler from
+            // sinking the reads to just before their use (it did: every step then opened with an exposed LDS round trip).
             f4 d[2][4], vcur[4], vnext[4];
             read_d(d, 0);
             transform(d, vcur);
-            read_d(d, 1);
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 const int half = st >> 1, j = st & 1;
@@ -379,15 +383,24 @@ __global__ __launch_bounds__(w64::NT64, 1) void wino64_kernel(Args a) {
                 if (j == 0) load_u(ub[half ^ 1], min(2 * p + half + 1, KC - 1));          // (the last one re-reads: uniform counts)
 #endif
 #ifndef WINO_EXP_NOREAD
+                if (st < 3) read_d(d, st + 1);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[half][b][j][e], vcur[b][e], acc[b], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#ifndef WINO_EXP_NOREAD
                 if (st < 3) transform(d, vnext);
-                if (st < 2) read_d(d, st + 2);
 #else
                 if (st < 3) { for (int b = 0; b < 4; ++b) vnext[b] = vcur[b]; }
 #endif
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e = 2; e < 4; ++e)
 #pragma unroll
                     for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[half][b][j][e], vcur[b][e], acc[b], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
                 if (st < 3) {
 #pragma unroll
                     for (int b = 0; b < 4; ++b) vcur[b] = vnext[b];
