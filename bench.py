@@ -388,7 +388,7 @@ class E2E(object):
             tpath = os.path.join(ROOT, "profiles", tname)
             if traffic is None and os.path.exists(tpath):
                 for name, rec in json.load(open(tpath)).items():
-                    if name.startswith("void dcap::" + dom[:40]):
+                    if name.startswith("void dcap::" + dom[:40]) or ("::" + dom.split("<")[0] + "(") in name:
                         traffic = rec["hbm_bytes_per_launch_corrected"]
         out = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "measured": main + " (HIP events on the launch stream"

@@ -475,12 +475,15 @@ class Vgg16Plan(EncoderPlan):
     The first convolution reads the RGBX image zero-padded to 32 channels (the implicit-GEMM loader wants Cin % 32 == 0)."""
     feat_channels = 512
 
-    def __init__(self, weights, batch, height, width, device, mean_pixel=(123.7, 116.8, 103.9), use_graph=True, math=None):
+    def __init__(self, weights, batch, height, width, device, mean_pixel=(123.7, 116.8, 103.9), use_graph=True, math=None, winograd=None):
         from .layers import vgg16_convs
+        import os
         if height % 16 or width % 16:
             raise ValueError("Image size must be dividable by 16 (got %dx%d)" % (height, width))
         self.lib = _lib.load()
         self.math = conv_math_mode(math)
+        self.winograd = (os.environ.get("DCAP_WINOGRAD", "1") != "0") if winograd is None else bool(winograd)      # all 13 layers are 3x3 / stride 1
+        self._wwino = {}
         self.B, self.H, self.W = batch, height, width
         self.device = torch.device(device)
         self.mean_pixel = [float(v) for v in mean_pixel]

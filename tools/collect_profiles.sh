@@ -28,11 +28,27 @@ python3 $root/tools/vocab_ce_bench.py 2>&1 | grep -v amdgpu.ids > $out/vocab_ce_
 (for t in 0 64 128; do echo "== tile $t (0 = the library's cost model)"; python3 $root/tools/bconv_bench.py --tile $t 2>&1 | grep -v amdgpu.ids; done) > $out/bconv_bench.txt
 (echo "== one launch per timestep (default)"; python3 $root/tools/lstm_bench.py 2>&1 | grep B=; echo "== DCAP_LSTM_BWD=steps (gate kernel + split-K GEMM + slab reduce per backward timestep)"; DCAP_LSTM_BWD=steps python3 $root/tools/lstm_bench.py 2>&1 | grep B=) > $out/lstm_bench.txt
 (echo "== default (128x64 producer/consumer rule + streaming short-K kernel)"; python3 $root/tools/conv_bench.py --reps 50 2>&1 | grep -v amdgpu.ids; echo "== DCAP_PW_RULE=0 DCAP_PW_STREAM=0 (round-1 tile rule, no streaming kernel)"; DCAP_PW_RULE=0 DCAP_PW_STREAM=0 python3 $root/tools/conv_bench.py --reps 50 2>&1 | grep -v amdgpu.ids) > $out/conv_bench.txt
+(echo "== 3x3 layers, Winograd F(2x2,3x3) (default for frozen weights)"; python3 $root/tools/conv_bench.py --filter 3x3 --winograd --reps 50 2>&1 | grep -v amdgpu.ids
+ echo "== the same layers, direct implicit GEMM"; python3 $root/tools/conv_bench.py --filter 3x3 --reps 50 2>&1 | grep -v amdgpu.ids
+ echo "== DCAP_WINO_TILES=32 (the first kernel: 32-tile blocks, register-staged transform through a V image)"; DCAP_WINO_TILES=32 python3 $root/tools/conv_bench.py --filter 3x3 --winograd --reps 50 2>&1 | grep -v amdgpu.ids
+ for v in NOU NODMA NOBAR NOREAD ALL; do
+   if [ -f $root/tools/variants/libdcap_y$v.so ]; then echo "== ablation build $v of wino64_kernel (tools/build_variant.sh y$v conv_wino.hip -DWINO_EXP_...: results are wrong, only the time matters)"; DCAP_LIB=$root/tools/variants/libdcap_y$v.so python3 $root/tools/conv_bench.py --filter 3x3 --winograd --reps 50 2>&1 | grep -E "res4|fpn_p2|fpn_p3|res2"; fi
+ done) > $out/winograd_bench.txt
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $out/pmc_wino -- python3 $root/tools/conv_bench.py --filter fpn_p3 --winograd --reps 3 > $out/pmc_wino.log 2>&1
+python3 - $out <<'PYEOF'
+import csv, glob, collections, sys, json
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+for f in glob.glob(out + "/pmc_wino/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]] += float(r["Counter_Value"])
+json.dump({k: dict(v) for k, v in agg.items() if "wino" in k}, open(out + "/winograd_sq_counters.json", "w"), indent=1)
+PYEOF
 rocprofv3 --kernel-trace --stats -d $out/dec -o dec -- python3 $root/tools/decoder_bench.py --captions 64 --steps 50 > $out/dec.log 2>&1
 python3 $root/tools/prof_summary.py $out/dec/dec_results.db $out/decoder_kernels.csv 53
 cd $root
 timeout -k 10 300 python3 bench.py --gpus 2 --steps 5 --warmup 2 > $out/rehearsal_2rank_selflaunch.log 2>&1 || true
 timeout -k 10 300 python3 bench.py --config joint --gpus 2 --steps 5 --warmup 2 --no-roofline > $out/rehearsal_2rank_joint.log 2>&1 || true
 bash tools/roialign_profile.sh > /dev/null 2>&1 && cp gpurun_out/roialign_profile.txt $out/roialign_hbm.txt || true
-rm -rf $out/trace $out/joint $out/dec $out/pmc_fetch $out/pmc_write
+rm -rf $out/trace $out/joint $out/dec $out/pmc_fetch $out/pmc_write $out/pmc_wino
 ls $out
