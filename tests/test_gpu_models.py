@@ -76,6 +76,36 @@ def test_encoder_matches_oracle(gpu, conv_math):
     assert rel_err(out[1]['features'], want[1]) < 2e-4
 
 
+def test_encoder_winograd_and_direct_plans_agree(gpu):
+    """EncoderPlan(winograd=True) (the default for conv_math='f32': frozen 3x3 / stride 1 layers in the Winograd F(2x2,3x3) form) against
+    winograd=False (the direct implicit GEMM everywhere): the same layers report the Winograd kernels, every pyramid map and the RoI
+    features agree to fp32 rounding, and both stay within the oracle tolerance of test_encoder_matches_oracle."""
+    from image_captioning_amd import synth
+    from image_captioning_amd.encoder import EncoderPlan
+    Wt = synth.encoder_weights(0, stage4_blocks=2)
+    img = torch.tensor(synth.images(0, 2, 256, 256), device="cuda")
+    rois = synth.rois(1, 2, 16, 256, 256, lo=16, hi=256)
+    want = M.encoder_features(img.cpu().numpy(), rois, Wt, MEAN, stage4_blocks=2)
+    feats, maps = {}, {}
+    for wino in (True, False):
+        plan = EncoderPlan(Wt, 2, 256, 256, "cuda", stage4_blocks=2, mean_pixel=MEAN, winograd=wino)
+        names = {name: key for name, fl, bm, bn, sk, key in plan.conv_table()}
+        wl = sorted(n for n, k in names.items() if k.startswith("wino"))
+        if wino:
+            assert "res2a_branch2b" in wl and "res4b_branch2b" in wl and "fpn_p2" in wl and "fpn_p5" in wl and len(wl) == 3 + 4 + 3 + 3 + 4
+            assert not any(n.endswith("branch2a") or n.endswith("branch2c") or n.startswith("fpn_c") or n == "conv1" for n in wl)
+        else:
+            assert not wl
+        for _ in range(2):                                 # eager, then the captured graph
+            plan.forward(img)
+            feats[wino] = plan.roi_features(rois).cpu().numpy()
+        maps[wino] = [t.cpu().numpy() for t in plan.P]
+        assert rel_err(feats[wino], want) < 2e-4
+    assert rel_err(feats[True], feats[False]) < 2e-5
+    for a, b in zip(maps[True], maps[False]):
+        assert rel_err(a, b) < 2e-5
+
+
 @pytest.mark.parametrize("inject", [True, False])
 def test_v2_as_written_batch(gpu, inject):
     """The reference's own batch layout: predict, loss, every trainable gradient, three optimizer steps."""
