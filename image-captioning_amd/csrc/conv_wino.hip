@@ -252,7 +252,7 @@ namespace w64 {
 constexpr int NT64 = 512, TG = 8, PW = 2 * TG + 2, NPIX = PW * PW, SLOTS = NPIX * 8, NDMA = (SLOTS + NT64 - 1) / NT64;
 constexpr int BUF = 65536;                               // one patch buffer (41.5 KiB used); buffer 1 = buffer 0 ^ BUF
 constexpr int LDS_BYTES = 2 * BUF;
-static_assert(NDMA * NT64 * 16 <= BUF, "patch buffer");
+static_assert(NDMA * NT64 * 16 <= BUF && NDMA == 6, "patch buffer; the kernel issues the pieces three per step");
 // Patch image: pixel (y, x) of the 18 x 18 patch is 128 bytes at index y * 18 + (x >> 1) + 9 (x & 1) (a row's even columns first,
 // so that horizontally neighbouring TILES alternate between the two halves of the 256-byte bank row), its 16-byte channel chunk c
 // at position c ^ swizzle(y, x).  A ds_read_b128 is served in 16-lane groups that hold four tile rows x four consecutive tile
@@ -298,21 +298,23 @@ __global__ __launch_bounds__(w64::NT64, 1) void wino64_kernel(Args a) {
         }
         ubase = a.u + lane + (((long)(4 * wa) * NTG + nb) * KC << 7);
     };
-    auto issue_dma = [&](int pair, int buf) {
+    auto issue_dma_pieces = [&](int pair, int buf, int n0, int n1) {
 #pragma unroll
-        for (int n = 0; n < NDMA; ++n)
+        for (int n = n0; n < n1; ++n)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem + buf * BUF + (n * NT64 + wave * 64) * 16), 16,
                                                      (int)doff[n], pair * 128, 0, 0);
     };
+    auto issue_dma = [&](int pair, int buf) { issue_dma_pieces(pair, buf, 0, NDMA); };
     const long ustep = (long)NTG * KC << 7;                // xi -> xi + 1
-    auto load_u = [&](f4 (&dst)[4][2], int kc) {
+    auto load_u_part = [&](f4 (&dst)[4][2], int kc, int b0, int b1) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+        for (int b = b0; b < b1; ++b) {
             const f4* p = ubase + b * ustep + ((long)kc << 7);
             dst[b][0] = p[0];
             dst[b][1] = p[64];
         }
     };
+    auto load_u = [&](f4 (&dst)[4][2], int kc) { load_u_part(dst, kc, 0, 4); };
 
     // ---- fragment geometry: lane (tile i of this wave's half, k-half h); transform row wa combines patch rows r1, r2
     const int fi = lane & 31, fh = lane >> 5;
@@ -359,16 +361,11 @@ __global__ __launch_bounds__(w64::NT64, 1) void wino64_kernel(Args a) {
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-        for (int p = 0; p < KP; ++p) {
+        auto pair = [&](int p, auto more_c) {
+            constexpr bool more = decltype(more_c)::value;      // a pair p + 1 of this item exists: request its patch
 #ifndef WINO_EXP_NOBAR
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the patch (and its U fragments) have landed
             __syncthreads();                               // every wave's have; every wave is done with the other buffer
-#endif
-#ifndef WINO_EXP_NODMA
-            if (p + 1 < KP) issue_dma(p + 1, (p + 1) & 1);
-#endif
-#ifdef WINO_EXP_STAGGER
-            if (th) __builtin_amdgcn_s_sleep(WINO_EXP_STAGGER);
 #endif
             // four steps of 16 MFMAs.  The patch reads of step st + 1 are issued at the top of step st, ahead of its first eight MFMAs;
             // the transform of step st + 1 is VALU work placed beside the last eight.  The scheduling fences keep the compiler from
@@ -379,17 +376,29 @@ __global__ __launch_bounds__(w64::NT64, 1) void wino64_kernel(Args a) {
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 const int half = st >> 1, j = st & 1;
-#ifndef WINO_EXP_NOU
-                if (j == 0) load_u(ub[half ^ 1], min(2 * p + half + 1, KC - 1));          // (the last one re-reads: uniform counts)
-#endif
 #ifndef WINO_EXP_NOREAD
                 if (st < 3) read_d(d, st + 1);
 #endif
                 __builtin_amdgcn_sched_barrier(0);
+                // vector-memory instructions cost the wave tens of issue cycles each (an LDS-DMA piece 60 - 185: MI355X_MICROARCH.md):
+                // they go out ONE per MFMA inside the first eight of a step -- the next pair's patch in steps 0 and 1 (three pieces
+                // each), the U fragments of the next 16-channel chunk half per step -- instead of in a burst behind the barrier, where
+                // both waves of a SIMD issued theirs at the same time with no MFMA in flight
+#ifndef WINO_EXP_NODMA
+                if constexpr (more) if (st < 2) issue_dma_pieces(p + 1, (p + 1) & 1, 3 * st, 3 * st + 3);
+#endif
+#ifndef WINO_EXP_NOU
+                load_u_part(ub[half ^ 1], min(2 * p + half + 1, KC - 1), 2 * j, 2 * j + 2);          // (the last one re-reads: uniform counts)
+#endif
 #pragma unroll
                 for (int e = 0; e < 2; ++e)
 #pragma unroll
                     for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[half][b][j][e], vcur[b][e], acc[b], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);          // one vector-memory read (where there is one left)
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #ifndef WINO_EXP_NOREAD
                 if (st < 3) transform(d, vnext);
@@ -400,6 +409,15 @@ __global__ __launch_bounds__(w64::NT64, 1) void wino64_kernel(Args a) {
                 for (int e = 2; e < 4; ++e)
 #pragma unroll
                     for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[half][b][j][e], vcur[b][e], acc[b], 0, 0, 0);
+#ifndef WINO_EXP_NOREAD
+                if (st < 3) {                              // the transform's VALU work spread over the eight MFMAs: none of them waits for it
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    }
+                }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 if (st < 3) {
 #pragma unroll
@@ -410,7 +428,9 @@ __global__ __launch_bounds__(w64::NT64, 1) void wino64_kernel(Args a) {
             for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) paddr[rr][c] ^= (unsigned)BUF;      // the other buffer
-        }
+        };
+        for (int p = 0; p < KP - 1; ++p) pair(p, std::true_type{});
+        pair(KP - 1, std::false_type{});
         if (KP & 1) {                                      // every item starts in buffer 0
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr)
@@ -421,6 +441,12 @@ __global__ __launch_bounds__(w64::NT64, 1) void wino64_kernel(Args a) {
         // ---- this item is summed.  Start the next item's first patch and U loads, then finish this one beside them.
         const int onb = nb, oimg = img, ogy = gyi, ogx = gxi;
         const int next = item + (int)gridDim.x;
+        // this item's epilogue operands, requested BEFORE anything of the next item: vmcnt retires in issue order, so waiting for them
+        // later must not mean waiting for the next patch
+        const int oq = tid & 7, ocout = onb * 32 + 4 * oq;
+        f4 sc = (f4)(1.f), sh = (f4)(0.f);
+        if (a.scale) sc = *reinterpret_cast<const f4*>(a.scale + ocout);
+        if (a.shift) sh = *reinterpret_cast<const f4*>(a.shift + ocout);
         __syncthreads();                                   // every wave is done with both patch buffers
         if (next < total) {
             setup(next);
@@ -441,16 +467,13 @@ __global__ __launch_bounds__(w64::NT64, 1) void wino64_kernel(Args a) {
         }
         __syncthreads();
         {
-            const int oth = tid >> 8, ti = (tid >> 3) & 31, oq = tid & 7;
+            const int oth = tid >> 8, ti = (tid >> 3) & 31;
             f4 sv[4][2];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int qx = 0; qx < 2; ++qx) sv[r][qx] = *reinterpret_cast<const f4*>(smem + BUF + oth * 32768 + img32_addr(2 * r + qx, ti, oq));
-            const int otile = 32 * oth + ti, ty = ogy * TG + (otile >> 3), tx = ogx * TG + (otile & 7), cout = onb * 32 + 4 * oq;
-            f4 sc = (f4)(1.f), sh = (f4)(0.f);
-            if (a.scale) sc = *reinterpret_cast<const f4*>(a.scale + cout);
-            if (a.shift) sh = *reinterpret_cast<const f4*>(a.shift + cout);
+            const int otile = 32 * oth + ti, ty = ogy * TG + (otile >> 3), tx = ogx * TG + (otile & 7), cout = ocout;
 #pragma unroll
             for (int qx = 0; qx < 2; ++qx) {
                 const f4 o[2] = {sv[0][qx] + sv[1][qx] + sv[2][qx], sv[1][qx] - sv[2][qx] - sv[3][qx]};
