@@ -8,27 +8,24 @@
 //   M[xi]  = V[xi] (tiles x cin) . U[xi] (cin x cout)        16 independent GEMMs on the matrix pipe
 //   Y      = A^T M A                       2 x 2 output pixels per tile, then scale / shift / ReLU (frozen BN + bias folded)
 //
-// One kernel does all of it (nothing of V or M ever reaches HBM).  Common to both kernels below: 256 threads = 4 waves, a block
-// = a group of tiles x 32 output channels x all 16 xi; wave w owns xi = 4 w .. 4 w + 3 (no two waves share a weight), so U goes
-// from L2 STRAIGHT INTO REGISTERS -- it is packed in fragment order, 1 KiB contiguous per wave-instruction; the MFMA takes U as
-// its A operand (rows = output channels), so a lane ends up with four consecutive output channels of one tile per accumulator
-// quad; the input transform is done by thread (tile, channel quad): 16 dwordx4 of its 4 x 4 patch (out-of-image pixels carry an
-// out-of-range buffer offset: hardware zeros = TF 'SAME' padding), 32 adds per channel, 16 ds_write_b128 into the V image
-// (swizzled 16-byte chunks, conflict-free for these writes and for the fragment reads); the output transform sends the 16 M[xi]
-// through the same LDS, thread (tile, channel quad) gathers its 16 values, applies A^T . A and the epilogue and stores 16-byte
-// pieces (128 contiguous bytes per pixel and block).  Grid: block -> (output-channel slice, tile group), slice-major through the
-// XCD remap, so an XCD's L2 keeps ONE slice of U (16 x Cin x 32 x 4 bytes) and streams the activations once.
+// One kernel does all of it (nothing of V or M ever reaches HBM).  Two kernels; common to both: a work item = a group of tiles x
+// 32 output channels x all 16 xi; a wave owns whole xi positions (no two waves of a tile group share a weight), so U goes from L2
+// STRAIGHT INTO REGISTERS -- it is packed in fragment order, 1 KiB contiguous per wave-instruction; the MFMA takes U as its A
+// operand (rows = output channels), so a lane ends up with four consecutive output channels of one tile per accumulator quad;
+// the output transform goes through LDS, thread (tile, channel quad) applies A^T . A and the epilogue and stores 16-byte pieces
+// (128 contiguous bytes per pixel and item).  Items are ordered slice-major through the XCD remap, so an XCD's L2 keeps ONE
+// slice of U (16 x Cin x 32 x 4 bytes).
 //
-// What bounds it is not the matrix pipe alone: per MFMA the form moves 2.25x the operand bytes of the direct one (U is 16/9 of
-// the kernel and is re-read by every tile group; 4 x 4 patches overlap), and a CU takes 66-73 GB/s from L2
-// (MI355X_MICROARCH.md).  First version (wino32_kernel: 32 tiles, 32-channel K-chunks, V single-buffered, two blocks per CU
-// to overlap one block's transform with the other's MFMAs): 128 KB requested per 1.05 MFLOP-chunk and block -- measured
-// 810 us on fpn_p2, where the MFMAs alone need 437 and everything but the MFMAs 395: the two did not overlap, both blocks
-// waited on memory.  wino64_kernel: 64 tiles (8 x 8: U bytes per MFMA halved), 16-channel K-chunks, V double-buffered
-// (2 x 64 KiB), ONE block per CU with the overlap inside each wave: U for the whole next chunk and the next chunk's
-// patch are in flight (<= 24 loads per lane) during a chunk's 64 MFMAs, the transform's VALU work and LDS writes are
-// interleaved with the second half of them, one barrier per chunk.  wino32_kernel stays for layers with too few tiles to
-// give every CU a 64-tile block.
+// What bounds the form is not the matrix pipe alone: per MFMA it moves 2.25x the operand bytes of the direct one (U is 16/9 of
+// the kernel and is re-read by every tile group; 4 x 4 patches overlap), a CU takes 66-73 GB/s from L2, and every vector-memory
+// instruction costs the issuing wave tens of cycles (MI355X_MICROARCH.md).
+//   wino32v1_kernel (the first version; DCAP_WINO_TILES=1, kept for the comparison in profiles/): 32 tiles, 32-channel chunks,
+//     thread (tile, channel quad) loads its 4 x 4 patch into registers, transforms it and writes a V image, two blocks per CU.
+//     128 KB requested per 1.05 MFLOP-chunk and block: 810 us on fpn_p2, where the MFMAs alone need 437.
+//   wino64_kernel / wino32_kernel = wino_body<2 / 1> (DESIGN.md section 5 has the measurements that led here): 64 / 32 tiles per
+//     item, the input patch staged ONCE per 32 channels by LDS-DMA, no V image -- every wave makes its own MFMA fragments straight
+//     from the patch --, persistent blocks, vector-memory instructions issued one per MFMA: 639 us.  64-tile items (512 threads,
+//     one block per CU) where every CU gets one, 32-tile items (256 threads, two blocks per CU) for the small layers.
 #include "igemm_core.h"
 #include <algorithm>
 
@@ -143,14 +140,14 @@ __device__ __forceinline__ void patch_offsets(const Args& a, int img, int ty, in
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// wino32_kernel: 32 tiles (4 x 8: 8 x 16 output pixels), K-chunks of 32 channels, V single-buffered (64 KiB), two blocks per CU.
+// wino32v1_kernel: 32 tiles (4 x 8: 8 x 16 output pixels), K-chunks of 32 channels, V single-buffered (64 KiB), two blocks per CU.
 // ------------------------------------------------------------------------------------------------------------------------
 namespace w32 {
 constexpr int TGY = 4, TGX = 8, KCH = 32;
 constexpr int LDS_BYTES = 16 * 32 * KCH * 4;             // 64 KiB
 }
 
-__global__ __launch_bounds__(NTHREADS, 2) void wino32_kernel(Args a) {
+__global__ __launch_bounds__(NTHREADS, 2) void wino32v1_kernel(Args a) {
     using namespace w32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -234,7 +231,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino32_kernel(Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// wino64_kernel: 64 tiles (8 x 8: 16 x 16 output pixels) x 32 output channels, 512 threads = 8 waves, one block per CU.
+// wino_body<HALVES>: 32 HALVES tiles (HALVES = 2: 8 x 8 tiles = 16 x 16 output pixels, 512 threads = 8 waves, one block per CU;
+// described below.  HALVES = 1: 4 x 8 tiles, 256 threads, a 10 x 18 patch, two blocks per CU) x 32 output channels.
 //
 // No V image at all.  The block's 18 x 18-pixel input patch goes to LDS ONCE per 32 channels -- LDS-DMA, whole 128-byte lines,
 // every byte of the patch fetched once per block (the register-staged transform of wino32_kernel asks for every interior pixel
@@ -245,15 +243,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino32_kernel(Args a) {
 // values its next 16 MFMAs take as B operands.  Nothing is transformed twice, nothing transformed is stored.
 // Per 16-channel chunk and wave: 16 ds_read_b128, 64 VALU, 8 global_load_dwordx4 of U (one chunk ahead), 32 MFMAs; two waves
 // per SIMD (the two tile halves of one row: the same U lines, the second finds them in L1), one barrier per 32 channels.
+// Persistent: one block per CU walks the work items; the next item's first patch and U loads are requested before this item's
+// output transform.  Inside a pair of chunks the vector-memory instructions go out one per MFMA (sched_group_barrier), the
+// transform's VALU work four per MFMA: issued in bursts they stalled both waves of a SIMD at the same time.
 // Patch image: pixel p = 128 bytes = eight 16-byte chunks, chunk c at c ^ ((p >> 1) & 7): the DMA permutes the SOURCE chunk per
 // lane (its LDS destination is lane-linear), the eight tiles of a row then read eight different chunks.
 // ------------------------------------------------------------------------------------------------------------------------
-namespace w64 {
-constexpr int NT64 = 512, TG = 8, PW = 2 * TG + 2, NPIX = PW * PW, SLOTS = NPIX * 8, NDMA = (SLOTS + NT64 - 1) / NT64;
-constexpr int BUF = 65536;                               // one patch buffer (41.5 KiB used); buffer 1 = buffer 0 ^ BUF
-constexpr int LDS_BYTES = 2 * BUF;
-static_assert(NDMA * NT64 * 16 <= BUF && NDMA == 6, "patch buffer; the kernel issues the pieces three per step");
-// Patch image: pixel (y, x) of the 18 x 18 patch is 128 bytes at index y * 18 + (x >> 1) + 9 (x & 1) (a row's even columns first,
+namespace wp {
+constexpr int PW = 18, NDMA = 6;                         // patch width (8 tiles + halo) in pixels; DMA pieces per thread and pair
+// Patch image: pixel (y, x) of the patch is 128 bytes at index y * 18 + (x >> 1) + 9 (x & 1) (a row's even columns first,
 // so that horizontally neighbouring TILES alternate between the two halves of the 256-byte bank row), its 16-byte channel chunk c
 // at position c ^ swizzle(y, x).  A ds_read_b128 is served in 16-lane groups that hold four tile rows x four consecutive tile
 // columns (MI355X_MICROARCH.md, LDS: {0-3, 12-15, 20-27}, ...): per half of the bank row that is 4 rows x 2 columns two tiles
@@ -261,10 +259,22 @@ static_assert(NDMA * NT64 * 16 <= BUF && NDMA == 6, "patch buffer; the kernel is
 // conflict-free.  (First version: index y * 18 + x, swizzle (index >> 1) & 7: SQ_LDS_BANK_CONFLICT = 74 % of SQ_LDS_IDX_ACTIVE.)
 __device__ __forceinline__ int patch_index(int y, int x) { return y * PW + (x >> 1) + (PW / 2) * (x & 1); }
 __device__ __forceinline__ int patch_swizzle(int y, int x) { return ((x >> 2) & 1) | (((y >> 1) & 3) << 1); }
+// HALVES 32-tile halves per work item: 2 = 64 tiles (8 x 8), 512 threads, one block per CU; 1 = 32 tiles (4 rows x 8), 256 threads,
+// two blocks per CU -- for layers with too few tiles to give every CU a 64-tile item (stage 5, fpn_p5, one-image batches).
+template <int HALVES>
+struct Cfg {
+    static constexpr int NT = 256 * HALVES, TGY = 4 * HALVES, TGX = 8, PH = 2 * TGY + 2, NPIX = PH * PW, SLOTS = NPIX * 8;
+    static constexpr int BUF = 32768 * HALVES;           // one patch buffer (HALVES = 2: 41.5 KiB used); buffer 1 = buffer 0 ^ BUF
+    static constexpr int LDS_BYTES = 2 * BUF;
+    static_assert(NDMA * NT >= SLOTS && NDMA * NT * 16 <= BUF, "patch buffer; the kernel issues the pieces three per step");
+};
 }
 
-__global__ __launch_bounds__(w64::NT64, 1) void wino64_kernel(Args a) {
-    using namespace w64;
+template <int HALVES>
+__device__ __forceinline__ void wino_body(const Args& a) {
+    using namespace wp;
+    typedef Cfg<HALVES> C;
+    constexpr int NT64 = C::NT, SLOTS = C::SLOTS, BUF = C::BUF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -291,7 +301,7 @@ __global__ __launch_bounds__(w64::NT64, 1) void wino64_kernel(Args a) {
         for (int n = 0; n < NDMA; ++n) {
             const int s = n * NT64 + tid, pq = s >> 3, py = pq / PW, rem = pq - py * PW;
             const int px = rem < PW / 2 ? 2 * rem : 2 * (rem - PW / 2) + 1;          // inverse of patch_index(): even columns first
-            const int iy = gyi * 2 * TG - 1 + py, ix = gxi * 2 * TG - 1 + px;
+            const int iy = gyi * 2 * C::TGY - 1 + py, ix = gxi * 2 * C::TGX - 1 + px;
             const bool in = s < SLOTS && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
             const int c8 = (s & 7) ^ patch_swizzle(py, px);
             doff[n] = in ? (unsigned)(((((long)img * a.H + iy) * a.W + ix) * a.Cin + 4 * c8) * 4) : kOobOffset;
@@ -473,7 +483,7 @@ __global__ __launch_bounds__(w64::NT64, 1) void wino64_kernel(Args a) {
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int qx = 0; qx < 2; ++qx) sv[r][qx] = *reinterpret_cast<const f4*>(smem + BUF + oth * 32768 + img32_addr(2 * r + qx, ti, oq));
-            const int otile = 32 * oth + ti, ty = ogy * TG + (otile >> 3), tx = ogx * TG + (otile & 7), cout = ocout;
+            const int otile = 32 * oth + ti, ty = ogy * C::TGY + (otile >> 3), tx = ogx * C::TGX + (otile & 7), cout = ocout;
 #pragma unroll
             for (int qx = 0; qx < 2; ++qx) {
                 const f4 o[2] = {sv[0][qx] + sv[1][qx] + sv[2][qx], sv[1][qx] - sv[2][qx] - sv[3][qx]};
@@ -491,6 +501,9 @@ __global__ __launch_bounds__(w64::NT64, 1) void wino64_kernel(Args a) {
     }
 }
 
+__global__ __launch_bounds__(512, 1) void wino64_kernel(Args a) { wino_body<2>(a); }
+__global__ __launch_bounds__(256, 2) void wino32_kernel(Args a) { wino_body<1>(a); }
+
 }  // namespace wino
 
 bool conv_winograd_supported(const dc_conv_desc* d) {
@@ -499,14 +512,20 @@ bool conv_winograd_supported(const dc_conv_desc* d) {
            aligned16(d->w_wino) && (!d->scale || aligned16(d->scale)) && (!d->shift || aligned16(d->shift));
 }
 
-// tiles per block: 64 where every CU still gets a block (half the U bytes per MFMA, overlap inside the block), else 32.
-// DCAP_WINO_TILES = 32 / 64 forces one (measurements and tests).
-int conv_winograd_tiles(const dc_conv_desc* d) {
+// tiles per work item: 64 where every CU still gets an item, else 32.  DCAP_WINO_TILES = 32 / 64 forces one; 1 = the first
+// 32-tile kernel (register-staged transform through a V image: kept for the comparison in profiles/) -- measurements and tests.
+static int wino_force() {
     static const int force = env_int("DCAP_WINO_TILES", 0);
+    return force;
+}
+
+int conv_winograd_tiles(const dc_conv_desc* d) {
+    const int force = wino_force();
     if (force == 32 || force == 64) return force;
+    if (force == 1) return 32;
     const int th = (d->H + 1) / 2, tw = (d->W + 1) / 2;
-    const long blocks64 = (long)d->N * ((th + 7) / 8) * ((tw + 7) / 8) * (d->Cout / 32);
-    return blocks64 >= kNumCU ? 64 : 32;
+    const long items64 = (long)d->N * ((th + 7) / 8) * ((tw + 7) / 8) * (d->Cout / 32);
+    return items64 >= kNumCU ? 64 : 32;
 }
 
 int conv2d_winograd(const dc_conv_desc* d, hipStream_t s) {
@@ -520,19 +539,25 @@ int conv2d_winograd(const dc_conv_desc* d, hipStream_t s) {
     const int th = (d->H + 1) / 2, tw = (d->W + 1) / 2;
     a.x_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->Cin * sizeof(float));
     const bool big = conv_winograd_tiles(d) == 64;
-    a.gy = big ? (th + 7) / 8 : (th + wino::w32::TGY - 1) / wino::w32::TGY;
-    a.gx = big ? (tw + 7) / 8 : (tw + wino::w32::TGX - 1) / wino::w32::TGX;
+    a.gy = (th + (big ? 8 : 4) - 1) / (big ? 8 : 4);
+    a.gx = (tw + 7) / 8;
     a.groups = d->N * a.gy * a.gx;
-    const long blocks = (long)a.groups * (d->Cout / 32);
-    DC_REQUIRE(blocks < (1l << 31), DC_EINVAL, "dc_conv2d (winograd): grid too large");
+    const long items = (long)a.groups * (d->Cout / 32);
+    DC_REQUIRE(items < (1l << 31), DC_EINVAL, "dc_conv2d (winograd): grid too large");
+    if (!big && wino_force() == 1) {
+        DC_ENSURE_DYN_LDS(wino::wino32v1_kernel, wino::w32::LDS_BYTES);
+        hipLaunchKernelGGL(wino::wino32v1_kernel, dim3((unsigned)items), dim3(wino::NTHREADS), wino::w32::LDS_BYTES, s, a);
+        return check_launch("dc_conv2d (winograd)");
+    }
+    // persistent: the blocks that fit the chip walk the work items (a multiple of 8 blocks, so that an item's XCD is fixed by item % 8)
+    const long slots = big ? kNumCU : 2 * kNumCU;
+    const unsigned grid = items >= slots ? (unsigned)slots : (unsigned)std::max<long>(8, items / 8 * 8);
     if (big) {
-        DC_ENSURE_DYN_LDS(wino::wino64_kernel, wino::w64::LDS_BYTES);
-        // persistent: one block per CU walks the work items (a multiple of 8 blocks, so that an item's XCD is fixed by item % 8)
-        const unsigned grid = blocks >= kNumCU ? (unsigned)kNumCU : (unsigned)std::max<long>(8, blocks / 8 * 8);
-        hipLaunchKernelGGL(wino::wino64_kernel, dim3(grid), dim3(wino::w64::NT64), wino::w64::LDS_BYTES, s, a);
+        DC_ENSURE_DYN_LDS(wino::wino64_kernel, wino::wp::Cfg<2>::LDS_BYTES);
+        hipLaunchKernelGGL(wino::wino64_kernel, dim3(grid), dim3(wino::wp::Cfg<2>::NT), wino::wp::Cfg<2>::LDS_BYTES, s, a);
     } else {
-        DC_ENSURE_DYN_LDS(wino::wino32_kernel, wino::w32::LDS_BYTES);
-        hipLaunchKernelGGL(wino::wino32_kernel, dim3((unsigned)blocks), dim3(wino::NTHREADS), wino::w32::LDS_BYTES, s, a);
+        DC_ENSURE_DYN_LDS(wino::wino32_kernel, wino::wp::Cfg<1>::LDS_BYTES);
+        hipLaunchKernelGGL(wino::wino32_kernel, dim3(grid), dim3(wino::wp::Cfg<1>::NT), wino::wp::Cfg<1>::LDS_BYTES, s, a);
     }
     return check_launch("dc_conv2d (winograd)");
 }

@@ -1,6 +1,8 @@
 """Kernel-level parity: every C-ABI entry point against the NumPy oracle on seeded inputs (-m gpu).
 Tolerances: fp32 MFMA accumulation vs float64 oracle => 2e-5 of the output scale unless stated
 (index outputs -- argmax, pyramid levels -- are bit-exact)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -190,6 +192,33 @@ def test_conv2d_winograd_matches_oracle_and_direct(ops, case):
     direct = ops.conv2d(*args)
     assert not ops.conv2d_kernel_name(*args).startswith("wino")
     close(got, direct.cpu().numpy().astype(np.float64), 2e-5)
+
+
+@pytest.mark.parametrize("force", ["1", "32", "64"])
+def test_conv2d_winograd_forced_kernels_in_a_child_process(ops, force):
+    """DCAP_WINO_TILES (read once per process) forces a kernel: 1 = the first 32-tile kernel kept for the comparison in profiles/,
+    32 / 64 = the patch-staging kernel with 32- / 64-tile items whatever the layer's size.  Each against the direct kernel."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, torch\n"
+        "from image_captioning_amd import ops\n"
+        "torch.manual_seed(0)\n"
+        "for (N, H, W, Cin, Cout) in ((1, 12, 20, 64, 64), (2, 33, 17, 32, 96)):\n"
+        "    x = torch.randn(N, H, W, Cin, device='cuda'); w = torch.randn(Cout, 9 * Cin, device='cuda') / (9 * Cin) ** 0.5\n"
+        "    sh = torch.randn(Cout, device='cuda')\n"
+        "    u = ops.winograd_pack(w, Cin, Cout)\n"
+        "    a = ops.conv2d(x, w, 3, 3, 1, 1, 1, H, W, None, sh, None, 0, True, w_wino=u)\n"
+        "    b = ops.conv2d(x, w, 3, 3, 1, 1, 1, H, W, None, sh, None, 0, True)\n"
+        "    name = ops.conv2d_kernel_name(x, w, 3, 3, 1, 1, 1, H, W, None, sh, None, 0, True, w_wino=u)\n"
+        "    err = float((a - b).abs().max() / b.abs().max())\n"
+        "    assert err < 2e-5, (name, err)\n"
+        "    print(name, err)\n")
+    env = dict(os.environ, DCAP_WINO_TILES=force)
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert ("wino64_kernel" if force == "64" else "wino32_kernel") in r.stdout
 
 
 def test_conv2d_winograd_falls_back_where_the_form_does_not_apply(ops):

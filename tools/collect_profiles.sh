@@ -30,7 +30,8 @@ python3 $root/tools/vocab_ce_bench.py 2>&1 | grep -v amdgpu.ids > $out/vocab_ce_
 (echo "== default (128x64 producer/consumer rule + streaming short-K kernel)"; python3 $root/tools/conv_bench.py --reps 50 2>&1 | grep -v amdgpu.ids; echo "== DCAP_PW_RULE=0 DCAP_PW_STREAM=0 (round-1 tile rule, no streaming kernel)"; DCAP_PW_RULE=0 DCAP_PW_STREAM=0 python3 $root/tools/conv_bench.py --reps 50 2>&1 | grep -v amdgpu.ids) > $out/conv_bench.txt
 (echo "== 3x3 layers, Winograd F(2x2,3x3) (default for frozen weights)"; python3 $root/tools/conv_bench.py --filter 3x3 --winograd --reps 50 2>&1 | grep -v amdgpu.ids
  echo "== the same layers, direct implicit GEMM"; python3 $root/tools/conv_bench.py --filter 3x3 --reps 50 2>&1 | grep -v amdgpu.ids
- echo "== DCAP_WINO_TILES=32 (the first kernel: 32-tile blocks, register-staged transform through a V image)"; DCAP_WINO_TILES=32 python3 $root/tools/conv_bench.py --filter 3x3 --winograd --reps 50 2>&1 | grep -v amdgpu.ids
+ echo "== DCAP_WINO_TILES=1 (the FIRST kernel everywhere: 32-tile blocks, register-staged transform through a V image)"; DCAP_WINO_TILES=1 python3 $root/tools/conv_bench.py --filter 3x3 --winograd --reps 50 2>&1 | grep -v amdgpu.ids
+ echo "== DCAP_WINO_TILES=32 (the patch-staging kernel with 32-tile items everywhere)"; DCAP_WINO_TILES=32 python3 $root/tools/conv_bench.py --filter 3x3 --winograd --reps 50 2>&1 | grep -v amdgpu.ids
  for v in NOU NODMA NOBAR NOREAD ALL; do
    if [ -f $root/tools/variants/libdcap_y$v.so ]; then echo "== ablation build $v of wino64_kernel (tools/build_variant.sh y$v conv_wino.hip -DWINO_EXP_...: results are wrong, only the time matters)"; DCAP_LIB=$root/tools/variants/libdcap_y$v.so python3 $root/tools/conv_bench.py --filter 3x3 --winograd --reps 50 2>&1 | grep -E "res4|fpn_p2|fpn_p3|res2"; fi
  done) > $out/winograd_bench.txt
@@ -50,5 +51,6 @@ cd $root
 timeout -k 10 300 python3 bench.py --gpus 2 --steps 5 --warmup 2 > $out/rehearsal_2rank_selflaunch.log 2>&1 || true
 timeout -k 10 300 python3 bench.py --config joint --gpus 2 --steps 5 --warmup 2 --no-roofline > $out/rehearsal_2rank_joint.log 2>&1 || true
 bash tools/roialign_profile.sh > /dev/null 2>&1 && cp gpurun_out/roialign_profile.txt $out/roialign_hbm.txt || true
+python3 $root/tools/wino_fit.py 2>&1 | grep -v amdgpu.ids > $out/winograd_fit.txt
 rm -rf $out/trace $out/joint $out/dec $out/pmc_fetch $out/pmc_write $out/pmc_wino
 ls $out
