@@ -73,6 +73,37 @@ def conv2d_nhwc(x, w, b=None, stride=1, padding='valid'):
     return out
 
 
+# Winograd F(2x2, 3x3) (Lavin & Gray, "Fast Algorithms for Convolutional Neural Networks", 2015): the form the product evaluates its
+# frozen 3x3 / stride 1 / 'same' layers in (csrc/conv_wino.hip).  Not in the reference's source -- it is what cuDNN runs those
+# KL.Conv2D layers with under TF -- so this restatement checks the ALGORITHM against conv2d_nhwc above, in the precision asked for.
+WINO_G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], F64)
+WINO_BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], F64)
+WINO_AT = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], F64)
+
+
+def conv2d_winograd_nhwc(x, w, dtype=F64):
+    """3x3 / stride 1 / 'same' convolution as  Y = A^T [ (G g G^T) . (B^T d B) ] A  per 2x2 output tile, every product, sum and
+    transform rounded to `dtype` (float32 = the arithmetic of the kernel; sums over channels in one np.matmul)."""
+    x = np.asarray(x, dtype)
+    w = np.asarray(w, dtype)
+    N, H, W, C = x.shape
+    assert w.shape[:3] == (3, 3, C)
+    O = w.shape[3]
+    G, BT, AT = WINO_G.astype(dtype), WINO_BT.astype(dtype), WINO_AT.astype(dtype)
+    U = np.einsum('ai,ijck,bj->abck', G, w, G).astype(dtype)
+    th, tw = (H + 1) // 2, (W + 1) // 2
+    xp = np.zeros((N, 2 * th + 2, 2 * tw + 2, C), dtype)
+    xp[:, 1:H + 1, 1:W + 1] = x
+    out = np.zeros((N, 2 * th, 2 * tw, O), dtype)
+    for ty in range(th):
+        for tx in range(tw):
+            d = xp[:, 2 * ty:2 * ty + 4, 2 * tx:2 * tx + 4]                       # top-left pixel (2 ty - 1, 2 tx - 1) of the image
+            V = np.einsum('ai,nijc,bj->nabc', BT, d, BT).astype(dtype)
+            M = np.einsum('nabc,abck->nabk', V, U).astype(dtype)
+            out[:, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = np.einsum('pa,nabk,qb->npqk', AT, M, AT).astype(dtype)
+    return out[:, :H, :W]
+
+
 def conv2d_nhwc_loops(x, w, b=None, stride=1, padding='valid'):
     """Loop-level twin of conv2d_nhwc for tiny shapes (self-check of the vectorised form)."""
     x = np.asarray(x, F64)

@@ -134,6 +134,31 @@ def test_lstm_backward_matches_finite_differences():
         assert abs(num - grad[idx]) < 1e-6 * max(1, abs(num))
 
 
+def test_winograd_f2x2_3x3_is_the_same_convolution():
+    """The minimal-filtering form of a 3x3 / stride 1 / 'same' convolution (what csrc/conv_wino.hip evaluates): exact in float64
+    (odd sizes: half-empty edge tiles), and in float32 arithmetic within a few fp32 roundings of the float64 convolution -- the same
+    order as the direct float32 sum, far inside the 2e-5 tolerance the GPU tests hold both kernels to."""
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((2, 7, 9, 24))
+    w = rng.standard_normal((3, 3, 24, 8)) / np.sqrt(9 * 24)
+    want = O.conv2d_nhwc(x, w, None, 1, 'same')
+    np.testing.assert_allclose(O.conv2d_winograd_nhwc(x, w), want, rtol=0, atol=1e-13)
+    scale = np.abs(want).max()
+    e_wino = np.abs(O.conv2d_winograd_nhwc(x, w, np.float32).astype(np.float64) - want).max() / scale
+    x32, w32 = x.astype(np.float32), w.astype(np.float32)
+    direct32 = np.zeros(want.shape, np.float32)
+    xp = np.pad(x32, ((0, 0), (1, 1), (1, 1), (0, 0)))
+    for ky in range(3):
+        for kx in range(3):
+            direct32 += xp[:, ky:ky + 7, kx:kx + 9] @ w32[ky, kx]
+    e_direct = np.abs(direct32.astype(np.float64) - want).max() / scale
+    assert e_wino < 2e-6 and e_direct < 2e-6 and e_wino < 8 * e_direct + 1e-7, (e_wino, e_direct)
+    # the transform matrices: G and A^T rows sum the taps / outputs the way the 1-D F(2,3) identity needs
+    d, g = rng.standard_normal(4), rng.standard_normal(3)
+    y = O.WINO_AT @ ((O.WINO_G @ g) * (O.WINO_BT @ d))
+    np.testing.assert_allclose(y, [d[0] * g[0] + d[1] * g[1] + d[2] * g[2], d[1] * g[0] + d[2] * g[1] + d[3] * g[2]], atol=1e-14)
+
+
 def test_lstm_recurrent_dropout_masks_and_gradients():
     """Keras recurrent_dropout (training phase): masks of ones reproduce the plain LSTM; kept units are scaled by 1/(1-rate); the
     hand-written backward with masks matches finite differences (incl. through masked timesteps)."""
