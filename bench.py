@@ -15,11 +15,14 @@ All arithmetic is fp32 (exact-f32 MFMA).  Inputs are resident in HBM before the 
                                       1024x1024 image per GPU and step, 2000 proposals -> 200 RoIs, V = 50 000
 
 Rank 0 prints ONE JSON line (see the driver contract) with extra objects:
-  roofline      -- the dominant kernel (the conv implicit-GEMM instantiation with the largest time share): algorithmic FLOPs
-                   per launch / mean launch time against the fp32 MFMA peak (157.3 TFLOP/s).  The time is measured in this
-                   process with HIP events on the launch stream while a decoder step runs beside the encoder on its own
-                   stream, as in the timed pipeline -- the condition a rocprofv3 kernel trace of this command sees
-                   (profiles/r02_bench_kernel_stats.csv); `isolated` holds the same quantities with the chip to itself;
+  roofline      -- the dominant kernel (the conv instantiation with the largest time share): the FLOPs the matrix pipe EXECUTES per
+                   launch / mean launch time against the fp32 MFMA peak (157.3 TFLOP/s); `frac` <= 1 by construction.  For the
+                   Winograd F(2x2,3x3) kernels executed = direct-form FLOPs / 2.25, and the direct-form rate is reported
+                   beside it as `achieved_direct_form`.  `algorithmic_bytes` = compulsory HBM bytes per launch (input + output +
+                   weights), `traffic` = measured HBM bytes per launch (committed rocprofv3 PMC passes), `traffic_ratio` their
+                   quotient.  The time is measured in this process with HIP events on the launch stream while a decoder step runs
+                   beside the encoder on its own stream, as in the timed pipeline -- the condition a rocprofv3 kernel trace of this
+                   command sees (profiles/r04_bench_kernel_stats.csv); `isolated` holds the same quantities with the chip to itself;
   cpu_baseline  -- the reference-as-written algorithm (oracle/torch_ref.py, float32, all host threads) timed on a bounded
                    sample of the same workload (N = 1 only);
   other_configs -- BASELINE configs[2] proper (ONE image per step), configs[1] (v2-inject decoder on precomputed RoI
@@ -348,6 +351,7 @@ class E2E(object):
         """Per-instantiation conv timing, in the pipeline's conditions and alone; the dominant kernel's roofline numbers."""
         plan = self.plan
         table = plan.conv_table()
+        alg_bytes = plan.conv_algorithmic_bytes()
         self.inner.grad_sync = None        # rank 0 alone runs this leg (after the timed region): its decoder steps must not enter a collective
         beside = None
         if self.pipe is not None:
@@ -364,11 +368,12 @@ class E2E(object):
             torch.cuda.synchronize()
             groups = {}
             for name, fl, bm, bn, sk, key in table:                 # key: rocprof's spelling of the layer's kernel
-                g = groups.setdefault(key, {"flops": 0.0, "alg": 0.0, "ms": 0.0, "launches": 0})
+                g = groups.setdefault(key, {"flops": 0.0, "alg": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0})
                 g["alg"] += fl                                       # the layer's direct-form FLOPs
                 g["flops"] += fl / WINOGRAD_GAIN if key.startswith("wino") else fl      # what the matrix pipe executes
                 g["ms"] += times[name]
                 g["launches"] += 1
+                g["bytes"] += alg_bytes[name]                        # compulsory HBM bytes: input + output + weights (+ residual)
             res[label] = (groups, times)
         main = "pipeline" if "pipeline" in res else "isolated"
         groups, times = res[main]
@@ -383,35 +388,43 @@ class E2E(object):
         g = groups[dom]
         achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
         conv_ms = sum(v["ms"] for v in groups.values())
-        traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
-        for tname in (("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json") if args.backbone == "resnet101" else ()):
+        # HBM bytes per launch: from the committed rocprofv3 PMC passes of this same command (tools/pmc_traffic.py: separate --pmc
+        # passes, FETCH_SIZE / WRITE_SIZE with the guide's gfx950 corrections) -- counters cannot be read from inside the process
+        traffic, traffic_src = None, None
+        for tname in (("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json") if args.backbone == "resnet101" else ()):
             tpath = os.path.join(ROOT, "profiles", tname)
             if traffic is None and os.path.exists(tpath):
                 for name, rec in json.load(open(tpath)).items():
                     if name.startswith("void dcap::" + dom[:40]) or ("::" + dom.split("<")[0] + "(") in name:
-                        traffic = rec["hbm_bytes_per_launch_corrected"]
+                        traffic, traffic_src = rec["hbm_bytes_per_launch_corrected"], "profiles/" + tname
+        # `achieved` / `frac`: the FLOPs the matrix pipe EXECUTES for the kernel's launches over their time (<= 1 of the peak by
+        # construction).  For the Winograd F(2x2,3x3) kernels that is the layers' direct-form FLOPs / 2.25 -- 16 products per
+        # 2x2 output tile and channel pair instead of 36 --; the direct-form rate the layers are credited with is `achieved_direct_form`
+        # (it may exceed the peak: that is what the algorithm is for, and it is not a roofline fraction).
+        wino = dom.startswith("wino")
+        alg_b = g["bytes"] / g["launches"]
         out = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-               "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "measured": main + " (HIP events on the launch stream"
+               "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "algorithmic_bytes": alg_b,
+               "traffic_ratio": (traffic / alg_b) if traffic else None,
+               "traffic_source": traffic_src,
+               "measured": main + " (HIP events on the launch stream"
                + (", one decoder train step running beside every encoder pass on the decoder stream)" if main == "pipeline" else ")"),
                "launches_per_step": g["launches"], "gflop_per_launch": g["flops"] / g["launches"] / 1e9,
                "avg_launch_us": 1e3 * g["ms"] / g["launches"],
                "all_conv": {"gflop_per_step": plan.flops / 1e9, "ms_per_step": conv_ms, "tflops": plan.flops / (conv_ms * 1e-3) / 1e12,
-                            "mfma_gflop_per_step": sum(v["flops"] for v in groups.values()) / 1e9},
+                            "mfma_gflop_per_step": sum(v["flops"] for v in groups.values()) / 1e9,
+                            "mfma_frac": sum(v["flops"] for v in groups.values()) / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
                "kernels": {k: dict({"launches": v["launches"], "ms": round(v["ms"], 4), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)},
                                    **({"tflops_direct_form": round(v["alg"] / (v["ms"] * 1e-3) / 1e12, 2)} if v["alg"] != v["flops"] else {}))
                            for k, v in groups.items()}}
-        if dom.startswith("wino"):
-            # Winograd F(2x2,3x3).  `achieved` / `frac` follow the contract: the layers' ALGORITHMIC (direct-form) FLOPs over the
-            # kernel's time -- above the fp32 MFMA peak, which is the point of the algorithm.  `executed` counts the products the matrix
-            # pipe actually performs (16 per 2x2 output tile and channel pair instead of 36): its frac is the pipe's utilisation.
-            out["achieved"] = g["alg"] / (g["ms"] * 1e-3) / 1e12
-            out["frac"] = out["achieved"] / PEAK_F32_MFMA_TFLOPS
-            out["gflop_per_launch"] = g["alg"] / g["launches"] / 1e9
-            out["executed"] = {"gflop_per_launch": g["flops"] / g["launches"] / 1e9, "achieved": achieved, "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                               "note": "MFMA FLOPs executed = direct-form FLOPs / 2.25 (Winograd F(2x2,3x3), fp32 transforms and products)"}
+        if wino:
+            out["achieved_direct_form"] = g["alg"] / (g["ms"] * 1e-3) / 1e12
+            out["gflop_per_launch_direct_form"] = g["alg"] / g["launches"] / 1e9
+            out["note"] = ("Winograd F(2x2,3x3), fp32 transforms and products: executed MFMA FLOPs = direct-form FLOPs / 2.25; "
+                           "frac = executed / peak")
         if main == "pipeline":
             gi = res["isolated"][0][dom]
-            ai = gi["alg" if dom.startswith("wino") else "flops"] / (gi["ms"] * 1e-3) / 1e12
+            ai = gi["flops"] / (gi["ms"] * 1e-3) / 1e12
             iso_ms = sum(v["ms"] for v in res["isolated"][0].values())
             out["isolated"] = {"achieved": ai, "frac": ai / PEAK_F32_MFMA_TFLOPS, "avg_launch_us": 1e3 * gi["ms"] / gi["launches"],
                                "all_conv_ms_per_step": iso_ms, "all_conv_tflops": plan.flops / (iso_ms * 1e-3) / 1e12}
@@ -497,46 +510,64 @@ def self_launch(n, argv=None, script=None, timeout_s=None, extra_env=None):
     share devices over the gloo backend -- a rehearsal of the multi-process path, flagged as such in the JSON line
     (`dist_backend`)."""
     import socket
+    import tempfile
     script = script or os.path.abspath(__file__)
     argv = list(sys.argv[1:] if argv is None else argv)
     timeout_s = float(os.environ.get("DCAP_BENCH_TIMEOUT", 1500) if timeout_s is None else timeout_s)
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env0 = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    env0.update(extra_env or {})
-    if "DCAP_DIST_BACKEND" not in env0 and torch.cuda.device_count() < n:      # device_count() does not initialise the GPU
+    # NOTE: this launcher must only ever START CHILD PROCESSES, never exec: device_count() below may initialise the HIP runtime in this
+    # process (without amdsmi it falls back to hipGetDeviceCount), and exec-ing from a process that has is forbidden on the GPU pool.
+    shared = "DCAP_DIST_BACKEND" not in os.environ and torch.cuda.device_count() < n
+    if shared:
         sys.stderr.write("bench.py: %d rank(s) on %d visible GPU(s): ranks share devices, gradient exchange over gloo (rehearsal)\n"
                          % (n, torch.cuda.device_count()))
-        env0["DCAP_DIST_BACKEND"] = "gloo"
-    procs = []
-    for rank in range(n):
-        env = dict(env0, RANK=str(rank), LOCAL_RANK=str(rank))
-        procs.append(subprocess.Popen([sys.executable, script] + argv, env=env, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL,
-                                      text=True))
     deadline = time.monotonic() + timeout_s
-    rc = 0
-    try:
-        while True:
-            codes = [p.poll() for p in procs]
-            if any(c not in (None, 0) for c in codes):                # a rank died: the others would wait in a collective forever
-                rc = next(c for c in codes if c not in (None, 0))
-                break
-            if all(c == 0 for c in codes):
-                break
-            if time.monotonic() > deadline:
-                sys.stderr.write("bench.py: ranks still running after %.0f s -- killing them\n" % timeout_s)
-                rc = 124
-                break
-            time.sleep(0.2)
-    finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
-    out = procs[0].stdout.read() if procs[0].stdout else ""
-    for p in procs:
-        p.wait()
+    rc, out = 1, ""
+    for attempt in range(3):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()               # (released before the children bind it: a race another process can win -- hence the retry below)
+        env0 = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env0.update(extra_env or {})
+        if shared:
+            env0["DCAP_DIST_BACKEND"] = "gloo"
+        # rank 0's stdout goes to a FILE, not a pipe: a pipe is read only after the ranks have exited, and a JSON line that outgrows the
+        # 64 KB pipe buffer would block rank 0 in write() until the timeout
+        procs, t_start = [], time.monotonic()
+        with tempfile.TemporaryFile(mode="w+") as out0, tempfile.TemporaryFile(mode="w+") as err0:
+            for rank in range(n):
+                env = dict(env0, RANK=str(rank), LOCAL_RANK=str(rank))
+                procs.append(subprocess.Popen([sys.executable, script] + argv, env=env, stdout=out0 if rank == 0 else subprocess.DEVNULL,
+                                              stderr=err0 if rank == 0 else None, text=True))
+            rc = 0
+            try:
+                while True:
+                    codes = [p.poll() for p in procs]
+                    if any(c not in (None, 0) for c in codes):                # a rank died: the others would wait in a collective forever
+                        rc = next(c for c in codes if c not in (None, 0))
+                        break
+                    if all(c == 0 for c in codes):
+                        break
+                    if time.monotonic() > deadline:
+                        sys.stderr.write("bench.py: ranks still running after %.0f s -- killing them\n" % timeout_s)
+                        rc = 124
+                        break
+                    time.sleep(0.2)
+            finally:
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+                for p in procs:
+                    p.wait()
+            out0.seek(0)
+            err0.seek(0)
+            out, err = out0.read(), err0.read()
+        sys.stderr.write(err)
+        # the rendezvous port was taken between its release here and the children's bind: try again on a fresh one
+        if rc not in (0, 124) and time.monotonic() - t_start < 60 and ("EADDRINUSE" in err or "Address already in use" in err or "address already in use" in err):
+            sys.stderr.write("bench.py: rendezvous port %d was taken, retrying on a fresh port\n" % port)
+            continue
+        break
     sys.stdout.write(out)
     sys.stdout.flush()
     return rc

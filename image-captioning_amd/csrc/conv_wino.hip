@@ -509,7 +509,8 @@ __global__ __launch_bounds__(256, 2) void wino32_kernel(Args a) { wino_body<1>(a
 bool conv_winograd_supported(const dc_conv_desc* d) {
     return d->w_wino != nullptr && d->math == DC_MATH_F32 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 &&
            d->Ho == d->H && d->Wo == d->W && d->Cin % 32 == 0 && d->Cout % 32 == 0 && d->res_mode == 0 && d->split_k <= 1 && aligned16(d->y) &&
-           aligned16(d->w_wino) && (!d->scale || aligned16(d->scale)) && (!d->shift || aligned16(d->shift));
+           aligned16(d->w_wino) && (!d->scale || aligned16(d->scale)) && (!d->shift || aligned16(d->shift)) &&
+           (size_t)d->N * d->H * d->W * d->Cin * sizeof(float) < (1ull << 31);      // one buffer resource, 32-bit offsets: larger inputs take the direct kernels
 }
 
 // tiles per work item: 64 where every CU still gets an item, else 32.  DCAP_WINO_TILES = 32 / 64 forces one; 1 = the first
@@ -537,7 +538,11 @@ int conv2d_winograd(const dc_conv_desc* d, hipStream_t s) {
     a.shift = d->shift;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.relu = d->relu;
     const int th = (d->H + 1) / 2, tw = (d->W + 1) / 2;
-    a.x_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->Cin * sizeof(float));
+    const size_t x_bytes = (size_t)d->N * d->H * d->W * d->Cin * sizeof(float);
+    // the kernels address the input through ONE buffer resource with 32-bit byte offsets (and a signed num_records): a P2-level input of
+    // 32 or more 1024 x 1024 images does not fit -- split the batch
+    DC_REQUIRE(x_bytes < (1ull << 31), DC_EINVAL, "dc_conv2d (winograd): the input tensor has %zu bytes, the kernel addresses < 2 GiB", x_bytes);
+    a.x_bytes = (unsigned)x_bytes;
     const bool big = conv_winograd_tiles(d) == 64;
     a.gy = (th + (big ? 8 : 4) - 1) / (big ? 8 : 4);
     a.gx = (tw + 7) / 8;

@@ -311,18 +311,22 @@ __global__ __launch_bounds__(256) void sumsq_finish_kernel(const float* __restri
 }
 
 // L2 weight regulariser of the joint model over the flat parameter bucket: coef[i] = WEIGHT_DECAY / size(tensor of i)
-// for regularised tensors, 0 elsewhere (BN gamma/beta, padding).  grad += 2*coef*w ; loss += sum coef*w^2.
-__global__ __launch_bounds__(256) void l2_reg_kernel(const float* __restrict__ w, const float* __restrict__ coef, float* __restrict__ g,
-                                                     size_t n, float* __restrict__ loss) {
+// for regularised tensors, 0 elsewhere (BN gamma/beta, padding).  grad = grad * mask + 2*coef*w (mask: the 0/1 trainable subset of
+// set_trainable(), NULL = everything trains) ; loss = sum coef*w^2, block partials in block order through the caller's workspace
+// and one block adding them in a fixed tree (bit-reproducible, like dc_sumsq).
+__global__ __launch_bounds__(256) void l2_reg_kernel(const float* __restrict__ w, const float* __restrict__ coef, const float* __restrict__ mask,
+                                                     float* __restrict__ g, size_t n, float* __restrict__ partial) {
     __shared__ float red[4];
     float s = 0.f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const float c = coef[i], x = w[i];
-        if (g) g[i] += 2.f * c * x;
+        if (g) g[i] = (mask ? g[i] * mask[i] : g[i]) + 2.f * c * x;
         s += c * x * x;
     }
-    s = block_reduce<false>(s, red);
-    if (threadIdx.x == 0 && loss) atomicAdd(loss, s);
+    if (partial) {
+        s = block_reduce<false>(s, red);
+        if (threadIdx.x == 0) partial[blockIdx.x] = s;
+    }
 }
 
 __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
@@ -503,16 +507,24 @@ extern "C" int dc_sumsq_f32(const float* x, size_t n, float* out, int accumulate
     return check_launch("sumsq_finish_kernel");
 }
 
-extern "C" int dc_l2_reg_f32(const float* w, const float* coef, float* grad, size_t n, float* loss, void* stream) {
+static int l2_reg_blocks(size_t n) { return (int)std::min<size_t>((n + 1023) / 1024, (size_t)kNumCU * 4); }
+
+extern "C" size_t dc_l2_reg_workspace_bytes(size_t n) { return n ? (size_t)l2_reg_blocks(n) * sizeof(float) : 0; }
+
+extern "C" int dc_l2_reg_f32(const float* w, const float* coef, const float* mask, float* grad, size_t n, float* loss, void* workspace,
+                             size_t workspace_bytes, void* stream) {
     DC_REQUIRE(w && coef && n > 0 && (grad || loss), DC_EINVAL, "dc_l2_reg: bad arguments");
+    DC_REQUIRE(!mask || grad, DC_EINVAL, "dc_l2_reg: a mask without a gradient");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (loss) {
-        hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), s);
-        DC_REQUIRE(e == hipSuccess, DC_ELAUNCH, "dc_l2_reg: memset failed: %s", hipGetErrorString(e));
-    }
-    const int blocks = (int)std::min<size_t>((n + 1023) / 1024, (size_t)kNumCU * 4);
-    hipLaunchKernelGGL(l2_reg_kernel, dim3(blocks), dim3(256), 0, s, w, coef, grad, n, loss);
-    return check_launch("l2_reg_kernel");
+    const int blocks = l2_reg_blocks(n);
+    DC_REQUIRE(!loss || (workspace && workspace_bytes >= (size_t)blocks * sizeof(float)), DC_EWORKSPACE, "dc_l2_reg: the loss needs %zu workspace bytes",
+               (size_t)blocks * sizeof(float));
+    float* partial = loss ? static_cast<float*>(workspace) : nullptr;
+    hipLaunchKernelGGL(l2_reg_kernel, dim3(blocks), dim3(256), 0, s, w, coef, mask, grad, n, partial);
+    int rc = check_launch("l2_reg_kernel");
+    if (rc || !loss) return rc;
+    hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, s, partial, blocks, loss, 0);
+    return check_launch("l2_reg_kernel (finish)");
 }
 
 extern "C" int dc_axpy_f32(float a, const float* x, float* y, size_t n, void* stream) {
@@ -581,9 +593,15 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float4* __restrict__ 
         float4 vb = make_float4(0.f, 0.f, 0.f, 0.f);
         if (b) vb = b[i];
         dacc[i] = make_float4(g.x * sc.x, g.y * sc.y, g.z * sc.z, g.w * sc.w);
-        // where dz == 0 the recovered n is meaningless (and may be inf for gamma == 0): the product is defined as 0 there
-        dzn[i] = make_float4(g.x != 0.f ? g.x * ((va.x - vb.x - be.x) / ga.x) : 0.f, g.y != 0.f ? g.y * ((va.y - vb.y - be.y) / ga.y) : 0.f,
-                             g.z != 0.f ? g.z * ((va.z - vb.z - be.z) / ga.z) : 0.f, g.w != 0.f ? g.w * ((va.w - vb.w - be.w) / ga.w) : 0.f);
+        // where dz == 0 the recovered n is meaningless: the product is defined as 0 there.  A DEAD channel (gamma == 0, as pretrained
+        // ResNet BatchNorm layers contain) has bn_out == beta everywhere, n is not recoverable from it and 0 / 0 would put a NaN into
+        // dgamma and from there into the AMSGrad state of the whole bucket: such a channel gets dgamma = 0 (it stays dead; dbeta and
+        // the data gradient, which is scale * dz = 0, are exact)
+        auto prod = [](float dzv, float av, float bv, float bev, float gav) {
+            return (dzv != 0.f && fabsf(gav) > 1e-20f) ? dzv * ((av - bv - bev) / gav) : 0.f;
+        };
+        dzn[i] = make_float4(prod(g.x, va.x, vb.x, be.x, ga.x), prod(g.y, va.y, vb.y, be.y, ga.y), prod(g.z, va.z, vb.z, be.z, ga.z),
+                             prod(g.w, va.w, vb.w, be.w, ga.w));
     }
 }
 

@@ -202,41 +202,59 @@ __global__ void subsample2_kernel(const float4* __restrict__ x, float4* __restri
 
 // RPN losses and their gradients w.r.t. the padded head outputs, one thread per selected (non-neutral) anchor.
 // class: sparse softmax CE over {bg, fg}, mean over the n_sel anchors; bbox: smooth-L1 against the target rows
-// of the positive anchors (in anchor order), mean over 4*n_pos elements.  Loss sums use float atomics on 2 words.
+// of the positive anchors (in anchor order), mean over 4*n_pos elements.  ONE block walks the selection (256 anchors per image in
+// the reference's configuration: RPN_TRAIN_ANCHORS_PER_IMAGE); the two loss sums are per-thread partials in anchor order combined by
+// a fixed tree in LDS -- no atomics: the reported losses are bit-reproducible like the gradients.
 __global__ __launch_bounds__(256) void rpn_loss_grad_kernel(dc_rpn_loss_desc d) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= d.n_sel) return;
-    const int l = d.sel_level[i], idx = d.sel_index[i], m = d.sel_match[i];
+    __shared__ float red[2][256];
     const int A = d.anchors_per_loc;
-    const int cell = idx / A, a = idx - cell * A;
-    if (l < 0 || l >= d.levels || idx < 0 || cell >= d.Hs[l] * d.Ws[l]) return;      // a malformed selection must not write out of bounds
-    const float* h = d.heads[l] + (long)cell * d.head_stride;
-    float* g = d.dheads[l] + (long)cell * d.head_stride;
-    const float l0 = h[a * 2], l1 = h[a * 2 + 1];
-    const float mx = fmaxf(l0, l1);
-    const float e0 = expf(l0 - mx), e1 = expf(l1 - mx), inv = 1.f / (e0 + e1);
-    const float p0 = e0 * inv, p1 = e1 * inv;
-    const int cls = (m == 1) ? 1 : 0;
     const float invn = 1.f / (float)d.n_sel;
-    g[a * 2] = (p0 - (cls == 0 ? 1.f : 0.f)) * invn;
-    g[a * 2 + 1] = (p1 - (cls == 1 ? 1.f : 0.f)) * invn;
-    atomicAdd(&d.losses[0], (logf(e0 + e1) - ((cls ? l1 : l0) - mx)) * invn);      // log-sum-exp form: finite for any logits
-    if (m == 1) {
-        // rank of this positive among the positives = number of positives before it in sel (sel is in anchor order)
-        int rank = 0;
-        for (int j = 0; j < i; ++j) rank += (d.sel_match[j] == 1);
-        const float* t = d.target_deltas + (long)rank * 4;
-        const float* bb = h + A * 2 + a * 4;
-        float* gb = g + A * 2 + a * 4;
-        const float invp = 1.f / (4.f * (float)d.n_pos);
-        float ls = 0.f;
+    float lc = 0.f, lb = 0.f;
+    for (int i = threadIdx.x; i < d.n_sel; i += 256) {
+        const int l = d.sel_level[i], idx = d.sel_index[i], m = d.sel_match[i];
+        const int cell = idx / A, a = idx - cell * A;
+        if (l < 0 || l >= d.levels || idx < 0 || cell >= d.Hs[l] * d.Ws[l]) continue;      // a malformed selection must not write out of bounds
+        const float* h = d.heads[l] + (long)cell * d.head_stride;
+        float* g = d.dheads[l] + (long)cell * d.head_stride;
+        const float l0 = h[a * 2], l1 = h[a * 2 + 1];
+        const float mx = fmaxf(l0, l1);
+        const float e0 = expf(l0 - mx), e1 = expf(l1 - mx), inv = 1.f / (e0 + e1);
+        const float p0 = e0 * inv, p1 = e1 * inv;
+        const int cls = (m == 1) ? 1 : 0;
+        g[a * 2] = (p0 - (cls == 0 ? 1.f : 0.f)) * invn;
+        g[a * 2 + 1] = (p1 - (cls == 1 ? 1.f : 0.f)) * invn;
+        lc += (logf(e0 + e1) - ((cls ? l1 : l0) - mx)) * invn;      // log-sum-exp form: finite for any logits
+        if (m == 1) {
+            // rank of this positive among the positives = number of positives before it in sel (sel is in anchor order)
+            int rank = 0;
+            for (int j = 0; j < i; ++j) rank += (d.sel_match[j] == 1);
+            const float* t = d.target_deltas + (long)rank * 4;
+            const float* bb = h + A * 2 + a * 4;
+            float* gb = g + A * 2 + a * 4;
+            const float invp = 1.f / (4.f * (float)d.n_pos);
+            float ls = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float diff = t[k] - bb[k], ad = fabsf(diff);
-            if (ad < 1.f) { ls += 0.5f * ad * ad; gb[k] = -diff * invp; }
-            else { ls += ad - 0.5f; gb[k] = (diff > 0.f ? -1.f : 1.f) * invp; }
+            for (int k = 0; k < 4; ++k) {
+                const float diff = t[k] - bb[k], ad = fabsf(diff);
+                if (ad < 1.f) { ls += 0.5f * ad * ad; gb[k] = -diff * invp; }
+                else { ls += ad - 0.5f; gb[k] = (diff > 0.f ? -1.f : 1.f) * invp; }
+            }
+            lb += ls * invp;
         }
-        atomicAdd(&d.losses[1], ls * invp);
+    }
+    red[0][threadIdx.x] = lc;
+    red[1][threadIdx.x] = lb;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + w];
+            red[1][threadIdx.x] += red[1][threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        d.losses[0] = red[0][0];
+        d.losses[1] = red[1][0];
     }
 }
 
@@ -593,7 +611,7 @@ extern "C" int dc_rpn_loss_grad_f32(const dc_rpn_loss_desc* d, void* stream) {
     hipError_t e = hipMemsetAsync(d->losses, 0, 2 * sizeof(float), s);
     DC_REQUIRE(e == hipSuccess, DC_ELAUNCH, "dc_rpn_loss_grad: memset failed");
     if (d->n_sel == 0) return DC_OK;
-    hipLaunchKernelGGL(rpn_loss_grad_kernel, dim3((d->n_sel + 255) / 256), dim3(256), 0, s, *d);
+    hipLaunchKernelGGL(rpn_loss_grad_kernel, dim3(1), dim3(256), 0, s, *d);
     return check_launch("rpn_loss_grad_kernel");
 }
 

@@ -454,7 +454,10 @@ class DenseImageCapRCNN(object):
         # the reference keeps the caption decoder inside TimeDistributed(caption_model, name='imgcap_caption_td'): a Keras-layout
         # file stores those layers under that group, where its load_weights(by_name=True) finds them
         nested = {l: "imgcap_caption_td" for l in ("imgcap_embedding_layer", "imgcap_lstm1", "imgcap_lstm2", "imgcap_lstm_d1", "imgcap_lstm_d2")}
-        save_weight_file(tmp, self.get_weights_dict(), layer_groups=nested)
+        # ... in the order of TimeDistributed(Model).weights, which Keras' by-name loader assigns BY POSITION: the wrapped model's
+        # trainable weights in layer order (word_generation_model, dense_model.py:758-784: lstm1, lstm2, d1, d2), then the frozen embedding
+        order = {"imgcap_caption_td": ["imgcap_lstm1", "imgcap_lstm2", "imgcap_lstm_d1", "imgcap_lstm_d2", "imgcap_embedding_layer"]}
+        save_weight_file(tmp, self.get_weights_dict(), layer_groups=nested, group_member_order=order)
         os.replace(tmp, path)
 
     def set_log_dir(self, model_path=None):
@@ -828,9 +831,7 @@ class DenseImageCapRCNN(object):
             coef_, mask_ = self._masks()
 
             def early(lo, hi):                              # regulariser gradient + mask of one layer range, then it may travel
-                if mask_ is not None:
-                    st.flat_grad[lo:hi].mul_(mask_[lo:hi])
-                ops.l2_reg(st.flat[lo:hi], coef_[lo:hi], st.flat_grad[lo:hi])
+                ops.l2_reg(st.flat[lo:hi], coef_[lo:hi], st.flat_grad[lo:hi], mask=None if mask_ is None else mask_[lo:hi])
                 self._reg_done.append((lo, hi))
             cm.before_sync, cm.grad_sync, cm.overlap_sync = early, self.grad_sync, True
         else:
@@ -841,7 +842,7 @@ class DenseImageCapRCNN(object):
                 early(lo, hi)
                 self.grad_sync.ready(st.flat_grad, lo, hi)
         dX = cm._backward(want_dx=True)
-        # dP already holds the RPN branch's data gradients; the RoI features' gradient is scattered on top (atomic adds)
+        # dP already holds the RPN branch's data gradients; the RoI features' gradient is added on top (a fixed-order gather per pyramid pixel: reproducible)
         ops.roi_align_pyramid_bwd(dP[:4], boxes, float(H * W), dX.view(1, R, cfg.POOL_SIZE, cfg.POOL_SIZE, 256), cfg.POOL_SIZE)
         ops.scatter2_add(dP[4], dP[3])                       # P6 = MaxPooling2D(1, strides=2)(P5)
 
@@ -876,15 +877,11 @@ class DenseImageCapRCNN(object):
             n, pos = st.flat.numel(), 0
             for lo, hi in sorted(self._reg_done) + [(n, n)]:
                 if lo > pos:
-                    if mask is not None:
-                        st.flat_grad[pos:lo].mul_(mask[pos:lo])
-                    ops.l2_reg(st.flat[pos:lo], coef[pos:lo], st.flat_grad[pos:lo])
+                    ops.l2_reg(st.flat[pos:lo], coef[pos:lo], st.flat_grad[pos:lo], mask=None if mask is None else mask[pos:lo])
                 pos = max(pos, hi)
             ops.l2_reg(st.flat, coef, None, loss=losses[3:4])      # the loss term alone (weights only)
         else:
-            if mask is not None:
-                st.flat_grad.mul_(mask)
-            ops.l2_reg(st.flat, coef, st.flat_grad, loss=losses[3:4])
+            ops.l2_reg(st.flat, coef, st.flat_grad, loss=losses[3:4], mask=mask)          # one pass: trainable subset, regulariser gradient, loss term
         self._loss_scale = float(loss_rows.numel())
         return losses
 

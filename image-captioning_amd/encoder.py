@@ -211,9 +211,10 @@ class EncoderPlan:
                 self._wsplit[name] = ops.split_bf16x3(wp)
             d.w_split = self._wsplit[name].data_ptr()
         if (self.winograd and self.math == _lib.MATH_F32 and s.k == 3 and s.stride == 1 and s.padding == "same" and residual is None and
-                name not in self._external and s.cin % 32 == 0 and Cout % 32 == 0):
+                name not in self._external and Cin % 32 == 0 and Cout % 32 == 0 and wp.shape[1] == 9 * Cin):
+            # (Cin = the channels of the tensor the layer READS: VGG16's block1_conv1 reads RGB zero-padded to 32 channels)
             if name not in self._wwino:
-                self._wwino[name] = ops.winograd_pack(wp, s.cin, Cout)
+                self._wwino[name] = ops.winograd_pack(wp, Cin, Cout)
             d.w_wino = self._wwino[name].data_ptr()
         self._ws_bytes = max(self._ws_bytes, self.lib.dc_conv2d_workspace_bytes(C.byref(d)))
         self._ops.append(("conv", d, name))
@@ -351,6 +352,23 @@ class EncoderPlan:
             s = self._specs[op[2]]
             rows.append((op[2], 2.0 * d.N * d.Ho * d.Wo * d.Cout * s.k * s.k * s.cin, bm.value, bn.value, sk.value, buf.value.decode()))
         return rows
+
+    def conv_algorithmic_bytes(self):
+        """{layer: compulsory HBM bytes of one launch} = input + output + weights (the 16-position Winograd image where that is what
+        the kernel reads) + the residual / upsample-add operand: what `roofline.algorithmic_bytes` in bench.py sums (fp32 plans)."""
+        out = {}
+        for op in self._ops:
+            if op[0] != "conv":
+                continue
+            d, s = op[1], self._specs[op[2]]
+            wbytes = (16 if op[2] in self._wwino else s.k * s.k) * d.Cin * s.cout * 4
+            b = 4.0 * d.N * d.H * d.W * d.Cin + 4.0 * d.N * d.Ho * d.Wo * d.Cout + wbytes
+            if d.res_mode == 1:
+                b += 4.0 * d.N * d.Ho * d.Wo * d.Cout
+            elif d.res_mode == 2:
+                b += 1.0 * d.N * d.Ho * d.Wo * d.Cout
+            out[op[2]] = b
+        return out
 
     def time_convs(self, reps=3, beside=None):
         """Eager replay with a HIP event pair around every conv launch on the launch stream; returns

@@ -484,19 +484,35 @@ def _chunked_attrs(name, values, limit=64512):
     return {"%s%d" % (name, i): c for i, c in enumerate(np.array_split(arr, parts))}
 
 
-def save_keras_weights(path, weights, layer_order=None, layer_groups=None):
+# position of a weight inside its Keras layer's `weights` list (Conv2D / Dense: kernel, bias; LSTM: kernel, recurrent_kernel, bias;
+# BatchNormalization: gamma, beta, moving_mean, moving_variance; Embedding: embeddings).  Keras' by-name loader matches the GROUP by
+# name and then assigns weight_values[i] to layer.weights[i] BY POSITION, so a file must list them in this order.
+_KERAS_WEIGHT_RANK = {"kernel": 0, "recurrent_kernel": 1, "bias": 2, "gamma": 0, "beta": 1, "moving_mean": 2, "moving_variance": 3,
+                      "embeddings": 0}
+
+
+def keras_weight_order(items):
+    """[(weight name, array)] of one layer in the order of Keras' layer.weights (stable for names Keras does not know)."""
+    return sorted(items, key=lambda it: _KERAS_WEIGHT_RANK.get(it[0], 99))
+
+
+def save_keras_weights(path, weights, layer_order=None, layer_groups=None, group_member_order=None):
     """Write {'<layer>/<weight>': ndarray} as a Keras weights file: /<layer>/<layer>/<weight>:0 datasets, weight_names and
     layer_names attributes (fixed-length byte strings), float32 data.  layer_order: Keras lists layers in model order; default
     is first-seen order of `weights`.
     layer_groups: {inner layer: outer layer} for layers that live inside a wrapper or nested model -- Keras stores those under the
     OUTER layer's group with the inner names (the joint model's decoder: TimeDistributed(caption_model, name='imgcap_caption_td'),
     dense_img_cap/dense_model.py:1554-1560: /imgcap_caption_td/imgcap_lstm1/kernel:0 with weight_names 'imgcap_lstm1/kernel:0'),
-    which is where the reference's load_weights(by_name=True) looks for them."""
+    which is where the reference's load_weights(by_name=True) looks for them.
+    group_member_order: {outer layer: [inner layers in the order of the wrapped model's `weights` list]} -- for a Model that is its
+    trainable weights in layer order followed by the non-trainable ones (the frozen embedding of the caption decoder comes LAST);
+    default: the order the members appear in `layer_order`."""
     w = _Writer()
     layers = {}
     for key, arr in weights.items():
         layer, name = key.split("/", 1)
         layers.setdefault(layer, []).append((name, np.asarray(arr, np.float32)))
+    layers = {l: keras_weight_order(items) for l, items in layers.items()}
     order = list(layer_order) if layer_order is not None else list(layers)
     groups = dict(layer_groups or {})
     outer_order, members = [], {}
@@ -506,6 +522,9 @@ def save_keras_weights(path, weights, layer_order=None, layer_groups=None):
             members[g] = []
             outer_order.append(g)
         members[g].append(layer)
+    for g, want in (group_member_order or {}).items():
+        if g in members:
+            members[g] = [l for l in want if l in members[g]] + [l for l in members[g] if l not in want]
     top = {}
     for g in outer_order:
         inner_groups, names = {}, []

@@ -42,12 +42,12 @@ def load_weight_file(filepath):
     raise ValueError("unknown weight file type: %s" % filepath)
 
 
-def save_weight_file(filepath, weights, layer_groups=None):
+def save_weight_file(filepath, weights, layer_groups=None, group_member_order=None):
     """Checkpoint writer: .npz, or a Keras-layout HDF5 weight file (Keras' ModelCheckpoint(save_weights_only=True) format)
     when the name ends in .h5 / .hdf5 (layer_groups: hdf5_lite.save_keras_weights -- layers nested in a wrapper layer)."""
     if filepath.endswith(".h5") or filepath.endswith(".hdf5"):
         from .hdf5_lite import save_keras_weights
-        save_keras_weights(filepath, weights, layer_groups=layer_groups)
+        save_keras_weights(filepath, weights, layer_groups=layer_groups, group_member_order=group_member_order)
     else:
         np.savez(filepath, **weights)
 

@@ -647,10 +647,13 @@ def scatter2_add(coarse, fine):
     return fine
 
 
-def l2_reg(w, coef, grad=None, loss=None):
+def l2_reg(w, coef, grad=None, loss=None, mask=None):
+    """grad = grad * mask + 2 coef w (mask None: all ones); loss[0] = sum coef w^2 in a fixed order."""
     lib = _lib.load()
-    check(lib.dc_l2_reg_f32(_ptr(_chk(w, name="w")), _ptr(_chk(coef, name="coef")), None if grad is None else _ptr(grad), w.numel(),
-                            None if loss is None else _ptr(loss), _stream()), "dc_l2_reg_f32")
+    ws, wsb = WORKSPACE.get(lib.dc_l2_reg_workspace_bytes(w.numel()), w.device) if loss is not None else (None, 0)
+    check(lib.dc_l2_reg_f32(_ptr(_chk(w, name="w")), _ptr(_chk(coef, name="coef")), None if mask is None else _ptr(_chk(mask, name="mask")),
+                            None if grad is None else _ptr(grad), w.numel(), None if loss is None else _ptr(loss),
+                            None if ws is None else _ptr(ws), wsb, _stream()), "dc_l2_reg_f32")
     return loss
 
 

@@ -120,6 +120,12 @@ class ParallelModel(object):
             for k in self.inner_model.store.frozen_names:
                 dist.broadcast(self.inner_model.store.w[k], src=0)
             self.inner_model._weights_changed()
+            # the reference's towers draw INDEPENDENT K.dropout masks for their shards (recurrent_dropout=0.2, text_generation_model.py:
+            # 141-142); every rank built its model from the same seed, so fold the rank into the Philox key of the mask stream
+            for m in (self.inner_model, getattr(self.inner_model, "caption_model", None)):
+                if m is not None and hasattr(m, "_drop_seed"):
+                    base = m.__dict__.setdefault("_drop_seed_base", m._drop_seed)          # idempotent: derived from the build seed every time
+                    m._drop_seed = (base ^ (self.rank * 0x9E3779B9)) & 0xFFFFFFFF
 
     def __getattr__(self, name):
         return getattr(self.inner_model, name)

@@ -24,8 +24,13 @@ class CaptionTrainPipeline(object):
         self.ev_free = [torch.cuda.Event() for _ in range(2)]       # decoder done reading slot
         self.pending = None                                          # (slot, tables) awaiting its decoder pass
         self.n = 0
-        self._hold = []        # inputs of the last steps: their memory must not go back to the allocator (and be handed to the next
-                               # step's uploads, made on another stream) while kernels that read them are still queued
+        # inputs of the steps in flight, each with the event recorded behind its decoder pass (which itself waits for its encoder
+        # pass): their memory -- allocated on the PRODUCER's stream -- must not go back to the allocator, and from there into the next
+        # upload, while a kernel that reads them is still queued.  Lifetime follows the GPU, not a host step count: an entry is
+        # dropped once its event has completed, and the host blocks on the oldest one when more than `max_in_flight` are pending
+        # (which also bounds how far the host runs ahead of the device).
+        self._hold = []
+        self.max_in_flight = 4
         cur = torch.cuda.current_stream(dev)
         self.s_enc.wait_stream(cur)
         self.s_dec.wait_stream(cur)
@@ -44,14 +49,28 @@ class CaptionTrainPipeline(object):
             f = self.feat[slot]
             loss = self.dec.train_step(f.view(-1, 7, 7, self.fc), tables)
             self.ev_free[slot].record(self.s_dec)
+            for h in self._hold:                        # this batch's inputs may go once the pass just enqueued has run
+                if h[0] is tables and h[2] is None:
+                    h[2] = torch.cuda.Event()
+                    h[2].record(self.s_dec)
+                    break                               # (the oldest pending entry: the one this pass belongs to)
         return loss
+
+    def _release(self):
+        hold = self._hold
+        while hold and hold[0][2] is not None and hold[0][2].query():
+            hold.pop(0)
+        while len(hold) > self.max_in_flight and hold[0][2] is not None:
+            hold[0][2].synchronize()                    # the host is more than max_in_flight batches ahead of the GPU: wait for the oldest
+            hold.pop(0)
 
     def step(self, images, boxes, tables):
         """Enqueue the encoder of this batch and the decoder of the previous one.  images: uint8 [B,H,W,3]
         device tensor or None (already in plan.images); boxes: normalised [B,R,4]; tables: SampleTables.
         Returns the previous batch's loss (device scalar) or None on the first call."""
         slot = self.n & 1
-        self._hold = (self._hold + [(images, boxes, tables)])[-3:]
+        self._release()
+        self._hold.append([tables, (images, boxes), None])
         self._encode(slot, images, boxes)
         loss = None
         if self.pending is not None:

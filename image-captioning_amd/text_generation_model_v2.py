@@ -251,13 +251,11 @@ def train_on_dataset(model, features_model, dataset, images_per_step, rois_per_i
     enq = GeneratorEnqueuer(batches(), workers=1, max_queue_size=max_queue_size)
     feed = enq.get()
     history = []
-    keep = []                                        # the last few batches stay referenced until their kernels have certainly run
     try:
         for epoch in range(epochs):
             acc, n = None, 0
             for _ in range(steps_per_epoch):
-                batch = next(feed)
-                keep = (keep + [batch])[-4:]
+                batch = next(feed)                               # (the pipeline keeps the batch referenced until the GPU is done with it)
                 loss = pipe.step(*batch)
                 if loss is not None:
                     with torch.cuda.stream(pipe.s_dec):          # the loss buffer belongs to the decoder's stream (and is reused by the next step)

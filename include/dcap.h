@@ -465,8 +465,12 @@ int dc_rpn_loss_grad_f32(const dc_rpn_loss_desc* d, void* stream);
 int dc_scatter2_add_f32(const float* coarse, float* fine, int N, int Hc, int Wc, int C, void* stream);
 /* keras.regularizers.l2(WEIGHT_DECAY)(w) / size(w) summed over the trainable non-BN weights
  * (dense_img_cap/dense_model.py:1712-1718) over one flat bucket: coef[i] = WEIGHT_DECAY/size of i's tensor (0 where not
- * regularised).  grad[i] += 2*coef[i]*w[i] (grad may be NULL); loss[0] = sum coef[i]*w[i]^2 (loss may be NULL). */
-int dc_l2_reg_f32(const float* w, const float* coef, float* grad, size_t n, float* loss, void* stream);
+ * regularised).  grad[i] = grad[i]*mask[i] + 2*coef[i]*w[i] (grad may be NULL; mask = the 0/1 subset set_trainable() left
+ * trainable, :1732-1774, NULL = all of it); loss[0] = sum coef[i]*w[i]^2 (loss may be NULL), summed in a fixed order through
+ * `workspace` (dc_l2_reg_workspace_bytes; only needed with a loss): bit-reproducible. */
+size_t dc_l2_reg_workspace_bytes(size_t n);
+int dc_l2_reg_f32(const float* w, const float* coef, const float* mask, float* grad, size_t n, float* loss, void* workspace,
+                  size_t workspace_bytes, void* stream);
 
 int dc_axpy_f32(float a, const float* x, float* y, size_t n, void* stream);
 

@@ -208,3 +208,55 @@ def test_full_size_vgg16_plan_and_bf16_storage_plan(ops):
         assert bool(torch.isfinite(a).all())
         rel = float((a - b).norm() / b.norm())
         assert rel < 5e-2, rel
+
+
+def test_full_size_encoder_winograd_plan_tracks_the_direct_plan(ops):
+    """ResNet-101 + FPN at 1024x1024, TWO images, all 22 stage-4 blocks (the benchmark's own encoder pass: 33 wino64_kernel layers deep,
+    persistent blocks walking 2..16 work items each): every pyramid map and the RoI features of the Winograd plan against the plan
+    that runs the direct implicit GEMM everywhere (winograd=False), 1e-4 of each map's scale.  The direct kernels are the ones
+    test_encoder_matches_oracle holds to the float64 oracle."""
+    from image_captioning_amd import synth
+    from image_captioning_amd.encoder import EncoderPlan
+    W = synth.encoder_weights(0, 22)
+    img = torch.tensor(synth.images(5, 2), device="cuda")
+    rois = synth.rois(3, 2, 32, 1024, 1024)
+    direct = EncoderPlan(W, 2, 1024, 1024, "cuda", winograd=False)
+    assert not direct._wwino
+    ref = [p.clone() for p in direct.forward(img)]
+    ref_feat = direct.roi_features(rois).clone()
+    del direct
+    torch.cuda.empty_cache()
+    wino = EncoderPlan(W, 2, 1024, 1024, "cuda", winograd=True)
+    assert len(wino._wwino) == 3 + 4 + 23 + 3 + 4                                   # every 2b branch + the four FPN output layers
+    for rep in range(3):                                                            # eager, capture, replay: the replay is what is compared
+        got = [p.clone() for p in wino.forward(img)]
+    feat = wino.roi_features(rois)
+    for name, a, b in zip(("P2", "P3", "P4", "P5"), got, ref):
+        assert a.shape == b.shape and bool(torch.isfinite(a).all())
+        err = float((a - b).abs().max()) / float(b.abs().max())
+        assert err < 1e-4, (name, err)
+    err = float((feat - ref_feat).abs().max()) / float(ref_feat.abs().max())
+    assert err < 1e-4, ("roi features", err)
+
+
+def test_full_size_vgg16_winograd_plan_tracks_the_direct_plan(ops):
+    """The VGG16 alternative backbone at 1024x1024: 13 Winograd layers in a row (the first with 29 of its 32 input channels zero)
+    against the same plan on the direct kernels, 1e-4 of the scale of conv5_3 and of the RoI features."""
+    from image_captioning_amd import synth
+    from image_captioning_amd.encoder import Vgg16Plan
+    W = synth.vgg16_weights(0)
+    img = torch.tensor(synth.images(5, 1), device="cuda")
+    rois = synth.rois(3, 1, 32, 1024, 1024)
+    direct = Vgg16Plan(W, 1, 1024, 1024, "cuda", winograd=False)
+    direct.forward(img)
+    ref, ref_feat = direct.C[0].clone(), direct.roi_features(rois).clone()
+    del direct
+    torch.cuda.empty_cache()
+    wino = Vgg16Plan(W, 1, 1024, 1024, "cuda", winograd=True)
+    assert len(wino._wwino) == 13
+    for rep in range(3):
+        wino.forward(img)
+    got, feat = wino.C[0], wino.roi_features(rois)
+    assert bool(torch.isfinite(got).all())
+    assert float((got - ref).abs().max()) / float(ref.abs().max()) < 1e-4
+    assert float((feat - ref_feat).abs().max()) / float(ref_feat.abs().max()) < 1e-4

@@ -160,7 +160,7 @@ WINO_CASES = [
     (1, 5, 40, 64, 32, True, True),           # one tile row of three, several group columns
     (2, 64, 64, 64, 256, True, True),         # 256 blocks of 64 tiles: the large-group kernel (wino64), four K-chunks of 16
     (1, 71, 119, 32, 288, False, True),       # wino64 with ragged 8 x 8 groups and half-empty edge tiles, two K-chunks, nine slices
-    (1, 128, 128, 96, 32, True, False),       # wino64, six K-chunks (odd number of 32-channel pairs), one slice
+    (1, 128, 128, 96, 32, True, False),       # 64 items of 64 tiles < 256 CUs: wino32 (128 items), three 32-channel pairs (odd), one slice
 ]
 
 
@@ -192,6 +192,69 @@ def test_conv2d_winograd_matches_oracle_and_direct(ops, case):
     direct = ops.conv2d(*args)
     assert not ops.conv2d_kernel_name(*args).startswith("wino")
     close(got, direct.cpu().numpy().astype(np.float64), 2e-5)
+
+
+WINO_PERSISTENT_CASES = [
+    # N,H,W,Cin,Cout -- the benchmark's own layer shapes at two images: every persistent wino64 block walks
+    # SEVERAL work items, with an even number KP of 32-channel pairs (the buffer hand-over conv_wino.hip makes between items)
+    (2, 256, 256, 64, 64),       # res2_2b:  1024 items = 4 per block, KP 2
+    (2, 128, 128, 128, 128),     # res3_2b:   512 items = 2 per block, KP 4
+    (2, 128, 128, 256, 256),     # fpn_p3:   1024 items = 4 per block, KP 8
+    (2, 256, 256, 256, 256),     # fpn_p2:   4096 items = 16 per block, KP 8
+    (2, 128, 128, 96, 128),      # odd KP = 3 with 2 items per block (every item starts in buffer 0 again)
+    (3, 104, 88, 160, 96),       # ragged: 7 x 6 groups x 3 images x 3 slices = 378 items: blocks with 1 AND 2 items, KP 5, half-empty edge groups
+]
+
+
+def _wino_items_per_block(N, H, W, Cout):
+    th, tw = (H + 1) // 2, (W + 1) // 2
+    items = N * ((th + 7) // 8) * ((tw + 7) // 8) * (Cout // 32)
+    return items, items / 256.0
+
+
+@pytest.mark.parametrize("case", WINO_PERSISTENT_CASES)
+def test_conv2d_winograd_persistent_multi_item_blocks_at_benchmark_shapes(ops, case):
+    """The kernel behind the headline number on the code path the headline runs: wino64_kernel with >= 2 work items per persistent
+    block (next-item patch prefetch, M image in buffer 1 while buffer 0 refills, even / odd KP).  Whole tensor against the direct
+    implicit-GEMM kernel (2e-5), and against the float64 oracle on windows that straddle image corners, image edges, the
+    16-pixel item boundaries and the image-0 / image-1 seam, over ALL output channels (every slice of every sampled item)."""
+    N, H, W, Cin, Cout = case
+    items, per_block = _wino_items_per_block(N, H, W, Cout)
+    assert items >= 256 and per_block > 1.0, "case does not reach the multi-item loop: %d items" % items
+    g = torch.Generator(device="cuda").manual_seed(N * 1000003 + H * 1009 + Cin * 31 + Cout)
+    x = torch.randn(N, H, W, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, 9 * Cin, device="cuda", generator=g) / (9 * Cin) ** 0.5            # packed [Cout][tap][Cin]
+    sc = torch.rand(Cout, device="cuda", generator=g) + 0.5
+    sh = torch.randn(Cout, device="cuda", generator=g)
+    u = ops.winograd_pack(w, Cin, Cout)
+    args = (x, w, 3, 3, 1, 1, 1, H, W, sc, sh, None, 0, True)
+    assert ops.conv2d_kernel_name(*args, w_wino=u) == "wino64_kernel"
+    out = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+    got = ops.conv2d(*args, out=out, w_wino=u)
+    assert bool(torch.isfinite(got).all())
+    direct = ops.conv2d(*args)
+    assert not ops.conv2d_kernel_name(*args).startswith("wino")
+    scale = max(1.0, float(direct.abs().max()))
+    assert float((got - direct).abs().max()) / scale < 2e-5
+    # float64 oracle on windows
+    xh = x.cpu().numpy().astype(np.float64)
+    wk = w.cpu().numpy().astype(np.float64).reshape(Cout, 3, 3, Cin).transpose(1, 2, 3, 0)     # HWIO
+    sch, shh = sc.cpu().numpy().astype(np.float64), sh.cpu().numpy().astype(np.float64)
+    gh = got.cpu().numpy().astype(np.float64)
+    S = 12
+    ys = sorted({0, H - S, max(0, 16 - S // 2), max(0, (H // 32) * 16 - S // 2), max(0, H - 16 - S // 2)})
+    xs = sorted({0, W - S, max(0, 16 - S // 2), max(0, (W // 32) * 16 - S // 2), max(0, W - 16 - S // 2)})
+    worst = 0.0
+    for n in sorted({0, N - 1}):
+        for y0 in ys:
+            for x0 in xs:
+                y1, x1 = min(H, y0 + S), min(W, x0 + S)
+                patch = np.zeros((1, y1 - y0 + 2, x1 - x0 + 2, Cin))
+                sy0, sx0, sy1, sx1 = max(0, y0 - 1), max(0, x0 - 1), min(H, y1 + 1), min(W, x1 + 1)
+                patch[0, sy0 - (y0 - 1):sy1 - (y0 - 1), sx0 - (x0 - 1):sx1 - (x0 - 1)] = xh[n, sy0:sy1, sx0:sx1]
+                want = np.maximum(O.conv2d_nhwc(patch, wk, None, 1, 'valid')[0] * sch + shh, 0)
+                worst = max(worst, float(np.abs(gh[n, y0:y1, x0:x1] - want).max()))
+    assert worst / scale < 2e-5, "windows vs float64 oracle: %.3e" % (worst / scale)
 
 
 @pytest.mark.parametrize("force", ["1", "32", "64"])
@@ -691,6 +754,18 @@ def test_dgrad_weight_pack_scatter_l2(ops):
     ops.l2_reg(dev(wv), dev(coef), gd, loss)
     close(gd, g + 2 * coef * wv, 1e-6)
     close(loss, np.array([(coef * wv * wv).sum()]), 1e-5)
+    mask = (rng.random(n) < 0.5).astype(np.float64)           # the 0/1 trainable subset folded into the same pass
+    gd2, loss2 = dev(g), torch.empty(1, device="cuda")
+    ops.l2_reg(dev(wv), dev(coef), gd2, loss2, mask=dev(mask))
+    close(gd2, g * mask + 2 * coef * wv, 1e-6)
+    assert torch.equal(loss, loss2)                           # fixed-order sum: the same bits every time
+    big = torch.randn(3_000_001, device="cuda")
+    cb = torch.rand(3_000_001, device="cuda")
+    l1, l2 = torch.empty(1, device="cuda"), torch.empty(1, device="cuda")
+    ops.l2_reg(big, cb, None, l1)
+    ops.l2_reg(big, cb, None, l2)
+    assert torch.equal(l1, l2)
+    assert abs(float(l1) - float((cb.double() * big.double() ** 2).sum())) < 1e-5 * float(l1)
 
 
 @pytest.mark.parametrize("case", [(1, 2, 2, 64, 20, 1), (1, 4, 4, 256, 512, 3), (1, 16, 16, 512, 20, 1), (1, 8, 8, 2048, 256, 1)])
@@ -812,3 +887,25 @@ def test_dropout_mask_is_keras_inverted_dropout_of_ones(ops):
     k = (a.reshape(4, 200, 512) > 0)
     assert abs(np.corrcoef(k[0].ravel(), k[1].ravel())[0, 1]) < 0.02    # the four gate masks are uncorrelated
     assert np.all(ops.dropout_mask(torch.empty(64, device="cuda"), 0.0, 1, 1).cpu().numpy() == 1.0)
+
+
+def test_bn_bwd_recovers_the_normalised_activation_and_survives_dead_channels(ops):
+    """dc_bn_bwd_f32: dacc = dz * scale, dzn = dz * n with n = (bn_out - beta) / gamma recovered from the stored BN output.  A dead
+    channel (gamma == 0: pretrained ResNet BatchNorm layers have them) must give dzn = 0, not 0 / 0 = NaN: a NaN in
+    dgamma would reach the AMSGrad state of the whole flat bucket through the clip norm."""
+    rng = np.random.default_rng(21)
+    rows, Cc = 37, 16
+    n = rng.standard_normal((rows, Cc))
+    gamma, beta = rng.uniform(0.5, 1.5, Cc), rng.standard_normal(Cc)
+    gamma[3], gamma[10] = 0.0, 0.0
+    short = rng.standard_normal((rows, Cc))
+    a = n * gamma + beta + short                              # a block's last convolution: out - shortcut is the BN output
+    dz = rng.standard_normal((rows, Cc)) * (rng.random((rows, Cc)) < 0.7)
+    scale = gamma / np.sqrt(rng.uniform(0.5, 1.5, Cc) + 1e-3)
+    dacc, dzn = torch.empty(rows, Cc, device="cuda"), torch.empty(rows, Cc, device="cuda")
+    ops.bn_bwd(dev(dz), dev(a), dev(short), dev(gamma), dev(beta), dev(scale), dacc, dzn)
+    assert bool(torch.isfinite(dzn).all()) and bool(torch.isfinite(dacc).all())
+    want = dz * n
+    want[:, [3, 10]] = 0.0
+    close(dacc, dz * scale, 1e-6)
+    close(dzn, want, 2e-5)

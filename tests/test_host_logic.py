@@ -525,6 +525,38 @@ def test_hdf5_writer_nests_wrapped_layers_like_keras(tmp_path):
     assert set(back) == set(W) and all(np.array_equal(back[k], W[k]) for k in W)
 
 
+def test_hdf5_writer_lists_weights_in_keras_layer_weights_order(tmp_path):
+    """Keras' load_weights_from_hdf5_group_by_name matches a GROUP by name and then assigns weight_values[i] to layer.weights[i] by
+    POSITION: Conv2D / Dense = kernel, bias; LSTM = kernel, recurrent_kernel, bias; BatchNorm = gamma, beta, moving_mean,
+    moving_variance; TimeDistributed(Model) = the model's trainable weights in layer order, then its non-trainable ones
+    (word_generation_model, dense_img_cap/dense_model.py:758-784: lstm1, lstm2, d1, d2, then the frozen embedding).  The writer
+    must list them so whatever order the parameter store hands them over in (sorted by name here, like ParamStore)."""
+    from image_captioning_amd import hdf5_lite as H
+    rng = np.random.default_rng(2)
+    r = lambda *s: rng.standard_normal(s).astype(np.float32)
+    W = {"imgcap_embedding_layer/embeddings": r(9, 3),
+         "imgcap_lstm1/bias": r(8), "imgcap_lstm1/kernel": r(5, 8), "imgcap_lstm1/recurrent_kernel": r(2, 8),
+         "imgcap_lstm2/bias": r(8), "imgcap_lstm2/kernel": r(2, 8), "imgcap_lstm2/recurrent_kernel": r(2, 8),
+         "imgcap_lstm_d1/bias": r(4), "imgcap_lstm_d1/kernel": r(4, 4), "imgcap_lstm_d2/bias": r(9), "imgcap_lstm_d2/kernel": r(4, 9),
+         "mrcnn_class_bn1/beta": r(4), "mrcnn_class_bn1/gamma": r(4), "mrcnn_class_bn1/moving_mean": r(4), "mrcnn_class_bn1/moving_variance": r(4),
+         "mrcnn_class_conv1/bias": r(4), "mrcnn_class_conv1/kernel": r(7, 7, 2, 4)}
+    W = {k: W[k] for k in sorted(W)}
+    inner = ["imgcap_lstm1", "imgcap_lstm2", "imgcap_lstm_d1", "imgcap_lstm_d2", "imgcap_embedding_layer"]
+    path = str(tmp_path / "order.h5")
+    H.save_keras_weights(path, W, layer_groups={l: "imgcap_caption_td" for l in inner}, group_member_order={"imgcap_caption_td": inner})
+    f = H.H5File(path)
+    assert H._attr_list(f["imgcap_caption_td"], "weight_names") == [
+        "imgcap_lstm1/kernel:0", "imgcap_lstm1/recurrent_kernel:0", "imgcap_lstm1/bias:0",
+        "imgcap_lstm2/kernel:0", "imgcap_lstm2/recurrent_kernel:0", "imgcap_lstm2/bias:0",
+        "imgcap_lstm_d1/kernel:0", "imgcap_lstm_d1/bias:0", "imgcap_lstm_d2/kernel:0", "imgcap_lstm_d2/bias:0",
+        "imgcap_embedding_layer/embeddings:0"]
+    assert H._attr_list(f["mrcnn_class_bn1"], "weight_names") == ["mrcnn_class_bn1/gamma:0", "mrcnn_class_bn1/beta:0",
+                                                                  "mrcnn_class_bn1/moving_mean:0", "mrcnn_class_bn1/moving_variance:0"]
+    assert H._attr_list(f["mrcnn_class_conv1"], "weight_names") == ["mrcnn_class_conv1/kernel:0", "mrcnn_class_conv1/bias:0"]
+    back = H.load_keras_weights(path)
+    assert set(back) == set(W) and all(np.array_equal(back[k], W[k]) for k in W)
+
+
 def test_hdf5_reader_rejects_what_it_does_not_implement(tmp_path):
     from image_captioning_amd import hdf5_lite as H
     with pytest.raises(H.Hdf5Error):
