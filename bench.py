@@ -226,6 +226,41 @@ def gpu_configs1(dev, steps=30):
             "ms_per_step": 1e3 * dt, "steps": steps, "final_loss": float(loss.item())}
 
 
+def gpu_configs0(dev, steps=30):
+    """BASELINE configs[0] on the GPU (the reference's own CPU-runnable case, timed beside configs0_cpu): text_generation_model.py
+    Model 3 -- trainable RoI head + 2 x LSTM-512 + Dense-1024 + Dense-V, batch 8, V = 1000, T = 10 -- one train_on_batch-equivalent
+    step (forward, roi_caption_loss, backward incl. the head, AMSGrad) through the single masked pass, with the reference's
+    recurrent_dropout = 0.2 (device-side Philox masks) and with dropout off."""
+    from image_captioning_amd import synth
+    from image_captioning_amd.text_generation_model import DenseCapConfig, build_lstm_model, Adam, roi_caption_loss, caption_targets
+    V, T, B = 1000, 10, 8
+    out = {"workload": "BASELINE configs[0]: text_generation_model.py decoder (Model 3), RoI features [8,7,7,256], V=1000, T=10, trainable head, "
+                       "train step, fp32; single masked pass == the reference's T-prefix graph (tests/test_gpu_models.py)", "unit": "captions/s",
+           "steps": steps}
+    rng = np.random.default_rng(5)
+    feat = torch.tensor(rng.standard_normal((B, 7, 7, 256)).astype(np.float32), device=dev)
+    caps = synth.captions_v1(6, B, T, V)
+    tgt = caption_targets(caps).astype(np.int32)
+    for rate in (0.2, 0.0):
+        cfg = DenseCapConfig(V, synth.embedding_matrix(3, V), B)
+        cfg.PADDING_SIZE = T
+        model = build_lstm_model([7, 7, 256], cfg, 512, 'training', device=dev, seed=0)
+        model.recurrent_dropout = rate
+        model.compile(optimizer=Adam(amsgrad=True), loss=roi_caption_loss)
+        for _ in range(3):
+            model.train_step(feat, caps, tgt)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = model.train_step(feat, caps, tgt)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out["recurrent_dropout_%.1f" % rate] = {"value": B / dt, "ms_per_step": 1e3 * dt, "final_loss": float(loss.item())}
+    out["value"] = out["recurrent_dropout_0.2"]["value"]              # the reference's training default
+    out["ms_per_step"] = out["recurrent_dropout_0.2"]["ms_per_step"]
+    return out
+
+
 def dataset_pipeline_leg(args, dev, steps=40):
     """The headline workload driven through the training script's objects instead of bench.py's resident buffers:
     text_generation_model_v2.train_on_dataset on a synthetic in-memory Dataset (8 images of the benchmark's size, `rois` regions with
@@ -338,6 +373,9 @@ class E2E(object):
         for _ in range(max(warmup, 2)):               # >= 2: the second call captures the encoder hipGraph
             loss = self.step()
         self.flush()
+        if self.sync is not None:
+            self.sync.exposed_ms()                    # (drop the warm-up's marks)
+            self.sync.timing = True
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -492,6 +530,9 @@ def run_joint(args, dev, rank, world, barrier):
     model, inner, inputs, cfg = build_joint(args, dev, rank, world)
     for _ in range(max(args.warmup, 2)):
         out = inner.train_on_batch(inputs)
+    if world > 1 and getattr(inner, "grad_sync", None) is not None and hasattr(inner.grad_sync, "exposed_ms"):
+        inner.grad_sync.exposed_ms()
+        inner.grad_sync.timing = True
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -660,11 +701,21 @@ def main():
 
     ranks_seen = GradAllReduce().check_ranks(dev)        # an actual all-reduce of ones: the ranks the backend connected
     backend = dist.get_backend() if world > 1 else None
+    if world > 1:
+        # one rank per GPU over RCCL whenever the node has a GPU per rank: a silent fall-back to gloo must not produce a scaling number
+        if torch.cuda.device_count() >= world and "DCAP_DIST_BACKEND" not in os.environ:
+            assert backend == "nccl", "%d GPUs for %d ranks but the process group runs on %r" % (torch.cuda.device_count(), world, backend)
+        assert ranks_seen == world, "the backend connected %d of %d ranks" % (ranks_seen, world)
+        from image_captioning_amd.parallel_model import reserve_cus_for_collectives
+        persistent_cus = reserve_cus_for_collectives(world)      # before any encoder graph is captured
+    else:
+        persistent_cus = None
     S, V, T, R, B = args.image_size, args.vocab, args.tokens, args.rois, args.images_per_gpu
 
     if args.config == "joint":
         dt, losses, rois_per_step, inner = run_joint(args, dev, rank, world, barrier)
         dt = max_over_ranks(dt)
+        ar = inner.grad_sync.exposed_ms() if (world > 1 and getattr(inner, "grad_sync", None) is not None) else None
         out = {
             "metric": "captions/sec (train step) on 1024px joint model (2000 proposals -> 200 RoI x 15tok) synth",
             "value": world * rois_per_step * args.steps / dt, "unit": "captions/s", "n_gpus": world, "steps": args.steps,
@@ -675,7 +726,9 @@ def main():
                                    "+ 4 losses + Adam(amsgrad, clipnorm 0.5); %dx%d synth image, 1 image/GPU, V=%d, %d-token captions"
                                    % (S, S, V, T), "images_per_gpu": 1, "rois_per_image": rois_per_step, "parallelism": "dp%d" % world,
                        "decoder_dtype": args.joint_dtype, "recurrent_dropout": args.joint_dropout, "conv_math": inner.conv_math_name, "losses": [float(v) for v in losses],
-                       "rccl_ranks": ranks_seen, "dist_backend": backend},
+                       "rccl_ranks": ranks_seen, "dist_backend": backend, "persistent_cus": persistent_cus,
+                       "allreduce_exposed_ms_per_step": None if ar is None else round(ar[0], 4),
+                       "allreduce_host_wait_ms_per_step": None if ar is None else round(ar[1], 4)},
         }
         if rank == 0 and not args.no_roofline and args.joint_dtype == "bf16" and inner.conv_math_name == "bf16":
             inner.grad_sync = None
@@ -692,6 +745,7 @@ def main():
     e2e = E2E(args, dev, rank, world, B)
     dt, loss = e2e.timed(args.warmup, args.steps, barrier)
     dt = max_over_ranks(dt)
+    ar = e2e.sync.exposed_ms() if e2e.sync is not None else None      # rank 0's view: time its decoder stream stood still for the exchange
     captions = world * B * R * args.steps
     final_loss = float(loss.item())
 
@@ -710,7 +764,9 @@ def main():
                    "images_per_gpu": B, "global_batch_images": B * world, "captions_per_step": B * R * world,
                    "parallelism": "dp%d" % world, "stage4_blocks": args.stage4_blocks, "final_loss": final_loss,
                    "pipeline": "encoder(i+1) || decoder(i), 2 HIP streams" if e2e.pipe is not None else "single stream",
-                   "rccl_ranks": ranks_seen, "dist_backend": backend,
+                   "rccl_ranks": ranks_seen, "dist_backend": backend, "persistent_cus": persistent_cus,
+                   "allreduce_exposed_ms_per_step": None if ar is None else round(ar[0], 4),
+                   "allreduce_host_wait_ms_per_step": None if ar is None else round(ar[1], 4),
                    "grad_allreduce": ("per layer group, asynchronous, issued as each group's backward is enqueued" if world > 1 else None)},
     }
 
@@ -721,8 +777,9 @@ def main():
         # fp32 accumulate; csrc/igemm_bf16s.h), each mode timed by a child process of this one after the headline run.
         # Reported beside the headline, which stays on exact fp32 products.
         torch.cuda.synchronize()
-        labels = {"bf16x3": "3-piece bf16 split of both operands, 6 MFMA products, fp32 accumulate (fp32-grade: same test tolerances)",
-                  "bf16x2": "2-piece bf16 split, 3 MFMA products, fp32 accumulate (2^-16 products; features within 1e-3 of the oracle)"}
+        # (the 3-piece split, DCAP_CONV_MATH=bf16x3, stays available and tested, but since the fp32 default runs its 3x3 layers in the
+        # Winograd form it is slower than the headline and no longer a bench leg)
+        labels = {"bf16x2": "2-piece bf16 split, 3 MFMA products, fp32 accumulate (2^-16 products; features within 1e-3 of the oracle)"}
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-alt-math",
                "--no-cpu-baseline", "--no-other-configs", "--images-per-gpu", str(B), "--rois", str(R), "--tokens", str(T),
                "--vocab", str(V), "--image-size", str(S), "--stage4-blocks", str(args.stage4_blocks)] + (["--no-pipeline"] if args.no_pipeline else [])
@@ -754,6 +811,7 @@ def main():
             four = json.loads(r4.stdout.strip().splitlines()[-1])
             other["four_images_per_gpu"] = {"workload": "the headline's model at 4 images x %d RoI per step and GPU (not a BASELINE config)" % R,
                                             "value": four["value"], "unit": "captions/s", "ms_per_step": four["ms_per_step"], "steps": four["steps"]}
+            other["configs0_gpu"] = gpu_configs0(dev)
             other["configs1_gpu"] = gpu_configs1(dev)
             other["train_on_dataset"] = dataset_pipeline_leg(args, dev)
             # configs[2]'s label taken literally: the VGG16 13-conv backbone (child process; its roofline leg gives the conv TFLOP/s)

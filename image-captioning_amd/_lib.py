@@ -185,6 +185,8 @@ SYMBOLS = {
     "dc_conv_weight_dgrad_pack_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dc_rpn_loss_grad_f32": (C.c_int, [C.POINTER(RpnLossDesc), C.c_void_p]),
     "dc_scatter2_add_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dc_set_persistent_cus": (C.c_int, [C.c_int]),
+    "dc_get_persistent_cus": (C.c_int, []),
     "dc_l2_reg_workspace_bytes": (C.c_size_t, [C.c_size_t]),
     "dc_l2_reg_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_axpy_f32": (C.c_int, [C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

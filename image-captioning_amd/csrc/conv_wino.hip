@@ -520,6 +520,20 @@ static int wino_force() {
     return force;
 }
 
+// CUs the PERSISTENT grids may occupy (a multiple of 8, one share per XCD).  A persistent block never yields its CU: with one block
+// per CU on all 256 a kernel of another queue -- RCCL's all-reduce in a data-parallel run -- would wait for the whole encoder pass.
+// dc_set_persistent_cus(n) / DCAP_WINO_CUS leave 256 - n CUs free for it (bench.py and ParallelModel set 248 when world > 1).
+static std::atomic<int> g_persistent_cus{-1};
+static int persistent_cus() {
+    int v = g_persistent_cus.load(std::memory_order_relaxed);
+    if (v < 0) {
+        static const int env = env_int("DCAP_WINO_CUS", kNumCU);
+        v = env;
+    }
+    v = std::max(8, std::min(v, kNumCU));
+    return v / 8 * 8;
+}
+
 int conv_winograd_tiles(const dc_conv_desc* d) {
     const int force = wino_force();
     if (force == 32 || force == 64) return force;
@@ -555,7 +569,7 @@ int conv2d_winograd(const dc_conv_desc* d, hipStream_t s) {
         return check_launch("dc_conv2d (winograd)");
     }
     // persistent: the blocks that fit the chip walk the work items (a multiple of 8 blocks, so that an item's XCD is fixed by item % 8)
-    const long slots = big ? kNumCU : 2 * kNumCU;
+    const long slots = big ? persistent_cus() : 2 * persistent_cus();
     const unsigned grid = items >= slots ? (unsigned)slots : (unsigned)std::max<long>(8, items / 8 * 8);
     if (big) {
         DC_ENSURE_DYN_LDS(wino::wino64_kernel, wino::wp::Cfg<2>::LDS_BYTES);
@@ -585,3 +599,11 @@ extern "C" int dc_conv2d_winograd_pack_f32(const float* w, float* u, int Cin, in
     hipLaunchKernelGGL(wino::wino_pack_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w, u, Cin, Cout);
     return check_launch("dc_conv2d_winograd_pack_f32");
 }
+
+extern "C" int dc_set_persistent_cus(int n) {
+    DC_REQUIRE(n == 0 || (n >= 8 && n <= kNumCU), DC_EINVAL, "dc_set_persistent_cus: 0 (default: DCAP_WINO_CUS or all 256) or 8..256, got %d", n);
+    dcap::g_persistent_cus.store(n == 0 ? -1 : n, std::memory_order_relaxed);
+    return DC_OK;
+}
+
+extern "C" int dc_get_persistent_cus(void) { return dcap::persistent_cus(); }

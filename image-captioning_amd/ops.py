@@ -657,6 +657,13 @@ def l2_reg(w, coef, grad=None, loss=None, mask=None):
     return loss
 
 
+def set_persistent_cus(n):
+    """CUs the persistent Winograd grids may occupy (0 = default); see dc_set_persistent_cus in include/dcap.h."""
+    lib = _lib.load()
+    check(lib.dc_set_persistent_cus(int(n)), "dc_set_persistent_cus")
+    return int(lib.dc_get_persistent_cus())
+
+
 def axpy(a, x, y):
     lib = _lib.load()
     check(lib.dc_axpy_f32(float(a), _ptr(_chk(x, name="x")), _ptr(_chk(y, name="y")), x.numel(), _stream()), "dc_axpy_f32")

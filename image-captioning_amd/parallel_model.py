@@ -34,6 +34,17 @@ def init_process_group_from_env(backend=None):
     return rank, world, local_rank
 
 
+def reserve_cus_for_collectives(world, cus=None):
+    """world > 1: the encoder's persistent Winograd grids (one block per CU, held for the whole launch) leave 8 of the 256 CUs --
+    one per XCD -- to the RCCL kernels of the gradient all-reduce, which otherwise could only start between encoder launches.
+    DCAP_WINO_CUS overrides; call before the encoder plan captures its hipGraph (a captured graph keeps its grid)."""
+    if world <= 1 or not torch.cuda.is_available():
+        return None
+    from . import ops
+    want = int(os.environ.get("DCAP_WINO_CUS", cus if cus is not None else 248))
+    return ops.set_persistent_cus(want)
+
+
 def shard(x, rank, world):
     """tf.split(x, gpu_count) on axis 0, keeping this rank's slice (parallel_model.py:60-62)."""
     n = x.shape[0] if hasattr(x, "shape") else len(x)
@@ -54,6 +65,10 @@ class GradAllReduce(object):
 
         self._pending = []              # (work handle, lo, hi) of the ranges already on the wire this step
         self.ranks_seen = None          # world size RCCL reported after a real all-reduce (bench.py prints it)
+        # timing=True: a HIP event pair on the CURRENT stream around the step's waits -- the time the compute stream stood still for
+        # the exchange (the EXPOSED part of the all-reduce; what overlapped the backward does not show) -- plus the host's own wait
+        self.timing = False
+        self._marks, self._host_wait = [], 0.0
 
     def ready(self, flat_grad, lo, hi):
         """A contiguous range [lo, hi) of the gradient bucket is final (its layer group's backward has been enqueued):
@@ -77,10 +92,32 @@ class GradAllReduce(object):
             if lo > pos:
                 self.ready(flat_grad, pos, lo)
             pos = max(pos, hi)
+        if self.timing and flat_grad.is_cuda:
+            import time
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            t0 = time.perf_counter()
         for work, _, _ in self._pending:
             work.wait()
+        if self.timing and flat_grad.is_cuda:
+            e1.record()
+            self._host_wait += time.perf_counter() - t0
+            self._marks.append((e0, e1))
         self._pending = []
         return 1.0 / self.world
+
+    def exposed_ms(self, reset=True):
+        """(mean exposed all-reduce time per step on the compute stream in ms, mean host wait per step in ms, steps) since the last
+        reset; synchronises the device."""
+        if not self._marks:
+            return None
+        torch.cuda.synchronize()
+        n = len(self._marks)
+        dev_ms = sum(a.elapsed_time(b) for a, b in self._marks) / n
+        host_ms = 1e3 * self._host_wait / n
+        if reset:
+            self._marks, self._host_wait = [], 0.0
+        return dev_ms, host_ms, n
 
     def barrier(self):
         if self.world > 1:
@@ -108,6 +145,7 @@ class ParallelModel(object):
         self.inner_model = keras_model
         self.gpu_count = gpu_count
         self.rank = dist.get_rank() if dist.is_initialized() else 0
+        reserve_cus_for_collectives(world)
         keras_model.grad_sync = GradAllReduce()
         keras_model.is_chief = self.rank == 0          # one rank prints and writes checkpoints (the others barrier)
         keras_model._outer = self                      # the wrapped model's train() loop feeds global batches through this wrapper

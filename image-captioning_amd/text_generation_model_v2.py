@@ -15,7 +15,7 @@ import os
 import numpy as np
 import torch
 
-from . import ops, synth
+from . import ops, synth, utils
 from .config import Config
 from .keras_like import KerasLikeModel, ModelCheckpoint, CSVLogger  # noqa: F401  (re-exported for scripts)
 from .layers import V2_WORD_LSTM
@@ -221,6 +221,7 @@ def train_on_dataset(model, features_model, dataset, images_per_step, rois_per_i
     def batches():
         ids = np.array(dataset.image_ids)
         pos = 0
+        stage = np.empty((images_per_step, H, W, 3), np.uint8)      # molded images are written here one by one: no np.stack copy
         while True:
             imgs, boxes, caps = [], [], []
             while len(imgs) < images_per_step:
@@ -235,14 +236,16 @@ def train_on_dataset(model, features_model, dataset, images_per_step, rois_per_i
                     words = [[int(np.argmax(w)) for w in c] for c in captions[:rois_per_image]]
                 if len(rois) < rois_per_image:
                     continue
-                molded, _, _ = features_model.mold_inputs([dataset.load_image(image_id)])
-                imgs.append(molded[0])
+                molded = utils.resize_image(dataset.load_image(image_id), min_dim=cfg.IMAGE_MIN_DIM, max_dim=cfg.IMAGE_MAX_DIM,
+                                            padding=cfg.IMAGE_PADDING)[0]       # mold_inputs() without its stack / meta (mean pixel: on the GPU)
+                stage[len(imgs)] = molded
+                imgs.append(image_id)
                 boxes.append(np.asarray(rois[:rois_per_image], np.float32))
                 caps += [[int(t) for t in c] for c in words[:rois_per_image]]
             # everything the step needs goes to the GPU here, on the producer thread (blocking copies on its stream: complete when
             # the batch is queued), so the training loop below only enqueues kernels
             with torch.cuda.stream(s_copy):
-                images_dev = torch.as_tensor(np.stack(imgs)).to(dev)
+                images_dev = torch.as_tensor(stage).to(dev)              # blocking copy: `stage` is free again when it returns
                 boxes_dev = plan.normalize_boxes(np.stack(boxes))
                 tables = SampleTables.from_captions(caps, dev)
                 s_copy.synchronize()

@@ -97,9 +97,10 @@ def resize_image(image, min_dim=None, max_dim=None, padding=False):
         top = (max_dim - h) // 2
         left = (max_dim - w) // 2
         padding = [(top, max_dim - h - top), (left, max_dim - w - left), (0, 0)]
-        image = np.pad(image, padding, mode='constant', constant_values=0)
+        if any(p != (0, 0) for p in padding):            # (an image that already has the molded size is handed on as it is: no copies)
+            image = np.pad(image, padding, mode='constant', constant_values=0)
         window = (top, left, h + top, w + left)
-    return image.astype(dtype), window, scale, padding
+    return image.astype(dtype, copy=False), window, scale, padding
 
 
 def compose_image_meta(image_id, image_shape, window):

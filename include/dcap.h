@@ -213,6 +213,13 @@ int    dc_conv2d_is_pointwise(const dc_conv_desc* d);
  * feature_generation/dense_model.py:85-100, :1417-1421 are evaluated. */
 size_t dc_conv2d_winograd_weight_bytes(int Cin, int Cout);
 int    dc_conv2d_winograd_pack_f32(const float* w, float* u, int Cin, int Cout, void* stream);
+/* CUs the persistent Winograd grids may occupy (process-wide; a multiple of 8 -- one share per XCD; 0 restores the default:
+ * DCAP_WINO_CUS or all 256).  A persistent block holds its CU for the whole launch: in a data-parallel run (parallel_model.py:58-102
+ * -> one rank per GPU here) the RCCL all-reduce of another queue needs CUs of its own to overlap the encoder pass, so
+ * ParallelModel / bench.py set 248 when world > 1.  Takes effect at the next launch; a captured hipGraph keeps the grid it was
+ * captured with. */
+int    dc_set_persistent_cus(int n);
+int    dc_get_persistent_cus(void);
 
 /* ------------------------------------------------------------------------------------------------
  * conv2d weight gradient (for the layers the joint model trains: fpn_*, rpn_*, dense_img_cap/dense_model.py

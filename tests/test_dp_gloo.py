@@ -175,3 +175,43 @@ def test_param_store_layer_ranges_are_contiguous_layer_groups():
         st2.add(k, np.ones(shp), True)
     st2.finalize()
     assert st2.layer_range("a") == (0, 24) and st2.layer_range("b") == (24, 28)
+
+
+def _worker_configs3(rank, world, port, out_dir):
+    """configs[3]'s layout: 16 images x 32 RoIs split tf.split-wise into 2 images per rank; the flat gradient bucket travels in
+    layer-group ranges announced out of order through ready() (as the backward enqueues them) plus the final call that covers the
+    rest -- every element must be summed over the 8 ranks EXACTLY once."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from image_captioning_amd.parallel_model import GradAllReduce, init_process_group_from_env, shard
+    r, w, _ = init_process_group_from_env(backend="gloo")
+    images = np.arange(16 * 3).reshape(16, 3)                       # stand-ins: row i = image i
+    rois = np.arange(16 * 32 * 4).reshape(16, 32, 4)
+    mine_i, mine_r = shard(images, rank, world), shard(rois, rank, world)
+    assert mine_i.shape == (2, 3) and mine_r.shape == (2, 32, 4)
+    assert mine_i[0, 0] == 3 * 2 * rank and mine_r[0, 0, 0] == 2 * rank * 128       # rank k owns images 2k, 2k+1 (axis-0 split)
+    n = 300_007                                                     # not a multiple of anything
+    g = torch.arange(n, dtype=torch.float64) * (rank + 1)           # rank-dependent "gradient"
+    sync = GradAllReduce(bucket_bytes=1 << 18)                      # 65 536-element pieces: several per range
+    ranges = [(250_000, 300_007), (120_001, 250_000), (0, 40_000)]  # d1 -> inject-LSTM -> ...; (40 000, 120 001) is left to the final call
+    for lo, hi in ranges:
+        sync.ready(g, lo, hi)
+    scale = sync(g)
+    assert scale == 1.0 / world and not sync._pending
+    want = torch.arange(n, dtype=torch.float64) * sum(range(1, world + 1))
+    ok = bool(torch.equal(g, want))
+    # a second step reuses the object: nothing may be left over from the first
+    g2 = torch.ones(1000, dtype=torch.float64)
+    sync.ready(g2, 10, 20)
+    sync(g2)
+    ok = ok and bool(torch.equal(g2, torch.full((1000,), float(world), dtype=torch.float64)))
+    if rank == 0:
+        np.save(os.path.join(out_dir, "ok.npy"), np.array([int(ok)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_shard_and_bucket_coverage_at_configs3_layout(tmp_path):
+    world = 8
+    mp.spawn(_worker_configs3, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert int(np.load(tmp_path / "ok.npy")[0]) == 1
