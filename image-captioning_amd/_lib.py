@@ -123,7 +123,15 @@ class RpnLossDesc(C.Structure):
                 ("heads", C.c_void_p * 5), ("dheads", C.c_void_p * 5), ("Hs", C.c_int * 5), ("Ws", C.c_int * 5),
                 ("n_sel", C.c_int), ("n_pos", C.c_int),
                 ("sel_level", C.c_void_p), ("sel_index", C.c_void_p), ("sel_match", C.c_void_p),
-                ("target_deltas", C.c_void_p), ("losses", C.c_void_p)]
+                ("target_deltas", C.c_void_p), ("losses", C.c_void_p), ("counts_dev", C.c_void_p)]
+
+
+class DetectionTargetsDesc(C.Structure):
+    _fields_ = [("n_proposals", C.c_int), ("n_gt", C.c_int), ("n_rois", C.c_int), ("T", C.c_int),
+                ("proposals", C.c_void_p), ("gt_boxes", C.c_void_p), ("gt_captions", C.c_void_p),
+                ("max_positive", C.c_int), ("inv_ratio", C.c_float), ("shuffle", C.c_int),
+                ("seed", C.c_uint32), ("offset", C.c_uint32), ("offset_dev", C.c_void_p),
+                ("rois", C.c_void_p), ("captions", C.c_void_p), ("counts", C.c_void_p)]
 
 
 class AmsgradDesc(C.Structure):
@@ -131,7 +139,7 @@ class AmsgradDesc(C.Structure):
                 ("v", C.c_void_p), ("vhat", C.c_void_p),
                 ("lr_t", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("grad_scale", C.c_float), ("gnorm_sq", C.c_void_p), ("clipnorm", C.c_float),
-                ("p_bf16", C.c_void_p), ("n_bf16", C.c_size_t)]
+                ("p_bf16", C.c_void_p), ("n_bf16", C.c_size_t), ("lr_t_dev", C.c_void_p)]
 
 
 # name -> (restype, argtypes): every symbol include/dcap.h declares
@@ -185,6 +193,8 @@ SYMBOLS = {
     "dc_conv_weight_dgrad_pack_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dc_rpn_loss_grad_f32": (C.c_int, [C.POINTER(RpnLossDesc), C.c_void_p]),
     "dc_scatter2_add_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dc_detection_targets_f32": (C.c_int, [C.POINTER(DetectionTargetsDesc), C.c_void_p]),
+    "dc_caption_tables_i32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dc_set_persistent_cus": (C.c_int, [C.c_int]),
     "dc_get_persistent_cus": (C.c_int, []),
     "dc_l2_reg_workspace_bytes": (C.c_size_t, [C.c_size_t]),
@@ -201,7 +211,7 @@ SYMBOLS = {
     "dc_bn_bwd_f32": (C.c_int, [C.c_void_p] * 8 + [C.c_long, C.c_int, C.c_void_p]),
     "dc_mul_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_maxpool3x3s2_same_bwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
-    "dc_dropout_mask_f32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "dc_dropout_mask_f32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "dc_amsgrad_step_f32": (C.c_int, [C.POINTER(AmsgradDesc), C.c_void_p]),
 }
 

@@ -63,4 +63,37 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / kNumXCD;
 }
 
+// Zero `bytes` bytes at `p` (both multiples of 4) with a KERNEL.  Used instead of hipMemsetAsync wherever a launch sequence may be
+// captured into a hipGraph: a captured memset becomes a memset NODE, and on this runtime the joint train step replayed as a graph
+// faulted on its second launch inside the top-k radix select (whose histograms a memset node was supposed to clear) while the same
+// sequence issued eagerly, or with this kernel in the graph, is fine (round 4; tools/diag_joint_graph4.py).
+__global__ __launch_bounds__(256) inline void zero_fill_kernel(unsigned* __restrict__ p, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+inline int zero_fill_async(void* p, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return DC_OK;
+    if ((reinterpret_cast<uintptr_t>(p) & 3u) || (bytes & 3u)) {
+        set_error("zero_fill: pointer and size must be multiples of 4");
+        return DC_EALIGN;
+    }
+    const size_t words = bytes / 4;
+    const int blocks = (int)((words + 1023) / 1024 < 2048 ? (words + 1023) / 1024 : 2048);
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, static_cast<unsigned*>(p), words);
+    return check_launch("zero_fill_kernel");
+}
+
+// Philox-2x32-10 (counter (c0, c1), key): element i of stream (seed, offset) depends on nothing else -- dropout masks (loss.hip) and
+// the detection-target shuffle (proposal.hip) draw from it.
+__device__ __forceinline__ unsigned philox2x32(unsigned c0, unsigned c1, unsigned key) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p = (unsigned long long)0xD256D193u * c0;
+        const unsigned hi = (unsigned)(p >> 32), lo = (unsigned)p;
+        c0 = hi ^ key ^ c1;
+        c1 = lo;
+        key += 0x9E3779B9u;
+    }
+    return c0;
+}
+
 }  // namespace dcap

@@ -344,6 +344,7 @@ __global__ __launch_bounds__(256) void amsgrad_kernel(dc_amsgrad_desc d) {
         if (norm >= d.clipnorm) gscale *= d.clipnorm / norm;
     }
     const float b1 = d.beta1, b2 = d.beta2;
+    if (d.lr_t_dev) d.lr_t = d.lr_t_dev[0];
     const size_t n4 = d.n >> 2;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         float4 g = reinterpret_cast<const float4*>(d.g)[i];
@@ -537,20 +538,9 @@ extern "C" int dc_axpy_f32(float a, const float* x, float* y, size_t n, void* st
 // Keras K.dropout(ones, rate) (tf.nn.dropout: keep with probability 1 - rate, kept entries scaled by 1 / (1 - rate)) from a
 // counter-based generator: element i of stream (seed, offset) depends on nothing else, so a mask is reproducible and
 // independent of the launch geometry.  Philox-2x32-10 keyed by the seed, counter = (i, offset).
-__device__ __forceinline__ unsigned philox2x32(unsigned c0, unsigned c1, unsigned key) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned long long p = (unsigned long long)0xD256D193u * c0;
-        const unsigned hi = (unsigned)(p >> 32), lo = (unsigned)p;
-        c0 = hi ^ key ^ c1;
-        c1 = lo;
-        key += 0x9E3779B9u;
-    }
-    return c0;
-}
-
 __global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ out, size_t n, float rate, float keep_scale, unsigned seed,
-                                                           unsigned offset) {
+                                                           unsigned offset, const unsigned* __restrict__ offset_dev) {
+    if (offset_dev) offset += offset_dev[0];
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const unsigned r = philox2x32((unsigned)i, offset ^ (unsigned)(i >> 32), seed);
         const float u = (float)(r >> 8) * (1.0f / 16777216.0f);                 // uniform [0, 1) on 24 bits
@@ -558,10 +548,10 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ o
     }
 }
 
-extern "C" int dc_dropout_mask_f32(float* out, size_t n, float rate, uint32_t seed, uint32_t offset, void* stream) {
+extern "C" int dc_dropout_mask_f32(float* out, size_t n, float rate, uint32_t seed, uint32_t offset, const uint32_t* offset_dev, void* stream) {
     DC_REQUIRE(out && n > 0 && rate >= 0.f && rate < 1.f, DC_EINVAL, "dc_dropout_mask: needs out, n > 0 and 0 <= rate < 1");
     const int blocks = (int)std::min<size_t>((n + 255) / 256, (size_t)kNumCU * 8);
-    hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), out, n, rate, 1.0f / (1.0f - rate), seed, offset);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), out, n, rate, 1.0f / (1.0f - rate), seed, offset, offset_dev);
     return check_launch("dropout_mask_kernel");
 }
 

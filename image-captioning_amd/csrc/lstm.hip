@@ -573,8 +573,8 @@ extern "C" int dc_lstm_seq_bwd_f32(const dc_lstm_bwd_desc* d, void* workspace, s
         tmp4 = reinterpret_cast<float*>(end - hs - t4);
         gws_bytes = (size_t)(reinterpret_cast<char*>(tmp4) - static_cast<char*>(gws));
     }
-    hipError_t e = hipMemsetAsync(wsp, 0, 2 * state_bytes, s);
-    DC_REQUIRE(e == hipSuccess, DC_ELAUNCH, "dc_lstm_seq_bwd: memset failed: %s", hipGetErrorString(e));
+    int zrc = zero_fill_async(wsp, 2 * state_bytes, s);
+    if (zrc) return zrc;
     const bool fused = (U & 15) == 0 && !d->rec_masks && lstm_bwd_fused_enabled();
     static const int force_rt = env_int("DCAP_LSTM_BWD_RT", 0), force_nw = env_int("DCAP_LSTM_BWD_NW", 0);
     int rt_rows = ((U / 16) * ((B + 15) / 16) <= kNumCU) ? 16 : 32;      // measured: 200 x 512 is 1.2x faster with 32-row blocks
@@ -646,8 +646,8 @@ extern "C" int dc_lstm_seq_bwd_f32(const dc_lstm_bwd_desc* d, void* workspace, s
         return dc_gemm_f32(&g, gws, gws_bytes, stream);
     }
     if (!d->accumulate_dU) {
-        e = hipMemsetAsync(d->dU_rec, 0, (size_t)U * 4 * U * sizeof(float), s);
-        DC_REQUIRE(e == hipSuccess, DC_ELAUNCH, "dc_lstm_seq_bwd: memset failed: %s", hipGetErrorString(e));
+        zrc = zero_fill_async(d->dU_rec, (size_t)U * 4 * U * sizeof(float), s);
+        if (zrc) return zrc;
     }
     return DC_OK;
 }

@@ -208,7 +208,11 @@ __global__ void subsample2_kernel(const float4* __restrict__ x, float4* __restri
 __global__ __launch_bounds__(256) void rpn_loss_grad_kernel(dc_rpn_loss_desc d) {
     __shared__ float red[2][256];
     const int A = d.anchors_per_loc;
-    const float invn = 1.f / (float)d.n_sel;
+    if (d.counts_dev) {                                        // this image's counts from device memory (the fields hold the capacities)
+        d.n_sel = min(d.n_sel, d.counts_dev[0]);
+        d.n_pos = min(d.n_pos, d.counts_dev[1]);
+    }
+    const float invn = 1.f / (float)max(d.n_sel, 1);
     float lc = 0.f, lb = 0.f;
     for (int i = threadIdx.x; i < d.n_sel; i += 256) {
         const int l = d.sel_level[i], idx = d.sel_index[i], m = d.sel_match[i];
@@ -231,6 +235,7 @@ __global__ __launch_bounds__(256) void rpn_loss_grad_kernel(dc_rpn_loss_desc d) 
             const float* t = d.target_deltas + (long)rank * 4;
             const float* bb = h + A * 2 + a * 4;
             float* gb = g + A * 2 + a * 4;
+            if (rank >= d.n_pos) continue;                         // (more positives in sel than target rows: nothing to regress to)
             const float invp = 1.f / (4.f * (float)d.n_pos);
             float ls = 0.f;
 #pragma unroll
@@ -478,8 +483,8 @@ static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 static int topk_select(const float* scores, int B, int A_total, int k, TopkState* st, unsigned* cnt, unsigned long long* cand,
                        int* vals, float* keys, hipStream_t s) {
     const int nblk = (A_total + TK_CHUNK - 1) / TK_CHUNK, P = next_pow2(k);
-    hipError_t e = hipMemsetAsync(st, 0, sizeof(TopkState) * (size_t)B, s);
-    DC_REQUIRE(e == hipSuccess, DC_ELAUNCH, "dc_proposals: memset failed: %s", hipGetErrorString(e));
+    int zrc = zero_fill_async(st, sizeof(TopkState) * (size_t)B, s);
+    if (zrc) return zrc;
     const dim3 hgrid(std::min((A_total + 255) / 256, 128), B);
     hipLaunchKernelGGL(topk_hist_kernel<0>, hgrid, dim3(256), 0, s, scores, A_total, st);
     hipLaunchKernelGGL(topk_pick_kernel<0>, dim3(B), dim3(256), 0, s, st, k);
@@ -602,15 +607,169 @@ extern "C" int dc_proposals_f32(const dc_proposal_desc* d, void* workspace, size
     return DC_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// DetectionTargetLayer on the device (dense_img_cap/dense_model.py:450-572, detection_targets_graph for ONE image): the IoU
+// matrix proposals x GT boxes in float32 (overlaps_graph :421-447), positives = best IoU >= 0.5, negatives = best IoU < 0.5 (a NaN
+// row -- 0/0 of two empty boxes -- is neither, as in the graph), tf.random_shuffle of each index list realised as a sort by
+// counter-based random keys (Philox(compacted proposal index, offset, seed); without a seed: proposal order), at most
+// int(n_rois * ratio) positives, int32(float32(1 / ratio) * float32(n_pos)) - n_pos negatives, every positive takes the caption of
+// its best GT box (first maximum, tf.argmax), the rest of the n_rois rows is zero.  ONE workgroup (2000 proposals, <= 100 GT boxes):
+// classification, a ballot scan for the compacted index, ranks by counting smaller (class, key, index) triples in LDS.
+// Replaces the device -> host -> device hop in the middle of the joint train step: nothing here needs the host.
+// ------------------------------------------------------------------------------------------------
+constexpr int DT_MAX_PROPOSALS = 4096, DT_MAX_GT = 512, DT_THREADS = 1024;
+
+__global__ __launch_bounds__(DT_THREADS) void detection_targets_kernel(dc_detection_targets_desc d) {
+    __shared__ unsigned long long v[DT_MAX_PROPOSALS];       // (class << 62) | (key << 16 ...) see below
+    __shared__ float4 gbox[DT_MAX_GT];
+    __shared__ unsigned short best_g[DT_MAX_PROPOSALS];
+    __shared__ int wave_nz[DT_THREADS / 64];
+    __shared__ int cnt[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = d.n_proposals, G = d.n_gt;
+    const float4* props = reinterpret_cast<const float4*>(d.proposals);
+    for (int g = tid; g < G; g += DT_THREADS) gbox[g] = reinterpret_cast<const float4*>(d.gt_boxes)[g];
+    if (tid < 2) cnt[tid] = 0;
+    __syncthreads();
+    const unsigned offset = d.offset + (d.offset_dev ? d.offset_dev[0] : 0u);
+    int base = 0;                                            // non-zero proposals in the chunks before this one
+    for (int i0 = 0; i0 < N; i0 += DT_THREADS) {
+        const int i = i0 + tid;
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < N) b = props[i];                             // (y1, x1, y2, x2)
+        const bool nz = i < N && (fabsf(b.x) + fabsf(b.y) + fabsf(b.z) + fabsf(b.w)) > 0.f;
+        // ---- class and best GT box
+        int cls = 2;                                         // 0 positive, 1 negative, 2 neither (padding row, NaN row)
+        int bg = 0;
+        if (nz) {
+            float best = 0.f;
+            bool any = false, isnan_ = false;
+            const float a1 = (b.z - b.x) * (b.w - b.y);
+            for (int g = 0; g < G; ++g) {
+                const float4 q = gbox[g];
+                if (!((fabsf(q.x) + fabsf(q.y) + fabsf(q.z) + fabsf(q.w)) > 0.f)) continue;      // trim_zeros_graph on the GT boxes
+                const float y1 = fmaxf(b.x, q.x), x1 = fmaxf(b.y, q.y), y2 = fminf(b.z, q.z), x2 = fminf(b.w, q.w);
+                const float inter = fmaxf(x2 - x1, 0.f) * fmaxf(y2 - y1, 0.f);
+                const float a2 = (q.z - q.x) * (q.w - q.y);
+                const float iou = inter / (a1 + a2 - inter);
+                if (iou != iou) isnan_ = true;
+                if (!any || iou > best) { best = iou; bg = g; any = true; }
+            }
+            // no GT box at all: the graph's reduce_max over an empty axis; every proposal is a negative (iou_max = 0 in the oracle)
+            if (!any) cls = 1;
+            else if (isnan_) cls = 2;
+            else cls = best >= 0.5f ? 0 : 1;
+        }
+        // ---- compacted index (position among the non-zero proposals): ballot scan
+        const unsigned long long bal = __ballot(nz);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_nz[wave] = __popcll(bal);
+        __syncthreads();
+        int wbase = base;
+        for (int w = 0; w < wave; ++w) wbase += wave_nz[w];
+        int chunk = 0;
+        for (int w = 0; w < DT_THREADS / 64; ++w) chunk += wave_nz[w];
+        const unsigned cidx = (unsigned)(wbase + before);
+        const unsigned key = d.shuffle ? philox2x32(cidx, offset, d.seed) : cidx;
+        if (i < N) {
+            v[i] = ((unsigned long long)cls << 62) | ((unsigned long long)key << 16) | (unsigned long long)(cidx & 0xFFFFu);
+            best_g[i] = (unsigned short)bg;
+            if (cls < 2) atomicAdd(&cnt[cls], 1);
+        }
+        base += chunk;
+        __syncthreads();
+    }
+    // ---- selection sizes
+    const int total_pos = cnt[0], total_neg = cnt[1];
+    const int npos = min(total_pos, d.max_positive);
+    const int want_neg = (int)(d.inv_ratio * (float)npos) - npos;          // tf.cast(r * tf.cast(positive_count, tf.float32), tf.int32) - positive_count
+    const int nneg = max(0, min(min(total_neg, want_neg), d.n_rois - npos));
+    // ---- zero fill, then the selected rows on top (disjoint rows: no ordering issue after the barrier)
+    const int T = d.T;
+    for (int r = tid; r < d.n_rois; r += DT_THREADS)
+        if (r >= npos + nneg) reinterpret_cast<float4*>(d.rois)[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = tid; e < d.n_rois * T; e += DT_THREADS)
+        if (e / T >= npos) d.captions[e] = 0;
+    if (tid == 0) { d.counts[0] = npos; d.counts[1] = nneg; }
+    // ---- ranks: number of (class, key, index) triples below mine
+    for (int i0 = 0; i0 < N; i0 += DT_THREADS) {
+        const int i = i0 + tid;
+        if (i >= N) continue;
+        const unsigned long long mine = v[i];
+        const int cls = (int)(mine >> 62);
+        if (cls == 2) continue;
+        int rank = 0;
+        for (int j = 0; j < N; ++j) rank += v[j] < mine ? 1 : 0;
+        if (cls == 0) {
+            if (rank < npos) {
+                reinterpret_cast<float4*>(d.rois)[rank] = props[i];
+                const int32_t* src = d.gt_captions + (long)best_g[i] * T;
+                for (int t = 0; t < T; ++t) d.captions[(long)rank * T + t] = src[t];
+            }
+        } else {
+            rank -= total_pos;
+            if (rank < nneg) reinterpret_cast<float4*>(d.rois)[npos + rank] = props[i];
+        }
+    }
+}
+
+// The decoder's index tables from device-resident captions [B][T] (dense_img_cap/dense_model.py:1572-1580 + imgcap_caption_loss_graph
+// :936-946): time-major token ids and Keras masks (ids != 0), time-major targets = the caption shifted left by one (last = 0),
+// row weights = [target > 0] / max(count, 1) (the masked mean of the loss; count summed in a fixed order).  One workgroup.
+__global__ __launch_bounds__(1024) void caption_tables_kernel(const int32_t* __restrict__ caps, int B, int T, int32_t* __restrict__ ids_tm,
+                                                               unsigned char* __restrict__ mask, int32_t* __restrict__ targets_tm,
+                                                               float* __restrict__ row_weights, int32_t* __restrict__ live_count) {
+    __shared__ int red[1024];
+    const int n = B * T;
+    int mine = 0;
+    for (int e = threadIdx.x; e < n; e += 1024) {
+        const int t = e / B, b = e - t * B;
+        const int id = caps[(long)b * T + t];
+        const int tg = t + 1 < T ? caps[(long)b * T + t + 1] : 0;
+        ids_tm[e] = id;
+        mask[e] = id != 0;
+        targets_tm[e] = tg;
+        mine += tg > 0;
+    }
+    red[threadIdx.x] = mine;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    const int count = red[0];
+    const float inv = 1.f / (float)max(count, 1);
+    for (int e = threadIdx.x; e < n; e += 1024) row_weights[e] = targets_tm[e] > 0 ? inv : 0.f;
+    if (threadIdx.x == 0 && live_count) live_count[0] = count;
+}
+
+extern "C" int dc_detection_targets_f32(const dc_detection_targets_desc* d, void* stream) {
+    DC_REQUIRE(d && d->proposals && d->gt_boxes && d->gt_captions && d->rois && d->captions && d->counts, DC_EINVAL,
+               "dc_detection_targets: null pointer");
+    DC_REQUIRE(d->n_proposals > 0 && d->n_proposals <= DT_MAX_PROPOSALS && d->n_gt >= 0 && d->n_gt <= DT_MAX_GT && d->n_rois > 0 && d->T > 0 &&
+                   d->max_positive >= 0 && d->max_positive <= d->n_rois && d->inv_ratio > 0.f,
+               DC_EINVAL, "dc_detection_targets: needs 1..%d proposals, 0..%d GT boxes, n_rois > 0, 0 <= max_positive <= n_rois", DT_MAX_PROPOSALS,
+               DT_MAX_GT);
+    DC_REQUIRE(aligned16(d->proposals) && aligned16(d->gt_boxes) && aligned16(d->rois), DC_EALIGN, "dc_detection_targets: boxes must be 16-byte aligned");
+    hipLaunchKernelGGL(detection_targets_kernel, dim3(1), dim3(DT_THREADS), 0, static_cast<hipStream_t>(stream), *d);
+    return check_launch("detection_targets_kernel");
+}
+
+extern "C" int dc_caption_tables_i32(const int32_t* captions, int B, int T, int32_t* ids_tm, uint8_t* mask, int32_t* targets_tm, float* row_weights,
+                                     int32_t* live_count, void* stream) {
+    DC_REQUIRE(captions && ids_tm && mask && targets_tm && row_weights && B > 0 && T > 0, DC_EINVAL, "dc_caption_tables: bad arguments");
+    hipLaunchKernelGGL(caption_tables_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), captions, B, T, ids_tm, mask, targets_tm,
+                       row_weights, live_count);
+    return check_launch("caption_tables_kernel");
+}
+
 extern "C" int dc_rpn_loss_grad_f32(const dc_rpn_loss_desc* d, void* stream) {
     DC_REQUIRE(d && d->losses && d->levels >= 1 && d->levels <= 5 && d->anchors_per_loc > 0 && d->head_stride >= d->anchors_per_loc * 6,
                DC_EINVAL, "dc_rpn_loss_grad: bad descriptor");
     DC_REQUIRE(d->n_sel == 0 || (d->sel_level && d->sel_index && d->sel_match), DC_EINVAL, "dc_rpn_loss_grad: missing selection");
     DC_REQUIRE(d->n_pos == 0 || d->target_deltas, DC_EINVAL, "dc_rpn_loss_grad: missing target deltas");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(d->losses, 0, 2 * sizeof(float), s);
-    DC_REQUIRE(e == hipSuccess, DC_ELAUNCH, "dc_rpn_loss_grad: memset failed");
-    if (d->n_sel == 0) return DC_OK;
+    if (d->n_sel == 0) return zero_fill_async(d->losses, 2 * sizeof(float), s);      // (the kernel below writes both losses itself)
     hipLaunchKernelGGL(rpn_loss_grad_kernel, dim3(1), dim3(256), 0, s, *d);
     return check_launch("rpn_loss_grad_kernel");
 }

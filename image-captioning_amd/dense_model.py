@@ -18,6 +18,7 @@ The detection-target sampling uses tf.random_shuffle in the reference (order is 
 numpy permutation on the host, the only host round trip of the step (2000x4 floats down, 200x4 up).
 """
 import datetime
+import math
 import os
 import re
 
@@ -237,6 +238,53 @@ def data_generator(dataset, config, shuffle=True, augment=True, batch_size=1, rn
 # the model
 # ------------------------------------------------------------------------------------------------
 
+class StepInputs(object):
+    """Everything the host contributes to one joint train step, packed into ONE buffer of 4-byte words and moved with ONE asynchronous
+    copy at the start of the step: the RPN selection (counts, level / index / match of the non-neutral anchors, target deltas -- fixed
+    capacity, the image's own counts travel as words), the normalised GT boxes, the GT captions and the step scalars (Keras' lr_t,
+    the dropout-mask and detection-target stream positions).  The device side is a persistent buffer whose views the kernels read
+    (fixed addresses: a captured hipGraph replays them); the host side is a small ring of page-locked buffers, each guarded by the
+    event of its last copy, so the host never waits for the device and never rewrites a buffer whose copy is still queued."""
+    SLOTS = 4
+
+    def __init__(self, device, cap, n_gt, T):
+        self.cap, self.n_gt, self.T = cap, n_gt, T
+        sizes = [("counts", 2), ("lvl", cap), ("idx", cap), ("mt", cap), ("deltas", 4 * cap), ("gt", 4 * n_gt), ("gtc", n_gt * T), ("scalars", 4)]
+        self.off, pos = {}, 0
+        for k, n in sizes:
+            self.off[k] = (pos, n)
+            pos += (n + 3) // 4 * 4                         # 16-byte aligned parts
+        self.words = pos
+        self.dev = torch.zeros(pos, dtype=torch.int32, device=device)
+        self.pins = [torch.zeros(pos, dtype=torch.int32, pin_memory=True) for _ in range(self.SLOTS)]
+        self.events = [None] * self.SLOTS
+        self.k = 0
+
+    def view(self, key, dtype=torch.int32):
+        o, n = self.off[key]
+        v = self.dev[o:o + n]
+        return v if dtype == torch.int32 else v.view(dtype)
+
+    def upload(self, parts):
+        """parts: {key: numpy array (int32 or float32)}; missing keys keep zeros."""
+        k = self.k
+        self.k = (k + 1) % self.SLOTS
+        if self.events[k] is not None:
+            self.events[k].synchronize()                    # (four steps old: complete long ago unless the host runs far ahead)
+        host = self.pins[k].numpy()
+        host[:] = 0
+        for key, a in parts.items():
+            o, n = self.off[key]
+            a = np.ascontiguousarray(a).reshape(-1)
+            if a.size > n:
+                raise ValueError("%s: %d words do not fit the %d reserved" % (key, a.size, n))
+            host[o:o + a.size] = a.view(np.int32) if a.dtype != np.int32 else a
+        self.dev.copy_(self.pins[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
+
+
 class DenseImageCapRCNN(object):
     LOSS_NAMES = ("rpn_class_loss", "rpn_bbox_loss", "imgcap_loss")
     LAYER_REGEX = {                       # dense_img_cap/dense_model.py:1829-1845
@@ -268,8 +316,11 @@ class DenseImageCapRCNN(object):
         self.A = len(config.RPN_ANCHOR_RATIOS)
         if 6 * self.A > HEAD_PAD:
             raise ValueError("at most 3 anchors per location")
-        self._rng = np.random.RandomState(seed)
-        self._val_rng = np.random.RandomState(seed + 1)      # detection-target sampling of forward-only (validation) passes
+        self._seed = int(seed)
+        self.use_step_graph = os.environ.get("DCAP_JOINT_GRAPH", "1") != "0"
+        self._dt_step = self._dt_val_step = 0                # detection-target sampling streams (training / forward-only validation passes)
+        self._last_targets = None
+        self._step_in = None
         self.optimizer = None
         self.grad_sync = None
         self.is_chief = True               # ParallelModel clears it on ranks > 0: one rank prints and writes checkpoints
@@ -341,8 +392,14 @@ class DenseImageCapRCNN(object):
         self._reg_coef = None
         self._bufs = {}
         self._bf16_cache = {}
+        self._invalidate_graphs()
         if weights is not None:
             self.set_weights({k: v for k, v in weights.items() if k not in self._backbone})
+
+    def _invalidate_graphs(self):
+        """Captured step graphs bake buffer addresses, the plan's outputs, the trainable subset and the optimizer state: anything
+        that replaces one of those drops them (the next steps run eagerly and re-capture)."""
+        self._graphs, self._graph_warm, self._graph_out = {}, {}, {}
 
     def _buf(self, key, shape, dtype=torch.float32, zero=False):
         b = self._bufs.get(key)
@@ -431,6 +488,7 @@ class DenseImageCapRCNN(object):
                 backbone_changed = True
         if backbone_changed:
             self._plan = None
+            self._invalidate_graphs()
         st.refresh_shadow()                  # the bf16 operand copies: once per call, not once per weight
 
     def load_weights(self, filepath, by_name=False, exclude=None):
@@ -523,6 +581,7 @@ class DenseImageCapRCNN(object):
             self.optimizer = None
         self._trainable_regex = layer_regex
         self._reg_coef = None
+        self._invalidate_graphs()
 
     # ---- compile ----------------------------------------------------------------------------
     def compile(self, learning_rate):
@@ -530,6 +589,7 @@ class DenseImageCapRCNN(object):
         trainable non-BN weights (:1694-1730)."""
         self.optimizer = Adam(lr=learning_rate, clipnorm=0.5, amsgrad=True)
         self.caption_model.optimizer = self.optimizer
+        self._invalidate_graphs()
 
     def _masks(self):
         """Per-element L2 coefficient over the flat bucket, and a 0/1 gradient mask when set_trainable() froze a
@@ -637,7 +697,43 @@ class DenseImageCapRCNN(object):
             self._pins[key] = b
         return b
 
-    def _rpn_backward(self, p, rpn_match, rpn_bbox, losses, up):
+    def _step_uploads(self, p, rpn_match, rpn_bbox, gt_norm, gt_caps, training):
+        """This step's host inputs -> the device, one asynchronous copy (StepInputs).  Returns the device views the step's kernels read."""
+        cfg = self.config
+        lvl, idx, mt = self._rpn_selection(rpn_match[0])
+        tdl = np.asarray(rpn_bbox[0], np.float32).reshape(-1, 4)
+        n_pos = int((mt == 1).sum())
+        if n_pos > tdl.shape[0]:
+            raise ValueError("%d positive anchors but only %d target rows" % (n_pos, tdl.shape[0]))
+        gt_norm = np.asarray(gt_norm, np.float32).reshape(-1, 4)
+        gtc = np.asarray(gt_caps).astype(np.int32)
+        cap = max(int(cfg.RPN_TRAIN_ANCHORS_PER_IMAGE), len(lvl), tdl.shape[0], 1)
+        si = self._step_in
+        if si is None or si.cap < cap or si.n_gt != gt_norm.shape[0] or si.T != gtc.shape[1]:
+            si = self._step_in = StepInputs(self.device, cap, gt_norm.shape[0], gtc.shape[1])
+            self._invalidate_graphs()                       # captured graphs hold the old views
+        if training:
+            self._dt_step += 1
+        else:
+            self._dt_val_step += 1
+        opt = self.optimizer
+        lr_next = 0.0
+        if training and opt is not None:
+            t = opt.iterations + 1                          # the update at the end of THIS step
+            lr_next = opt.lr * math.sqrt(1.0 - opt.beta_2 ** t) / (1.0 - opt.beta_1 ** t)
+        cm = self.caption_model
+        scal = np.zeros(4, np.int32)
+        scal[0:1] = np.array([lr_next], np.float32).view(np.int32)
+        scal[1] = (2 * (cm._drop_step + 1)) & 0x7FFFFFFF    # Philox offset of this step's recurrent-dropout masks (lstm l: + l)
+        scal[2] = (self._dt_step if training else self._dt_val_step) & 0x7FFFFFFF
+        si.upload({"counts": np.array([len(lvl), n_pos], np.int32), "lvl": lvl, "idx": idx, "mt": mt, "deltas": tdl[:si.cap],
+                   "gt": gt_norm, "gtc": gtc, "scalars": scal})
+        sc = si.view("scalars")
+        return dict(counts=si.view("counts"), lvl=si.view("lvl"), idx=si.view("idx"), mt=si.view("mt"),
+                    deltas=si.view("deltas", torch.float32).view(si.cap, 4), gt=si.view("gt", torch.float32).view(-1, 4),
+                    gtc=si.view("gtc").view(si.n_gt, si.T), cap=si.cap, lr_t=sc[0:1].view(torch.float32), drop_offset=sc[1:2], dt_offset=sc[2:3])
+
+    def _rpn_backward(self, p, rpn_up, losses):
         """RPN losses (dense_model.py:1008-1075) and the backward of the RPN branch: gradients of the fused head and of the shared
         3x3 convolution (accumulated over the five pyramid levels) and the data gradients into dP2..dP6, which this call creates
         (zeroed) and returns together with the pyramid maps.  Independent of the detection targets."""
@@ -647,17 +743,12 @@ class DenseImageCapRCNN(object):
         dP = [self._buf("dP%d" % i, tuple(m.shape)) for i, m in enumerate(maps)]
         for t in dP:
             t.zero_()
-        # ---- RPN losses and their gradients w.r.t. the fused head outputs
-        lvl, idx, mt = self._rpn_selection(rpn_match[0])
-        n_pos = int((mt == 1).sum())
+        # ---- RPN losses and their gradients w.r.t. the fused head outputs (selection and counts: this step's StepInputs views)
         dheads = [self._buf("dhead%d" % i, tuple(h.shape)) for i, h in enumerate(p.rpn_heads)]
         for t in dheads:
             t.zero_()
-        tdl = np.asarray(rpn_bbox[0], np.float32)
-        if n_pos > tdl.shape[0]:
-            raise ValueError("%d positive anchors but only %d target rows" % (n_pos, tdl.shape[0]))
-        ops.rpn_loss_grad(p.rpn_heads, dheads, up(lvl, torch.int32), up(idx, torch.int32), up(mt, torch.int32),
-                          up(tdl if tdl.size else np.zeros((1, 4), np.float32)), n_pos, losses[0:2], anchors_per_loc=self.A)
+        ops.rpn_loss_grad(p.rpn_heads, dheads, rpn_up["lvl"], rpn_up["idx"], rpn_up["mt"], rpn_up["deltas"], rpn_up["cap"], losses[0:2],
+                          anchors_per_loc=self.A, counts_dev=rpn_up["counts"])
 
         # ---- RPN backward (shared weights over the five levels: gradients accumulate)
         wd_shared = ops.conv_weight_dgrad_pack(w["rpn_conv_shared/kernel"], 3, 3, 256, out=self._buf("wd_shared", (256, 9 * 512)))
@@ -762,6 +853,17 @@ class DenseImageCapRCNN(object):
             gk.zero_()
             gk[:, :, :7, :3].copy_(gw.view(64, 7, 7, 64)[..., :3])
 
+    @property
+    def last_targets(self):
+        """The last step's detection targets as host values: dict(rois [R,4], caps [R,T], npos, nneg).  The step itself leaves them on
+        the device; reading this property is what copies them (and waits for the step)."""
+        t = self._last_targets
+        if t is None or isinstance(t, dict):
+            return t
+        rois, caps, counts = t
+        c = counts.cpu().numpy()
+        return dict(rois=rois.cpu().numpy(), caps=caps.cpu().numpy(), npos=int(c[0]), nneg=int(c[1]))
+
     def forward_backward(self, inputs, shuffle="rng", backward=True):
         """Losses and gradients of one image into the flat gradient bucket (no optimizer step).
         Returns the device tensor [rpn_class_loss, rpn_bbox_loss, imgcap_loss, reg_loss].
@@ -778,48 +880,95 @@ class DenseImageCapRCNN(object):
         H, W = p.H, p.W
         up = lambda a, dt=torch.float32: torch.tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
 
-        # ---- forward: backbone + FPN + RPN (hipGraph), proposals, detection targets, RoIAlign, head + decoder
-        self._bf16_cache = {}
-        p.forward(self._images_u8(images))
-        proposals = p.proposals()
+        # ---- this step's host inputs go to the device FIRST (GT boxes, GT captions, the RPN selection): a copy from pageable host
+        # memory makes the host wait for everything queued before it, so none may sit in the middle of the step
         gt_norm = (np.asarray(gt_boxes[0], np.float32) / np.array([H, W, H, W], np.float32)).astype(np.float32)
-        rng = self._rng if backward else self._val_rng
-        mix = None if shuffle is None else (rng.permutation if shuffle == "rng" else shuffle)
+        device_targets = shuffle is None or shuffle == "rng"
+        rpn_up = self._step_uploads(p, rpn_match, rpn_bbox, gt_norm, gt_caps[0], backward)
+        gt_dev, gtc_dev = rpn_up["gt"], rpn_up["gtc"]
+
+        # ---- forward: backbone + FPN + RPN (the plan's hipGraph), then everything behind the encoder
+        p.forward(self._images_u8(images))
+        return self._after_encoder(p, rpn_up, shuffle, backward, gt_caps[0], gt_norm)
+
+    def _after_encoder(self, p, rpn_up, shuffle, backward, gt_caps0, gt_norm):
+        """The step behind the encoder pass: proposals, detection targets, RoIAlign, head + decoder, the four losses and (backward)
+        every gradient into the flat bucket.  With device-side targets (shuffle None / "rng") nothing in here depends on a host value
+        that changes from step to step -- counts, stream positions and lr_t are device words of StepInputs -- so train_on_batch_device
+        captures it (plus the optimizer) as ONE hipGraph."""
+        cfg, st, cm = self.config, self.store, self.caption_model
+        w, g = st.w, st.grad
+        dev = self.device
+        H, W = p.H, p.W
+        up = lambda a, dt=torch.float32: torch.tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+        device_targets = shuffle is None or shuffle == "rng"
+        gt_dev, gtc_dev = rpn_up["gt"], rpn_up["gtc"]
+        gt_caps = [gt_caps0]
+        self._bf16_cache = {}
+        proposals = p.proposals()
         losses = self._buf("losses", (4,))
-        if backward:
-            # The detection-target sample is drawn on the host (the step's one round trip).  The proposals start their way to
-            # the host first; the RPN branch's backward -- which needs only the plan's outputs and the step's RPN targets --
-            # is enqueued behind that copy, so the GPU works through it while the host samples the RoIs.
-            host_props = self._pinned("props", tuple(proposals[0].shape))
-            host_props.copy_(proposals[0], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            maps, dP = self._rpn_backward(p, rpn_match, rpn_bbox, losses, up)
-            ev.synchronize()
-            props_np = host_props.numpy()
+        R = cfg.TRAIN_ROIS_PER_IMAGE
+        maps = dP = None
+        if device_targets:
+            # DetectionTargetLayer on the device (dc_detection_targets_f32): IoU, the >= 0.5 / < 0.5 split, the shuffle (Philox keys drawn
+            # from (model seed, step): reproducible, where tf.random_shuffle is not), the 1:2 sample and the caption gather.  Nothing
+            # comes back to the host: counts travel as device words, every shape downstream is static (TRAIN_ROIS_PER_IMAGE rows).
+            seed = None if shuffle is None else ((self._seed + (0 if backward else 1)) * 2654435761 + 12345) & 0xFFFFFFFF
+            T = int(np.asarray(gt_caps[0]).shape[1])
+            rois_d, caps_d, counts_d = ops.detection_targets(
+                proposals[0], gt_dev, gtc_dev, R, cfg.ROI_POSITIVE_RATIO, seed=seed, offset=0, offset_dev=rpn_up["dt_offset"],
+                out=(self._buf("dt_rois", (R, 4)), self._buf("dt_caps", (R, T), torch.int32), self._buf("dt_counts", (2,), torch.int32)))
+            self._last_targets = (rois_d, caps_d, counts_d)
+            boxes = rois_d.view(1, R, 4)
+            feats = p.roi_features(boxes_norm=boxes, out=self._buf("feats", (1, R, cfg.POOL_SIZE, cfg.POOL_SIZE, 256)))
+            tables = ops.caption_tables(caps_d, out=(self._buf("ct_ids", (T * R,), torch.int32), self._buf("ct_mask", (T * R,), torch.uint8),
+                                                     self._buf("ct_tg", (T * R,), torch.int32), self._buf("ct_rw", (T * R,))))
+            if cm._prefix_rows(backward):
+                # DROPOUT_ROWS = 'prefix' (one mask per (RoI, prefix) row, as the reference's TimeDistributed graph draws them): the T-fold
+                # prefix tables are built on the host, so this non-default mode reads the sampled captions back (one synchronisation)
+                cm._drop_offset_dev = None
+                caps_h = caps_d.cpu().numpy()
+                tg_h = caption_targets(caps_h)
+                live = (tg_h > 0).astype(np.float32)
+                loss_rows, _ = cm._forward_train(feats[0], caps_h, tg_h, want_grad=backward, row_weights=live / max(float(live.sum()), 1.0),
+                                                 keras_sparse=True)
+            else:
+                cm._drop_offset_dev = rpn_up["drop_offset"]
+                loss_rows, _ = cm._forward_train(feats[0], None, want_grad=backward, keras_sparse=True, device_tables=tables + (R, T))
+            if backward:
+                maps, dP = self._rpn_backward(p, rpn_up, losses)
         else:
-            props_np = proposals[0].cpu().numpy()
-        rois, caps, npos, nneg = detection_targets(props_np, gt_caps[0], gt_norm, cfg, mix)
-        self.last_targets = dict(rois=rois, caps=caps, npos=npos, nneg=nneg)
-        boxes = up(rois[None])
-        R = rois.shape[0]
-        feats = p.roi_features(boxes_norm=boxes, out=self._buf("feats", (1, R, cfg.POOL_SIZE, cfg.POOL_SIZE, 256)))
-        tg = caption_targets(caps)
-        live = (tg > 0).astype(np.float32)
-        count = float(live.sum())
-        loss_rows, _ = cm._forward_train(feats[0], caps, tg, want_grad=backward, row_weights=live / max(count, 1.0), keras_sparse=True)
+            # a caller-supplied permutation (shuffle = callable): the sample is drawn on the host, as until round 3.  The proposals start
+            # their way to the host first; the RPN branch's backward is enqueued behind that copy, so the GPU works while the host samples.
+            mix = shuffle
+            if backward:
+                host_props = self._pinned("props", tuple(proposals[0].shape))
+                host_props.copy_(proposals[0], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                maps, dP = self._rpn_backward(p, rpn_up, losses)
+                ev.synchronize()
+                props_np = host_props.numpy()
+            else:
+                props_np = proposals[0].cpu().numpy()
+            cm._drop_offset_dev = None
+            rois, caps, npos, nneg = detection_targets(props_np, gt_caps[0], gt_norm, cfg, mix)
+            self._last_targets = dict(rois=rois, caps=caps, npos=npos, nneg=nneg)
+            boxes = up(rois[None])
+            feats = p.roi_features(boxes_norm=boxes, out=self._buf("feats", (1, R, cfg.POOL_SIZE, cfg.POOL_SIZE, 256)))
+            tg = caption_targets(caps)
+            live = (tg > 0).astype(np.float32)
+            count = float(live.sum())
+            loss_rows, _ = cm._forward_train(feats[0], caps, tg, want_grad=backward, row_weights=live / max(count, 1.0), keras_sparse=True)
         ops.mean(loss_rows, out=losses[2:3])                 # x rows below: the weights already carry 1/count
         self._loss_scale = float(loss_rows.numel())
         if not backward:
             # RPN losses need the heads only (their gradient goes to scratch), the regulariser the weights only
-            lvl, idx, mt = self._rpn_selection(rpn_match[0])
-            n_pos = int((mt == 1).sum())
             scratch = [self._buf("dhead%d" % i, tuple(h.shape)) for i, h in enumerate(p.rpn_heads)]
             for t in scratch:
                 t.zero_()
-            tdl = np.asarray(rpn_bbox[0], np.float32)
-            ops.rpn_loss_grad(p.rpn_heads, scratch, up(lvl, torch.int32), up(idx, torch.int32), up(mt, torch.int32),
-                              up(tdl if tdl.size else np.zeros((1, 4), np.float32)), n_pos, losses[0:2], anchors_per_loc=self.A)
+            ops.rpn_loss_grad(p.rpn_heads, scratch, rpn_up["lvl"], rpn_up["idx"], rpn_up["mt"], rpn_up["deltas"], rpn_up["cap"], losses[0:2],
+                              anchors_per_loc=self.A, counts_dev=rpn_up["counts"])
             coef, _ = self._masks()
             ops.l2_reg(st.flat, coef, None, loss=losses[3:4])
             return losses
@@ -902,10 +1051,54 @@ class DenseImageCapRCNN(object):
         assert self.mode == "training", "Create model in training mode."
         if self.optimizer is None:
             raise RuntimeError("compile(learning_rate) first")
-        losses = self.forward_backward(inputs)
-        scale = self.grad_sync(self.store.flat_grad) if self.grad_sync is not None else 1.0
-        self.optimizer.apply(self.store, grad_scale=scale)
-        return losses
+        world = getattr(self.grad_sync, "world", 1) if self.grad_sync is not None else 1
+        cm = self.caption_model
+        if not self.use_step_graph or world > 1 or cm._prefix_rows(True):
+            # eager: the data-parallel step (its collectives are issued from Python as layer groups finish), DROPOUT_ROWS='prefix'
+            losses = self.forward_backward(inputs)
+            scale = self.grad_sync(self.store.flat_grad) if self.grad_sync is not None else 1.0
+            self.optimizer.apply(self.store, grad_scale=scale)
+            return losses
+        # ---- single GPU: [one async upload] -> [encoder hipGraph] -> [step hipGraph: proposals .. losses .. gradients .. AMSGrad]
+        images, _meta, rpn_match, rpn_bbox, gt_caps, gt_boxes = inputs[:6]
+        if len(images) != 1:
+            raise ValueError("one image per step and GPU (IMAGES_PER_GPU = 1)")
+        p = self.plan()
+        gt_norm = (np.asarray(gt_boxes[0], np.float32) / np.array([p.H, p.W, p.H, p.W], np.float32)).astype(np.float32)
+        rpn_up = self._step_uploads(p, rpn_match, rpn_bbox, gt_norm, gt_caps[0], True)
+        p.forward(self._images_u8(images))
+        opt = self.optimizer
+
+        def body():
+            losses = self._after_encoder(p, rpn_up, "rng", True, gt_caps[0], gt_norm)
+            opt.apply(self.store, grad_scale=1.0, lr_t_dev=rpn_up["lr_t"])
+            return losses
+        key = "train"
+        graph = self._graphs.get(key)
+        if graph is not None:
+            graph.replay()
+            opt.iterations += 1                                  # what the captured Python did once: the host-side counters
+            if float(cm.recurrent_dropout or 0.0) > 0.0:
+                cm._drop_step += 1
+            return self._graph_out[key]
+        if self._graph_warm.get(key, 0) < 2 or p._graph is None:
+            self._graph_warm[key] = self._graph_warm.get(key, 0) + 1      # eager: sizes every buffer and workspace, builds the masks
+            return body()
+        saved = (opt.iterations, cm._drop_step)
+        try:
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                out = body()
+        except Exception as e:                                   # something in the step is not capturable here: stay eager
+            import warnings
+            warnings.warn("joint step: hipGraph capture failed (%s); running eagerly" % (repr(e)[:200],))
+            opt.iterations, cm._drop_step = saved
+            self.use_step_graph = False
+            return body()
+        self._graphs[key], self._graph_out[key] = graph, out
+        graph.replay()                                           # (capture records, it does not run: this is the step itself)
+        return out
 
     def train_on_batch(self, inputs, targets=None):
         """One optimizer step; returns [loss, rpn_class_loss, rpn_bbox_loss, imgcap_loss] like the compiled Keras model

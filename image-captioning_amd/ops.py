@@ -7,7 +7,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (ConvBf16Desc, AmsgradDesc, BnReluDesc, ConvDesc, ConvWgradBf16Desc, GemmBf16Desc, VocabCeDesc, ProposalDesc, RpnLossDesc, GemmDesc, LstmBwdDesc, LstmFwdDesc, RoiAlignDesc,
+from ._lib import (ConvBf16Desc, AmsgradDesc, DetectionTargetsDesc, BnReluDesc, ConvDesc, ConvWgradBf16Desc, GemmBf16Desc, VocabCeDesc, ProposalDesc, RpnLossDesc, GemmDesc, LstmBwdDesc, LstmFwdDesc, RoiAlignDesc,
                    SoftmaxCeDesc, check)
 
 
@@ -622,8 +622,9 @@ def conv_weight_dgrad_pack(w_packed, kh, kw, cin, out=None):
     return out
 
 
-def rpn_loss_grad(heads, dheads, sel_level, sel_index, sel_match, target_deltas, n_pos, losses, image=0, anchors_per_loc=3):
-    """RPN class + bbox losses of image `image` and their gradients scattered into the (pre-zeroed) dheads."""
+def rpn_loss_grad(heads, dheads, sel_level, sel_index, sel_match, target_deltas, n_pos, losses, image=0, anchors_per_loc=3, counts_dev=None):
+    """RPN class + bbox losses of image `image` and their gradients scattered into the (pre-zeroed) dheads.  counts_dev: int32 device
+    tensor {n_sel, n_pos} overriding the host counts (sel_* / target_deltas then have fixed capacities: graph-capturable)."""
     lib = _lib.load()
     d = RpnLossDesc()
     d.levels, d.anchors_per_loc, d.head_stride = len(heads), anchors_per_loc, heads[0].shape[-1]
@@ -637,7 +638,52 @@ def rpn_loss_grad(heads, dheads, sel_level, sel_index, sel_match, target_deltas,
         d.sel_level, d.sel_index, d.sel_match = (_chk(t, torch.int32, "sel").data_ptr() for t in (sel_level, sel_index, sel_match))
     d.target_deltas = _chk(target_deltas, name="target_deltas").data_ptr()
     d.losses = _chk(losses, name="losses").data_ptr()
+    if counts_dev is not None:
+        d.counts_dev = _chk(counts_dev, torch.int32, "counts_dev").data_ptr()
+        d.n_pos = min(int(n_pos), target_deltas.shape[0])
     check(lib.dc_rpn_loss_grad_f32(C.byref(d), _stream()), "dc_rpn_loss_grad_f32")
+
+
+def detection_targets(proposals, gt_boxes, gt_captions, n_rois, positive_ratio, seed=None, offset=0, offset_dev=None, out=None):
+    """DetectionTargetLayer for one image on the device (dc_detection_targets_f32).  proposals [N,4] / gt_boxes [G,4] float32
+    normalised, gt_captions [G,T] int32.  seed None: proposal order (no shuffle).  Returns (rois [n_rois,4], captions [n_rois,T] int32,
+    counts int32 [2] = {n_pos, n_neg}) -- device tensors, nothing is read back."""
+    lib = _lib.load()
+    _chk(proposals, name="proposals"), _chk(gt_boxes, name="gt_boxes"), _chk(gt_captions, torch.int32, "gt_captions")
+    N, G, T = proposals.shape[0], gt_boxes.shape[0], gt_captions.shape[1]
+    if gt_captions.shape[0] != G or not (proposals.is_contiguous() and gt_boxes.is_contiguous() and gt_captions.is_contiguous()):
+        raise _lib.DcapError("detection_targets: gt_captions must have one row per GT box; operands contiguous")
+    if out is None:
+        out = (torch.empty((n_rois, 4), dtype=torch.float32, device=proposals.device),
+               torch.empty((n_rois, T), dtype=torch.int32, device=proposals.device),
+               torch.empty((2,), dtype=torch.int32, device=proposals.device))
+    rois, caps, counts = out
+    d = DetectionTargetsDesc()
+    d.n_proposals, d.n_gt, d.n_rois, d.T = N, G, int(n_rois), T
+    d.proposals, d.gt_boxes, d.gt_captions = proposals.data_ptr(), gt_boxes.data_ptr(), gt_captions.data_ptr()
+    d.max_positive = int(n_rois * positive_ratio)
+    import numpy as _np
+    d.inv_ratio = float(_np.float32(1.0 / positive_ratio))
+    d.shuffle, d.seed, d.offset = int(seed is not None), (int(seed or 0) & 0xFFFFFFFF), int(offset) & 0xFFFFFFFF
+    d.offset_dev = None if offset_dev is None else _chk(offset_dev, torch.int32, "offset_dev").data_ptr()
+    d.rois, d.captions, d.counts = _chk(rois, name="rois").data_ptr(), _chk(caps, torch.int32, "captions").data_ptr(), _chk(counts, torch.int32, "counts").data_ptr()
+    check(lib.dc_detection_targets_f32(C.byref(d), _stream()), "dc_detection_targets_f32")
+    return rois, caps, counts
+
+
+def caption_tables(captions, out=None, live_count=None):
+    """captions int32 [B,T] (device) -> (ids_tm int32 [T*B], mask uint8 [T*B], targets_tm int32 [T*B], row_weights f32 [T*B])."""
+    lib = _lib.load()
+    _chk(captions, torch.int32, "captions")
+    B, T = captions.shape
+    dev = captions.device
+    if out is None:
+        out = (torch.empty(T * B, dtype=torch.int32, device=dev), torch.empty(T * B, dtype=torch.uint8, device=dev),
+               torch.empty(T * B, dtype=torch.int32, device=dev), torch.empty(T * B, dtype=torch.float32, device=dev))
+    ids, mask, tg, rw = out
+    check(lib.dc_caption_tables_i32(_ptr(captions), B, T, _ptr(ids), _ptr(mask), _ptr(tg), _ptr(rw),
+                                    None if live_count is None else _ptr(live_count), _stream()), "dc_caption_tables_i32")
+    return ids, mask, tg, rw
 
 
 def scatter2_add(coarse, fine):
@@ -715,10 +761,11 @@ def mean(x, out=None):
     return out
 
 
-def dropout_mask(out, rate, seed, offset):
-    """K.dropout(ones, rate): out filled with 1/(1-rate) (kept) or 0, element i a pure function of (i, seed, offset)."""
+def dropout_mask(out, rate, seed, offset, offset_dev=None):
+    """K.dropout(ones, rate): out filled with 1/(1-rate) (kept) or 0, element i a pure function of (i, seed, offset [+ *offset_dev])."""
     lib = _lib.load()
-    check(lib.dc_dropout_mask_f32(_ptr(_chk(out, name="out")), out.numel(), float(rate), int(seed) & 0xFFFFFFFF, int(offset) & 0xFFFFFFFF, _stream()),
+    check(lib.dc_dropout_mask_f32(_ptr(_chk(out, name="out")), out.numel(), float(rate), int(seed) & 0xFFFFFFFF, int(offset) & 0xFFFFFFFF,
+                                  None if offset_dev is None else _ptr(_chk(offset_dev, torch.int32, "offset_dev")), _stream()),
           "dc_dropout_mask_f32")
     return out
 
@@ -760,7 +807,8 @@ def maxpool3x3s2_same_bwd(x, y, dy, out=None):
     return out
 
 
-def amsgrad_step(p, g, m, v, vhat, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, gnorm_sq=None, clipnorm=0.0, p_bf16=None):
+def amsgrad_step(p, g, m, v, vhat, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, gnorm_sq=None, clipnorm=0.0, p_bf16=None,
+                 lr_t_dev=None):
     lib = _lib.load()
     d = AmsgradDesc()
     d.n = p.numel()
@@ -771,4 +819,6 @@ def amsgrad_step(p, g, m, v, vhat, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_
     d.clipnorm = float(clipnorm or 0.0)
     if p_bf16 is not None:
         d.p_bf16, d.n_bf16 = _chk(p_bf16, BF16, "p_bf16").data_ptr(), p_bf16.numel()
+    if lr_t_dev is not None:
+        d.lr_t_dev = _chk(lr_t_dev, name="lr_t_dev").data_ptr()
     check(lib.dc_amsgrad_step_f32(C.byref(d), _stream()), "dc_amsgrad_step_f32")

@@ -120,9 +120,11 @@ class Adam:
         t = self.iterations
         return self.lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
 
-    def apply(self, store, grad_scale=1.0):
+    def apply(self, store, grad_scale=1.0, lr_t_dev=None):
         """One update of every trainable weight from store.flat_grad (scaled by grad_scale, e.g.
-        1/world_size after a summing all-reduce)."""
+        1/world_size after a summing all-reduce).  lr_t_dev: a float32 device word holding this step's lr_t (the caller wrote
+        lr * sqrt(1 - b2^t) / (1 - b1^t) for t = iterations + 1 there): the launch then carries no per-step host value and can be
+        replayed from a captured hipGraph."""
         if self._state is None:
             self._init(store)
         self.iterations += 1
@@ -131,4 +133,5 @@ class Adam:
         if self.clipnorm:
             gn = ops.sumsq(store.flat_grad, out=self._gnorm)
         ops.amsgrad_step(store.flat, store.flat_grad, m, v, vh, self.lr_t(), self.beta_1, self.beta_2, self.epsilon,
-                         grad_scale=grad_scale, gnorm_sq=gn, clipnorm=self.clipnorm or 0.0, p_bf16=getattr(store, "flat_bf16", None))
+                         grad_scale=grad_scale, gnorm_sq=gn, clipnorm=self.clipnorm or 0.0, p_bf16=getattr(store, "flat_bf16", None),
+                         lr_t_dev=lr_t_dev)

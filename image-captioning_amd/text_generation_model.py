@@ -213,6 +213,7 @@ class CaptionModelV1(KerasLikeModel):
         self.grad_sync = None
         self._bufs = {}
         self._drop_seed, self._drop_step = (seed + 77) & 0xFFFFFFFF, 0
+        self._drop_offset_dev = None
         self._rec_masks = (None, None)           # device masks of the current train step (lstm1, lstm2) or None
 
     @property
@@ -238,6 +239,12 @@ class CaptionModelV1(KerasLikeModel):
             self._rec_masks = (None, None)
             return
         self._drop_step += 1
+        if self._drop_offset_dev is not None:
+            # the stream position comes from a device word (= 2 * _drop_step, written by the caller before the step): the launch is the
+            # same every step, so a captured hipGraph draws fresh masks on every replay
+            self._rec_masks = tuple(ops.dropout_mask(self._buf('rec_mask%d' % l, (4, B, self.units)), rate, self._drop_seed, l,
+                                                     offset_dev=self._drop_offset_dev) for l in range(2))
+            return
         self._rec_masks = tuple(ops.dropout_mask(self._buf('rec_mask%d' % l, (4, B, self.units)), rate, self._drop_seed, 2 * self._drop_step + l)
                                 for l in range(2))
 
@@ -348,11 +355,20 @@ class CaptionModelV1(KerasLikeModel):
         up = lambda a, dt: torch.tensor(np.ascontiguousarray(a), dtype=dt, device=self.device)
         return up(ids.T.reshape(-1), torch.int32), up((ids != 0).T.reshape(-1), torch.uint8), B, T
 
-    def _forward_train(self, feat, caps, targets=None, want_probs=False, want_grad=False, row_weights=None, keras_sparse=False):
+    def _forward_train(self, feat, caps, targets=None, want_probs=False, want_grad=False, row_weights=None, keras_sparse=False,
+                       device_tables=None):
         """row_weights [B,T] + keras_sparse: the joint model's masked K.sparse_categorical_crossentropy
-        (dense_img_cap/dense_model.py:936-946); loss rows and dlogits are then weighted per row instead of 1/N."""
+        (dense_img_cap/dense_model.py:936-946); loss rows and dlogits are then weighted per row instead of 1/N.
+        device_tables = (ids_tm, mask, targets_tm, row_weights_tm, B, T): the index tables already on the device
+        (ops.caption_tables from device-resident captions: the joint model's step never builds them on the host); caps / targets /
+        row_weights are then ignored."""
         pr = self._prefix_rows(want_grad)
-        ids_tm, mask, B, T = self._tables(caps, prefix_rows=pr)
+        if device_tables is not None:
+            if pr:
+                raise NotImplementedError("dropout_rows='prefix' builds its prefix tables on the host: pass captions, not device_tables")
+            ids_tm, mask, tg_dev, rw_dev, B, T = device_tables
+        else:
+            ids_tm, mask, B, T = self._tables(caps, prefix_rows=pr)
         Bl = T * B if pr else B
         self._draw_rec_masks(Bl, training=want_grad)
         X = feat.reshape(B, -1)
@@ -361,11 +377,13 @@ class CaptionModelV1(KerasLikeModel):
         w, g = self.store.w, self.store.grad
         N = T * B
         tg = loss_rows = None
-        if targets is not None:
+        rw = None
+        if device_tables is not None:
+            tg, rw, loss_rows = tg_dev, rw_dev, self._buf('loss_rows', (N,))
+        elif targets is not None:
             tg = torch.tensor(np.ascontiguousarray(np.asarray(targets, np.int32).T.reshape(-1)), device=self.device)
             loss_rows = self._buf('loss_rows', (N,))
-        rw = None
-        if row_weights is not None:
+        if device_tables is None and row_weights is not None:
             rw = torch.tensor(np.ascontiguousarray(np.asarray(row_weights, np.float32).T.reshape(-1)), device=self.device)
         gscale = 1.0 if rw is not None else 1.0 / N
         Wv, Wvb = self._wview('imgcap_lstm_d2/kernel')

@@ -467,9 +467,42 @@ typedef struct {
     const int32_t* sel_match;     /* [n_sel] +1 / -1 */
     const float*   target_deltas; /* [n_pos][4] */
     float* losses;                /* [2] */
+    const int32_t* counts_dev;    /* optional: device words {n_sel, n_pos} that override the two fields above (which then give the
+                                     CAPACITY of sel_* / target_deltas): the launch is the same whatever the image's counts are, so a
+                                     captured hipGraph can replay it */
 } dc_rpn_loss_desc;
 int dc_rpn_loss_grad_f32(const dc_rpn_loss_desc* d, void* stream);
 int dc_scatter2_add_f32(const float* coarse, float* fine, int N, int Hc, int Wc, int C, void* stream);
+/* DetectionTargetLayer for one image on the device (dense_img_cap/dense_model.py:450-572 detection_targets_graph; :421-447
+ * overlaps_graph in float32).  proposals [n_proposals][4] / gt_boxes [n_gt][4]: (y1,x1,y2,x2) normalised, all-zero rows are padding;
+ * gt_captions [n_gt][T] token ids.  Positives: best IoU >= 0.5 (at most max_positive = int(TRAIN_ROIS_PER_IMAGE * ROI_POSITIVE_RATIO)),
+ * negatives: best IoU < 0.5, int32(inv_ratio * float32(n_pos)) - n_pos of them (inv_ratio = float32(1 / ROI_POSITIVE_RATIO)).
+ * tf.random_shuffle of the two index lists = ascending order of Philox-2x32-10(counter = (position of the proposal among the non-zero
+ * ones, offset + *offset_dev), key = seed) with the position breaking ties (shuffle = 0: proposal order); the reference's shuffle is
+ * non-deterministic, this one is reproducible from (seed, offset).  offset_dev (optional): a device word added to `offset`, so that a
+ * captured hipGraph draws a fresh sample every replay.
+ * Writes rois [n_rois][4] (positives, then negatives, zero padded), captions [n_rois][T] (the best GT box's caption for positives,
+ * zeros otherwise) and counts = {n_pos, n_neg}.  Limits: n_proposals <= 4096, n_gt <= 512.  One workgroup; no workspace. */
+typedef struct {
+    int n_proposals, n_gt, n_rois, T;
+    const float*   proposals;
+    const float*   gt_boxes;
+    const int32_t* gt_captions;
+    int   max_positive;
+    float inv_ratio;
+    int   shuffle;
+    uint32_t seed, offset;
+    const uint32_t* offset_dev;
+    float*   rois;
+    int32_t* captions;
+    int32_t* counts;          /* [2] */
+} dc_detection_targets_desc;
+int dc_detection_targets_f32(const dc_detection_targets_desc* d, void* stream);
+/* Index tables of the Model-3 decoder from device-resident captions [B][T] (dense_img_cap/dense_model.py:1572-1580: target = caption
+ * shifted left by one; imgcap_caption_loss_graph :936-946: mean over positions with target > 0): ids_tm / targets_tm [T*B] time-major
+ * (row t*B + b), mask = ids != 0, row_weights = [target > 0] / max(count, 1), live_count[0] = count (may be NULL). */
+int dc_caption_tables_i32(const int32_t* captions, int B, int T, int32_t* ids_tm, uint8_t* mask, int32_t* targets_tm, float* row_weights,
+                          int32_t* live_count, void* stream);
 /* keras.regularizers.l2(WEIGHT_DECAY)(w) / size(w) summed over the trainable non-BN weights
  * (dense_img_cap/dense_model.py:1712-1718) over one flat bucket: coef[i] = WEIGHT_DECAY/size of i's tensor (0 where not
  * regularised).  grad[i] = grad[i]*mask[i] + 2*coef[i]*w[i] (grad may be NULL; mask = the 0/1 subset set_trainable() left
@@ -504,8 +537,9 @@ int dc_sumsq_f32(const float* x, size_t n, float* out, int accumulate, void* wor
 /* Inverted-dropout mask of ones: out[i] = 1/(1-rate) with probability 1-rate, else 0 -- K.dropout(K.ones_like(h), rate), the
  * per-gate recurrent_dropout masks Keras' LSTMCell draws in the training phase (recurrent.py _generate_recurrent_dropout_mask;
  * used by text_generation_model.py:141-142 and dense_img_cap/dense_model.py:769-770 with rate 0.2).  Counter-based
- * (Philox-2x32-10): element i of stream (seed, offset) is a pure function of (i, seed, offset). */
-int dc_dropout_mask_f32(float* out, size_t n, float rate, uint32_t seed, uint32_t offset, void* stream);
+ * (Philox-2x32-10): element i of stream (seed, offset) is a pure function of (i, seed, offset).  offset_dev (optional): a device
+ * word added to `offset` (a captured hipGraph then draws fresh masks every replay: the host bumps the word between replays). */
+int dc_dropout_mask_f32(float* out, size_t n, float rate, uint32_t seed, uint32_t offset, const uint32_t* offset_dev, void* stream);
 
 /* Training ResNet stages (dense_img_cap/dense_model.py:1829-1845: layers "3+" | "4+" | "5+" | "all"; BatchNorm with frozen
  * statistics :51-61, trainable gamma / beta and convolution).
@@ -548,6 +582,8 @@ typedef struct {
     float clipnorm;
     uint16_t* p_bf16;         /* optional: bf16 shadow of p (the operand copy the bf16 GEMMs read), refreshed in the same pass */
     size_t n_bf16;            /* the shadow covers p[0 .. n_bf16) (a multiple of 4) */
+    const float* lr_t_dev;    /* optional: a device word that overrides lr_t (Keras' lr_t depends on the iteration count; a captured
+                                 hipGraph reads this step's value from memory the host refreshed before the replay) */
 } dc_amsgrad_desc;
 
 int dc_amsgrad_step_f32(const dc_amsgrad_desc* d, void* stream);

@@ -81,26 +81,35 @@ WINO_BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], 
 WINO_AT = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], F64)
 
 
-def conv2d_winograd_nhwc(x, w, dtype=F64):
-    """3x3 / stride 1 / 'same' convolution as  Y = A^T [ (G g G^T) . (B^T d B) ] A  per 2x2 output tile, every product, sum and
-    transform rounded to `dtype` (float32 = the arithmetic of the kernel; sums over channels in one np.matmul)."""
+# F(4x4, 3x3), same paper, interpolation points 0, +-1, +-2, infinity: 36 products per 4x4 output tile and channel pair where the
+# direct form needs 144 (4x fewer; F(2x2,3x3): 2.25x).  NOT what the product runs -- restated to size the float32 error of the larger
+# transform before a kernel is written for it (tests/test_oracle_kat.py).
+WINO4_G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], F64)
+WINO4_BT = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], F64)
+WINO4_AT = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], F64)
+
+
+def conv2d_winograd_nhwc(x, w, dtype=F64, m=2):
+    """3x3 / stride 1 / 'same' convolution as  Y = A^T [ (G g G^T) . (B^T d B) ] A  per m x m output tile (m = 2: the form
+    csrc/conv_wino.hip evaluates; m = 4: F(4x4,3x3), see above), every product, sum and transform rounded to `dtype` (float32 = the
+    arithmetic of the kernel; sums over channels in one np.matmul)."""
     x = np.asarray(x, dtype)
     w = np.asarray(w, dtype)
     N, H, W, C = x.shape
-    assert w.shape[:3] == (3, 3, C)
+    assert w.shape[:3] == (3, 3, C) and m in (2, 4)
     O = w.shape[3]
-    G, BT, AT = WINO_G.astype(dtype), WINO_BT.astype(dtype), WINO_AT.astype(dtype)
+    G, BT, AT = [a.astype(dtype) for a in ((WINO_G, WINO_BT, WINO_AT) if m == 2 else (WINO4_G, WINO4_BT, WINO4_AT))]
     U = np.einsum('ai,ijck,bj->abck', G, w, G).astype(dtype)
-    th, tw = (H + 1) // 2, (W + 1) // 2
-    xp = np.zeros((N, 2 * th + 2, 2 * tw + 2, C), dtype)
+    th, tw = (H + m - 1) // m, (W + m - 1) // m
+    xp = np.zeros((N, m * th + 2, m * tw + 2, C), dtype)
     xp[:, 1:H + 1, 1:W + 1] = x
-    out = np.zeros((N, 2 * th, 2 * tw, O), dtype)
+    out = np.zeros((N, m * th, m * tw, O), dtype)
     for ty in range(th):
         for tx in range(tw):
-            d = xp[:, 2 * ty:2 * ty + 4, 2 * tx:2 * tx + 4]                       # top-left pixel (2 ty - 1, 2 tx - 1) of the image
+            d = xp[:, m * ty:m * ty + m + 2, m * tx:m * tx + m + 2]             # top-left pixel (m ty - 1, m tx - 1) of the image
             V = np.einsum('ai,nijc,bj->nabc', BT, d, BT).astype(dtype)
             M = np.einsum('nabc,abck->nabk', V, U).astype(dtype)
-            out[:, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = np.einsum('pa,nabk,qb->npqk', AT, M, AT).astype(dtype)
+            out[:, m * ty:m * ty + m, m * tx:m * tx + m] = np.einsum('pa,nabk,qb->npqk', AT, M, AT).astype(dtype)
     return out[:, :H, :W]
 
 

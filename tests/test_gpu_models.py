@@ -593,11 +593,11 @@ def test_joint_model_validation_is_forward_only(gpu):
     inputs = joint_inputs(S, V, T)
     model.forward_backward(inputs)                                   # some gradient in the bucket
     g0 = model.store.flat_grad.clone()
-    state = model._rng.get_state()
+    state = (model._dt_step, model.caption_model._drop_step)          # positions of the training run's sampling / dropout streams
     out = model.test_on_batch(inputs)
     assert len(out) == 4 and np.isfinite(out).all()
     assert torch.equal(model.store.flat_grad, g0)
-    assert all(np.array_equal(a, b) for a, b in zip(state[1:2], model._rng.get_state()[1:2])) and state[2] == model._rng.get_state()[2]
+    assert state == (model._dt_step, model.caption_model._drop_step) and model._dt_val_step == 1
     fwd = model._loss_list(model.forward_backward(inputs, shuffle=None, backward=False))
     full = model._loss_list(model.forward_backward(inputs, shuffle=None))
     for k in full:
@@ -917,3 +917,47 @@ def test_v2_script_flow_device_resident_generator_and_train_on_dataset(gpu, tmp_
     for n in want:
         d = np.abs(got[n] - want[n])
         assert d.max() <= 1e-3 * epochs * steps + 1e-6 and d.mean() < 0.25 * np.abs(want[n] - start[n]).mean() + 1e-7, (n, d.mean(), d.max())
+
+
+def test_joint_train_step_as_a_captured_graph_equals_the_eager_step(gpu):
+    """train_on_batch on one GPU: after two eager steps everything behind the encoder pass -- proposals, DetectionTargetLayer on the
+    device, RoIAlign, head + decoder forward / backward, RPN / FPN backward, regulariser, clip + AMSGrad -- is ONE captured hipGraph
+    whose per-step inputs (RPN selection and counts, GT boxes / captions, lr_t, dropout and sampling stream positions) are device
+    words refreshed by one asynchronous copy.  Seven steps on inputs that CHANGE every step (other GT boxes, other selected
+    anchors, other counts) with the reference's recurrent_dropout = 0.2: weights and losses bit-equal to the same model stepping
+    eagerly (DCAP_JOINT_GRAPH=0's path), and the RoI sample differs from step to step."""
+    S, V, T, blocks = 128, 24, 5, 1
+    _, cfg, Wt = make_joint(S, V, T, blocks)
+    del type(cfg).RECURRENT_DROPOUT
+    assert cfg.RECURRENT_DROPOUT == 0.2
+    from image_captioning_amd.dense_model import DenseImageCapRCNN
+    steps = [joint_inputs(S, V, T, seed=8 + (k % 3)) for k in range(7)]
+    for k, inp in enumerate(steps):                           # other GT boxes / captions and another number of positive anchors per step
+        inp[5] = inp[5].copy()
+        inp[5][0, :3] += np.float32(2 * (k % 3))
+        inp[2] = inp[2].copy()
+        pos = np.nonzero(inp[2][0, :, 0] == 1)[0]
+        inp[2][0, pos[:k % 4], 0] = 0
+    runs = {}
+    for mode in ("graph", "eager"):
+        model = DenseImageCapRCNN("training", cfg, "logs", stage4_blocks=blocks)
+        model.set_weights(Wt)
+        model.compile(1e-4)
+        model.use_step_graph = mode == "graph"
+        dev_inputs = []
+        losses, samples = [], []
+        for inp in steps:
+            inp = list(inp)
+            inp[0] = torch.tensor(inp[0], device="cuda")     # device-resident uint8 image: the step then has no blocking copy at all
+            dev_inputs.append(inp)
+            losses.append(model.train_on_batch(inp))
+            samples.append(model.last_targets["rois"].copy())
+        if mode == "graph":
+            assert "train" in model._graphs and model.use_step_graph, "the step was not captured"
+            assert model.optimizer.iterations == len(steps) and model.caption_model._drop_step == len(steps)
+        runs[mode] = (np.array(losses), model.store.flat.cpu().numpy(), samples)
+    np.testing.assert_array_equal(runs["graph"][0], runs["eager"][0])
+    np.testing.assert_array_equal(runs["graph"][1], runs["eager"][1])
+    for a, b in zip(runs["graph"][2], runs["eager"][2]):
+        np.testing.assert_array_equal(a, b)
+    assert not np.array_equal(runs["graph"][2][3], runs["graph"][2][6])      # same inputs (seed 8 + 0), another step: another sample

@@ -159,6 +159,30 @@ def test_winograd_f2x2_3x3_is_the_same_convolution():
     np.testing.assert_allclose(y, [d[0] * g[0] + d[1] * g[1] + d[2] * g[2], d[1] * g[0] + d[2] * g[1] + d[3] * g[2]], atol=1e-14)
 
 
+def test_winograd_f4x4_3x3_restatement_and_its_float32_error():
+    """F(4x4,3x3) (36 products per 4x4 tile instead of 144): exact in float64 incl. ragged sizes; in float32 its error at a
+    ResNet-sized reduction (256 post-ReLU input channels) is an order of magnitude above F(2x2,3x3)'s and the direct sum's -- about
+    1e-5 of the output scale at the worst element, 6e-7 rms -- which still fits the 2e-5 per-layer / 2e-4 feature tolerances the
+    GPU tests hold the encoder to.  This sizes the error budget for a kernel that does not exist yet."""
+    rng = np.random.default_rng(14)
+    x = rng.standard_normal((2, 7, 9, 24))
+    w = rng.standard_normal((3, 3, 24, 8)) / np.sqrt(9 * 24)
+    want = O.conv2d_nhwc(x, w, None, 1, 'same')
+    np.testing.assert_allclose(O.conv2d_winograd_nhwc(x, w, m=4), want, rtol=0, atol=1e-12)
+    d, g = rng.standard_normal(6), rng.standard_normal(3)
+    y = O.WINO4_AT @ ((O.WINO4_G @ g) * (O.WINO4_BT @ d))
+    np.testing.assert_allclose(y, [sum(d[i + k] * g[k] for k in range(3)) for i in range(4)], atol=1e-13)
+    x = np.maximum(rng.standard_normal((1, 16, 16, 256)), 0)
+    w = rng.standard_normal((3, 3, 256, 32)) / np.sqrt(9 * 256)
+    want = O.conv2d_nhwc(x, w, None, 1, 'same')
+    scale = np.abs(want).max()
+    e2 = np.abs(O.conv2d_winograd_nhwc(x, w, np.float32, m=2).astype(np.float64) - want)
+    e4 = np.abs(O.conv2d_winograd_nhwc(x, w, np.float32, m=4).astype(np.float64) - want)
+    assert e2.max() / scale < 2e-6 and e4.max() / scale < 2e-5, (e2.max() / scale, e4.max() / scale)
+    assert np.sqrt((e4 ** 2).mean()) / scale < 2e-6
+    assert e4.max() > 3 * e2.max()                         # the larger transform does cost accuracy: it is not free
+
+
 def test_lstm_recurrent_dropout_masks_and_gradients():
     """Keras recurrent_dropout (training phase): masks of ones reproduce the plain LSTM; kept units are scaled by 1/(1-rate); the
     hand-written backward with masks matches finite differences (incl. through masked timesteps)."""
