@@ -261,6 +261,50 @@ def gpu_configs0(dev, steps=30):
     return out
 
 
+def hbm_kernels_leg(dev, images_per_gpu, rois_per_image, S=1024):
+    """The HBM-bound kernels north_star names, against the 8 TB/s peak (MI355X_MICROARCH.md), measured live: PyramidROIAlign at the
+    benchmark's per-GPU size (2 images x 32 RoIs: a 5 us kernel that moves 16 MB -- launch- and latency-bound, it cannot reach a
+    bandwidth figure) and at a size where the 60 % target is a property of the kernel (16 images x 32 RoIs = configs[3]'s global
+    batch on one GPU), and the decoder's embedding-row gather.  Kernel time = a captured hipGraph of 20 back-to-back launches / 20
+    (HIP events around the replay: no launch gaps).  Algorithmic bytes: SURVEY 8(d), 250 880 B per RoI (4 corner rows read, 1 row
+    written per bin)."""
+    from image_captioning_amd import ops, synth
+    out = {"peak": 8000.0, "unit": "GB/s", "note": "algorithmic bytes (SURVEY 8d) / kernel time; the 60 % north-star bar applies where the kernel "
+                                                     "is bandwidth-bound (16 images); at the benchmark's 64 RoIs it runs 5 us and is latency-bound"}
+
+    def timed(fn, reps=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                fn()
+        g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3            # us per launch
+    for label, B, R in (("roialign_bench_size", images_per_gpu, rois_per_image), ("roialign_16_images", 16, rois_per_image)):
+        maps = [torch.randn(B, S // st, S // st, 256, device=dev) for st in (4, 8, 16, 32)]
+        boxes = torch.tensor(synth.rois(1, B, R, S, S) / np.array([S, S, S, S], np.float32), device=dev)
+        o = torch.empty(B, R, 7, 7, 256, device=dev)
+        us = timed(lambda: ops.roi_align_pyramid(maps, boxes, float(S * S), 7, out=o))
+        alg = B * R * 250880.0
+        out[label] = {"images": B, "rois": B * R, "kernel_us": round(us, 2), "algorithmic_bytes": alg, "achieved": round(alg / us / 1e3, 1),
+                      "frac": round(alg / us / 1e3 / 8000.0, 3)}
+        del maps, o
+    table = torch.randn(131072, 1024, device=dev)
+    idx = torch.randint(0, 131072, (131072,), dtype=torch.int32, device=dev)
+    o = torch.empty(131072, 1024, device=dev)
+    us = timed(lambda: ops.gather_rows(table, idx, o))
+    b = 2.0 * 131072 * 1024 * 4
+    out["gather_rows_131072x1024"] = {"kernel_us": round(us, 2), "algorithmic_bytes": b, "achieved": round(b / us / 1e3, 1), "frac": round(b / us / 1e3 / 8000.0, 3)}
+    return out
+
+
 def dataset_pipeline_leg(args, dev, steps=40):
     """The headline workload driven through the training script's objects instead of bench.py's resident buffers:
     text_generation_model_v2.train_on_dataset on a synthetic in-memory Dataset (8 images of the benchmark's size, `rois` regions with
@@ -811,6 +855,7 @@ def main():
             four = json.loads(r4.stdout.strip().splitlines()[-1])
             other["four_images_per_gpu"] = {"workload": "the headline's model at 4 images x %d RoI per step and GPU (not a BASELINE config)" % R,
                                             "value": four["value"], "unit": "captions/s", "ms_per_step": four["ms_per_step"], "steps": four["steps"]}
+            out["hbm_kernels"] = hbm_kernels_leg(dev, B, R, S)
             other["configs0_gpu"] = gpu_configs0(dev)
             other["configs1_gpu"] = gpu_configs1(dev)
             other["train_on_dataset"] = dataset_pipeline_leg(args, dev)

@@ -573,9 +573,10 @@ class DenseImageCapRCNN(object):
         if need is not None and (self.backbone_from is None or need < self.backbone_from):
             # ResNet stages join the trainable set: their weights move from the folded, frozen backbone into the parameter
             # bucket (kernels, biases, BN gamma / beta; moving statistics stay frozen), the encoder plan is rebuilt around them
-            if self.conv_math_name == "bf16":
-                raise NotImplementedError("training ResNet stages runs the exact-fp32 (or split-bf16) convolutions: build the model with "
-                                          "conv_math='f32' (compute_dtype='bf16' for the decoder is fine)")
+            # (conv_math='bf16', configs[4]'s arithmetic: the trainable stages' forward runs in bf16 storage like the rest of the trunk --
+            # their packed kernels are re-cast inside every forward, fp32 copies of their activations are kept for the backward --, the
+            # 3x3 data gradients and the stride-1 weight gradients take the bf16 matrix pipe, the 1x1 data gradients and the strided entry
+            # convolutions' weight gradients stay exact fp32 GEMMs on the master weights; BatchNorm's backward is fp32 throughout)
             self.backbone_from = need
             self._build(self._seed, weights=self.get_weights_dict())
             self.optimizer = None
