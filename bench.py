@@ -305,7 +305,7 @@ def hbm_kernels_leg(dev, images_per_gpu, rois_per_image, S=1024):
     return out
 
 
-def dataset_pipeline_leg(args, dev, steps=40):
+def dataset_pipeline_leg(args, dev, steps=120):
     """The headline workload driven through the training script's objects instead of bench.py's resident buffers:
     text_generation_model_v2.train_on_dataset on a synthetic in-memory Dataset (8 images of the benchmark's size, `rois` regions with
     `tokens`-word captions each): images are molded and uploaded, box and sample tables built and uploaded per step by the

@@ -67,7 +67,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // captured into a hipGraph: a captured memset becomes a memset NODE, and on this runtime the joint train step replayed as a graph
 // faulted on its second launch inside the top-k radix select (whose histograms a memset node was supposed to clear) while the same
 // sequence issued eagerly, or with this kernel in the graph, is fine (round 4; tools/diag_joint_graph4.py).
-__global__ __launch_bounds__(256) inline void zero_fill_kernel(unsigned* __restrict__ p, size_t words) {
+static __global__ __launch_bounds__(256) void zero_fill_kernel(unsigned* __restrict__ p, size_t words) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) p[i] = 0u;
 }
 inline int zero_fill_async(void* p, size_t bytes, hipStream_t s) {

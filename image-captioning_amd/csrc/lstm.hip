@@ -109,12 +109,20 @@ __global__ __launch_bounds__(256) void lstm_pack_urec_kernel(const float* __rest
 // NW/2.. publish, waves 0..NW/2-1 add theirs on top): 16.9 KB at <1,8> and <2,4> -- in the training pipeline this kernel runs
 // beside the encoder's convolutions, whose two resident blocks leave ~19 KB of a CU's LDS; with 33.8 KB its blocks could only
 // start at conv-kernel boundaries (78-100 us per step in the pipeline against 18 us alone).
-template <int RT, int NW>
+// MASKED (Keras recurrent_dropout in the training phase, round 4): h_{t-1} enters gate g through its own mask m_g, so the product is
+// four products (h * m_g) U_g.  The A operand then comes from FOUR pre-masked copies hm_prev [4][B][U] (written by the previous
+// step's epilogue -- or by lstm_mask_rows_kernel for the first step --, double-buffered: other blocks still read this step's copies
+// while a block's epilogue writes the next step's), one accumulator tile per gate against the same 32-column B fragment, of which a
+// lane keeps the tile of the gate its column belongs to (columns 8 g .. 8 g + 7 of the block are gate g's units).  Four times the
+// MFMAs of the plain step -- irrelevant: the step is latency-bound -- and ONE launch per timestep instead of six.
+template <int RT, int NW, bool MASKED = false>
 __global__ __launch_bounds__(NW * 64) void lstm_step_fused_kernel(float* __restrict__ z_t, const float* __restrict__ Upk,
                                                                   const float* __restrict__ h_prev, const float* __restrict__ c_prev,
                                                                   const uint8_t* __restrict__ mask_t, float* __restrict__ h_t,
-                                                                  float* __restrict__ c_t, int B, int U) {
+                                                                  float* __restrict__ c_t, int B, int U, const float* __restrict__ hm_prev = nullptr,
+                                                                  const float* __restrict__ rec_masks = nullptr, float* __restrict__ hm_next = nullptr) {
     constexpr int HALF = NW / 2, THREADS = NW * 64, ITEMS = RT * 256, IT = (ITEMS + THREADS - 1) / THREADS;
+    constexpr int NG = MASKED ? 4 : 1;
     __shared__ float part[HALF][RT * 32][33];
 #ifdef DCAP_LSTM_STAMPS
     const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
@@ -131,27 +139,32 @@ __global__ __launch_bounds__(NW * 64) void lstm_step_fused_kernel(float* __restr
     const int i = lane & 31, h = lane >> 5;
     const int kq = U / NW, kbeg = wave * kq;
     const int nch = kq / 8;                                                   // 8 k values per chunk (4 MFMAs of K = 2)
-    f32x16_t acc[RT];
-    const float* ap[RT];
+    f32x16_t acc[NG][RT];
+    const float* ap[NG][RT];
+    const long gstride = (long)B * U;                                         // MASKED: between the masked copies of h
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
+    for (int g = 0; g < NG; ++g)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
-        ap[rt] = h_prev + (long)min(r0 + 32 * rt + i, B - 1) * U + kbeg + 4 * h;
-    }
+        for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][rt][r] = 0.f;
+            ap[g][rt] = (MASKED ? hm_prev + g * gstride : h_prev) + (long)min(r0 + 32 * rt + i, B - 1) * U + kbeg + 4 * h;
+        }
     const long kstride = (long)(U / 8) * 32;                                  // floats between consecutive k rows of Upk
     const float* bp = Upk + (long)(kbeg + 4 * h) * kstride + (long)ub * 32 + i;
 #ifndef DCAP_LSTM_PF
 #define DCAP_LSTM_PF 8
 #endif
-    constexpr int PF = DCAP_LSTM_PF;
-    f4_t a[PF][RT];
+    constexpr int PF = MASKED ? 4 : DCAP_LSTM_PF;                            // (four A streams: a shallower ring keeps the registers)
+    f4_t a[PF][NG][RT];
     float b[PF][4];
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
         const int c = min(p, nch - 1);
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) a[p][rt] = *reinterpret_cast<const f4_t*>(ap[rt] + 8 * c);
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) a[p][g][rt] = *reinterpret_cast<const f4_t*>(ap[g][rt] + 8 * c);
 #pragma unroll
         for (int j = 0; j < 4; ++j) b[p][j] = bp[(long)(8 * c + j) * kstride];
     }
@@ -172,40 +185,59 @@ __global__ __launch_bounds__(NW * 64) void lstm_step_fused_kernel(float* __restr
     for (int c0 = 0; c0 < nch; c0 += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
-            f4_t x[RT];
+            f4_t x[NG][RT];
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) x[rt] = a[p][rt];
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) x[g][rt] = a[p][g][rt];
             const float b0 = b[p][0], b1 = b[p][1], b2 = b[p][2], b3 = b[p][3];
             if (c0 + PF < nch) {                                              // the next ring of chunks (clamped at the end)
                 const int cn = min(c0 + p + PF, nch - 1);
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) a[p][rt] = *reinterpret_cast<const f4_t*>(ap[rt] + 8 * cn);
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) a[p][g][rt] = *reinterpret_cast<const f4_t*>(ap[g][rt] + 8 * cn);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) b[p][j] = bp[(long)(8 * cn + j) * kstride];
             }
             if (c0 + p < nch) {
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[rt].x, b0, acc[rt], 0, 0, 0);
-                    acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[rt].y, b1, acc[rt], 0, 0, 0);
-                    acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[rt].z, b2, acc[rt], 0, 0, 0);
-                    acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[rt].w, b3, acc[rt], 0, 0, 0);
-                }
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        acc[g][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[g][rt].x, b0, acc[g][rt], 0, 0, 0);
+                        acc[g][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[g][rt].y, b1, acc[g][rt], 0, 0, 0);
+                        acc[g][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[g][rt].z, b2, acc[g][rt], 0, 0, 0);
+                        acc[g][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[g][rt].w, b3, acc[g][rt], 0, 0, 0);
+                    }
             }
+        }
+    }
+    // this lane's column i = 8 gate + unit: of the four gate tiles it keeps its own gate's
+    f32x16_t mine[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        if constexpr (MASKED) {
+            const int gsel = i >> 3;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                mine[rt][r] = gsel == 0 ? acc[0][rt][r] : (gsel == 1 ? acc[1][rt][r] : (gsel == 2 ? acc[2][rt][r] : acc[NG - 1][rt][r]));
+        } else {
+            mine[rt] = acc[0][rt];
         }
     }
     if (wave >= HALF) {                                // round 1: the upper waves publish their K share's partial tiles
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) part[wave - HALF][32 * rt + (r & 3) + 8 * (r >> 2) + 4 * h][i] = acc[rt][r];
+            for (int r = 0; r < 16; ++r) part[wave - HALF][32 * rt + (r & 3) + 8 * (r >> 2) + 4 * h][i] = mine[rt][r];
     }
     __syncthreads();
     if (wave < HALF) {                                 // round 2: the lower waves add theirs on top (same lane owns the same elements)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) part[wave][32 * rt + (r & 3) + 8 * (r >> 2) + 4 * h][i] += acc[rt][r];
+            for (int r = 0; r < 16; ++r) part[wave][32 * rt + (r & 3) + 8 * (r >> 2) + 4 * h][i] += mine[rt][r];
     }
     __syncthreads();
 #pragma unroll
@@ -228,8 +260,15 @@ __global__ __launch_bounds__(NW * 64) void lstm_step_fused_kernel(float* __restr
         const float ig = hard_sigmoid(zg[0]), fg = hard_sigmoid(zg[1]), gg = tanhf(zg[2]), og = hard_sigmoid(zg[3]);
         const float cn = fg * gcp[q] + ig * gg;
         const float hn = og * tanhf(cn);
-        h_t[o] = gmk[q] ? hn : ghp[q];
+        const float hv = gmk[q] ? hn : ghp[q];
+        h_t[o] = hv;
         c_t[o] = gmk[q] ? cn : gcp[q];
+        if constexpr (MASKED) {
+            if (hm_next) {                             // the next step's A operands: h_t through the four gate masks
+#pragma unroll
+                for (int g = 0; g < 4; ++g) hm_next[g * gstride + o] = hv * rec_masks[g * gstride + o];
+            }
+        }
     }
 #ifdef DCAP_LSTM_STAMPS
     __syncthreads();
@@ -256,7 +295,10 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step_fused_kernel(const floa
                                                                       const uint8_t* __restrict__ mask_t, const float* __restrict__ dh_out_t,
                                                                       const float* __restrict__ dz_next, const float* __restrict__ U_rec,
                                                                       float* __restrict__ dh_io, float* __restrict__ dc_io,
-                                                                      float* __restrict__ dz_t, int B, int U) {
+                                                                      float* __restrict__ dz_t, int B, int U,
+                                                                      const float* __restrict__ rec_masks = nullptr) {
+    // rec_masks [4][B][U] (recurrent dropout): dh_t += sum_g m_g * (dz_{t+1,g} U_g^T).  A wave's share of K = 4U lies inside ONE gate
+    // (NW = 4: wave = gate; NW = 8: two waves per gate), so its partial tile IS that gate's product: the masks apply where the tiles meet.
     __shared__ float part[NW][RT * 16][17];
     constexpr int THREADS = NW * 64, ITEMS = RT * 256, IT = (ITEMS + THREADS - 1) / THREADS;
 #ifndef DCAP_LSTM_NOPRIO
@@ -338,8 +380,14 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step_fused_kernel(const floa
         const int u = u0 + uu;
         const long idx = (long)brow * U + u;
         float rec = 0.f;
+        if (rec_masks) {
+            const long gs = (long)B * U;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) rec += part[w][row][uu];
+            for (int w = 0; w < NW; ++w) rec += part[w][row][uu] * rec_masks[(w * 4 / NW) * gs + idx];
+        } else {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) rec += part[w][row][uu];
+        }
         const float zi = gz[q][0], zf = gz[q][1], zc = gz[q][2], zo = gz[q][3];
         const float i = hard_sigmoid(zi), f = hard_sigmoid(zf), g = tanhf(zc), o = hard_sigmoid(zo);
         const float cp = gcp[q];
@@ -472,7 +520,9 @@ extern "C" size_t dc_lstm_seq_workspace_bytes(int B, int T, int U) {
     }
     const size_t drop = align_up(g) + 2 * align_up((size_t)B * U * sizeof(float)) + align_up((size_t)4 * B * U * sizeof(float)) +
                         align_up((size_t)4 * (size_t)std::max(T - 1, 1) * B * U * sizeof(float)) + 1024;
-    return std::max(std::max(fwd, bwd), drop);
+    // fused masked forward steps: the repacked U_rec + TWO sets of four masked copies of h
+    const size_t drop_fused = align_up(g) + align_up((size_t)4 * U * U * sizeof(float)) + 2 * align_up((size_t)4 * B * U * sizeof(float)) + 1024;
+    return std::max(std::max(std::max(fwd, bwd), drop), drop_fused);
 }
 
 extern "C" int dc_lstm_seq_fwd_f32(const dc_lstm_fwd_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
@@ -482,24 +532,35 @@ extern "C" int dc_lstm_seq_fwd_f32(const dc_lstm_fwd_desc* d, void* workspace, s
                DC_EWORKSPACE, "dc_lstm_seq_fwd: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int B = d->B, U = d->U, n = B * U, blocks = (n + 255) / 256;
-    const bool fused = (U & 31) == 0 && d->T > 1 && !d->rec_masks;
+    static const int masked_fused = env_int("DCAP_LSTM_MASKED_FUSED", 1);      // 0: the round-3 path (mask kernel + 4 GEMMs + gate kernel per step)
+    const bool fused = (U & 31) == 0 && d->T > 1 && (!d->rec_masks || masked_fused);
     static const int force_rt = env_int("DCAP_LSTM_FWD_RT", 0), force_nw = env_int("DCAP_LSTM_FWD_NW", 0);
     int frt = ((U / 8) * ((B + 31) / 32) <= 2 * kNumCU) ? 1 : 2;      // 32- or 64-row blocks
     int fnw = (frt == 2 && (U & 63) == 0) ? 8 : 4;                     // measured: 4 waves at 32 rows, 8 at 64
     if (force_rt == 1 || force_rt == 2) frt = force_rt;
     if (force_nw == 4 || (force_nw == 8 && (U & 63) == 0)) fnw = force_nw;
+    if (d->rec_masks && frt == 2) fnw = 4;          // the masked step keeps four gate tiles: <2, 8> would spill (297 VGPRs), <2, 4> fits
     float* Upk = nullptr;
     float* hm = nullptr;                            // dropout: [4][B][U] masked copies of h_{t-1}, at the END of the workspace
     void* gws = workspace;
     size_t gws_bytes = workspace_bytes;
+    float* hm2[2] = {nullptr, nullptr};             // fused masked steps: the double-buffered masked copies
+    size_t tail = 0;                                // bytes taken from the END of the workspace
     if (d->rec_masks) {
         const size_t hm_bytes = align_up((size_t)4 * n * sizeof(float));
-        hm = reinterpret_cast<float*>(static_cast<char*>(workspace) + (workspace_bytes - hm_bytes) / 256 * 256);
-        gws_bytes = (workspace_bytes - hm_bytes) / 256 * 256;
+        char* end = static_cast<char*>(workspace) + workspace_bytes / 256 * 256;
+        hm = reinterpret_cast<float*>(end - hm_bytes);
+        tail = hm_bytes + (workspace_bytes - workspace_bytes / 256 * 256);
+        hm2[0] = hm;
+        if (fused) {
+            hm2[1] = reinterpret_cast<float*>(end - 2 * hm_bytes);
+            tail += hm_bytes;
+        }
+        gws_bytes = workspace_bytes - tail;
     }
-    if (fused) {                                   // line-contiguous copy of the recurrent weights at the END of the workspace
+    if (fused) {                                   // line-contiguous copy of the recurrent weights at the END of the workspace (below the masked copies)
         const size_t pack_bytes = align_up((size_t)4 * U * U * sizeof(float));
-        Upk = reinterpret_cast<float*>(static_cast<char*>(workspace) + (workspace_bytes - pack_bytes) / 256 * 256);
+        Upk = reinterpret_cast<float*>(static_cast<char*>(workspace) + (workspace_bytes - tail - pack_bytes) / 256 * 256);
         const long total = (long)4 * U * U;
         hipLaunchKernelGGL(lstm_pack_urec_kernel, dim3((int)std::min<long>((total + 255) / 256, (long)kNumCU * 8)), dim3(256), 0, s, d->U_rec, Upk, U);
         int rc = check_launch("lstm_pack_urec_kernel");
@@ -514,6 +575,24 @@ extern "C" int dc_lstm_seq_fwd_f32(const dc_lstm_fwd_desc* d, void* workspace, s
             float* h_t = d->h_seq + (long)t * n;
             float* c_t = d->c_seq + (long)t * n;
             const dim3 grid(U / 8, (B + 32 * frt - 1) / (32 * frt));
+            if (d->rec_masks) {
+                if (t == 1) {                           // h_0 through the four masks (later steps: the previous step's epilogue)
+                    hipLaunchKernelGGL(lstm_mask_rows_kernel, dim3(std::min(blocks, kNumCU * 8)), dim3(256), 0, s, hp, d->rec_masks, hm2[1], (long)B, B, U);
+                    int rc = check_launch("lstm_mask_rows_kernel");
+                    if (rc) return rc;
+                }
+                const float* hm_prev = hm2[t & 1];       // written for step t: by the mask kernel (t = 1) or by step t - 1
+                float* hm_next = (t + 1 < d->T) ? hm2[(t + 1) & 1] : nullptr;
+#define DCAP_FWD_STEP_M(RT_, NW_) hipLaunchKernelGGL((lstm_step_fused_kernel<RT_, NW_, true>), grid, dim3(NW_ * 64), 0, s, z_t, Upk, hp, cp, mk, h_t, c_t, B, U, hm_prev, d->rec_masks, hm_next)
+                if (frt == 1 && fnw == 8) DCAP_FWD_STEP_M(1, 8);
+                else if (frt == 1) DCAP_FWD_STEP_M(1, 4);
+                else if (fnw == 8) DCAP_FWD_STEP_M(2, 8);
+                else DCAP_FWD_STEP_M(2, 4);
+#undef DCAP_FWD_STEP_M
+                int rc = check_launch("lstm_step_fused_kernel (masked)");
+                if (rc) return rc;
+                continue;
+            }
 #define DCAP_FWD_STEP(RT_, NW_) hipLaunchKernelGGL((lstm_step_fused_kernel<RT_, NW_>), grid, dim3(NW_ * 64), 0, s, z_t, Upk, hp, cp, mk, h_t, c_t, B, U)
             if (frt == 1 && fnw == 8) DCAP_FWD_STEP(1, 8);
             else if (frt == 1) DCAP_FWD_STEP(1, 4);
@@ -575,7 +654,8 @@ extern "C" int dc_lstm_seq_bwd_f32(const dc_lstm_bwd_desc* d, void* workspace, s
     }
     int zrc = zero_fill_async(wsp, 2 * state_bytes, s);
     if (zrc) return zrc;
-    const bool fused = (U & 15) == 0 && !d->rec_masks && lstm_bwd_fused_enabled();
+    static const int masked_fused = env_int("DCAP_LSTM_MASKED_FUSED", 1);
+    const bool fused = (U & 15) == 0 && (!d->rec_masks || masked_fused) && lstm_bwd_fused_enabled();
     static const int force_rt = env_int("DCAP_LSTM_BWD_RT", 0), force_nw = env_int("DCAP_LSTM_BWD_NW", 0);
     int rt_rows = ((U / 16) * ((B + 15) / 16) <= kNumCU) ? 16 : 32;      // measured: 200 x 512 is 1.2x faster with 32-row blocks
     int nw = (U & 31) == 0 ? 8 : 4;
@@ -590,7 +670,7 @@ extern "C" int dc_lstm_seq_bwd_f32(const dc_lstm_bwd_desc* d, void* workspace, s
             const float* dho = d->dh_seq ? d->dh_seq + (long)t * n : nullptr;
             const float* dz_next = dz_t + (long)B * 4 * U;
             const dim3 grid(U / 16, (B + rt_rows - 1) / rt_rows);
-#define DCAP_BWD_STEP(RT_, NW_) hipLaunchKernelGGL((lstm_bwd_step_fused_kernel<RT_, NW_>), grid, dim3(NW_ * 64), 0, s, z_t, cp, mk, dho, dz_next, d->U_rec, dh, dc, dz_t, B, U)
+#define DCAP_BWD_STEP(RT_, NW_) hipLaunchKernelGGL((lstm_bwd_step_fused_kernel<RT_, NW_>), grid, dim3(NW_ * 64), 0, s, z_t, cp, mk, dho, dz_next, d->U_rec, dh, dc, dz_t, B, U, d->rec_masks)
             if (rt_rows == 16 && nw == 8) DCAP_BWD_STEP(1, 8);
             else if (rt_rows == 16) DCAP_BWD_STEP(1, 4);
             else if (nw == 8) DCAP_BWD_STEP(2, 8);
@@ -604,7 +684,7 @@ extern "C" int dc_lstm_seq_bwd_f32(const dc_lstm_bwd_desc* d, void* workspace, s
                            d->dh_seq ? d->dh_seq + (long)t * n : nullptr, (t == T - 1) ? d->dh_last : nullptr, dh, dc, dz_t, B, U);
         int rc = check_launch("lstm_gate_bwd_kernel");
         if (rc) return rc;
-        if (t && d->rec_masks) {                                // dh_{t-1} += sum_g m_g * (dz_g U_g^T)
+        if (t && d->rec_masks && !fused) {                      // dh_{t-1} += sum_g m_g * (dz_g U_g^T)   (fused: the next iteration's kernel does it)
             for (int gate = 0; gate < 4; ++gate) {
                 dc_gemm_desc g{};
                 g.M = B; g.N = U; g.K = U;
