@@ -821,9 +821,12 @@ def main():
         # fp32 accumulate; csrc/igemm_bf16s.h), each mode timed by a child process of this one after the headline run.
         # Reported beside the headline, which stays on exact fp32 products.
         torch.cuda.synchronize()
-        # (the 3-piece split, DCAP_CONV_MATH=bf16x3, stays available and tested, but since the fp32 default runs its 3x3 layers in the
-        # Winograd form it is slower than the headline and no longer a bench leg)
-        labels = {"bf16x2": "2-piece bf16 split, 3 MFMA products, fp32 accumulate (2^-16 products; features within 1e-3 of the oracle)"}
+        # Round 4: in both modes the 3x3 layers with frozen weights run the fp32 Winograd kernel like the headline; the split arithmetic
+        # applies to the 1x1 / strided / stem layers.
+        labels = {"bf16x3": "1x1 / strided / stem layers: 3-piece bf16 split of both operands, 6 MFMA products, fp32 accumulate (fp32-grade: same "
+                            "test tolerances as f32); 3x3 layers: the headline's fp32 Winograd kernel",
+                  "bf16x2": "1x1 / strided / stem layers: 2-piece bf16 split, 3 MFMA products, fp32 accumulate (2^-16 products; features within "
+                            "1e-3 of the oracle); 3x3 layers: the headline's fp32 Winograd kernel"}
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-alt-math",
                "--no-cpu-baseline", "--no-other-configs", "--images-per-gpu", str(B), "--rois", str(R), "--tokens", str(T),
                "--vocab", str(V), "--image-size", str(S), "--stage4-blocks", str(args.stage4_blocks)] + (["--no-pipeline"] if args.no_pipeline else [])
@@ -878,7 +881,14 @@ def main():
             jt = json.loads(rj.stdout.strip().splitlines()[-1])
             other["configs4_joint"] = {"workload": jt["config"]["workload"], "value": jt["value"], "unit": "captions/s", "ms_per_step": jt["ms_per_step"],
                                        "steps": jt["steps"], "dtype": jt["dtype"], "positive_rois": jt["config"]["positive_rois"],
-                                       "rois_per_image": jt["config"]["rois_per_image"], "roofline": jt.get("roofline")}
+                                       "rois_per_image": jt["config"]["rois_per_image"], "recurrent_dropout": jt["config"]["recurrent_dropout"],
+                                       "roofline": jt.get("roofline")}
+            # the same step with the reference's recurrent_dropout = 0.2 on both LSTMs (dense_img_cap/dense_model.py:769-770): device-side
+            # Philox masks, one fused launch per LSTM timestep in both directions (round 4)
+            rd = subprocess.run(cmdj + ["--joint-dropout", "0.2", "--no-roofline"], capture_output=True, text=True, timeout=400)
+            jd = json.loads(rd.stdout.strip().splitlines()[-1])
+            other["configs4_joint_reference_dropout"] = {"value": jd["value"], "unit": "captions/s", "ms_per_step": jd["ms_per_step"], "steps": jd["steps"],
+                                                         "recurrent_dropout": jd["config"]["recurrent_dropout"]}
         except Exception as e:
             other["error_joint"] = repr(e)[:300]
         if not args.no_cpu_baseline:

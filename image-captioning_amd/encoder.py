@@ -205,17 +205,23 @@ class EncoderPlan:
         d.shift = sh.data_ptr()
         d.residual = None if residual is None else residual.data_ptr()
         d.res_mode, d.relu, d.split_k, d.math = res_mode, int(relu), 0, self.math
-        if self.math == _lib.MATH_BF16X3 and name != "conv1" and name not in self._external:
+        use_wino = (self.winograd and self.math in (_lib.MATH_F32, _lib.MATH_BF16X3, _lib.MATH_BF16X2) and s.k == 3 and s.stride == 1 and
+                    s.padding == "same" and residual is None and name not in self._external and Cin % 32 == 0 and Cout % 32 == 0 and
+                    wp.shape[1] == 9 * Cin)
+        if self.math == _lib.MATH_BF16X3 and name != "conv1" and name not in self._external and not use_wino:
             # frozen weights: the three-piece bf16 split is paid once here instead of in every K-tile
             if name not in self._wsplit:
                 self._wsplit[name] = ops.split_bf16x3(wp)
             d.w_split = self._wsplit[name].data_ptr()
-        if (self.winograd and self.math == _lib.MATH_F32 and s.k == 3 and s.stride == 1 and s.padding == "same" and residual is None and
-                name not in self._external and Cin % 32 == 0 and Cout % 32 == 0 and wp.shape[1] == 9 * Cin):
+        if use_wino:
             # (Cin = the channels of the tensor the layer READS: VGG16's block1_conv1 reads RGB zero-padded to 32 channels)
+            # The split-bf16 modes (round 4): their 3x3 layers with frozen weights ALSO run the fp32 Winograd kernel -- exact fp32 products,
+            # 2.25x fewer of them, faster than six (three) bf16 products per direct-form product --, the 1x1 / strided / residual layers
+            # keep the split arithmetic on the bf16 matrix pipe.
             if name not in self._wwino:
                 self._wwino[name] = ops.winograd_pack(wp, Cin, Cout)
             d.w_wino = self._wwino[name].data_ptr()
+            d.math = _lib.MATH_F32
         self._ws_bytes = max(self._ws_bytes, self.lib.dc_conv2d_workspace_bytes(C.byref(d)))
         self._ops.append(("conv", d, name))
         if self.fast_bf16 and bf16:                    # a layer the bf16 kernel does not take (the stem): cast its output

@@ -4,11 +4,13 @@
 # kernel summary, the bf16 GEMM micro-benchmark and the 2-rank rehearsal.  Outputs under gpurun_out/profiles_<tag>/ ; copy what
 # should be judged into profiles/.
 set -e
-tag=${1:-r03}
+tag=${1:-r04}
+part=${2:-all}          # a = bench line, kernel traces, PMC passes, joint legs; b = micro-benchmarks, rehearsals; all = both
 out=$PWD/gpurun_out/profiles_$tag
 mkdir -p $out
 root=$PWD
 cd /tmp && export TMPDIR=/tmp
+if [ "$part" = "a" ] || [ "$part" = "all" ]; then
 python3 $root/bench.py --steps 20 --warmup 3 --layer-table $out/conv_layers.tsv > $out/bench.log 2>&1
 tail -1 $out/bench.log > $out/bench.json
 rocprofv3 --kernel-trace --stats -d $out/trace -o bench -- python3 $root/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --no-alt-math --no-other-configs > $out/trace.log 2>&1
@@ -22,11 +24,18 @@ python3 $root/bench.py --config joint --steps 10 --joint-dtype f32 > $out/joint_
 tail -1 $out/joint_bench_f32.log > $out/joint_bench_f32.json
 rocprofv3 --kernel-trace --stats -d $out/joint -o joint -- python3 $root/bench.py --config joint --steps 10 > $out/joint.log 2>&1
 python3 $root/tools/prof_summary.py $out/joint/joint_results.db $out/joint_kernels.csv 13
+python3 $root/bench.py --config joint --steps 10 --joint-dropout 0.2 --no-roofline > $out/joint_bench_dropout.log 2>&1
+tail -1 $out/joint_bench_dropout.log > $out/joint_bench_dropout.json
+rm -rf $out/trace $out/joint $out/pmc_fetch $out/pmc_write
+fi
+if [ "$part" = "b" ] || [ "$part" = "all" ]; then
 python3 $root/tools/bgemm_bench.py 2>&1 | grep -v amdgpu.ids > $out/bgemm_bench.txt
 (echo "== DCAP_BGEMM_TILE=128 (the round-2 128 x 128 loop on the same shapes)"; DCAP_BGEMM_TILE=128 python3 $root/tools/bgemm_bench.py 2>&1 | grep -v amdgpu.ids) >> $out/bgemm_bench.txt
 python3 $root/tools/vocab_ce_bench.py 2>&1 | grep -v amdgpu.ids > $out/vocab_ce_bench.txt
 (for t in 0 64 128; do echo "== tile $t (0 = the library's cost model)"; python3 $root/tools/bconv_bench.py --tile $t 2>&1 | grep -v amdgpu.ids; done) > $out/bconv_bench.txt
-(echo "== one launch per timestep (default)"; python3 $root/tools/lstm_bench.py 2>&1 | grep B=; echo "== DCAP_LSTM_BWD=steps (gate kernel + split-K GEMM + slab reduce per backward timestep)"; DCAP_LSTM_BWD=steps python3 $root/tools/lstm_bench.py 2>&1 | grep B=) > $out/lstm_bench.txt
+(echo "== one launch per timestep (default)"; python3 $root/tools/lstm_bench.py 2>&1 | grep B=; echo "== DCAP_LSTM_BWD=steps (gate kernel + split-K GEMM + slab reduce per backward timestep)"; DCAP_LSTM_BWD=steps python3 $root/tools/lstm_bench.py 2>&1 | grep B=
+ echo "== recurrent_dropout masks, one fused launch per timestep (round 4 default)"; python3 $root/tools/lstm_bench.py --dropout 2>&1 | grep B=
+ echo "== recurrent_dropout masks, DCAP_LSTM_MASKED_FUSED=0 (round 3: mask kernel + 4 GEMMs + gate kernel per step)"; DCAP_LSTM_MASKED_FUSED=0 python3 $root/tools/lstm_bench.py --dropout 2>&1 | grep B=) > $out/lstm_bench.txt
 (echo "== default (128x64 producer/consumer rule + streaming short-K kernel)"; python3 $root/tools/conv_bench.py --reps 50 2>&1 | grep -v amdgpu.ids; echo "== DCAP_PW_RULE=0 DCAP_PW_STREAM=0 (round-1 tile rule, no streaming kernel)"; DCAP_PW_RULE=0 DCAP_PW_STREAM=0 python3 $root/tools/conv_bench.py --reps 50 2>&1 | grep -v amdgpu.ids) > $out/conv_bench.txt
 (echo "== 3x3 layers, Winograd F(2x2,3x3) (default for frozen weights)"; python3 $root/tools/conv_bench.py --filter 3x3 --winograd --reps 50 2>&1 | grep -v amdgpu.ids
  echo "== the same layers, direct implicit GEMM"; python3 $root/tools/conv_bench.py --filter 3x3 --reps 50 2>&1 | grep -v amdgpu.ids
@@ -52,5 +61,6 @@ timeout -k 10 300 python3 bench.py --gpus 2 --steps 5 --warmup 2 > $out/rehearsa
 timeout -k 10 300 python3 bench.py --config joint --gpus 2 --steps 5 --warmup 2 --no-roofline > $out/rehearsal_2rank_joint.log 2>&1 || true
 bash tools/roialign_profile.sh > /dev/null 2>&1 && cp gpurun_out/roialign_profile.txt $out/roialign_hbm.txt || true
 python3 $root/tools/wino_fit.py 2>&1 | grep -v amdgpu.ids > $out/winograd_fit.txt
-rm -rf $out/trace $out/joint $out/dec $out/pmc_fetch $out/pmc_write $out/pmc_wino
+rm -rf $out/dec $out/pmc_wino
+fi
 ls $out

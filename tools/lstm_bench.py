@@ -13,6 +13,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="64x15x512,32x15x512,200x15x512,64x15x1024")
     ap.add_argument("--reps", type=int, default=50)
+    ap.add_argument("--dropout", action="store_true", help="with Keras recurrent_dropout masks (rate 0.2) on the recurrence")
     a = ap.parse_args()
     from image_captioning_amd import ops
     dev = torch.device("cuda")
@@ -23,7 +24,8 @@ def main():
         Ur = torch.randn(U, 4 * U, device=dev, generator=g) / U ** 0.5
         dh = torch.randn(T * B, U, device=dev, generator=g)
         z = z0.clone()
-        h, c = ops.lstm_seq_fwd(z, Ur, None, B, T)
+        rm = ops.dropout_mask(torch.empty(4, B, U, device=dev), 0.2, 7, 1) if a.dropout else None
+        h, c = ops.lstm_seq_fwd(z, Ur, None, B, T, rec_masks=rm)
         dz = torch.empty_like(z)
         dU = torch.empty_like(Ur)
 
@@ -40,8 +42,8 @@ def main():
             return e0.elapsed_time(e1) * 1e3 / a.reps
 
         zz = z0.clone()
-        t_f = timed(lambda: ops.lstm_seq_fwd(zz, Ur, None, B, T, h_seq=h, c_seq=c))
-        t_b = timed(lambda: ops.lstm_seq_bwd(z, Ur, None, h, c, B, T, dh_seq=dh, dz=dz, dU=dU))
+        t_f = timed(lambda: ops.lstm_seq_fwd(zz, Ur, None, B, T, h_seq=h, c_seq=c, rec_masks=rm))
+        t_b = timed(lambda: ops.lstm_seq_bwd(z, Ur, None, h, c, B, T, dh_seq=dh, dz=dz, dU=dU, rec_masks=rm))
         print("B=%d T=%d U=%d  fwd %.1f us (%.1f/step)  bwd %.1f us (%.1f/step incl. dU)" % (B, T, U, t_f, t_f / T, t_b, t_b / T), flush=True)
 
 
