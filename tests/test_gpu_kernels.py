@@ -1005,3 +1005,32 @@ def test_caption_tables_on_the_device(ops):
     # all padding: count 0 -> weights 0, no division by zero
     ids, mask, tg, rw = ops.caption_tables(torch.zeros(8, 4, dtype=torch.int32, device="cuda"))
     assert float(rw.abs().max()) == 0.0
+
+
+def test_persistent_cu_budget_changes_the_grid_not_the_result(ops):
+    """dc_set_persistent_cus: the persistent Winograd grids on fewer than 256 CUs (248 in a data-parallel run: RCCL's kernels get a
+    CU per XCD; 8 = one block per XCD, every block walking 128 items here).  Results are bit-identical whatever the budget -- a work
+    item's arithmetic does not depend on which block takes it; bad values are refused; 0 restores the default."""
+    from image_captioning_amd import _lib
+    lib = _lib.load()
+    N, H, W, Cin, Cout = 2, 128, 128, 128, 128                # 512 items of 64 tiles
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(N, H, W, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, 9 * Cin, device="cuda", generator=g) / (9 * Cin) ** 0.5
+    u = ops.winograd_pack(w, Cin, Cout)
+    args = (x, w, 3, 3, 1, 1, 1, H, W, None, None, None, 0, True)
+    try:
+        assert ops.set_persistent_cus(0) == 256
+        ref = ops.conv2d(*args, w_wino=u).clone()
+        for cus, want in ((248, 248), (8, 8), (100, 96)):      # (rounded down to a multiple of 8: one share per XCD)
+            assert ops.set_persistent_cus(cus) == want
+            got = ops.conv2d(*args, w_wino=u)
+            assert torch.equal(got, ref), cus
+        with pytest.raises(DcapError):
+            ops.set_persistent_cus(4)
+        with pytest.raises(DcapError):
+            ops.set_persistent_cus(300)
+    finally:
+        assert ops.set_persistent_cus(0) == 256
+    direct = ops.conv2d(*args)
+    assert float((ref - direct).abs().max()) / float(direct.abs().max()) < 2e-5

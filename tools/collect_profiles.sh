@@ -29,6 +29,13 @@ tail -1 $out/joint_bench_dropout.log > $out/joint_bench_dropout.json
 rm -rf $out/trace $out/joint $out/pmc_fetch $out/pmc_write
 fi
 if [ "$part" = "b" ] || [ "$part" = "all" ]; then
+# the joint step issued EAGERLY (same launches as the captured graph): per-kernel durations comparable with the earlier rounds' traces
+# (export, not `env`: under rocprofv3 the program itself must follow `--`)
+export DCAP_JOINT_GRAPH=0
+rocprofv3 --kernel-trace --stats -d $out/joint_eager -o joint -- python3 $root/bench.py --config joint --steps 10 --no-roofline > $out/joint_eager.log 2>&1
+unset DCAP_JOINT_GRAPH
+python3 $root/tools/prof_summary.py $out/joint_eager/joint_results.db $out/joint_kernels_eager.csv 13
+rm -rf $out/joint_eager
 python3 $root/tools/bgemm_bench.py 2>&1 | grep -v amdgpu.ids > $out/bgemm_bench.txt
 (echo "== DCAP_BGEMM_TILE=128 (the round-2 128 x 128 loop on the same shapes)"; DCAP_BGEMM_TILE=128 python3 $root/tools/bgemm_bench.py 2>&1 | grep -v amdgpu.ids) >> $out/bgemm_bench.txt
 python3 $root/tools/vocab_ce_bench.py 2>&1 | grep -v amdgpu.ids > $out/vocab_ce_bench.txt
