@@ -569,7 +569,12 @@ int conv2d_winograd(const dc_conv_desc* d, hipStream_t s) {
         return check_launch("dc_conv2d (winograd)");
     }
     // persistent: the blocks that fit the chip walk the work items (a multiple of 8 blocks, so that an item's XCD is fixed by item % 8)
-    const long slots = big ? persistent_cus() : 2 * persistent_cus();
+    // the CU budget (dc_set_persistent_cus) applies to the LONG launches only -- eight or more rounds of work items per block -- where a
+    // grid that never yields would keep another queue's kernels (RCCL) waiting for hundreds of microseconds.  On a short launch a smaller
+    // grid costs a whole extra round (256 items on 248 blocks: two rounds instead of one, measured 69 -> 102 us on the stage-4 layers) and
+    // buys nothing: the launch is over in tens of microseconds.
+    const long full = big ? kNumCU : 2 * kNumCU;
+    const long slots = items >= 8 * full ? (big ? persistent_cus() : 2 * persistent_cus()) : full;
     const unsigned grid = items >= slots ? (unsigned)slots : (unsigned)std::max<long>(8, items / 8 * 8);
     if (big) {
         DC_ENSURE_DYN_LDS(wino::wino64_kernel, wino::wp::Cfg<2>::LDS_BYTES);

@@ -216,8 +216,9 @@ int    dc_conv2d_winograd_pack_f32(const float* w, float* u, int Cin, int Cout, 
 /* CUs the persistent Winograd grids may occupy (process-wide; a multiple of 8 -- one share per XCD; 0 restores the default:
  * DCAP_WINO_CUS or all 256).  A persistent block holds its CU for the whole launch: in a data-parallel run (parallel_model.py:58-102
  * -> one rank per GPU here) the RCCL all-reduce of another queue needs CUs of its own to overlap the encoder pass, so
- * ParallelModel / bench.py set 248 when world > 1.  Takes effect at the next launch; a captured hipGraph keeps the grid it was
- * captured with. */
+ * ParallelModel / bench.py set 248 when world > 1.  Applies to launches of at least eight rounds of work items per block (the
+ * long-running ones: fpn_p2 at the benchmark's size); shorter launches keep the full grid, where a smaller one would add a whole
+ * round.  Takes effect at the next launch; a captured hipGraph keeps the grid it was captured with. */
 int    dc_set_persistent_cus(int n);
 int    dc_get_persistent_cus(void);
 

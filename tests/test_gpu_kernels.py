@@ -954,7 +954,9 @@ def _dt_case(seed, n_props, n_gt, pad_props, pad_gt, T=6, jitter=0.08):
     return props.astype(np.float32), gt, caps
 
 
-@pytest.mark.parametrize("case", [(0, 2000, 40, 0, 60), (1, 1500, 7, 500, 3), (2, 300, 1, 0, 0), (3, 2000, 100, 48, 0), (4, 64, 0, 6, 4), (5, 3000, 12, 100, 0)])
+@pytest.mark.parametrize("case", [(0, 2000, 40, 0, 60), (1, 1500, 7, 500, 3), (2, 300, 1, 0, 0), (3, 2000, 100, 48, 0), (4, 64, 0, 6, 4), (5, 3000, 12, 100, 0),
+                                  (6, 90, 3, 10, 2),          # fewer positives than the quota: the negative count follows int32(f32(1/ratio) * n_pos) - n_pos
+                                  (7, 4000, 500, 96, 12)])    # the entry point's limits: 4096 proposals, 512 GT boxes
 @pytest.mark.parametrize("seed", [None, 1234])
 def test_detection_targets_on_the_device_equal_the_oracle(ops, case, seed):
     """dc_detection_targets_f32 (DetectionTargetLayer, dense_img_cap/dense_model.py:450-572) against oracle.detection_targets: RoIs,
@@ -976,6 +978,8 @@ def test_detection_targets_on_the_device_equal_the_oracle(ops, case, seed):
     assert np.array_equal(oc.cpu().numpy(), want_caps)
     if cs == 0:
         assert npos == 66 and nneg == 134                    # the benchmark's regime: both lists longer than their quota
+    if cs == 6:
+        assert 0 < npos < 66
     # the host implementation the joint model used until round 3 agrees as well
     from image_captioning_amd.dense_model import detection_targets as host_dt
 
@@ -983,6 +987,18 @@ def test_detection_targets_on_the_device_equal_the_oracle(ops, case, seed):
         TRAIN_ROIS_PER_IMAGE, ROI_POSITIVE_RATIO = n_rois, ratio
     h_rois, h_caps, h_pos, h_neg = host_dt(props, caps, gt, Cfg, shuffle)
     assert (h_pos, h_neg) == (npos, nneg) and np.array_equal(h_rois, want_rois) and np.array_equal(h_caps, want_caps)
+
+
+def test_detection_targets_rejects_what_it_does_not_cover(ops):
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device="cuda")
+    with pytest.raises(DcapError):
+        ops.detection_targets(z(5000, 4), z(4, 4), z(4, 6, dt=torch.int32), 200, 0.33)          # > 4096 proposals
+    with pytest.raises(DcapError):
+        ops.detection_targets(z(100, 4), z(600, 4), z(600, 6, dt=torch.int32), 200, 0.33)       # > 512 GT boxes
+    with pytest.raises(DcapError):
+        ops.detection_targets(z(100, 4), z(4, 4), z(5, 6, dt=torch.int32), 200, 0.33)           # captions / boxes mismatch
+    with pytest.raises(DcapError):
+        ops.detection_targets(torch.zeros(100, 4), z(4, 4), z(4, 6, dt=torch.int32), 200, 0.33)  # host tensor: no CPU path
 
 
 def test_caption_tables_on_the_device(ops):
@@ -1009,11 +1025,12 @@ def test_caption_tables_on_the_device(ops):
 
 def test_persistent_cu_budget_changes_the_grid_not_the_result(ops):
     """dc_set_persistent_cus: the persistent Winograd grids on fewer than 256 CUs (248 in a data-parallel run: RCCL's kernels get a
-    CU per XCD; 8 = one block per XCD, every block walking 128 items here).  Results are bit-identical whatever the budget -- a work
-    item's arithmetic does not depend on which block takes it; bad values are refused; 0 restores the default."""
+    CU per XCD; 8 = one block per XCD, every block walking 256 items here).  Results are bit-identical whatever the budget -- a work
+    item's arithmetic does not depend on which block takes it; bad values are refused; 0 restores the default.  (The budget applies
+    to launches of >= 8 rounds of items only: a short launch keeps the full grid, where 248 blocks for 256 items would mean two rounds.)"""
     from image_captioning_amd import _lib
     lib = _lib.load()
-    N, H, W, Cin, Cout = 2, 128, 128, 128, 128                # 512 items of 64 tiles
+    N, H, W, Cin, Cout = 2, 256, 256, 64, 128                 # 2048 items of 64 tiles = 8 rounds on 256 CUs: the budget applies
     g = torch.Generator(device="cuda").manual_seed(3)
     x = torch.randn(N, H, W, Cin, device="cuda", generator=g)
     w = torch.randn(Cout, 9 * Cin, device="cuda", generator=g) / (9 * Cin) ** 0.5

@@ -999,3 +999,49 @@ def test_joint_train_step_as_a_captured_graph_equals_the_eager_step(gpu):
     for a, b in zip(runs["graph"][2], runs["eager"][2]):
         np.testing.assert_array_equal(a, b)
     assert not np.array_equal(runs["graph"][2][3], runs["graph"][2][6])      # same inputs (seed 8 + 0), another step: another sample
+
+
+def test_joint_step_graph_is_dropped_and_recaptured_when_what_it_baked_changes(gpu):
+    """A captured step bakes buffer addresses, the trainable subset (regulariser mask), the optimizer state and the capacity of the
+    packed step inputs.  set_trainable() + compile() between steps, and a step whose RPN selection outgrows the packed buffer, must
+    drop the graph, step eagerly and capture again -- the weights stay bit-equal to a model that never uses a graph."""
+    S, V, T, blocks = 128, 24, 5, 1
+    _, cfg, Wt = make_joint(S, V, T, blocks)
+    from image_captioning_amd.dense_model import DenseImageCapRCNN
+    base = joint_inputs(S, V, T)
+    base[0] = torch.tensor(base[0], device="cuda")
+    big = list(base)
+    big[2] = base[2].copy()
+    rng = np.random.default_rng(3)
+    n_anchor = big[2].shape[1]
+    pick = rng.choice(n_anchor, 300, replace=False)             # 300 selected anchors > RPN_TRAIN_ANCHORS_PER_IMAGE = 256
+    big[2][0, :, 0] = 0
+    big[2][0, pick, 0] = np.where(rng.random(300) < 0.15, 1, -1)
+    big[3] = rng.standard_normal((1, 64, 4))
+    out = {}
+    for mode in ("graph", "eager"):
+        model = DenseImageCapRCNN("training", cfg, "logs", stage4_blocks=blocks)
+        model.set_weights(Wt)
+        model.compile(1e-4)
+        model.use_step_graph = mode == "graph"
+        seen = []
+        for _ in range(4):
+            model.train_on_batch(base)
+        seen.append("train" in model._graphs)
+        model.set_trainable(model.LAYER_REGEX["caption_only"])
+        seen.append("train" in model._graphs)
+        model.compile(1e-4)
+        for _ in range(4):
+            model.train_on_batch(base)
+        seen.append("train" in model._graphs)
+        cap0 = model._step_in.cap
+        model.train_on_batch(big)                               # the packed inputs grow: new buffer, graph dropped
+        seen.append(("train" in model._graphs, model._step_in.cap > cap0))
+        for _ in range(3):
+            model.train_on_batch(big)
+        seen.append("train" in model._graphs)
+        if mode == "graph":
+            assert seen == [True, False, True, (False, True), True], seen
+        out[mode] = model.store.flat.cpu().numpy()
+    np.testing.assert_array_equal(out["graph"], out["eager"])
+
