@@ -43,6 +43,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WINOGRAD_GAIN = 2.25            # direct 3x3: 36 products per 2x2 output tile and channel pair; Winograd F(2x2,3x3): 16
+WINOGRAD4_GAIN = 4.0            # F(4x4,3x3): 36 products per 4x4 output tile and channel pair instead of 144
+
+
+def winograd_gain(kernel):
+    """Direct-form FLOPs / FLOPs the matrix pipe executes for the layers that run on `kernel` (dc_conv2d_kernel_name's spelling)."""
+    return WINOGRAD4_GAIN if kernel.startswith("wino4_") else (WINOGRAD_GAIN if kernel.startswith("wino") else 1.0)
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
@@ -452,7 +458,7 @@ class E2E(object):
             for name, fl, bm, bn, sk, key in table:                 # key: rocprof's spelling of the layer's kernel
                 g = groups.setdefault(key, {"flops": 0.0, "alg": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0})
                 g["alg"] += fl                                       # the layer's direct-form FLOPs
-                g["flops"] += fl / WINOGRAD_GAIN if key.startswith("wino") else fl      # what the matrix pipe executes
+                g["flops"] += fl / winograd_gain(key)                # what the matrix pipe executes
                 g["ms"] += times[name]
                 g["launches"] += 1
                 g["bytes"] += alg_bytes[name]                        # compulsory HBM bytes: input + output + weights (+ residual)
@@ -502,8 +508,8 @@ class E2E(object):
         if wino:
             out["achieved_direct_form"] = g["alg"] / (g["ms"] * 1e-3) / 1e12
             out["gflop_per_launch_direct_form"] = g["alg"] / g["launches"] / 1e9
-            out["note"] = ("Winograd F(2x2,3x3), fp32 transforms and products: executed MFMA FLOPs = direct-form FLOPs / 2.25; "
-                           "frac = executed / peak")
+            out["note"] = ("Winograd %s, fp32 transforms and products: executed MFMA FLOPs = direct-form FLOPs / %.2f; frac = executed / peak"
+                           % ("F(4x4,3x3)" if dom.startswith("wino4_") else "F(2x2,3x3)", winograd_gain(dom)))
         if main == "pipeline":
             gi = res["isolated"][0][dom]
             ai = gi["flops"] / (gi["ms"] * 1e-3) / 1e12

@@ -81,7 +81,8 @@ class EncoderPlan:
         # F(2x2, 3x3) form -- fp32 transforms, fp32 MFMA, 16 products per 2x2 output tile instead of 36 (csrc/conv_wino.hip); their
         # kernels are transformed once here.  winograd=False / DCAP_WINOGRAD=0: the direct implicit GEMM everywhere.
         self.winograd = (os.environ.get("DCAP_WINOGRAD", "1") != "0") if winograd is None else bool(winograd)
-        self._wwino = {}
+        self.winograd4 = os.environ.get("DCAP_WINO4", "0") == "1"         # F(4x4,3x3): correct, slower than F(2x2,3x3) as measured: opt-in
+        self._wwino, self._wwino4 = {}, {}
         self._twin = {}
         self._wb = {}
         self.B, self.H, self.W = batch, height, width
@@ -222,6 +223,13 @@ class EncoderPlan:
                 self._wwino[name] = ops.winograd_pack(wp, Cin, Cout)
             d.w_wino = self._wwino[name].data_ptr()
             d.math = _lib.MATH_F32
+            # F(4x4, 3x3) (36 products per 4x4 tile instead of 64) where the layer has a 32-tile x 32-channel work item for every CU:
+            # at two images the stage-2 / stage-3 branches and the P2 / P3 output layers; the library applies the same rule
+            th4, tw4 = (H + 3) // 4, (W + 3) // 4
+            if self.winograd4 and N * ((th4 + 3) // 4) * ((tw4 + 7) // 8) * (Cout // 32) >= 256:
+                if name not in self._wwino4:
+                    self._wwino4[name] = ops.winograd4_pack(wp, Cin, Cout)
+                d.w_wino4 = self._wwino4[name].data_ptr()
         self._ws_bytes = max(self._ws_bytes, self.lib.dc_conv2d_workspace_bytes(C.byref(d)))
         self._ops.append(("conv", d, name))
         if self.fast_bf16 and bf16:                    # a layer the bf16 kernel does not take (the stem): cast its output
@@ -367,7 +375,7 @@ class EncoderPlan:
             if op[0] != "conv":
                 continue
             d, s = op[1], self._specs[op[2]]
-            wbytes = (16 if op[2] in self._wwino else s.k * s.k) * d.Cin * s.cout * 4
+            wbytes = (36 if op[2] in self._wwino4 else 16 if op[2] in self._wwino else s.k * s.k) * d.Cin * s.cout * 4
             b = 4.0 * d.N * d.H * d.W * d.Cin + 4.0 * d.N * d.Ho * d.Wo * d.Cout + wbytes
             if d.res_mode == 1:
                 b += 4.0 * d.N * d.Ho * d.Wo * d.Cout
@@ -507,7 +515,8 @@ class Vgg16Plan(EncoderPlan):
         self.lib = _lib.load()
         self.math = conv_math_mode(math)
         self.winograd = (os.environ.get("DCAP_WINOGRAD", "1") != "0") if winograd is None else bool(winograd)      # all 13 layers are 3x3 / stride 1
-        self._wwino = {}
+        self.winograd4 = os.environ.get("DCAP_WINO4", "0") == "1"
+        self._wwino, self._wwino4 = {}, {}
         self.B, self.H, self.W = batch, height, width
         self.device = torch.device(device)
         self.mean_pixel = [float(v) for v in mean_pixel]

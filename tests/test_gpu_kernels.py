@@ -257,6 +257,60 @@ def test_conv2d_winograd_persistent_multi_item_blocks_at_benchmark_shapes(ops, c
     assert worst / scale < 2e-5, "windows vs float64 oracle: %.3e" % (worst / scale)
 
 
+WINO4_CASES = [
+    # N,H,W,Cin,Cout -- layers with at least 256 work items of 32 tiles (4 x 4 output pixels each) x 32 channels: the F(4x4,3x3) kernel
+    (2, 256, 256, 64, 64),       # res2_2b: 512 items, two 32-channel chunks
+    (2, 128, 128, 128, 128),     # res3_2b: exactly 256 items, four chunks
+    (2, 128, 128, 256, 256),     # fpn_p3: 512 items, eight chunks (even: both U-buffer phases)
+    (3, 150, 170, 96, 128),      # ragged: 38 x 43 tiles in 10 x 6 groups (edge tiles with 2 of 4 rows / 3 of 4 columns), three chunks (odd)
+    (1, 256, 512, 32, 64),       # one chunk; a wide image
+]
+
+
+@pytest.mark.parametrize("case", WINO4_CASES)
+def test_conv2d_winograd_f4x4_matches_oracle_and_direct(ops, case):
+    """dc_conv_desc.w_wino4: the F(4x4, 3x3) kernel (36 products per 4 x 4 output tile instead of 144) where the layer has a work item
+    per CU.  Whole tensor against the direct implicit-GEMM kernel and windows (corners, edges, group boundaries, image seams, all
+    output channels) against the float64 oracle, both at 5e-5 of the output scale: the larger transform costs accuracy -- 1e-5 at
+    the worst element of a 256-channel layer in exact float32 arithmetic (tests/test_oracle_kat.py) -- and the test says so instead
+    of borrowing F(2x2,3x3)'s 2e-5.  The kernel is correct and, as measured, slower than wino64: the plan does not use it by default."""
+    N, H, W, Cin, Cout = case
+    g = torch.Generator(device="cuda").manual_seed(N * 1000003 + H * 1009 + Cin * 31 + Cout + 4)
+    x = torch.relu(torch.randn(N, H, W, Cin, device="cuda", generator=g))                     # post-ReLU activations, like the real layers' inputs
+    w = torch.randn(Cout, 9 * Cin, device="cuda", generator=g) / (9 * Cin) ** 0.5
+    sc = torch.rand(Cout, device="cuda", generator=g) + 0.5
+    sh = torch.randn(Cout, device="cuda", generator=g)
+    u2, u4 = ops.winograd_pack(w, Cin, Cout), ops.winograd4_pack(w, Cin, Cout)
+    assert u4.shape == (36 * Cin * Cout,)
+    args = (x, w, 3, 3, 1, 1, 1, H, W, sc, sh, None, 0, True)
+    assert ops.conv2d_kernel_name(*args, w_wino4=u4) == "wino4_kernel"                      # its weights alone: the caller asked for it
+    assert ops.conv2d_kernel_name(*args, w_wino=u2, w_wino4=u4) == "wino64_kernel"          # both: the faster kernel (DCAP_WINO4=1 would pick F(4,3) here)
+    out = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+    got = ops.conv2d(*args, out=out, w_wino4=u4)
+    assert bool(torch.isfinite(got).all())
+    direct = ops.conv2d(*args)
+    scale = max(1.0, float(direct.abs().max()))
+    assert float((got - direct).abs().max()) / scale < 5e-5
+    xh = x.cpu().numpy().astype(np.float64)
+    wk = w.cpu().numpy().astype(np.float64).reshape(Cout, 3, 3, Cin).transpose(1, 2, 3, 0)
+    sch, shh = sc.cpu().numpy().astype(np.float64), sh.cpu().numpy().astype(np.float64)
+    gh = got.cpu().numpy().astype(np.float64)
+    S = 12
+    ys = sorted({0, H - S, max(0, 16 - S // 2), max(0, (H // 32) * 16 - S // 2), max(0, H - 16 - S // 2)})
+    xs = sorted({0, W - S, max(0, 32 - S // 2), max(0, (W // 64) * 32 - S // 2), max(0, W - 32 - S // 2)})
+    worst = 0.0
+    for n in sorted({0, N - 1}):
+        for y0 in ys:
+            for x0 in xs:
+                y1, x1 = min(H, y0 + S), min(W, x0 + S)
+                patch = np.zeros((1, y1 - y0 + 2, x1 - x0 + 2, Cin))
+                sy0, sx0, sy1, sx1 = max(0, y0 - 1), max(0, x0 - 1), min(H, y1 + 1), min(W, x1 + 1)
+                patch[0, sy0 - (y0 - 1):sy1 - (y0 - 1), sx0 - (x0 - 1):sx1 - (x0 - 1)] = xh[n, sy0:sy1, sx0:sx1]
+                want = np.maximum(O.conv2d_nhwc(patch, wk, None, 1, 'valid')[0] * sch + shh, 0)
+                worst = max(worst, float(np.abs(gh[n, y0:y1, x0:x1] - want).max()))
+    assert worst / scale < 5e-5, "windows vs float64 oracle: %.3e" % (worst / scale)
+
+
 @pytest.mark.parametrize("force", ["1", "32", "64"])
 def test_conv2d_winograd_forced_kernels_in_a_child_process(ops, force):
     """DCAP_WINO_TILES (read once per process) forces a kernel: 1 = the first 32-tile kernel kept for the comparison in profiles/,
