@@ -874,19 +874,12 @@ class DenseImageCapRCNN(object):
         images, _meta, rpn_match, rpn_bbox, gt_caps, gt_boxes = inputs[:6]
         if len(images) != 1:
             raise ValueError("one image per step and GPU (IMAGES_PER_GPU = 1)")
-        cfg, st, cm = self.config, self.store, self.caption_model
-        w, g = st.w, st.grad
-        dev = self.device
         p = self.plan()
         H, W = p.H, p.W
-        up = lambda a, dt=torch.float32: torch.tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
-
-        # ---- this step's host inputs go to the device FIRST (GT boxes, GT captions, the RPN selection): a copy from pageable host
-        # memory makes the host wait for everything queued before it, so none may sit in the middle of the step
+        # ---- this step's host inputs go to the device FIRST (GT boxes, GT captions, the RPN selection, the step scalars: one asynchronous
+        # copy, StepInputs): nothing the host contributes may sit in the middle of the step
         gt_norm = (np.asarray(gt_boxes[0], np.float32) / np.array([H, W, H, W], np.float32)).astype(np.float32)
-        device_targets = shuffle is None or shuffle == "rng"
         rpn_up = self._step_uploads(p, rpn_match, rpn_bbox, gt_norm, gt_caps[0], backward)
-        gt_dev, gtc_dev = rpn_up["gt"], rpn_up["gtc"]
 
         # ---- forward: backbone + FPN + RPN (the plan's hipGraph), then everything behind the encoder
         p.forward(self._images_u8(images))
