@@ -1105,3 +1105,35 @@ def test_persistent_cu_budget_changes_the_grid_not_the_result(ops):
         assert ops.set_persistent_cus(0) == 256
     direct = ops.conv2d(*args)
     assert float((ref - direct).abs().max()) / float(direct.abs().max()) < 2e-5
+
+
+def test_lstm_masked_fused_and_unfused_paths_agree(ops, tmp_path):
+    """DCAP_LSTM_MASKED_FUSED=0 (read once per process) keeps the round-3 recurrent-dropout path -- mask kernel + four per-gate GEMMs +
+    gate kernel per timestep -- which is also what runs for a U that is no multiple of 32: a child process computes a sequence with
+    it, this process with the fused steps; states and gradients agree to fp32 rounding."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch\n"
+        "from image_captioning_amd import ops\n"
+        "g = torch.Generator(device='cuda').manual_seed(5)\n"
+        "B, T, U = 200, 6, 512\n"
+        "z = torch.randn(T * B, 4 * U, device='cuda', generator=g)\n"
+        "Ur = torch.randn(U, 4 * U, device='cuda', generator=g) / U ** 0.5\n"
+        "dh = torch.randn(T * B, U, device='cuda', generator=g)\n"
+        "mk = (torch.rand(T * B, device='cuda', generator=g) > 0.2).to(torch.uint8)\n"
+        "rm = ops.dropout_mask(torch.empty(4, B, U, device='cuda'), 0.2, 9, 3)\n"
+        "h, c = ops.lstm_seq_fwd(z, Ur, mk, B, T, rec_masks=rm)\n"
+        "dz, dU = ops.lstm_seq_bwd(z, Ur, mk, h, c, B, T, dh_seq=dh, rec_masks=rm)\n"
+        "np.savez(sys.argv[1], h=h.cpu().numpy(), c=c.cpu().numpy(), dz=dz.cpu().numpy(), dU=dU.cpu().numpy())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for mode in ("1", "0"):
+        path = str(tmp_path / ("lstm_%s.npz" % mode))
+        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, DCAP_LSTM_MASKED_FUSED=mode), cwd=root,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out[mode] = np.load(path)
+    for k in ("h", "c", "dz", "dU"):
+        a, b = out["1"][k].astype(np.float64), out["0"][k].astype(np.float64)
+        assert np.abs(a - b).max() < 2e-5 * max(1.0, np.abs(b).max()), k
