@@ -318,6 +318,8 @@ class DenseImageCapRCNN(object):
             raise ValueError("at most 3 anchors per location")
         self._seed = int(seed)
         self.use_step_graph = os.environ.get("DCAP_JOINT_GRAPH", "1") != "0"
+        self.use_side_stream = os.environ.get("DCAP_JOINT_FORK", "1") != "0"      # RPN backward beside the proposals / decoder-forward chain
+        self._side_stream = None
         self._dt_step = self._dt_val_step = 0                # detection-target sampling streams (training / forward-only validation passes)
         self._last_targets = None
         self._step_in = None
@@ -899,10 +901,25 @@ class DenseImageCapRCNN(object):
         gt_dev, gtc_dev = rpn_up["gt"], rpn_up["gtc"]
         gt_caps = [gt_caps0]
         self._bf16_cache = {}
-        proposals = p.proposals()
         losses = self._buf("losses", (4,))
-        R = cfg.TRAIN_ROIS_PER_IMAGE
+        # The RPN branch's backward (RPN losses, head / shared-convolution weight gradients, data gradients into dP2..dP6: ~1.2 ms of
+        # large kernels) needs only the encoder's outputs and the step's RPN targets, while the chain proposals -> top-k -> NMS scan ->
+        # detection targets -> RoIAlign -> head + LSTM forward is a string of small, latency-bound launches (the NMS scan alone is one
+        # wave for 0.28 ms).  They run side by side: the RPN backward on a second stream, forked here and joined before the RoIAlign
+        # backward adds into dP.  (Captured: two branches of the step's hipGraph.  Data parallel: serial as before -- the RPN ranges'
+        # all-reduce is issued from Python right behind their backward.)
+        overlap_dp = self.grad_sync is not None and hasattr(self.grad_sync, "ready") and getattr(self.grad_sync, "world", 1) > 1
+        fork = backward and device_targets and not overlap_dp and self.use_side_stream
         maps = dP = None
+        if fork:
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=dev)
+            cur = torch.cuda.current_stream(dev)
+            self._side_stream.wait_stream(cur)
+            with torch.cuda.stream(self._side_stream):
+                maps, dP = self._rpn_backward(p, rpn_up, losses)
+        proposals = p.proposals()
+        R = cfg.TRAIN_ROIS_PER_IMAGE
         if device_targets:
             # DetectionTargetLayer on the device (dc_detection_targets_f32): IoU, the >= 0.5 / < 0.5 split, the shuffle (Philox keys drawn
             # from (model seed, step): reproducible, where tf.random_shuffle is not), the 1:2 sample and the caption gather.  Nothing
@@ -929,7 +946,7 @@ class DenseImageCapRCNN(object):
             else:
                 cm._drop_offset_dev = rpn_up["drop_offset"]
                 loss_rows, _ = cm._forward_train(feats[0], None, want_grad=backward, keras_sparse=True, device_tables=tables + (R, T))
-            if backward:
+            if backward and not fork:
                 maps, dP = self._rpn_backward(p, rpn_up, losses)
         else:
             # a caller-supplied permutation (shuffle = callable): the sample is drawn on the host, as until round 3.  The proposals start
@@ -984,7 +1001,14 @@ class DenseImageCapRCNN(object):
                 lo, hi = st.layer_range(layer)
                 early(lo, hi)
                 self.grad_sync.ready(st.flat_grad, lo, hi)
+        # (tried and measured without gain, round 4: the decoder's weight-gradient GEMMs on the side stream beside its LSTM backward
+        # chain -- 8.77 ms against 8.68 captured, 8.57 against 8.58 eager)
         dX = cm._backward(want_dx=True)
+        if fork:
+            torch.cuda.current_stream(dev).wait_stream(self._side_stream)      # join: dP, the RPN gradients and losses[0:2] are complete
+            # (a SECOND fork was tried and removed, round 4: the decoder's / head's share of the regulariser pass -- HBM-bound, 290 of the
+            # bucket's 308 MB -- on the side stream beside the RoIAlign / FPN backward: 8.59 ms against 8.58 eager, 9.07 against 8.68
+            # captured -- every extra branch costs the graph replay more than the overlap returns)
         # dP already holds the RPN branch's data gradients; the RoI features' gradient is added on top (a fixed-order gather per pyramid pixel: reproducible)
         ops.roi_align_pyramid_bwd(dP[:4], boxes, float(H * W), dX.view(1, R, cfg.POOL_SIZE, cfg.POOL_SIZE, 256), cfg.POOL_SIZE)
         ops.scatter2_add(dP[4], dP[3])                       # P6 = MaxPooling2D(1, strides=2)(P5)

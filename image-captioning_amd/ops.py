@@ -30,18 +30,29 @@ def _chk(t, dtype=torch.float32, name="tensor"):
 
 
 class _Workspace:
-    """One grow-only scratch buffer per device (kernels never allocate)."""
+    """One grow-only scratch buffer per (device, stream) (kernels never allocate).  Per STREAM since round 4: the joint step runs its
+    RPN backward on a side stream beside the proposals / decoder chain, and two streams must not scribble over one scratch buffer.  A
+    buffer created for a new stream starts at the largest size any stream of the device has asked for, so that a hipGraph capture --
+    which runs on a stream of its own, after eager steps have seen every size -- never has to grow (= free) a buffer whose address
+    earlier nodes of the same capture have baked."""
 
     def __init__(self):
         self.buf = {}
+        self.hi = {}
 
     def get(self, nbytes, device):
         if nbytes == 0:
             return None, 0
-        b = self.buf.get(device)
+        device = torch.device(device)
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        hi = max(self.hi.get(device, 0), nbytes)
+        self.hi[device] = hi
+        b = self.buf.get(key)
         if b is None or b.numel() < nbytes:
-            b = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-            self.buf[device] = b
+            b = torch.empty(max(hi, 1 << 20), dtype=torch.uint8, device=device)
+            self.buf[key] = b
         return b, b.numel()
 
     def reserve(self, nbytes, device):
