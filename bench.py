@@ -283,7 +283,7 @@ def hbm_kernels_leg(dev, images_per_gpu, rois_per_image, S=1024):
             fn()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with ops.no_gc_during_capture(), torch.cuda.graph(g):
             for _ in range(reps):
                 fn()
         g.replay()

@@ -1106,7 +1106,7 @@ class DenseImageCapRCNN(object):
         try:
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            with ops.no_gc_during_capture(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 out = body()
         except Exception as e:                                   # something in the step is not capturable here: stay eager
             import warnings

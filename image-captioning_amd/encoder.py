@@ -89,7 +89,7 @@ class EncoderPlan:
         self.device = torch.device(device)
         self.mean_pixel = [float(v) for v in mean_pixel]
         self.stage4_blocks = stage4_blocks
-        self.use_graph = use_graph
+        self.use_graph = use_graph and os.environ.get("DCAP_ENCODER_GRAPH", "1") != "0"      # (0: eager launches -- measurements)
         self._graph = None
         self._warm = False
         self._specs = {s.name: s for s in resnet_fpn_convs(stage4_blocks)}
@@ -468,7 +468,7 @@ class EncoderPlan:
             g = torch.cuda.CUDAGraph()
             # thread-local capture: the RCCL watchdog thread of a multi-GPU run polls events while this thread captures;
             # under the default (global) mode that would invalidate the capture
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with ops.no_gc_during_capture(), torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self._run_ops()
             self._graph = g
             g.replay()

@@ -29,6 +29,26 @@ def _chk(t, dtype=torch.float32, name="tensor"):
     return t
 
 
+class no_gc_during_capture(object):
+    """Context manager for hipGraph captures: collect garbage BEFORE the capture and keep the cyclic collector off while it lasts.  A
+    collection that happens to run inside a capture finalises whatever cyclic garbage is pending -- a dropped model's CUDAGraph, its
+    page-locked buffers, its events -- and runtime calls made by those finalisers (hipGraphExecDestroy, hipHostFree, ...) are illegal
+    on a capturing thread: round 4 saw the full GPU test suite die with SIGABRT inside `gc` in the middle of an encoder-plan capture."""
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self._was = gc.isenabled()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        if self._was:
+            gc.enable()
+        return False
+
+
 class _Workspace:
     """One grow-only scratch buffer per (device, stream) (kernels never allocate).  Per STREAM since round 4: the joint step runs its
     RPN backward on a side stream beside the proposals / decoder chain, and two streams must not scribble over one scratch buffer.  A
