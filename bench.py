@@ -75,6 +75,8 @@ def parse():
     ap.add_argument("--cpu-baseline-steps", type=int, default=5)
     ap.add_argument("--layer-table", default=None, help="write the per-layer conv timing table (TSV) to this path")
     ap.add_argument("--joint-dtype", default="bf16", choices=["bf16", "f32"], help="joint leg: decoder/head/vocabulary arithmetic")
+    ap.add_argument("--joint-prefetch", action="store_true", help="joint leg: hand every step the next image too (train_on_batch(next_images=): "
+                    "the frozen trunk of the next step runs beside this step's optimizer; measured without gain, round 4)")
     ap.add_argument("--joint-dropout", type=float, default=0.0, help="joint leg: recurrent_dropout of the two LSTMs (the reference trains with "
                     "0.2 = this package's default; the benchmark opts out so that runs are comparable: the masks cost one small kernel per LSTM)")
     ap.add_argument("--joint-host-images", action="store_true", help="joint leg: hand the image over as a host array every step")
@@ -578,15 +580,18 @@ def build_joint(args, dev, rank=0, world=1):
 def run_joint(args, dev, rank, world, barrier):
     """Times args.steps joint train steps (see build_joint); returns (seconds, last losses, RoIs per step, the model)."""
     model, inner, inputs, cfg = build_joint(args, dev, rank, world)
+    # --joint-prefetch: the loop hands every step the NEXT step's image as well (here the same synthetic image again): with the frozen
+    # trunk of configs[4] its ResNet pass then runs beside the current step's optimizer -- one trunk pass per step, as before, only earlier
+    nxt = inputs[0] if args.joint_prefetch else None
     for _ in range(max(args.warmup, 2)):
-        out = inner.train_on_batch(inputs)
+        out = inner.train_on_batch(inputs, next_images=nxt)
     if world > 1 and getattr(inner, "grad_sync", None) is not None and hasattr(inner.grad_sync, "exposed_ms"):
         inner.grad_sync.exposed_ms()
         inner.grad_sync.timing = True
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = inner.train_on_batch(inputs)              # per-rank image: every rank steps its own shard (weak scaling)
+        out = inner.train_on_batch(inputs, next_images=nxt)      # per-rank image: every rank steps its own shard (weak scaling)
     barrier()
     dt = time.perf_counter() - t0
     R = cfg.TRAIN_ROIS_PER_IMAGE

@@ -319,7 +319,13 @@ class DenseImageCapRCNN(object):
         self._seed = int(seed)
         self.use_step_graph = os.environ.get("DCAP_JOINT_GRAPH", "1") != "0"
         self.use_side_stream = os.environ.get("DCAP_JOINT_FORK", "1") != "0"      # RPN backward beside the proposals / decoder-forward chain
+        # next step's frozen trunk beside this step's optimizer (train_on_batch(next_images=...)).  Correct and bit-equal (tests), and
+        # measured WITHOUT gain (8.67 ms against 8.61: the trunk at one image and the bucket-wide optimizer passes both live off the memory
+        # system), so train() does not use it unless DCAP_JOINT_PREFETCH=1
+        self.use_trunk_prefetch = os.environ.get("DCAP_JOINT_PREFETCH", "0") == "1"
         self._side_stream = None
+        self._trunk_ready_for = None
+        self._trunk_in_flight = False
         self._dt_step = self._dt_val_step = 0                # detection-target sampling streams (training / forward-only validation passes)
         self._last_targets = None
         self._step_in = None
@@ -402,6 +408,7 @@ class DenseImageCapRCNN(object):
         """Captured step graphs bake buffer addresses, the plan's outputs, the trainable subset and the optimizer state: anything
         that replaces one of those drops them (the next steps run eagerly and re-capture)."""
         self._graphs, self._graph_warm, self._graph_out = {}, {}, {}
+        self._trunk_ready_for = None
 
     def _buf(self, key, shape, dtype=torch.float32, zero=False):
         b = self._bufs.get(key)
@@ -878,6 +885,7 @@ class DenseImageCapRCNN(object):
             raise ValueError("one image per step and GPU (IMAGES_PER_GPU = 1)")
         p = self.plan()
         H, W = p.H, p.W
+        self._trunk_ready_for = None                         # (this call runs the whole encoder: a prefetched trunk is overwritten)
         # ---- this step's host inputs go to the device FIRST (GT boxes, GT captions, the RPN selection, the step scalars: one asynchronous
         # copy, StepInputs): nothing the host contributes may sit in the middle of the step
         gt_norm = (np.asarray(gt_boxes[0], np.float32) / np.array([H, W, H, W], np.float32)).astype(np.float32)
@@ -887,7 +895,7 @@ class DenseImageCapRCNN(object):
         p.forward(self._images_u8(images))
         return self._after_encoder(p, rpn_up, shuffle, backward, gt_caps[0], gt_norm)
 
-    def _after_encoder(self, p, rpn_up, shuffle, backward, gt_caps0, gt_norm):
+    def _after_encoder(self, p, rpn_up, shuffle, backward, gt_caps0, gt_norm, prefetch_trunk=False):
         """The step behind the encoder pass: proposals, detection targets, RoIAlign, head + decoder, the four losses and (backward)
         every gradient into the flat bucket.  With device-side targets (shuffle None / "rng") nothing in here depends on a host value
         that changes from step to step -- counts, stream positions and lr_t are device words of StepInputs -- so train_on_batch_device
@@ -1037,8 +1045,16 @@ class DenseImageCapRCNN(object):
             announce(name)
         if self.backbone_from is not None:
             self._trunk_backward(p, dpre)
+        if prefetch_trunk and fork:
+            # The frozen ResNet trunk of the NEXT step's image (train_on_batch(next_images=...)): nothing this step trains feeds it, and
+            # the lateral weight gradients above were the last readers of this step's C2..C5.  It runs on the second stream beside the
+            # regulariser / clip / AMSGrad passes (HBM-bound; the trunk at one image is ~70 small, latency-bound launches); the caller joins
+            # the stream behind the optimizer, and the next step's encoder pass is the FPN / RPN half alone (EncoderPlan.forward_head).
+            self._side_stream.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(self._side_stream):
+                p.run_trunk(p.next_image_buffer())
+            self._trunk_in_flight = True
 
-        # ---- regulariser (+ frozen subset when set_trainable narrowed the set)
         coef, mask = self._masks()
         if self._reg_done:                                  # the ranges that did not go early (FPN / RPN, anything the decoder skipped)
             n, pos = st.flat.numel(), 0
@@ -1063,16 +1079,19 @@ class DenseImageCapRCNN(object):
         self.last_losses = d = self._loss_list(v)
         return [d["loss"], d["rpn_class_loss"], d["rpn_bbox_loss"], d["imgcap_loss"]]
 
-    def train_on_batch_device(self, inputs, targets=None):
+    def train_on_batch_device(self, inputs, targets=None, next_images=None):
         """One optimizer step; the raw loss terms as a float32 device tensor [4] (the loss all-reduce of ParallelModel and the
-        epoch sums of train() work on it; _losses_to_api makes the Keras return value from its host copy)."""
+        epoch sums of train() work on it; _losses_to_api makes the Keras return value from its host copy).
+        next_images: the image batch of the NEXT call (the same object that call will pass as inputs[0]).  With a frozen trunk (the
+        reference's layers="no_backbone") its ResNet pass then runs at the end of THIS step, beside the optimizer, and the next call
+        starts at the FPN: the pipeline the separate-models path runs between its encoder and decoder, inside the joint model."""
         assert self.mode == "training", "Create model in training mode."
         if self.optimizer is None:
             raise RuntimeError("compile(learning_rate) first")
         world = getattr(self.grad_sync, "world", 1) if self.grad_sync is not None else 1
         cm = self.caption_model
-        if not self.use_step_graph or world > 1 or cm._prefix_rows(True):
-            # eager: the data-parallel step (its collectives are issued from Python as layer groups finish), DROPOUT_ROWS='prefix'
+        if world > 1 or cm._prefix_rows(True):
+            # eager, serial: the data-parallel step (its collectives are issued from Python as layer groups finish), DROPOUT_ROWS='prefix'
             losses = self.forward_backward(inputs)
             scale = self.grad_sync(self.store.flat_grad) if self.grad_sync is not None else 1.0
             self.optimizer.apply(self.store, grad_scale=scale)
@@ -1082,46 +1101,67 @@ class DenseImageCapRCNN(object):
         if len(images) != 1:
             raise ValueError("one image per step and GPU (IMAGES_PER_GPU = 1)")
         p = self.plan()
+        dev = self.device
         gt_norm = (np.asarray(gt_boxes[0], np.float32) / np.array([p.H, p.W, p.H, p.W], np.float32)).astype(np.float32)
         rpn_up = self._step_uploads(p, rpn_match, rpn_bbox, gt_norm, gt_caps[0], True)
-        p.forward(self._images_u8(images))
+        have_trunk = self._trunk_ready_for is not None and images is self._trunk_ready_for
+        self._trunk_ready_for = None
+        if have_trunk:
+            p.forward_head()                                     # C2..C5 of this image are in the plan's buffers already
+        else:
+            p.forward(self._images_u8(images))
+        prefetch = next_images is not None and self.backbone_from is None and self.use_side_stream and len(next_images) == 1
+        if prefetch:
+            nxt = self._images_u8(next_images)
+            p.next_image_buffer().copy_(nxt, non_blocking=bool(nxt.is_cuda or nxt.is_pinned()))
         opt = self.optimizer
 
         def body():
-            losses = self._after_encoder(p, rpn_up, "rng", True, gt_caps[0], gt_norm)
+            self._trunk_in_flight = False
+            losses = self._after_encoder(p, rpn_up, "rng", True, gt_caps[0], gt_norm, prefetch_trunk=prefetch)
             opt.apply(self.store, grad_scale=1.0, lr_t_dev=rpn_up["lr_t"])
+            if self._trunk_in_flight:
+                torch.cuda.current_stream(dev).wait_stream(self._side_stream)      # join the trunk branch behind the optimizer
             return losses
-        key = "train"
-        graph = self._graphs.get(key)
-        if graph is not None:
-            graph.replay()
-            opt.iterations += 1                                  # what the captured Python did once: the host-side counters
-            if float(cm.recurrent_dropout or 0.0) > 0.0:
-                cm._drop_step += 1
-            return self._graph_out[key]
-        if self._graph_warm.get(key, 0) < 2 or p._graph is None:
-            self._graph_warm[key] = self._graph_warm.get(key, 0) + 1      # eager: sizes every buffer and workspace, builds the masks
-            return body()
-        saved = (opt.iterations, cm._drop_step)
-        try:
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with ops.no_gc_during_capture(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                out = body()
-        except Exception as e:                                   # something in the step is not capturable here: stay eager
-            import warnings
-            warnings.warn("joint step: hipGraph capture failed (%s); running eagerly" % (repr(e)[:200],))
-            opt.iterations, cm._drop_step = saved
-            self.use_step_graph = False
-            return body()
-        self._graphs[key], self._graph_out[key] = graph, out
-        graph.replay()                                           # (capture records, it does not run: this is the step itself)
+
+        def step():
+            if not self.use_step_graph:
+                return body()
+            key = "train+prefetch" if prefetch else "train"
+            graph = self._graphs.get(key)
+            if graph is not None:
+                graph.replay()
+                opt.iterations += 1                              # what the captured Python did once: the host-side counters
+                if float(cm.recurrent_dropout or 0.0) > 0.0:
+                    cm._drop_step += 1
+                return self._graph_out[key]
+            if self._graph_warm.get(key, 0) < 2:
+                self._graph_warm[key] = self._graph_warm.get(key, 0) + 1  # eager: sizes every buffer and workspace, builds the masks
+                return body()
+            saved = (opt.iterations, cm._drop_step)
+            try:
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with ops.no_gc_during_capture(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    out = body()
+            except Exception as e:                               # something in the step is not capturable here: stay eager
+                import warnings
+                warnings.warn("joint step: hipGraph capture failed (%s); running eagerly" % (repr(e)[:200],))
+                opt.iterations, cm._drop_step = saved
+                self.use_step_graph = False
+                return body()
+            self._graphs[key], self._graph_out[key] = graph, out
+            graph.replay()                                       # (capture records, it does not run: this is the step itself)
+            return out
+        out = step()
+        if prefetch:
+            self._trunk_ready_for = next_images                  # (valid until anything else runs the plan: forward_backward clears it)
         return out
 
-    def train_on_batch(self, inputs, targets=None):
+    def train_on_batch(self, inputs, targets=None, next_images=None):
         """One optimizer step; returns [loss, rpn_class_loss, rpn_bbox_loss, imgcap_loss] like the compiled Keras model
-        (metrics_names order, :1722-1730)."""
-        return self._losses_to_api(self.train_on_batch_device(inputs, targets))
+        (metrics_names order, :1722-1730).  next_images: see train_on_batch_device."""
+        return self._losses_to_api(self.train_on_batch_device(inputs, targets, next_images=next_images))
 
     def test_on_batch_device(self, inputs, targets=None):
         return self.forward_backward(inputs, backward=False)
@@ -1176,10 +1216,17 @@ class DenseImageCapRCNN(object):
         val_batch = next(val_generator)[0]
         names = ("loss",) + self.LOSS_NAMES
         history = []
+        ahead = None                                             # one batch of look-ahead: its frozen trunk runs beside this step's optimizer
         for epoch in range(self.epoch, epochs):
             acc = None                                           # raw loss terms summed on the device: one host copy per epoch
             for _ in range(cfg.STEPS_PER_EPOCH):
-                step = self._outer.train_on_batch_device(next(train_generator)[0])
+                cur = ahead if ahead is not None else next(train_generator)[0]
+                if self._outer is self and self.use_trunk_prefetch and self.backbone_from is None:
+                    ahead = next(train_generator)[0]
+                    step = self.train_on_batch_device(cur, next_images=ahead[0])
+                else:
+                    ahead = None
+                    step = self._outer.train_on_batch_device(cur)
                 acc = step.clone() if acc is None else acc.add_(step)
             logs = dict(zip(names, self._losses_to_api((acc / cfg.STEPS_PER_EPOCH).cpu().numpy())))
             # the reference validates on ONE fixed batch too: validation_data=next(val_generator) (:1878)

@@ -286,6 +286,7 @@ class EncoderPlan:
         C4 = stage(4, ["a"] + [chr(98 + i) for i in range(self.stage4_blocks)], 256, 1024, 2, C3)
         C5 = stage(5, "abc", 512, 2048, 2, C4)
         self.C = (C2, C3, C4, C5)
+        self._trunk_ops = len(self._ops)                # ops [0, _trunk_ops) = mold + ResNet trunk; the rest = FPN (+ RPN)
         self.pre = None
         t5, t4 = self._buf(H // 32, W // 32, 256), self._buf(H // 16, W // 16, 256)
         t3, t2 = self._buf(H // 8, W // 8, 256), self._buf(H // 4, W // 4, 256)
@@ -326,11 +327,13 @@ class EncoderPlan:
         self._ws = torch.empty(max(self._ws_bytes, 16), dtype=torch.uint8, device=self.device)
 
     # ------------------------------------------------------------------ run
-    def _run_ops(self):
+    def _run_ops(self, lo=0, hi=None, image_src=None):
+        """Enqueue ops [lo, hi) of the plan on the current stream.  image_src: another uint8 image tensor for the mold op (the joint
+        model's trunk prefetch reads the NEXT step's image from `images_next`)."""
         lib = self.lib
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         wsp, wsb = C.c_void_p(self._ws.data_ptr()), self._ws.numel()
-        for op in self._ops:
+        for op in self._ops[lo:hi]:
             kind = op[0]
             if kind == "conv":
                 rc = lib.dc_conv2d_nhwc_f32(C.byref(op[1]), wsp, wsb, stream)
@@ -346,7 +349,7 @@ class EncoderPlan:
                 b = op[1]
                 ops.bn_fold(b["gamma"], b["beta"], b["bias"], b["mean"], b["var"], op[2], op[3])
             elif kind == "mold":
-                ops.mold_image_rgbx(op[1], self.mean_pixel, out=op[2])
+                ops.mold_image_rgbx(op[1] if image_src is None else image_src, self.mean_pixel, out=op[2])
             elif kind == "sub2":
                 ops.subsample2(op[1], out=op[2])
             else:
@@ -471,6 +474,37 @@ class EncoderPlan:
             with ops.no_gc_during_capture(), torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self._run_ops()
             self._graph = g
+            g.replay()
+        return self.P
+
+    # ---- the pass in two halves (joint model, frozen trunk): the ResNet trunk does not depend on anything the step trains, so the
+    # trunk of step i + 1 can run while step i's optimizer (HBM-bound) is still busy -- DenseImageCapRCNN.train_on_batch(next_images=)
+    def run_trunk(self, image_src=None):
+        """mold + ResNet trunk (C2..C5) on the current stream, eagerly (the caller may be capturing).  image_src: uint8 [B,H,W,3] device
+        tensor (default: self.images)."""
+        if self._external_bn:
+            raise RuntimeError("the trunk of this plan is trainable: it cannot run ahead of the optimizer")
+        self._run_ops(0, self._trunk_ops, image_src)
+
+    def next_image_buffer(self):
+        if getattr(self, "images_next", None) is None:
+            self.images_next = torch.empty_like(self.images)
+        return self.images_next
+
+    def forward_head(self):
+        """FPN (+ RPN) on the trunk outputs already in the plan's buffers (run_trunk): first call eager, second captured, then replayed."""
+        if not self.use_graph:
+            self._run_ops(self._trunk_ops, None)
+        elif getattr(self, "_graph_head", None) is not None:
+            self._graph_head.replay()
+        elif not getattr(self, "_warm_head", False):
+            self._run_ops(self._trunk_ops, None)
+            self._warm_head = True
+        else:
+            g = torch.cuda.CUDAGraph()
+            with ops.no_gc_during_capture(), torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self._run_ops(self._trunk_ops, None)
+            self._graph_head = g
             g.replay()
         return self.P
 
