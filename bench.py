@@ -43,12 +43,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WINOGRAD_GAIN = 2.25            # direct 3x3: 36 products per 2x2 output tile and channel pair; Winograd F(2x2,3x3): 16
-WINOGRAD4_GAIN = 4.0            # F(4x4,3x3): 36 products per 4x4 output tile and channel pair instead of 144
 
 
 def winograd_gain(kernel):
     """Direct-form FLOPs / FLOPs the matrix pipe executes for the layers that run on `kernel` (dc_conv2d_kernel_name's spelling)."""
-    return WINOGRAD4_GAIN if kernel.startswith("wino4_") else (WINOGRAD_GAIN if kernel.startswith("wino") else 1.0)
+    return WINOGRAD_GAIN if kernel.startswith("wino") else 1.0
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
@@ -75,8 +74,6 @@ def parse():
     ap.add_argument("--cpu-baseline-steps", type=int, default=5)
     ap.add_argument("--layer-table", default=None, help="write the per-layer conv timing table (TSV) to this path")
     ap.add_argument("--joint-dtype", default="bf16", choices=["bf16", "f32"], help="joint leg: decoder/head/vocabulary arithmetic")
-    ap.add_argument("--joint-prefetch", action="store_true", help="joint leg: hand every step the next image too (train_on_batch(next_images=): "
-                    "the frozen trunk of the next step runs beside this step's optimizer; measured without gain, round 4)")
     ap.add_argument("--joint-dropout", type=float, default=0.0, help="joint leg: recurrent_dropout of the two LSTMs (the reference trains with "
                     "0.2 = this package's default; the benchmark opts out so that runs are comparable: the masks cost one small kernel per LSTM)")
     ap.add_argument("--joint-host-images", action="store_true", help="joint leg: hand the image over as a host array every step")
@@ -510,8 +507,8 @@ class E2E(object):
         if wino:
             out["achieved_direct_form"] = g["alg"] / (g["ms"] * 1e-3) / 1e12
             out["gflop_per_launch_direct_form"] = g["alg"] / g["launches"] / 1e9
-            out["note"] = ("Winograd %s, fp32 transforms and products: executed MFMA FLOPs = direct-form FLOPs / %.2f; frac = executed / peak"
-                           % ("F(4x4,3x3)" if dom.startswith("wino4_") else "F(2x2,3x3)", winograd_gain(dom)))
+            out["note"] = ("Winograd F(2x2,3x3), fp32 transforms and products: executed MFMA FLOPs = direct-form FLOPs / %.2f; frac = executed / peak"
+                           % winograd_gain(dom))
         if main == "pipeline":
             gi = res["isolated"][0][dom]
             ai = gi["flops"] / (gi["ms"] * 1e-3) / 1e12
@@ -580,18 +577,15 @@ def build_joint(args, dev, rank=0, world=1):
 def run_joint(args, dev, rank, world, barrier):
     """Times args.steps joint train steps (see build_joint); returns (seconds, last losses, RoIs per step, the model)."""
     model, inner, inputs, cfg = build_joint(args, dev, rank, world)
-    # --joint-prefetch: the loop hands every step the NEXT step's image as well (here the same synthetic image again): with the frozen
-    # trunk of configs[4] its ResNet pass then runs beside the current step's optimizer -- one trunk pass per step, as before, only earlier
-    nxt = inputs[0] if args.joint_prefetch else None
     for _ in range(max(args.warmup, 2)):
-        out = inner.train_on_batch(inputs, next_images=nxt)
+        out = inner.train_on_batch(inputs)
     if world > 1 and getattr(inner, "grad_sync", None) is not None and hasattr(inner.grad_sync, "exposed_ms"):
         inner.grad_sync.exposed_ms()
         inner.grad_sync.timing = True
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = inner.train_on_batch(inputs, next_images=nxt)      # per-rank image: every rank steps its own shard (weak scaling)
+        out = inner.train_on_batch(inputs)      # per-rank image: every rank steps its own shard (weak scaling)
     barrier()
     dt = time.perf_counter() - t0
     R = cfg.TRAIN_ROIS_PER_IMAGE
@@ -730,9 +724,6 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # started plainly: be the launcher (before anything touches the GPU)
         raise SystemExit(self_launch(args.gpus))
-    if os.environ.get("DCAP_HANG_DUMP"):                 # diagnostics: dump every thread's Python stack after N seconds and exit
-        import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ["DCAP_HANG_DUMP"]), exit=True)
     from image_captioning_amd.parallel_model import init_process_group_from_env, GradAllReduce
     rank, world, local_rank = init_process_group_from_env()
     if world != args.gpus:

@@ -385,7 +385,6 @@ inline BSplit split(int M, int N, int K, int user_split) {
 //   256 x 256 tile, one block per CU:    1.55 us per 64-deep K-tile (8.4 MFLOP), 4 us per block (prologue, epilogue)
 //   128 x 128 tile, two blocks per CU:   1.13 us per K-tile and block (2.1 MFLOP, two co-resident), 3 us per block
 //   split-K: (slices + 1) x M x N x 4 bytes at 4 TB/s + one more launch (3 us)
-// (DCAP_BGEMM_TILE = 128 | 256 forces a choice.)
 inline double tile_cost_us(int M, int N, int K, int tile, const BSplit& sp) {
     const long tiles = (long)((M + tile - 1) / tile) * ((N + tile - 1) / tile);
     const long blocks = tiles * sp.split, slots = tile == 256 ? kNumCU : 2 * kNumCU;
@@ -398,9 +397,6 @@ inline double tile_cost_us(int M, int N, int K, int tile, const BSplit& sp) {
 
 inline bool prefer(int M, int N, int K, int user_split, bool vec4 = true) {
     if (!vec4 || (N & 3) || M < 4 || N < 4) return false;       // the epilogue is 16-byte accesses only
-    static const int forced = [] { const char* e = getenv("DCAP_BGEMM_TILE"); return e ? atoi(e) : 0; }();
-    if (forced == 128) return false;
-    if (forced == 256) return true;
     const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     if ((double)tiles * BM * BN > 1.25 * (double)M * N) return false;              // padded / useful outputs
     return tile_cost_us(M, N, K, 256, split(M, N, K, user_split)) < tile_cost_us(M, N, K, 128, bgemm_split(M, N, K, user_split));

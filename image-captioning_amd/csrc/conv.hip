@@ -65,9 +65,8 @@ static inline TileChoice conv_tile(const dc_conv_desc* d, int M, int N, int K) {
     // Measured on the encoder's layer shapes (tools/conv_bench.py): with 128-row tiles, K >= 128 and N >= 128 the producer /
     // consumer kernel on 128x64 tiles beats the single-role 128x128 and 128x64 kernels (res4_2c 48.5 -> 42.5 us, fpn_p3
     // 293.6 -> 276.8, res3_2b 88.1 -> 82.6): twice the blocks of a 128x128 grid, so a short-K layer no longer runs as one
-    // lock-step round, and no wave waits on its own loads.  DCAP_PW_RULE=0 restores the round-1 rule (measurements only).
-    static const int rule = env_int("DCAP_PW_RULE", 1);
-    if (rule && d->Cin != 4 && t.bm == 128 && t.split == 1 && K >= 128 && N >= 128) {
+    // lock-step round, and no wave waits on its own loads (profiles/r02_conv_bench.txt has the round-1 rule beside it).
+    if (d->Cin != 4 && t.bm == 128 && t.split == 1 && K >= 128 && N >= 128) {
         t.bn = 64;
         t.pc = true;
     }
@@ -82,13 +81,11 @@ static inline void conv_dims(const dc_conv_desc* d, bool stem, int& M, int& N, i
 
 using WeightKC = DenseKCT<true>;   // packed weights: K = kh*kw*Cin is a multiple of 32, rows 16-byte aligned
 
-// producer / consumer kernel or single-role kernel for this tile?  DCAP_PC (experiments): 0 = single-role everywhere,
-// 2 = producer/consumer on every 128x64 tile, 3 = also on 128x128.
+// producer / consumer kernel or single-role kernel for this tile?  64x64 always, 128x64 where the tile rule asked for it.
 static bool conv_uses_pc(const TileChoice& t) {
-    static const int pc = env_int("DCAP_PC", 1);
-    if (t.bm == 128 && t.bn == 128) return pc == 3;
-    if (t.bm == 128 && t.bn == 64) return pc == 2 || (pc && t.pc);
-    return pc != 0;
+    if (t.bm == 128 && t.bn == 128) return false;
+    if (t.bm == 128 && t.bn == 64) return t.pc;
+    return true;
 }
 
 static Epilogue conv_epilogue(const dc_conv_desc* d) {

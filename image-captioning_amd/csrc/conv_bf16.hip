@@ -211,9 +211,9 @@ static int conv_bf16_validate(const dc_conv_bf16_desc* d) {
     return DC_OK;
 }
 
-// split-K for the convolution: `target` blocks on the chip (DCAP_BCONV_BLOCKS, default 2 per CU), >= 4 K-tiles per slice
+// split-K for the convolution: two blocks per CU on the chip, >= 4 K-tiles per slice
 static BSplit bconv_split(int M, int N, int K, int user_split) {
-    static const int target = env_int("DCAP_BCONV_BLOCKS", 2 * kNumCU);
+    constexpr int target = 2 * kNumCU;
     if (user_split > 0) return bgemm_split(M, N, K, user_split);
     const int tiles = ((M + BT - 1) / BT) * ((N + BT - 1) / BT);
     const int ktiles = (K + BKB - 1) / BKB;
@@ -233,11 +233,10 @@ using namespace dcap;
 
 // Which tile runs this layer: 256 (the P2 / P3-level FPN and RPN layers and their data gradients), 64 (the one-image trunk layers:
 // whole K loop in one block, no split-K slabs) or 128, by the cost model of bgemm256_core.h / bgemm64_core.h.
-// DCAP_BCONV_TILE = 64 | 128 | 256 forces a choice where the shape allows it.
+// dc_conv_bf16_desc.tile = 64 | 128 | 256 forces a choice where the shape allows it (tests, benches).
 static int bconv_tile(const dc_conv_bf16_desc* d, int M, int N, int K) {
     const bool vec4 = (d->Cout & 3) == 0 && (!d->residual || aligned16(d->residual)) && (!d->scale || aligned16(d->scale)) && (!d->shift || aligned16(d->shift));
-    static const int env_forced = [] { const char* e = getenv("DCAP_BCONV_TILE"); return e ? atoi(e) : 0; }();
-    const int forced = d->tile ? d->tile : env_forced;
+    const int forced = d->tile;
     if (!vec4 || M < 4 || N < 4) return 128;
     if (forced == 128) return 128;
     if (forced == 64 && d->split_k <= 1) return 64;

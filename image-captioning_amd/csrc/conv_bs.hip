@@ -7,13 +7,8 @@ namespace dcap {
 
 using WeightKCb = DenseKCT<true>;
 
-// v1 (single-role waves, two blocks per CU) is the default: it wins on 1x1 and small layers; v2 (producer / consumer waves,
-// pre-split weights) is ~2 % ahead on the large 3x3 layers only.  DCAP_BS_VER=2 selects it (experiments).
-static int bs_version() {
-    static const int ver = env_int("DCAP_BS_VER", 1);
-    return ver;
-}
-
+// Single-role waves, two blocks per CU.  (A producer / consumer version on pre-split weight planes was ~2 % ahead on the large 3x3
+// layers only and behind elsewhere -- profiles/r02_presplit_experiment.txt; removed in round 5.)
 template <class AL, class BL>
 static int dispatch_bs(const AL& al, const BL& bl, const Epilogue& ep, int M, int N, int K, int bm, int bn, int split, void* ws,
                        size_t wsb, hipStream_t s, int pieces) {
@@ -27,14 +22,9 @@ static int dispatch_bs(const AL& al, const BL& bl, const Epilogue& ep, int M, in
         if (bm == 128 && bn == 64) return launch_igemm_bs<128, 64, AL, BL, 2>(al, bl, ep, M, N, K, split, ws, wsb, s);
         return launch_igemm_bs<64, 64, AL, BL, 2>(al, bl, ep, M, N, K, split, ws, wsb, s);
     }
-    if (bs_version() == 1) {
-        if (bm == 128 && bn == 128) return launch_igemm_bs<128, 128, AL, BL>(al, bl, ep, M, N, K, split, ws, wsb, s);
-        if (bm == 128 && bn == 64) return launch_igemm_bs<128, 64, AL, BL>(al, bl, ep, M, N, K, split, ws, wsb, s);
-        return launch_igemm_bs<64, 64, AL, BL>(al, bl, ep, M, N, K, split, ws, wsb, s);
-    }
-    if (bm == 128 && bn == 128) return launch_igemm_bs2<128, 128, AL, BL>(al, bl, ep, M, N, K, split, ws, wsb, s);
-    if (bm == 128 && bn == 64) return launch_igemm_bs2<128, 64, AL, BL>(al, bl, ep, M, N, K, split, ws, wsb, s);
-    return launch_igemm_bs2<64, 64, AL, BL>(al, bl, ep, M, N, K, split, ws, wsb, s);
+    if (bm == 128 && bn == 128) return launch_igemm_bs<128, 128, AL, BL>(al, bl, ep, M, N, K, split, ws, wsb, s);
+    if (bm == 128 && bn == 64) return launch_igemm_bs<128, 64, AL, BL>(al, bl, ep, M, N, K, split, ws, wsb, s);
+    return launch_igemm_bs<64, 64, AL, BL>(al, bl, ep, M, N, K, split, ws, wsb, s);
 }
 
 __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ x, unsigned short* __restrict__ out, size_t n) {
@@ -57,15 +47,6 @@ int conv2d_bf16x3(const dc_conv_desc* d, bool stem, const Epilogue& ep, int M, i
         WeightKCb bl{d->w, K, N, nullptr};
         StemKC al{d->x, d->H, d->W, d->Ho, d->Wo, M, (unsigned)((size_t)d->N * d->H * d->W * 4 * sizeof(float))};
         return dispatch_bs(al, bl, ep, M, N, K, bm, bn, split, workspace, workspace_bytes, s, pieces);
-    }
-    if (d->w_split && !stem && bs_version() == 2 && pieces == 3) {
-        DC_REQUIRE(aligned16(d->w_split), DC_EALIGN, "dc_conv2d: w_split must be 16-byte aligned");
-        SplitWeightKC bl{d->w_split, K, N, d->kh * d->kw, d->Cin};
-        Im2colKCcm al{d->x, d->H, d->W, d->Cin, d->Ho, d->Wo, d->stride, d->pad_t, d->pad_l, d->kw, d->kh * d->kw, M,
-                    (unsigned)((size_t)d->N * d->H * d->W * d->Cin * sizeof(float))};
-        if (bm == 128 && bn == 128) return launch_igemm_bs2<128, 128, Im2colKCcm, SplitWeightKC>(al, bl, ep, M, N, K, split, workspace, workspace_bytes, s);
-        if (bm == 128 && bn == 64) return launch_igemm_bs2<128, 64, Im2colKCcm, SplitWeightKC>(al, bl, ep, M, N, K, split, workspace, workspace_bytes, s);
-        return launch_igemm_bs2<64, 64, Im2colKCcm, SplitWeightKC>(al, bl, ep, M, N, K, split, workspace, workspace_bytes, s);
     }
     ConvWeightKC bl{d->w, K, N, d->kh * d->kw, d->Cin};
     Im2colKCcm al{d->x, d->H, d->W, d->Cin, d->Ho, d->Wo, d->stride, d->pad_t, d->pad_l, d->kw, d->kh * d->kw, M,

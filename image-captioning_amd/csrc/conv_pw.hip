@@ -121,24 +121,22 @@ static int launch_pw(const dc_conv_desc* d, const Epilogue& ep, int M, int N, hi
     const int gx = (N + NC - 1) / NC;
     const int strips = (M + 31) / 32;
     const int gy = std::max(1, std::min((2 * kNumCU) / gx, (strips + 3) / 4));
-    static const int xcd_map = env_int("DCAP_PW_XCD", 1);                               // DCAP_PW_XCD=0: slices dealt over the XCDs (measurements only)
+    constexpr int xcd_map = 1;                           // the slices of one pixel group share an XCD (round 2: dealt over the XCDs, fpn_c2p2 fetched its input 4x)
     const dim3 grid(gx * ((gy + 7) / 8) * 8);            // whole rounds of 8 XCDs; the kernel drops the padding blocks
-#define DCAP_PW_LAUNCH(RES_)                                                                                                          \
+#define PW_LAUNCH(RES_)                                                                                                          \
     do {                                                                                                                              \
         DC_ENSURE_DYN_LDS((&pwconv_stream_kernel<K, RES_>), 160 * 1024);                                                              \
         hipLaunchKernelGGL((pwconv_stream_kernel<K, RES_>), grid, dim3(256), lds, s, d->x, d->w, ep, M, N, gx, gy, xcd_map);                           \
     } while (0)
-    if (ep.res_mode == 0) DCAP_PW_LAUNCH(0);
-    else if (ep.res_mode == 1) DCAP_PW_LAUNCH(1);
-    else DCAP_PW_LAUNCH(2);
-#undef DCAP_PW_LAUNCH
+    if (ep.res_mode == 0) PW_LAUNCH(0);
+    else if (ep.res_mode == 1) PW_LAUNCH(1);
+    else PW_LAUNCH(2);
+#undef PW_LAUNCH
     return check_launch("pwconv_stream_kernel");
 }
 
 // true when the streaming kernel takes this (already validated, f32-math, pointwise) convolution
 bool conv_pw_stream_supported(const dc_conv_desc* d, const Epilogue& ep) {
-    static const int on = env_int("DCAP_PW_STREAM", 1);
-    if (!on) return false;
     if (d->Cin != 64 && d->Cin != 128 && d->Cin != 256) return false;
     if (d->Cout < 64 || (d->Cout & 63) != 0 || !ep.vec4) return false;
     // measured (tools/conv_bench.py, 2 x 1024^2): 64>64 20.5 vs 22.0 us, 64>256 +res 84.2 vs 92.8, 128>512 +res 55.3 vs 62.0,

@@ -19,9 +19,9 @@
 // What bounds the form is not the matrix pipe alone: per MFMA it moves 2.25x the operand bytes of the direct one (U is 16/9 of
 // the kernel and is re-read by every tile group; 4 x 4 patches overlap), a CU takes 66-73 GB/s from L2, and every vector-memory
 // instruction costs the issuing wave tens of cycles (MI355X_MICROARCH.md).
-//   wino32v1_kernel (the first version; DCAP_WINO_TILES=1, kept for the comparison in profiles/): 32 tiles, 32-channel chunks,
-//     thread (tile, channel quad) loads its 4 x 4 patch into registers, transforms it and writes a V image, two blocks per CU.
-//     128 KB requested per 1.05 MFLOP-chunk and block: 810 us on fpn_p2, where the MFMAs alone need 437.
+//   The first version (round 3: thread (tile, channel quad) loads its 4 x 4 patch into registers, transforms it and writes a V image,
+//     two blocks per CU) asked L2 for 128 KB per 1.05 MFLOP-chunk and block: 810 us on fpn_p2, where the MFMAs alone need 437; it
+//     was removed in round 5 (profiles/r03_winograd_bench.txt keeps its numbers).
 //   wino64_kernel / wino32_kernel = wino_body<2 / 1> (DESIGN.md section 5 has the measurements that led here): 64 / 32 tiles per
 //     item, the input patch staged ONCE per 32 channels by LDS-DMA, no V image -- every wave makes its own MFMA fragments straight
 //     from the patch --, persistent blocks, vector-memory instructions issued one per MFMA: 639 us.  64-tile items (512 threads,
@@ -76,158 +76,16 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
-// [16 xi][32 tiles][32 floats]: 128-byte rows, 16-byte chunk c of row r at c ^ ((r >> 1) & 7).  V image of wino32_kernel and the M
-// (output transform) image of both kernels.
+// [16 xi][32 tiles][32 floats]: 128-byte rows, 16-byte chunk c of row r at c ^ ((r >> 1) & 7): the M (output transform) image.
 __device__ __forceinline__ unsigned img32_addr(int xi, int tile, int chunk) {
     return (unsigned)((((xi * 32 + tile) << 3) + (chunk ^ ((tile >> 1) & 7))) << 4);
 }
-// [16 xi][64 tiles][16 floats]: 64-byte rows, chunk c of row r at c ^ ((r >> 2) & 3).  V image of wino64_kernel.
-__device__ __forceinline__ unsigned img64_addr(int xi, int tile, int chunk) {
-    return (unsigned)((((xi * 64 + tile) << 2) + (chunk ^ ((tile >> 2) & 3))) << 4);
-}
-
-// B^T d B, in place friendly: first the rows (t = B^T d), then the columns.
-__device__ __forceinline__ void bt_rows(const f4 (&d)[4][4], f4 (&t)[4][4]) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        t[0][c] = d[0][c] - d[2][c];
-        t[1][c] = d[1][c] + d[2][c];
-        t[2][c] = d[2][c] - d[1][c];
-        t[3][c] = d[1][c] - d[3][c];
-    }
-}
+// the column half of B^T d B (the row half is one FMA per value in wino_body)
 __device__ __forceinline__ void bt_cols(const f4 (&t)[4], f4 (&v)[4]) {
     v[0] = t[0] - t[2];
     v[1] = t[1] + t[2];
     v[2] = t[2] - t[1];
     v[3] = t[1] - t[3];
-}
-
-// Output transform Y = A^T M A of one (tile, 4 output channels), epilogue and stores.  m[xi = 4 r + c].
-__device__ __forceinline__ void finish_tile(const Args& a, const f4 (&m)[4][4], int img, int ty, int tx, int cout) {
-    f4 sc = (f4)(1.f), sh = (f4)(0.f);
-    if (a.scale) sc = *reinterpret_cast<const f4*>(a.scale + cout);
-    if (a.shift) sh = *reinterpret_cast<const f4*>(a.shift + cout);
-    f4 s[2][4];                                            // A^T M
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        s[0][c] = m[0][c] + m[1][c] + m[2][c];
-        s[1][c] = m[1][c] - m[2][c] - m[3][c];
-    }
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const f4 o[2] = {s[p][0] + s[p][1] + s[p][2], s[p][1] - s[p][2] - s[p][3]};
-#pragma unroll
-        for (int qx = 0; qx < 2; ++qx) {
-            f4 val = o[qx] * sc + sh;
-            if (a.relu) val = f4{fmaxf(val[0], 0.f), fmaxf(val[1], 0.f), fmaxf(val[2], 0.f), fmaxf(val[3], 0.f)};
-            if (2 * ty + p < a.H && 2 * tx + qx < a.W)
-                *reinterpret_cast<f4*>(a.y + (((long)img * a.H + 2 * ty + p) * a.W + 2 * tx + qx) * a.Cout + cout) = val;
-        }
-    }
-}
-
-// byte offsets of this thread's 4 x 4 input patch (channel quad q of the chunk at soffset), kOobOffset outside the image
-__device__ __forceinline__ void patch_offsets(const Args& a, int img, int ty, int tx, int q, unsigned (&off)[4][4]) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int iy = 2 * ty - 1 + r, ix = 2 * tx - 1 + c;
-            const bool in = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            off[r][c] = in ? (unsigned)(((((long)img * a.H + iy) * a.W + ix) * a.Cin + 4 * q) * 4) : kOobOffset;
-        }
-}
-
-// ------------------------------------------------------------------------------------------------------------------------
-// wino32v1_kernel: 32 tiles (4 x 8: 8 x 16 output pixels), K-chunks of 32 channels, V single-buffered (64 KiB), two blocks per CU.
-// ------------------------------------------------------------------------------------------------------------------------
-namespace w32 {
-constexpr int TGY = 4, TGX = 8, KCH = 32;
-constexpr int LDS_BYTES = 16 * 32 * KCH * 4;             // 64 KiB
-}
-
-__global__ __launch_bounds__(NTHREADS, 2) void wino32v1_kernel(Args a) {
-    using namespace w32;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int nb = bid / a.groups, g = bid - nb * a.groups;
-    const int gpi = a.gy * a.gx;
-    const int img = g / gpi, gr = g - img * gpi;
-    const int gyi = gr / a.gx, gxi = gr - gyi * a.gx;
-    const int NTG = a.Cout >> 5, KC = a.Cin >> 5;
-
-    const int ti = tid >> 3, q = tid & 7;                  // this thread's tile and channel quad (input and output transforms)
-    const int ty = gyi * TGY + (ti >> 3), tx = gxi * TGX + (ti & 7);
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
-    unsigned off[4][4];
-    patch_offsets(a, img, ty, tx, q, off);
-    f4 raw[4][4];
-    auto load_raw = [&](int kc) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) raw[r][c] = buf_f4s(rsrc, off[r][c], (unsigned)(kc * KCH * 4));
-    };
-    const int fi = lane & 31, fh = lane >> 5;
-    const f4* ubase = a.u + lane;
-    auto load_u = [&](f4 (&dst)[4], int kc, int xl) {      // fragment jj of 16-channel half s = dst[2 s + jj]
-        const f4* p = ubase + (((long)((4 * wave + xl) * NTG + nb) * (2 * KC) + 2 * kc) << 7);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dst[j] = p[j * 64];
-    };
-    f32x16 acc[4];
-#pragma unroll
-    for (int xl = 0; xl < 4; ++xl)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[xl][r] = 0.f;
-    f4 ub[2][4];
-    load_raw(0);
-    load_u(ub[0], 0, 0);
-    for (int kc = 0; kc < KC; ++kc) {
-        f4 t[4][4], v[4][4];
-        bt_rows(raw, t);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bt_cols(t[r], v[r]);
-        __syncthreads();                                   // every wave is done reading the previous chunk's V
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) *reinterpret_cast<f4*>(smem + img32_addr(4 * r + c, ti, q)) = v[r][c];
-        load_raw(min(kc + 1, KC - 1));                     // in flight during the MFMA phase (the last one re-reads: uniform counts)
-        __syncthreads();
-#pragma unroll
-        for (int xl = 0; xl < 4; ++xl) {
-            const int cur = xl & 1;
-            if (xl < 3) load_u(ub[cur ^ 1], kc, xl + 1);
-            else load_u(ub[cur ^ 1], min(kc + 1, KC - 1), 0);
-            f4 vb[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)                    // channels 16 (j >> 1) + 8 h + 4 (j & 1) ..+3 of the chunk, like U's fragment j
-                vb[j] = *reinterpret_cast<const f4*>(smem + img32_addr(4 * wave + xl, fi, 4 * (j >> 1) + 2 * fh + (j & 1)));
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[xl] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[cur][j][e], vb[j][e], acc[xl], 0, 0, 0);
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int xl = 0; xl < 4; ++xl)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const f4 m = {acc[xl][4 * gq], acc[xl][4 * gq + 1], acc[xl][4 * gq + 2], acc[xl][4 * gq + 3]};
-            *reinterpret_cast<f4*>(smem + img32_addr(4 * wave + xl, fi, 2 * gq + fh)) = m;          // couts 8 gq + 4 h .. + 3 of tile fi
-        }
-    __syncthreads();
-    f4 m[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) m[r][c] = *reinterpret_cast<const f4*>(smem + img32_addr(4 * r + c, ti, q));
-    finish_tile(a, m, img, ty, tx, nb * 32 + 4 * q);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -362,9 +220,6 @@ __device__ __forceinline__ void wino_body(const Args& a) {
     issue_dma(0, 0);
     f4 ub[2][4][2];
     load_u(ub[0], 0);
-#ifdef WINO_EXP_NOU
-    load_u(ub[1], 1);
-#endif
     for (;;) {
         f32x16 acc[4];
 #pragma unroll
@@ -373,10 +228,8 @@ __device__ __forceinline__ void wino_body(const Args& a) {
             for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
         auto pair = [&](int p, auto more_c) {
             constexpr bool more = decltype(more_c)::value;      // a pair p + 1 of this item exists: request its patch
-#ifndef WINO_EXP_NOBAR
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the patch (and its U fragments) have landed
             __syncthreads();                               // every wave's have; every wave is done with the other buffer
-#endif
             // four steps of 16 MFMAs.  The patch reads of step st + 1 are issued at the top of step st, ahead of its first eight MFMAs;
             // the transform of step st + 1 is VALU work placed beside the last eight.  The scheduling fences keep the compiler from
             // sinking the reads to just before their use (it did: every step then opened with an exposed LDS round trip).
@@ -386,20 +239,14 @@ __device__ __forceinline__ void wino_body(const Args& a) {
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 const int half = st >> 1, j = st & 1;
-#ifndef WINO_EXP_NOREAD
                 if (st < 3) read_d(d, st + 1);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 // vector-memory instructions cost the wave tens of issue cycles each (an LDS-DMA piece 60 - 185: MI355X_MICROARCH.md):
                 // they go out ONE per MFMA inside the first eight of a step -- the next pair's patch in steps 0 and 1 (three pieces
                 // each), the U fragments of the next 16-channel chunk half per step -- instead of in a burst behind the barrier, where
                 // both waves of a SIMD issued theirs at the same time with no MFMA in flight
-#ifndef WINO_EXP_NODMA
                 if constexpr (more) if (st < 2) issue_dma_pieces(p + 1, (p + 1) & 1, 3 * st, 3 * st + 3);
-#endif
-#ifndef WINO_EXP_NOU
                 load_u_part(ub[half ^ 1], min(2 * p + half + 1, KC - 1), 2 * j, 2 * j + 2);          // (the last one re-reads: uniform counts)
-#endif
 #pragma unroll
                 for (int e = 0; e < 2; ++e)
 #pragma unroll
@@ -410,16 +257,11 @@ __device__ __forceinline__ void wino_body(const Args& a) {
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);          // one vector-memory read (where there is one left)
                 }
                 __builtin_amdgcn_sched_barrier(0);
-#ifndef WINO_EXP_NOREAD
                 if (st < 3) transform(d, vnext);
-#else
-                if (st < 3) { for (int b = 0; b < 4; ++b) vnext[b] = vcur[b]; }
-#endif
 #pragma unroll
                 for (int e = 2; e < 4; ++e)
 #pragma unroll
                     for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[half][b][j][e], vcur[b][e], acc[b], 0, 0, 0);
-#ifndef WINO_EXP_NOREAD
                 if (st < 3) {                              // the transform's VALU work spread over the eight MFMAs: none of them waits for it
 #pragma unroll
                     for (int m = 0; m < 8; ++m) {
@@ -427,7 +269,6 @@ __device__ __forceinline__ void wino_body(const Args& a) {
                         __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                     }
                 }
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 if (st < 3) {
 #pragma unroll
@@ -501,235 +342,6 @@ __device__ __forceinline__ void wino_body(const Args& a) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------------
-// wino4_kernel: F(4x4, 3x3) (round 4).  36 products per 4 x 4 output tile and (cin, cout) pair where F(2x2, 3x3) needs 64 and the
-// direct form 144: 1.78x fewer MFMAs than the kernels above on the layers that have enough tiles for it.
-//   U[xi] = (G4 g G4^T)[xi], xi = 6 a + b, packed once per weight;  V[xi] = (B4^T d B4)[xi], d = the 6 x 6 input patch whose top-left
-//   pixel is (4 ty - 1, 4 tx - 1);  M[xi] = V[xi] . U[xi];  Y = A4^T M A4  (interpolation points 0, +-1, +-2, inf: Lavin & Gray).
-// Float32 error: 1e-5 of the output scale at the worst element / 6e-7 rms at 256 post-ReLU input channels (oracle restatement,
-// tests/test_oracle_kat.py) -- 20x / 6x F(2,3)'s; the plan therefore uses it where it pays and the tests hold it to 5e-5.
-// Structure: the FIRST Winograd kernel's (wino32v1 above), which is what fits in one round of work: a work item = 32 tiles (4 x 8:
-// 16 x 32 output pixels) x 32 output channels, 256 threads = 4 waves, one block per CU (the V image of a 32-channel chunk is
-// 36 x 32 x 32 floats = 144 KiB of LDS).  Per chunk: thread (tile, channel quad) transforms its 6 x 6 patch in registers (loaded one
-// chunk ahead, behind the previous chunk's MFMA phase), writes the 36 V values; wave w then runs the nine transform positions
-// 9 w .. 9 w + 8 -- 144 MFMAs against 36 U loads (straight from L2, fragment order) and 36 fragment reads.  Not persistent, no LDS-DMA:
-// the transform VALU is serial with the MFMA phase.  MEASURED (round 4, tools/conv_bench.py --winograd4 and the W4_EXP_* ablation
-// builds): correct (tests/test_gpu_kernels.py::test_conv2d_winograd_f4x4_...), and SLOWER than wino64 -- 0.32 of the pipe executed
-// (fpn_p3 191 us against 160, fpn_p2 752 against 646).  With one wave per SIMD every one of its 72 vector-memory instructions per chunk
-// (36 patch pixels, 36 U fragments) stalls the SIMD's only MFMA issuer, and the bare MFMA phase (sixteen dependent MFMAs per position)
-// reaches 0.62.  Off by default; what it needs is wino_body's structure (two waves per SIMD, the patch by LDS-DMA, loads one per MFMA).
-// ------------------------------------------------------------------------------------------------------------------------
-namespace w4 {
-constexpr int TGY = 4, TGX = 8, KCH = 32;
-constexpr int LDS_BYTES = 36 * 32 * KCH * 4;             // 144 KiB
-}
-
-// one column / row of B4^T . : t = B4^T d for six values
-__device__ __forceinline__ void bt6(const f4 d0, const f4 d1, const f4 d2, const f4 d3, const f4 d4, const f4 d5, f4 (&t)[6]) {
-    const f4 p = d4 - 4.f * d2, q = d3 - 4.f * d1, r = d4 - d2, s2 = 2.f * (d3 - d1);
-    t[0] = 4.f * d0 - 5.f * d2 + d4;
-    t[1] = p + q;
-    t[2] = p - q;
-    t[3] = r + s2;
-    t[4] = r - s2;
-    t[5] = 4.f * d1 - 5.f * d3 + d5;
-}
-// A4^T . : four outputs from six values
-__device__ __forceinline__ void at4(const f4 m0, const f4 m1, const f4 m2, const f4 m3, const f4 m4, const f4 m5, f4 (&y)[4]) {
-    const f4 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
-    y[0] = m0 + s1 + s2;
-    y[1] = d1 + 2.f * d2;
-    y[2] = s1 + 4.f * s2;
-    y[3] = d1 + 8.f * d2 + m5;
-}
-
-// U = G4 g G4^T in fragment order (same layout as wino_pack_kernel, 36 positions); the transform in double, rounded once
-__global__ void wino4_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cin, int Cout) {
-    const long total = (long)Cin * Cout;
-    const int NTG = Cout / 32, KC = Cin / 16;
-    const double G[6][3] = {{0.25, 0., 0.}, {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6},
-                            {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0., 0., 1.}};
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int cin = (int)(idx % Cin), cout = (int)(idx / Cin);
-        double g[3][3], gg[6][3];
-        for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = (double)w[((long)cout * 9 + t) * Cin + cin];
-        for (int a = 0; a < 6; ++a)
-            for (int c = 0; c < 3; ++c) gg[a][c] = G[a][0] * g[0][c] + G[a][1] * g[1][c] + G[a][2] * g[2][c];
-        const int ntg = cout >> 5, i = cout & 31, kc = cin >> 4, kk = cin & 15, h = kk >> 3, j = (kk & 7) >> 2, e = kk & 3;
-        for (int a = 0; a < 6; ++a)
-            for (int b = 0; b < 6; ++b) {
-                const int xi = 6 * a + b;
-                const double v = gg[a][0] * G[b][0] + gg[a][1] * G[b][1] + gg[a][2] * G[b][2];
-                u[((((long)(xi * NTG + ntg) * KC + kc) * 2 + j) * 64 + (h * 32 + i)) * 4 + e] = (float)v;
-            }
-    }
-}
-
-__global__ __launch_bounds__(NTHREADS, 1) void wino4_kernel(Args a) {
-    using namespace w4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int nb = bid / a.groups, g = bid - nb * a.groups;
-    const int gpi = a.gy * a.gx;
-    const int img = g / gpi, gr = g - img * gpi;
-    const int gyi = gr / a.gx, gxi = gr - gyi * a.gx;
-    const int NTG = a.Cout >> 5, KC = a.Cin >> 5;
-    const int ti = tid >> 3, q = tid & 7;                  // this thread's tile and channel quad (input and output transforms)
-    const int ty = gyi * TGY + (ti >> 3), tx = gxi * TGX + (ti & 7);
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
-    unsigned off[6][6];
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            const int iy = 4 * ty - 1 + r, ix = 4 * tx - 1 + c;
-            const bool in = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            off[r][c] = in ? (unsigned)(((((long)img * a.H + iy) * a.W + ix) * a.Cin + 4 * q) * 4) : kOobOffset;
-        }
-    f4 raw[6][6];
-    auto load_raw = [&](int kc) {
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = 0; c < 6; ++c) raw[r][c] = buf_f4s(rsrc, off[r][c], (unsigned)(kc * KCH * 4));
-    };
-    const int fi = lane & 31, fh = lane >> 5;
-    const f4* ubase = a.u + lane;
-    auto load_u = [&](f4 (&dst)[4], int kc, int xl) {      // fragment jj of 16-channel half s = dst[2 s + jj]
-        const f4* p = ubase + (((long)((9 * wave + xl) * NTG + nb) * (2 * KC) + 2 * kc) << 7);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dst[j] = p[j * 64];
-    };
-    f32x16 acc[9];
-#pragma unroll
-    for (int xl = 0; xl < 9; ++xl)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[xl][r] = 0.f;
-    // U fragments: a ring of four positions, three in flight ahead of the MFMAs (an L2 access under this load takes longer than the
-    // sixteen MFMAs of one position).  Position p of chunk kc sits in ring slot (9 kc + p) & 3 = (kc + p) & 3.
-    f4 ub[4][4], vbr[2][4];
-    load_raw(0);
-    load_u(ub[0], 0, 0);
-    load_u(ub[1], 0, 1);
-    load_u(ub[2], 0, 2);
-    auto chunk = [&](int kc, auto phase_c) {
-        constexpr int PH = decltype(phase_c)::value;      // kc & 3
-        // B4^T d: the six columns in place, then B4 from the right row by row, each row's six values straight into the V image
-#ifndef W4_EXP_NOXFORM
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            f4 t[6];
-            bt6(raw[0][c], raw[1][c], raw[2][c], raw[3][c], raw[4][c], raw[5][c], t);
-#pragma unroll
-            for (int r = 0; r < 6; ++r) raw[r][c] = t[r];
-        }
-#endif
-        __syncthreads();                                   // every wave is done reading the previous chunk's V
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            f4 v[6];
-#ifndef W4_EXP_NOXFORM
-            bt6(raw[r][0], raw[r][1], raw[r][2], raw[r][3], raw[r][4], raw[r][5], v);
-#else
-#pragma unroll
-            for (int c = 0; c < 6; ++c) v[c] = raw[r][c];
-#endif
-#ifndef W4_EXP_NOVWRITE
-#pragma unroll
-            for (int c = 0; c < 6; ++c) *reinterpret_cast<f4*>(smem + img32_addr(6 * r + c, ti, q)) = v[c];
-#else
-            if (kc == 12345) *reinterpret_cast<f4*>(smem + img32_addr(6 * r, ti, q)) = v[0] + v[1] + v[2] + v[3] + v[4] + v[5];
-#endif
-        }
-        __syncthreads();
-        const unsigned raw_soff = (unsigned)(min(kc + 1, KC - 1) * KCH * 4);      // the next chunk's patch (the last one re-reads: uniform counts)
-#pragma unroll
-        for (int xl = 0; xl < 9; ++xl) {
-            const int cur = (xl + PH) & 3, nxt = (xl + PH + 3) & 3;
-#ifndef W4_EXP_NOU
-            if (xl + 3 < 9) load_u(ub[nxt], kc, xl + 3);
-            else load_u(ub[nxt], min(kc + 1, KC - 1), xl + 3 - 9);
-#endif
-#ifndef W4_EXP_NORAW
-            // the next chunk's patch, four of its 36 pixels per position, BEHIND this position's U request: vmcnt retires in issue order, so
-            // a patch requested in one burst ahead of the MFMA phase made the first U wait of the phase wait for the whole patch
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int pix = 4 * xl + i;
-                raw[pix / 6][pix % 6] = buf_f4s(rsrc, off[pix / 6][pix % 6], raw_soff);
-            }
-#endif
-            if (xl == 0) {
-#ifndef W4_EXP_NOVREAD
-#pragma unroll
-                for (int j = 0; j < 4; ++j) vbr[0][j] = *reinterpret_cast<const f4*>(smem + img32_addr(9 * wave, fi, 4 * (j >> 1) + 2 * fh + (j & 1)));
-#endif
-            }
-#ifndef W4_EXP_NOVREAD
-            if (xl < 8) {                                  // the next position's V fragments: an LDS round trip ahead of their MFMAs
-#pragma unroll
-                for (int j = 0; j < 4; ++j)                // channels 16 (j >> 1) + 8 h + 4 (j & 1) ..+3 of the chunk, like U's fragment j
-                    vbr[(xl + 1) & 1][j] = *reinterpret_cast<const f4*>(smem + img32_addr(9 * wave + xl + 1, fi, 4 * (j >> 1) + 2 * fh + (j & 1)));
-            }
-#endif
-            f4 (&vb)[4] = vbr[xl & 1];
-#ifndef W4_EXP_NOMFMA
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[xl] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[cur][j][e], vb[j][e], acc[xl], 0, 0, 0);
-#else
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[xl][j] += ub[cur][j][0] * vb[j][0];
-#endif
-        }
-    };
-    for (int kc = 0; kc < KC; kc += 4) {
-        chunk(kc, std::integral_constant<int, 0>{});
-        if (kc + 1 < KC) chunk(kc + 1, std::integral_constant<int, 1>{});
-        if (kc + 2 < KC) chunk(kc + 2, std::integral_constant<int, 2>{});
-        if (kc + 3 < KC) chunk(kc + 3, std::integral_constant<int, 3>{});
-    }
-    __syncthreads();
-#pragma unroll
-    for (int xl = 0; xl < 9; ++xl)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const f4 m = {acc[xl][4 * gq], acc[xl][4 * gq + 1], acc[xl][4 * gq + 2], acc[xl][4 * gq + 3]};
-            *reinterpret_cast<f4*>(smem + img32_addr(9 * wave + xl, fi, 2 * gq + fh)) = m;          // couts 8 gq + 4 h .. + 3 of tile fi
-        }
-    __syncthreads();
-    // A4^T M A4 of this thread's (tile, 4 output channels): columns first, then rows; epilogue and stores
-    f4 sc = (f4)(1.f), sh = (f4)(0.f);
-    const int cout = nb * 32 + 4 * q;
-    if (a.scale) sc = *reinterpret_cast<const f4*>(a.scale + cout);
-    if (a.shift) sh = *reinterpret_cast<const f4*>(a.shift + cout);
-    f4 S[4][6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        f4 m[6], y[4];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) m[r] = *reinterpret_cast<const f4*>(smem + img32_addr(6 * r + c, ti, q));
-        at4(m[0], m[1], m[2], m[3], m[4], m[5], y);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) S[p][c] = y[p];
-    }
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        f4 o[4];
-        at4(S[p][0], S[p][1], S[p][2], S[p][3], S[p][4], S[p][5], o);
-#pragma unroll
-        for (int qx = 0; qx < 4; ++qx) {
-            f4 val = o[qx] * sc + sh;
-            if (a.relu) val = f4{fmaxf(val[0], 0.f), fmaxf(val[1], 0.f), fmaxf(val[2], 0.f), fmaxf(val[3], 0.f)};
-            if (4 * ty + p < a.H && 4 * tx + qx < a.W)
-                *reinterpret_cast<f4*>(a.y + (((long)img * a.H + 4 * ty + p) * a.W + 4 * tx + qx) * a.Cout + cout) = val;
-        }
-    }
-}
-
 __global__ __launch_bounds__(512, 1) void wino64_kernel(Args a) { wino_body<2>(a); }
 __global__ __launch_bounds__(256, 2) void wino32_kernel(Args a) { wino_body<1>(a); }
 
@@ -742,25 +354,9 @@ static bool wino_shape_ok(const dc_conv_desc* d, const float* u) {
            (size_t)d->N * d->H * d->W * d->Cin * sizeof(float) < (1ull << 31);      // one buffer resource, 32-bit offsets: larger inputs take the direct kernels
 }
 
-// F(4x4, 3x3) runs (a) when the descriptor carries ONLY its weights (w_wino4 without w_wino: the caller asked for it), or (b) with
-// DCAP_WINO4 = 1, when both are given and the layer has a 32-tile x 32-channel work item for every CU (at the benchmark's two images:
-// stages 2 and 3 and the P2 / P3 output layers; a stage-4 layer has 128 such items).  (b) is OFF by default: as measured in round 4 the
-// kernel is correct but slower than wino64 / wino32 (fpn_p2 752 us against 646, fpn_p3 191 against 160: DESIGN section 11).
-static long wino4_items(const dc_conv_desc* d) {
-    const int th = (d->H + 3) / 4, tw = (d->W + 3) / 4;
-    return (long)d->N * ((th + wino::w4::TGY - 1) / wino::w4::TGY) * ((tw + wino::w4::TGX - 1) / wino::w4::TGX) * (d->Cout / 32);
-}
-static bool conv_winograd4_chosen(const dc_conv_desc* d) {
-    static const int mode = env_int("DCAP_WINO4", 0);
-    if (!wino_shape_ok(d, d->w_wino4)) return false;
-    if (!d->w_wino) return true;
-    return mode == 1 && wino4_items(d) >= kNumCU;
-}
+bool conv_winograd_supported(const dc_conv_desc* d) { return wino_shape_ok(d, d->w_wino); }
 
-bool conv_winograd_supported(const dc_conv_desc* d) { return conv_winograd4_chosen(d) || wino_shape_ok(d, d->w_wino); }
-
-// tiles per work item: 64 where every CU still gets an item, else 32.  DCAP_WINO_TILES = 32 / 64 forces one; 1 = the first
-// 32-tile kernel (register-staged transform through a V image: kept for the comparison in profiles/) -- measurements and tests.
+// tiles per work item: 64 where every CU still gets an item, else 32.  DCAP_WINO_TILES = 32 / 64 forces one (tests).
 static int wino_force() {
     static const int force = env_int("DCAP_WINO_TILES", 0);
     return force;
@@ -781,10 +377,8 @@ static int persistent_cus() {
 }
 
 int conv_winograd_tiles(const dc_conv_desc* d) {
-    if (conv_winograd4_chosen(d)) return 4;               // (reported as "wino4_kernel")
     const int force = wino_force();
     if (force == 32 || force == 64) return force;
-    if (force == 1) return 32;
     const int th = (d->H + 1) / 2, tw = (d->W + 1) / 2;
     const long items64 = (long)d->N * ((th + 7) / 8) * ((tw + 7) / 8) * (d->Cout / 32);
     return items64 >= kNumCU ? 64 : 32;
@@ -793,23 +387,6 @@ int conv_winograd_tiles(const dc_conv_desc* d) {
 int conv2d_winograd(const dc_conv_desc* d, hipStream_t s) {
     wino::Args a;
     a.x = d->x;
-    if (conv_winograd4_chosen(d)) {
-        a.u = reinterpret_cast<const f4*>(d->w_wino4);
-        a.y = d->y;
-        a.scale = d->scale;
-        a.shift = d->shift;
-        a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.relu = d->relu;
-        const int th = (d->H + 3) / 4, tw = (d->W + 3) / 4;
-        a.x_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->Cin * sizeof(float));
-        a.gy = (th + wino::w4::TGY - 1) / wino::w4::TGY;
-        a.gx = (tw + wino::w4::TGX - 1) / wino::w4::TGX;
-        a.groups = d->N * a.gy * a.gx;
-        const long items = wino4_items(d);
-        DC_REQUIRE(items < (1l << 31), DC_EINVAL, "dc_conv2d (winograd F(4,3)): grid too large");
-        DC_ENSURE_DYN_LDS(wino::wino4_kernel, wino::w4::LDS_BYTES);
-        hipLaunchKernelGGL(wino::wino4_kernel, dim3((unsigned)items), dim3(wino::NTHREADS), wino::w4::LDS_BYTES, s, a);
-        return check_launch("dc_conv2d (winograd F(4,3))");
-    }
     a.u = reinterpret_cast<const f4*>(d->w_wino);
     a.y = d->y;
     a.scale = d->scale;
@@ -827,11 +404,6 @@ int conv2d_winograd(const dc_conv_desc* d, hipStream_t s) {
     a.groups = d->N * a.gy * a.gx;
     const long items = (long)a.groups * (d->Cout / 32);
     DC_REQUIRE(items < (1l << 31), DC_EINVAL, "dc_conv2d (winograd): grid too large");
-    if (!big && wino_force() == 1) {
-        DC_ENSURE_DYN_LDS(wino::wino32v1_kernel, wino::w32::LDS_BYTES);
-        hipLaunchKernelGGL(wino::wino32v1_kernel, dim3((unsigned)items), dim3(wino::NTHREADS), wino::w32::LDS_BYTES, s, a);
-        return check_launch("dc_conv2d (winograd)");
-    }
     // persistent: the blocks that fit the chip walk the work items (a multiple of 8 blocks, so that an item's XCD is fixed by item % 8)
     // the CU budget (dc_set_persistent_cus) applies to the LONG launches only -- eight or more rounds of work items per block -- where a
     // grid that never yields would keep another queue's kernels (RCCL) waiting for hundreds of microseconds.  On a short launch a smaller
@@ -876,19 +448,3 @@ extern "C" int dc_set_persistent_cus(int n) {
 }
 
 extern "C" int dc_get_persistent_cus(void) { return dcap::persistent_cus(); }
-
-extern "C" size_t dc_conv2d_winograd4_weight_bytes(int Cin, int Cout) {
-    if (Cin <= 0 || Cout <= 0 || Cin % 32 || Cout % 32) return 0;
-    return (size_t)36 * Cin * Cout * sizeof(float);
-}
-
-extern "C" int dc_conv2d_winograd4_pack_f32(const float* w, float* u, int Cin, int Cout, void* stream) {
-    DC_REQUIRE(w && u, DC_EINVAL, "dc_conv2d_winograd4_pack: null pointer");
-    DC_REQUIRE(Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0, DC_EINVAL, "dc_conv2d_winograd4_pack: Cin and Cout must be multiples of 32");
-    DC_REQUIRE(aligned16(u), DC_EALIGN, "dc_conv2d_winograd4_pack: u must be 16-byte aligned");
-    const long total = (long)Cin * Cout;
-    const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(wino::wino4_pack_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w, u, Cin, Cout);
-    return check_launch("dc_conv2d_winograd4_pack_f32");
-}
-

@@ -89,15 +89,6 @@ static int gemm_validate(const dc_gemm_desc* d) {
 
 using namespace dcap;
 
-#ifdef DCAP_STAMPS
-namespace dcap { __device__ unsigned long long g_dcap_stamps[6]; }
-extern "C" int dc_debug_stamps(unsigned long long* out, int reset) {
-    hipDeviceSynchronize();
-    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(dcap::g_dcap_stamps), sizeof(unsigned long long) * 6);
-    if (reset) { unsigned long long z[6] = {0, 0, 0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(dcap::g_dcap_stamps), z, sizeof(z)); }
-    return 0;
-}
-#endif
 
 extern "C" int dc_version(void) { return 1; }
 extern "C" const char* dc_last_error(void) { return g_err; }

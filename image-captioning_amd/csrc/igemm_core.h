@@ -609,11 +609,7 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[TM][TN], float* smem, c
     const int c4 = tid % CPR, rp = tid / CPR;
     const int col = n0 + 4 * c4;
     const bool full = !partial && ep.vec4 && col + 3 < N;
-#ifdef DCAP_EXP_NORES       // ablation builds only (tools/build_variant.sh): the residual operand is not fetched
-    const bool pre_res = false, pre_acc = full && ep.accumulate;
-#else
     const bool pre_res = full && ep.res_mode != 0, pre_acc = full && ep.accumulate;
-#endif
     f4 qres[G], qacc[G];
     auto prefetch = [&](int p0) {
 #pragma unroll
@@ -671,12 +667,7 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[TM][TN], float* smem, c
                 if (pre_res) { v.x += qres[g][0]; v.y += qres[g][1]; v.z += qres[g][2]; v.w += qres[g][3]; }
                 if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 if (pre_acc) { v.x += qacc[g][0]; v.y += qacc[g][1]; v.z += qacc[g][2]; v.w += qacc[g][3]; }
-#ifdef DCAP_EXP_NOSTORE     // ablation builds only: the finished values are kept alive but not written
-                asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-                if (row < 0) {
-#else
                 if (row < M) {
-#endif
                     if (ep.C) *reinterpret_cast<float4*>(ep.C + (long)row * ep.ldc + col) = v;
                     if (ep.Cb) {
                         typedef unsigned short us4 __attribute__((ext_vector_type(4)));
@@ -730,11 +721,7 @@ __device__ __forceinline__ void igemm_mainloop(const AL& al, const BL& bl, float
 
     constexpr int KT = tiles_per_sync<BM, BN>();
     f4 ra[KT][BM / 32], rb[KT][BN / 32];
-#ifdef DCAP_EXP_NOMAIN      // ablation builds only: one K-tile instead of all (prologue + epilogue cost)
-    const int nkt = 1;
-#else
     const int nkt = (kend - kbeg + BK - 1) / BK;
-#endif
 #pragma unroll
     for (int j = 0; j < KT; ++j)
         if (j < nkt) {
@@ -748,13 +735,6 @@ __device__ __forceinline__ void igemm_mainloop(const AL& al, const BL& bl, float
             bl.template store<BN>(sb, smem + j * STAGE + A_FL, rb[j], tid);
         }
     __syncthreads();
-#ifdef DCAP_STAMPS
-    // diagnostic build only (tools/micro): where does a wave's K-tile go?  s_memtime per phase, summed.
-    unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
-#define DC_STAMP(v) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
-#else
-#define DC_STAMP(v)
-#endif
     // f32 MFMAs execute on the SIMD's fp32 lanes: VALU instructions do NOT overlap them (tools/micro/
     // coissue.hip: every extra VALU adds its full ~4 cycles per 64-cycle MFMA), so the loop keeps the
     // per-tile VALU count minimal (32-bit offsets, uniform bases, hardware zero-fill) and only memory
@@ -762,10 +742,6 @@ __device__ __forceinline__ void igemm_mainloop(const AL& al, const BL& bl, float
     // One pipeline step on compile-time LDS stages: fragment and store addresses become a constant VGPR plus an immediate
     // offset (a run-time stage index costs an address add per ds instruction -- VALU, i.e. MFMA time on this pipe).
     auto step = [&](int kt, float* cur, float* nxt) {
-#ifdef DCAP_STAMPS
-        unsigned long long t0, t1, t2, t3, t4, t5;
-#endif
-        DC_STAMP(t0)
         // unconditional (a conditional load merges with the old registers and the compiler then waits for
         // the data right here): tiles past the end are clamped / range-checked and never stored
 #pragma unroll
@@ -774,27 +750,16 @@ __device__ __forceinline__ void igemm_mainloop(const AL& al, const BL& bl, float
             al.template load<BM>(sa, ra[j], al.kclamp(k0, kend), kend, tid);
             bl.template load<BN>(sb, rb[j], bl.kclamp(k0, kend), kend, tid);
         }
-        DC_STAMP(t1)
 #pragma unroll
         for (int j = 0; j < KT; ++j)
             if (kt + j < nkt) mma_tile<BM, BN, AL::KC, BL::KC>(cur + j * STAGE, cur + j * STAGE + A_FL, acc, wm, wn, lane);
-        DC_STAMP(t2)
-#ifdef DCAP_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        DC_STAMP(t3)
 #pragma unroll
         for (int j = 0; j < KT; ++j)
             if (kt + KT + j < nkt) {
                 al.template store<BM>(sa, nxt + j * STAGE, ra[j], tid);
                 bl.template store<BN>(sb, nxt + j * STAGE + A_FL, rb[j], tid);
             }
-        DC_STAMP(t4)
         __syncthreads();
-        DC_STAMP(t5)
-#ifdef DCAP_STAMPS
-        st[0] += t1 - t0; st[1] += t2 - t1; st[2] += t3 - t2; st[3] += t4 - t3; st[4] += t5 - t4; st[5] += KT;
-#endif
     };
     float* const stage0 = smem;
     float* const stage1 = smem + KT * STAGE;
@@ -802,12 +767,6 @@ __device__ __forceinline__ void igemm_mainloop(const AL& al, const BL& bl, float
         step(kt, stage0, stage1);
         if (kt + KT < nkt) step(kt + KT, stage1, stage0);
     }
-#ifdef DCAP_STAMPS
-    if (lane == 0 && blockIdx.x < 4096) {
-        extern __device__ unsigned long long g_dcap_stamps[6];
-        for (int q = 0; q < 6; ++q) atomicAdd(&g_dcap_stamps[q], st[q]);
-    }
-#endif
 
 }
 
@@ -984,16 +943,13 @@ struct TileChoice {
 // (K >= 8192: weight gradients over pixels, the vocabulary GEMMs) are priced with a small model: waves of blocks over the
 // CUs (2 resident blocks per CU -> half-wave granularity) x K-tiles per slice x time per K-tile, where bigger tiles run
 // the MFMA pipe more efficiently (measured: ~0.70 / 0.58 / 0.45 of peak for 128x128 / 128x64 / 64x64), plus the split-K
-// slab traffic.  DCAP_TILE=64|12864|128 forces a tile (experiments only).
+// slab traffic.
 inline TileChoice choose_tile(int M, int N, int K, int user_split, bool allow_128 = true) {
     auto nb = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     TileChoice t{64, 64, 1};
-    static const int force = env_int("DCAP_TILE", 0);
     const int ktiles = (K + BK - 1) / BK;
     bool priced = false;
-    if (force == 64 || !allow_128) t = {64, 64, 1};
-    else if (force == 12864) t = {128, 64, 1};
-    else if (force == 128) t = {128, 128, 1};
+    if (!allow_128) t = {64, 64, 1};
     else if (N >= 128 && nb(128, 128) >= 2 * kNumCU) t = {128, 128, 1};
     else if (nb(128, 64) >= 2 * kNumCU) t = {128, 64, 1};
     else if (user_split <= 0 && N >= 64 && ktiles >= 256) priced = true;

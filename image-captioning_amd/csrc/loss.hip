@@ -489,10 +489,8 @@ extern "C" int dc_colsum_f32(const float* x, int M, int N, int ld, float* out, i
     return check_launch("colsum_finish_kernel");
 }
 
-static int opt_blocks_per_cu() {
-    static const int v = std::max(1, std::min(8, env_int("DCAP_OPT_BLOCKS_PER_CU", 8)));
-    return v;
-}
+// blocks per CU of the bucket-wide HBM-bound passes: every wave slot (round 4 measured 8 / 4 / 2 / 1 = 8.61 / 8.69 / 8.88 / 9.25 ms per joint step)
+static constexpr int opt_blocks_per_cu() { return 8; }
 static int sumsq_blocks(size_t n) { return (int)std::min<size_t>((n + 4095) / 4096, (size_t)kNumCU * std::min(4, opt_blocks_per_cu())); }
 
 extern "C" size_t dc_sumsq_workspace_bytes(size_t n) { return n ? (size_t)sumsq_blocks(n) * sizeof(float) : 0; }
@@ -644,10 +642,6 @@ extern "C" int dc_amsgrad_step_f32(const dc_amsgrad_desc* d, void* stream) {
                "dc_amsgrad_step: buffers must be 16-byte aligned");
     DC_REQUIRE(!d->p_bf16 || ((d->n_bf16 & 3) == 0 && d->n_bf16 <= (d->n & ~(size_t)3) && (reinterpret_cast<uintptr_t>(d->p_bf16) & 7u) == 0), DC_EINVAL,
                "dc_amsgrad_step: the bf16 shadow must be 8-byte aligned and cover a multiple of 4 elements inside the vectorised part of p");
-    // blocks per CU of the bucket-wide HBM-bound passes (AMSGrad here, L2 and the clip norm above; DCAP_OPT_BLOCKS_PER_CU, default 8 = every
-    // wave slot).  Measured in round 4 with the joint step (77 M parameters): 8 / 4 / 2 / 1 blocks per CU = 8.61 / 8.69 / 8.88 / 9.25 ms per
-    // step; fewer resident waves did NOT let the next step's trunk (on the second stream) make progress beside the pass -- both live off
-    // the same memory system -- so the knob stays at full occupancy.
     const int blocks = (int)std::min<size_t>((d->n / 4 + 255) / 256 + 1, (size_t)kNumCU * opt_blocks_per_cu());
     hipLaunchKernelGGL(amsgrad_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), *d);
     return check_launch("amsgrad_kernel");

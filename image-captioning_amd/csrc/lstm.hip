@@ -12,9 +12,6 @@
 
 namespace dcap {
 
-#ifdef DCAP_LSTM_STAMPS      // diagnostic builds only (tools/build_variant.sh): workgroup lifetimes of the forward step kernel
-__device__ unsigned long long g_lstm_stamps[2];
-#endif
 
 __device__ __forceinline__ float hard_sigmoid(float z) { return fminf(fmaxf(0.2f * z + 0.5f, 0.f), 1.f); }
 __device__ __forceinline__ float hard_sigmoid_grad(float z) {
@@ -124,16 +121,11 @@ __global__ __launch_bounds__(NW * 64) void lstm_step_fused_kernel(float* __restr
     constexpr int HALF = NW / 2, THREADS = NW * 64, ITEMS = RT * 256, IT = (ITEMS + THREADS - 1) / THREADS;
     constexpr int NG = MASKED ? 4 : 1;
     __shared__ float part[HALF][RT * 32][33];
-#ifdef DCAP_LSTM_STAMPS
-    const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
-#endif
-#ifndef DCAP_LSTM_NOPRIO
     // In the training pipeline these waves share their SIMDs with the encoder's convolution waves, which issue 64-clock fp32 MFMAs
     // back to back.  The recurrence is the decoder's serial chain and a step's MFMA work is tiny: ask for the issue slots first.
     // Measured in the pipeline: 91 -> 71 us per step launch (12 us alone); the step time itself does not move (8.44 ms either way), and
     // a register diet (84 instead of 135 VGPRs) changes nothing -- most of the remaining wait is workgroup placement, not issue.
     __builtin_amdgcn_s_setprio(3);
-#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ub = blockIdx.x, u0 = ub * 8, r0 = blockIdx.y * (RT * 32);
     const int i = lane & 31, h = lane >> 5;
@@ -152,10 +144,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_step_fused_kernel(float* __restr
         }
     const long kstride = (long)(U / 8) * 32;                                  // floats between consecutive k rows of Upk
     const float* bp = Upk + (long)(kbeg + 4 * h) * kstride + (long)ub * 32 + i;
-#ifndef DCAP_LSTM_PF
-#define DCAP_LSTM_PF 8
-#endif
-    constexpr int PF = MASKED ? 4 : DCAP_LSTM_PF;                            // (four A streams: a shallower ring keeps the registers)
+    constexpr int PF = MASKED ? 4 : 8;                            // (four A streams: a shallower ring keeps the registers)
     f4_t a[PF][NG][RT];
     float b[PF][4];
 #pragma unroll
@@ -270,13 +259,6 @@ __global__ __launch_bounds__(NW * 64) void lstm_step_fused_kernel(float* __restr
             }
         }
     }
-#ifdef DCAP_LSTM_STAMPS
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(&g_lstm_stamps[0], __builtin_amdgcn_s_memrealtime() - stamp0);      // 100 MHz ticks
-        atomicAdd(&g_lstm_stamps[1], 1ull);
-    }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -301,9 +283,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step_fused_kernel(const floa
     // (NW = 4: wave = gate; NW = 8: two waves per gate), so its partial tile IS that gate's product: the masks apply where the tiles meet.
     __shared__ float part[NW][RT * 16][17];
     constexpr int THREADS = NW * 64, ITEMS = RT * 256, IT = (ITEMS + THREADS - 1) / THREADS;
-#ifndef DCAP_LSTM_NOPRIO
     __builtin_amdgcn_s_setprio(3);                       // see lstm_step_fused_kernel
-#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int u0 = blockIdx.x * 16, r0 = blockIdx.y * (RT * 16);
     const int m = lane & 15, kk = lane >> 4;
@@ -443,15 +423,6 @@ __global__ __launch_bounds__(256) void lstm_masked_acc_kernel(float* __restrict_
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// DCAP_LSTM_BWD=steps selects the three-launch form of the backward timestep (measurements only).
-static bool lstm_bwd_fused_enabled() {
-    static const bool on = [] {
-        const char* e = getenv("DCAP_LSTM_BWD");
-        return !(e && std::string(e) == "steps");
-    }();
-    return on;
-}
-
 static dc_gemm_desc hU_desc(int B, int U, const float* h_prev, const float* U_rec, float* z_t) {
     dc_gemm_desc g{};
     g.M = B; g.N = 4 * U; g.K = U;
@@ -486,12 +457,6 @@ static dc_gemm_desc dU_desc(int B, int T, int U, const float* h_seq, const float
 
 using namespace dcap;
 
-#ifdef DCAP_LSTM_STAMPS
-extern "C" void dc_lstm_stamps(unsigned long long* out, int reset) {
-    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(dcap::g_lstm_stamps), sizeof(unsigned long long) * 2);
-    if (reset) { unsigned long long z[2] = {0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(dcap::g_lstm_stamps), z, sizeof(z)); }
-}
-#endif
 
 extern "C" size_t dc_lstm_seq_workspace_bytes(int B, int T, int U) {
     if (B <= 0 || T <= 0 || U <= 0) return 0;
@@ -532,13 +497,9 @@ extern "C" int dc_lstm_seq_fwd_f32(const dc_lstm_fwd_desc* d, void* workspace, s
                DC_EWORKSPACE, "dc_lstm_seq_fwd: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int B = d->B, U = d->U, n = B * U, blocks = (n + 255) / 256;
-    static const int masked_fused = env_int("DCAP_LSTM_MASKED_FUSED", 1);      // 0: the round-3 path (mask kernel + 4 GEMMs + gate kernel per step)
-    const bool fused = (U & 31) == 0 && d->T > 1 && (!d->rec_masks || masked_fused);
-    static const int force_rt = env_int("DCAP_LSTM_FWD_RT", 0), force_nw = env_int("DCAP_LSTM_FWD_NW", 0);
+    const bool fused = (U & 31) == 0 && d->T > 1;   // (else: per-step GEMM + gate kernel, with masks a mask kernel + four per-gate GEMMs)
     int frt = ((U / 8) * ((B + 31) / 32) <= 2 * kNumCU) ? 1 : 2;      // 32- or 64-row blocks
     int fnw = (frt == 2 && (U & 63) == 0) ? 8 : 4;                     // measured: 4 waves at 32 rows, 8 at 64
-    if (force_rt == 1 || force_rt == 2) frt = force_rt;
-    if (force_nw == 4 || (force_nw == 8 && (U & 63) == 0)) fnw = force_nw;
     if (d->rec_masks && frt == 2) fnw = 4;          // the masked step keeps four gate tiles: <2, 8> would spill (297 VGPRs), <2, 4> fits
     float* Upk = nullptr;
     float* hm = nullptr;                            // dropout: [4][B][U] masked copies of h_{t-1}, at the END of the workspace
@@ -583,22 +544,22 @@ extern "C" int dc_lstm_seq_fwd_f32(const dc_lstm_fwd_desc* d, void* workspace, s
                 }
                 const float* hm_prev = hm2[t & 1];       // written for step t: by the mask kernel (t = 1) or by step t - 1
                 float* hm_next = (t + 1 < d->T) ? hm2[(t + 1) & 1] : nullptr;
-#define DCAP_FWD_STEP_M(RT_, NW_) hipLaunchKernelGGL((lstm_step_fused_kernel<RT_, NW_, true>), grid, dim3(NW_ * 64), 0, s, z_t, Upk, hp, cp, mk, h_t, c_t, B, U, hm_prev, d->rec_masks, hm_next)
-                if (frt == 1 && fnw == 8) DCAP_FWD_STEP_M(1, 8);
-                else if (frt == 1) DCAP_FWD_STEP_M(1, 4);
-                else if (fnw == 8) DCAP_FWD_STEP_M(2, 8);
-                else DCAP_FWD_STEP_M(2, 4);
-#undef DCAP_FWD_STEP_M
+#define LAUNCH_FWD_STEP_M(RT_, NW_) hipLaunchKernelGGL((lstm_step_fused_kernel<RT_, NW_, true>), grid, dim3(NW_ * 64), 0, s, z_t, Upk, hp, cp, mk, h_t, c_t, B, U, hm_prev, d->rec_masks, hm_next)
+                if (frt == 1 && fnw == 8) LAUNCH_FWD_STEP_M(1, 8);
+                else if (frt == 1) LAUNCH_FWD_STEP_M(1, 4);
+                else if (fnw == 8) LAUNCH_FWD_STEP_M(2, 8);
+                else LAUNCH_FWD_STEP_M(2, 4);
+#undef LAUNCH_FWD_STEP_M
                 int rc = check_launch("lstm_step_fused_kernel (masked)");
                 if (rc) return rc;
                 continue;
             }
-#define DCAP_FWD_STEP(RT_, NW_) hipLaunchKernelGGL((lstm_step_fused_kernel<RT_, NW_>), grid, dim3(NW_ * 64), 0, s, z_t, Upk, hp, cp, mk, h_t, c_t, B, U)
-            if (frt == 1 && fnw == 8) DCAP_FWD_STEP(1, 8);
-            else if (frt == 1) DCAP_FWD_STEP(1, 4);
-            else if (fnw == 8) DCAP_FWD_STEP(2, 8);
-            else DCAP_FWD_STEP(2, 4);
-#undef DCAP_FWD_STEP
+#define LAUNCH_FWD_STEP(RT_, NW_) hipLaunchKernelGGL((lstm_step_fused_kernel<RT_, NW_>), grid, dim3(NW_ * 64), 0, s, z_t, Upk, hp, cp, mk, h_t, c_t, B, U)
+            if (frt == 1 && fnw == 8) LAUNCH_FWD_STEP(1, 8);
+            else if (frt == 1) LAUNCH_FWD_STEP(1, 4);
+            else if (fnw == 8) LAUNCH_FWD_STEP(2, 8);
+            else LAUNCH_FWD_STEP(2, 4);
+#undef LAUNCH_FWD_STEP
             int rc = check_launch("lstm_step_fused_kernel");
             if (rc) return rc;
             continue;
@@ -654,13 +615,9 @@ extern "C" int dc_lstm_seq_bwd_f32(const dc_lstm_bwd_desc* d, void* workspace, s
     }
     int zrc = zero_fill_async(wsp, 2 * state_bytes, s);
     if (zrc) return zrc;
-    static const int masked_fused = env_int("DCAP_LSTM_MASKED_FUSED", 1);
-    const bool fused = (U & 15) == 0 && (!d->rec_masks || masked_fused) && lstm_bwd_fused_enabled();
-    static const int force_rt = env_int("DCAP_LSTM_BWD_RT", 0), force_nw = env_int("DCAP_LSTM_BWD_NW", 0);
+    const bool fused = (U & 15) == 0;
     int rt_rows = ((U / 16) * ((B + 15) / 16) <= kNumCU) ? 16 : 32;      // measured: 200 x 512 is 1.2x faster with 32-row blocks
     int nw = (U & 31) == 0 ? 8 : 4;
-    if (force_rt == 1 || force_rt == 2) rt_rows = 16 * force_rt;
-    if (force_nw == 4 || (force_nw == 8 && (U & 31) == 0)) nw = force_nw;
     for (int t = T - 1; t >= 0; --t) {
         const float* z_t = d->z + (long)t * B * 4 * U;
         float* dz_t = d->dz + (long)t * B * 4 * U;
@@ -670,12 +627,12 @@ extern "C" int dc_lstm_seq_bwd_f32(const dc_lstm_bwd_desc* d, void* workspace, s
             const float* dho = d->dh_seq ? d->dh_seq + (long)t * n : nullptr;
             const float* dz_next = dz_t + (long)B * 4 * U;
             const dim3 grid(U / 16, (B + rt_rows - 1) / rt_rows);
-#define DCAP_BWD_STEP(RT_, NW_) hipLaunchKernelGGL((lstm_bwd_step_fused_kernel<RT_, NW_>), grid, dim3(NW_ * 64), 0, s, z_t, cp, mk, dho, dz_next, d->U_rec, dh, dc, dz_t, B, U, d->rec_masks)
-            if (rt_rows == 16 && nw == 8) DCAP_BWD_STEP(1, 8);
-            else if (rt_rows == 16) DCAP_BWD_STEP(1, 4);
-            else if (nw == 8) DCAP_BWD_STEP(2, 8);
-            else DCAP_BWD_STEP(2, 4);
-#undef DCAP_BWD_STEP
+#define LAUNCH_BWD_STEP(RT_, NW_) hipLaunchKernelGGL((lstm_bwd_step_fused_kernel<RT_, NW_>), grid, dim3(NW_ * 64), 0, s, z_t, cp, mk, dho, dz_next, d->U_rec, dh, dc, dz_t, B, U, d->rec_masks)
+            if (rt_rows == 16 && nw == 8) LAUNCH_BWD_STEP(1, 8);
+            else if (rt_rows == 16) LAUNCH_BWD_STEP(1, 4);
+            else if (nw == 8) LAUNCH_BWD_STEP(2, 8);
+            else LAUNCH_BWD_STEP(2, 4);
+#undef LAUNCH_BWD_STEP
             int rc = check_launch("lstm_bwd_step_fused_kernel");
             if (rc) return rc;
             continue;

@@ -318,15 +318,11 @@ class DenseImageCapRCNN(object):
             raise ValueError("at most 3 anchors per location")
         self._seed = int(seed)
         self.use_step_graph = os.environ.get("DCAP_JOINT_GRAPH", "1") != "0"
-        self.use_side_stream = os.environ.get("DCAP_JOINT_FORK", "1") != "0"      # RPN backward beside the proposals / decoder-forward chain
-        # next step's frozen trunk beside this step's optimizer (train_on_batch(next_images=...)).  Correct and bit-equal (tests), and
-        # measured WITHOUT gain (8.67 ms against 8.61: the trunk at one image and the bucket-wide optimizer passes both live off the memory
-        # system), so train() does not use it unless DCAP_JOINT_PREFETCH=1
-        self.use_trunk_prefetch = os.environ.get("DCAP_JOINT_PREFETCH", "0") == "1"
+        self.use_side_stream = True                          # RPN backward beside the proposals / decoder-forward chain (False: serial order)
         self._side_stream = None
-        self._trunk_ready_for = None
-        self._trunk_in_flight = False
+        self.step_graph_fallback = None                      # set to the error text when a step-graph capture failed and the model went eager
         self._dt_step = self._dt_val_step = 0                # detection-target sampling streams (training / forward-only validation passes)
+        self._dt_rank = 0                                    # ParallelModel sets the tower's rank: towers shuffle their proposals independently
         self._last_targets = None
         self._step_in = None
         self.optimizer = None
@@ -408,7 +404,6 @@ class DenseImageCapRCNN(object):
         """Captured step graphs bake buffer addresses, the plan's outputs, the trainable subset and the optimizer state: anything
         that replaces one of those drops them (the next steps run eagerly and re-capture)."""
         self._graphs, self._graph_warm, self._graph_out = {}, {}, {}
-        self._trunk_ready_for = None
 
     def _buf(self, key, shape, dtype=torch.float32, zero=False):
         b = self._bufs.get(key)
@@ -734,8 +729,9 @@ class DenseImageCapRCNN(object):
         cm = self.caption_model
         scal = np.zeros(4, np.int32)
         scal[0:1] = np.array([lr_next], np.float32).view(np.int32)
-        scal[1] = (2 * (cm._drop_step + 1)) & 0x7FFFFFFF    # Philox offset of this step's recurrent-dropout masks (lstm l: + l)
-        scal[2] = (self._dt_step if training else self._dt_val_step) & 0x7FFFFFFF
+        # Philox stream positions as 32-bit words, masked like the eager launches' host arguments (ops.dropout_mask / detection_targets)
+        scal[1:3] = np.array([(2 * (cm._drop_step + 1)) & 0xFFFFFFFF,            # this step's recurrent-dropout masks (lstm l: + l)
+                              (self._dt_step if training else self._dt_val_step) & 0xFFFFFFFF], np.uint32).view(np.int32)
         si.upload({"counts": np.array([len(lvl), n_pos], np.int32), "lvl": lvl, "idx": idx, "mt": mt, "deltas": tdl[:si.cap],
                    "gt": gt_norm, "gtc": gtc, "scalars": scal})
         sc = si.view("scalars")
@@ -885,7 +881,6 @@ class DenseImageCapRCNN(object):
             raise ValueError("one image per step and GPU (IMAGES_PER_GPU = 1)")
         p = self.plan()
         H, W = p.H, p.W
-        self._trunk_ready_for = None                         # (this call runs the whole encoder: a prefetched trunk is overwritten)
         # ---- this step's host inputs go to the device FIRST (GT boxes, GT captions, the RPN selection, the step scalars: one asynchronous
         # copy, StepInputs): nothing the host contributes may sit in the middle of the step
         gt_norm = (np.asarray(gt_boxes[0], np.float32) / np.array([H, W, H, W], np.float32)).astype(np.float32)
@@ -895,7 +890,7 @@ class DenseImageCapRCNN(object):
         p.forward(self._images_u8(images))
         return self._after_encoder(p, rpn_up, shuffle, backward, gt_caps[0], gt_norm)
 
-    def _after_encoder(self, p, rpn_up, shuffle, backward, gt_caps0, gt_norm, prefetch_trunk=False):
+    def _after_encoder(self, p, rpn_up, shuffle, backward, gt_caps0, gt_norm):
         """The step behind the encoder pass: proposals, detection targets, RoIAlign, head + decoder, the four losses and (backward)
         every gradient into the flat bucket.  With device-side targets (shuffle None / "rng") nothing in here depends on a host value
         that changes from step to step -- counts, stream positions and lr_t are device words of StepInputs -- so train_on_batch_device
@@ -932,7 +927,7 @@ class DenseImageCapRCNN(object):
             # DetectionTargetLayer on the device (dc_detection_targets_f32): IoU, the >= 0.5 / < 0.5 split, the shuffle (Philox keys drawn
             # from (model seed, step): reproducible, where tf.random_shuffle is not), the 1:2 sample and the caption gather.  Nothing
             # comes back to the host: counts travel as device words, every shape downstream is static (TRAIN_ROIS_PER_IMAGE rows).
-            seed = None if shuffle is None else ((self._seed + (0 if backward else 1)) * 2654435761 + 12345) & 0xFFFFFFFF
+            seed = None if shuffle is None else ((self._seed + (0 if backward else 1)) * 2654435761 + 12345 + self._dt_rank * 0x9E3779B9) & 0xFFFFFFFF
             T = int(np.asarray(gt_caps[0]).shape[1])
             rois_d, caps_d, counts_d = ops.detection_targets(
                 proposals[0], gt_dev, gtc_dev, R, cfg.ROI_POSITIVE_RATIO, seed=seed, offset=0, offset_dev=rpn_up["dt_offset"],
@@ -953,7 +948,10 @@ class DenseImageCapRCNN(object):
                                                  keras_sparse=True)
             else:
                 cm._drop_offset_dev = rpn_up["drop_offset"]
-                loss_rows, _ = cm._forward_train(feats[0], None, want_grad=backward, keras_sparse=True, device_tables=tables + (R, T))
+                try:
+                    loss_rows, _ = cm._forward_train(feats[0], None, want_grad=backward, keras_sparse=True, device_tables=tables + (R, T))
+                finally:
+                    cm._drop_offset_dev = None                  # a later standalone step of the shared caption model draws from ITS counter
             if backward and not fork:
                 maps, dP = self._rpn_backward(p, rpn_up, losses)
         else:
@@ -1045,16 +1043,6 @@ class DenseImageCapRCNN(object):
             announce(name)
         if self.backbone_from is not None:
             self._trunk_backward(p, dpre)
-        if prefetch_trunk and fork:
-            # The frozen ResNet trunk of the NEXT step's image (train_on_batch(next_images=...)): nothing this step trains feeds it, and
-            # the lateral weight gradients above were the last readers of this step's C2..C5.  It runs on the second stream beside the
-            # regulariser / clip / AMSGrad passes (HBM-bound; the trunk at one image is ~70 small, latency-bound launches); the caller joins
-            # the stream behind the optimizer, and the next step's encoder pass is the FPN / RPN half alone (EncoderPlan.forward_head).
-            self._side_stream.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(self._side_stream):
-                p.run_trunk(p.next_image_buffer())
-            self._trunk_in_flight = True
-
         coef, mask = self._masks()
         if self._reg_done:                                  # the ranges that did not go early (FPN / RPN, anything the decoder skipped)
             n, pos = st.flat.numel(), 0
@@ -1079,18 +1067,16 @@ class DenseImageCapRCNN(object):
         self.last_losses = d = self._loss_list(v)
         return [d["loss"], d["rpn_class_loss"], d["rpn_bbox_loss"], d["imgcap_loss"]]
 
-    def train_on_batch_device(self, inputs, targets=None, next_images=None):
+    def train_on_batch_device(self, inputs, targets=None):
         """One optimizer step; the raw loss terms as a float32 device tensor [4] (the loss all-reduce of ParallelModel and the
-        epoch sums of train() work on it; _losses_to_api makes the Keras return value from its host copy).
-        next_images: the image batch of the NEXT call (the same object that call will pass as inputs[0]).  With a frozen trunk (the
-        reference's layers="no_backbone") its ResNet pass then runs at the end of THIS step, beside the optimizer, and the next call
-        starts at the FPN: the pipeline the separate-models path runs between its encoder and decoder, inside the joint model."""
+        epoch sums of train() work on it; _losses_to_api makes the Keras return value from its host copy)."""
         assert self.mode == "training", "Create model in training mode."
         if self.optimizer is None:
             raise RuntimeError("compile(learning_rate) first")
-        world = getattr(self.grad_sync, "world", 1) if self.grad_sync is not None else 1
+        # a gradient hook without `.world` (a custom callable) counts as an exchange: it takes the eager path and is called
+        world = 1 if self.grad_sync is None else getattr(self.grad_sync, "world", None)
         cm = self.caption_model
-        if world > 1 or cm._prefix_rows(True):
+        if world != 1 or cm._prefix_rows(True):
             # eager, serial: the data-parallel step (its collectives are issued from Python as layer groups finish), DROPOUT_ROWS='prefix'
             losses = self.forward_backward(inputs)
             scale = self.grad_sync(self.store.flat_grad) if self.grad_sync is not None else 1.0
@@ -1104,30 +1090,18 @@ class DenseImageCapRCNN(object):
         dev = self.device
         gt_norm = (np.asarray(gt_boxes[0], np.float32) / np.array([p.H, p.W, p.H, p.W], np.float32)).astype(np.float32)
         rpn_up = self._step_uploads(p, rpn_match, rpn_bbox, gt_norm, gt_caps[0], True)
-        have_trunk = self._trunk_ready_for is not None and images is self._trunk_ready_for
-        self._trunk_ready_for = None
-        if have_trunk:
-            p.forward_head()                                     # C2..C5 of this image are in the plan's buffers already
-        else:
-            p.forward(self._images_u8(images))
-        prefetch = next_images is not None and self.backbone_from is None and self.use_side_stream and len(next_images) == 1
-        if prefetch:
-            nxt = self._images_u8(next_images)
-            p.next_image_buffer().copy_(nxt, non_blocking=bool(nxt.is_cuda or nxt.is_pinned()))
+        p.forward(self._images_u8(images))
         opt = self.optimizer
 
         def body():
-            self._trunk_in_flight = False
-            losses = self._after_encoder(p, rpn_up, "rng", True, gt_caps[0], gt_norm, prefetch_trunk=prefetch)
+            losses = self._after_encoder(p, rpn_up, "rng", True, gt_caps[0], gt_norm)
             opt.apply(self.store, grad_scale=1.0, lr_t_dev=rpn_up["lr_t"])
-            if self._trunk_in_flight:
-                torch.cuda.current_stream(dev).wait_stream(self._side_stream)      # join the trunk branch behind the optimizer
             return losses
 
         def step():
             if not self.use_step_graph:
                 return body()
-            key = "train+prefetch" if prefetch else "train"
+            key = "train"
             graph = self._graphs.get(key)
             if graph is not None:
                 graph.replay()
@@ -1144,24 +1118,26 @@ class DenseImageCapRCNN(object):
                 graph = torch.cuda.CUDAGraph()
                 with ops.no_gc_during_capture(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     out = body()
-            except Exception as e:                               # something in the step is not capturable here: stay eager
+            except RuntimeError as e:                            # a capture error (torch raises RuntimeError): stay eager from here on
                 import warnings
                 warnings.warn("joint step: hipGraph capture failed (%s); running eagerly" % (repr(e)[:200],))
                 opt.iterations, cm._drop_step = saved
                 self.use_step_graph = False
+                self.step_graph_fallback = repr(e)[:200]         # queryable (bench.py reports it): the eager step is a different schedule
+                # the failed capture may have pulled the side stream in (between fork and join): it is in an invalidated-capture state,
+                # so the eager retry forks onto a fresh one
+                self._side_stream = None
+                torch.cuda.synchronize()
                 return body()
             self._graphs[key], self._graph_out[key] = graph, out
             graph.replay()                                       # (capture records, it does not run: this is the step itself)
             return out
-        out = step()
-        if prefetch:
-            self._trunk_ready_for = next_images                  # (valid until anything else runs the plan: forward_backward clears it)
-        return out
+        return step()
 
-    def train_on_batch(self, inputs, targets=None, next_images=None):
+    def train_on_batch(self, inputs, targets=None):
         """One optimizer step; returns [loss, rpn_class_loss, rpn_bbox_loss, imgcap_loss] like the compiled Keras model
-        (metrics_names order, :1722-1730).  next_images: see train_on_batch_device."""
-        return self._losses_to_api(self.train_on_batch_device(inputs, targets, next_images=next_images))
+        (metrics_names order, :1722-1730)."""
+        return self._losses_to_api(self.train_on_batch_device(inputs, targets))
 
     def test_on_batch_device(self, inputs, targets=None):
         return self.forward_backward(inputs, backward=False)
@@ -1216,17 +1192,10 @@ class DenseImageCapRCNN(object):
         val_batch = next(val_generator)[0]
         names = ("loss",) + self.LOSS_NAMES
         history = []
-        ahead = None                                             # one batch of look-ahead: its frozen trunk runs beside this step's optimizer
         for epoch in range(self.epoch, epochs):
             acc = None                                           # raw loss terms summed on the device: one host copy per epoch
             for _ in range(cfg.STEPS_PER_EPOCH):
-                cur = ahead if ahead is not None else next(train_generator)[0]
-                if self._outer is self and self.use_trunk_prefetch and self.backbone_from is None:
-                    ahead = next(train_generator)[0]
-                    step = self.train_on_batch_device(cur, next_images=ahead[0])
-                else:
-                    ahead = None
-                    step = self._outer.train_on_batch_device(cur)
+                step = self._outer.train_on_batch_device(next(train_generator)[0])
                 acc = step.clone() if acc is None else acc.add_(step)
             logs = dict(zip(names, self._losses_to_api((acc / cfg.STEPS_PER_EPOCH).cpu().numpy())))
             # the reference validates on ONE fixed batch too: validation_data=next(val_generator) (:1878)

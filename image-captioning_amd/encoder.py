@@ -73,23 +73,21 @@ class EncoderPlan:
         self.math = conv_math_mode(math)
         # math = 'bf16' (BASELINE configs[4]): activations travel between the convolutions as bf16 tensors and every convolution with
         # Cin % 64 == 0 runs on dc_conv2d_bf16 (LDS-DMA im2col on the bf16 GEMM core); fp32 copies are written only where something
-        # reads fp32 (residual adds, RoIAlign, the joint model's backward).  DCAP_BF16_CONV=0 keeps fp32 activations and the
-        # split-bf16 loop with one product (the round-2 start; measurements only).
+        # reads fp32 (residual adds, RoIAlign, the joint model's backward).
         import os
-        self.fast_bf16 = self.math == _lib.MATH_BF16 and os.environ.get("DCAP_BF16_CONV", "1") != "0"
+        self.fast_bf16 = self.math == _lib.MATH_BF16
         # math = 'f32': the 3x3 / stride 1 layers with FROZEN weights (ResNet 2b branches, FPN output convolutions) run in the Winograd
         # F(2x2, 3x3) form -- fp32 transforms, fp32 MFMA, 16 products per 2x2 output tile instead of 36 (csrc/conv_wino.hip); their
         # kernels are transformed once here.  winograd=False / DCAP_WINOGRAD=0: the direct implicit GEMM everywhere.
         self.winograd = (os.environ.get("DCAP_WINOGRAD", "1") != "0") if winograd is None else bool(winograd)
-        self.winograd4 = os.environ.get("DCAP_WINO4", "0") == "1"         # F(4x4,3x3): correct, slower than F(2x2,3x3) as measured: opt-in
-        self._wwino, self._wwino4 = {}, {}
+        self._wwino = {}
         self._twin = {}
         self._wb = {}
         self.B, self.H, self.W = batch, height, width
         self.device = torch.device(device)
         self.mean_pixel = [float(v) for v in mean_pixel]
         self.stage4_blocks = stage4_blocks
-        self.use_graph = use_graph and os.environ.get("DCAP_ENCODER_GRAPH", "1") != "0"      # (0: eager launches -- measurements)
+        self.use_graph = bool(use_graph)
         self._graph = None
         self._warm = False
         self._specs = {s.name: s for s in resnet_fpn_convs(stage4_blocks)}
@@ -112,7 +110,6 @@ class EncoderPlan:
                 weights = dict(weights)
                 weights["rpn_head/kernel"], weights["rpn_head/bias"] = fuse_rpn_head(weights, hc)
         self._w = {}
-        self._wsplit = {}
         self._upload(weights)
         self._build()
 
@@ -209,11 +206,6 @@ class EncoderPlan:
         use_wino = (self.winograd and self.math in (_lib.MATH_F32, _lib.MATH_BF16X3, _lib.MATH_BF16X2) and s.k == 3 and s.stride == 1 and
                     s.padding == "same" and residual is None and name not in self._external and Cin % 32 == 0 and Cout % 32 == 0 and
                     wp.shape[1] == 9 * Cin)
-        if self.math == _lib.MATH_BF16X3 and name != "conv1" and name not in self._external and not use_wino:
-            # frozen weights: the three-piece bf16 split is paid once here instead of in every K-tile
-            if name not in self._wsplit:
-                self._wsplit[name] = ops.split_bf16x3(wp)
-            d.w_split = self._wsplit[name].data_ptr()
         if use_wino:
             # (Cin = the channels of the tensor the layer READS: VGG16's block1_conv1 reads RGB zero-padded to 32 channels)
             # The split-bf16 modes (round 4): their 3x3 layers with frozen weights ALSO run the fp32 Winograd kernel -- exact fp32 products,
@@ -223,13 +215,6 @@ class EncoderPlan:
                 self._wwino[name] = ops.winograd_pack(wp, Cin, Cout)
             d.w_wino = self._wwino[name].data_ptr()
             d.math = _lib.MATH_F32
-            # F(4x4, 3x3) (36 products per 4x4 tile instead of 64) where the layer has a 32-tile x 32-channel work item for every CU:
-            # at two images the stage-2 / stage-3 branches and the P2 / P3 output layers; the library applies the same rule
-            th4, tw4 = (H + 3) // 4, (W + 3) // 4
-            if self.winograd4 and N * ((th4 + 3) // 4) * ((tw4 + 7) // 8) * (Cout // 32) >= 256:
-                if name not in self._wwino4:
-                    self._wwino4[name] = ops.winograd4_pack(wp, Cin, Cout)
-                d.w_wino4 = self._wwino4[name].data_ptr()
         self._ws_bytes = max(self._ws_bytes, self.lib.dc_conv2d_workspace_bytes(C.byref(d)))
         self._ops.append(("conv", d, name))
         if self.fast_bf16 and bf16:                    # a layer the bf16 kernel does not take (the stem): cast its output
@@ -286,7 +271,6 @@ class EncoderPlan:
         C4 = stage(4, ["a"] + [chr(98 + i) for i in range(self.stage4_blocks)], 256, 1024, 2, C3)
         C5 = stage(5, "abc", 512, 2048, 2, C4)
         self.C = (C2, C3, C4, C5)
-        self._trunk_ops = len(self._ops)                # ops [0, _trunk_ops) = mold + ResNet trunk; the rest = FPN (+ RPN)
         self.pre = None
         t5, t4 = self._buf(H // 32, W // 32, 256), self._buf(H // 16, W // 16, 256)
         t3, t2 = self._buf(H // 8, W // 8, 256), self._buf(H // 4, W // 4, 256)
@@ -327,9 +311,8 @@ class EncoderPlan:
         self._ws = torch.empty(max(self._ws_bytes, 16), dtype=torch.uint8, device=self.device)
 
     # ------------------------------------------------------------------ run
-    def _run_ops(self, lo=0, hi=None, image_src=None):
-        """Enqueue ops [lo, hi) of the plan on the current stream.  image_src: another uint8 image tensor for the mold op (the joint
-        model's trunk prefetch reads the NEXT step's image from `images_next`)."""
+    def _run_ops(self, lo=0, hi=None):
+        """Enqueue ops [lo, hi) of the plan on the current stream."""
         lib = self.lib
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         wsp, wsb = C.c_void_p(self._ws.data_ptr()), self._ws.numel()
@@ -349,7 +332,7 @@ class EncoderPlan:
                 b = op[1]
                 ops.bn_fold(b["gamma"], b["beta"], b["bias"], b["mean"], b["var"], op[2], op[3])
             elif kind == "mold":
-                ops.mold_image_rgbx(op[1] if image_src is None else image_src, self.mean_pixel, out=op[2])
+                ops.mold_image_rgbx(op[1], self.mean_pixel, out=op[2])
             elif kind == "sub2":
                 ops.subsample2(op[1], out=op[2])
             else:
@@ -378,7 +361,7 @@ class EncoderPlan:
             if op[0] != "conv":
                 continue
             d, s = op[1], self._specs[op[2]]
-            wbytes = (36 if op[2] in self._wwino4 else 16 if op[2] in self._wwino else s.k * s.k) * d.Cin * s.cout * 4
+            wbytes = (16 if op[2] in self._wwino else s.k * s.k) * d.Cin * s.cout * 4
             b = 4.0 * d.N * d.H * d.W * d.Cin + 4.0 * d.N * d.Ho * d.Wo * d.Cout + wbytes
             if d.res_mode == 1:
                 b += 4.0 * d.N * d.Ho * d.Wo * d.Cout
@@ -477,37 +460,6 @@ class EncoderPlan:
             g.replay()
         return self.P
 
-    # ---- the pass in two halves (joint model, frozen trunk): the ResNet trunk does not depend on anything the step trains, so the
-    # trunk of step i + 1 can run while step i's optimizer (HBM-bound) is still busy -- DenseImageCapRCNN.train_on_batch(next_images=)
-    def run_trunk(self, image_src=None):
-        """mold + ResNet trunk (C2..C5) on the current stream, eagerly (the caller may be capturing).  image_src: uint8 [B,H,W,3] device
-        tensor (default: self.images)."""
-        if self._external_bn:
-            raise RuntimeError("the trunk of this plan is trainable: it cannot run ahead of the optimizer")
-        self._run_ops(0, self._trunk_ops, image_src)
-
-    def next_image_buffer(self):
-        if getattr(self, "images_next", None) is None:
-            self.images_next = torch.empty_like(self.images)
-        return self.images_next
-
-    def forward_head(self):
-        """FPN (+ RPN) on the trunk outputs already in the plan's buffers (run_trunk): first call eager, second captured, then replayed."""
-        if not self.use_graph:
-            self._run_ops(self._trunk_ops, None)
-        elif getattr(self, "_graph_head", None) is not None:
-            self._graph_head.replay()
-        elif not getattr(self, "_warm_head", False):
-            self._run_ops(self._trunk_ops, None)
-            self._warm_head = True
-        else:
-            g = torch.cuda.CUDAGraph()
-            with ops.no_gc_during_capture(), torch.cuda.graph(g, capture_error_mode="thread_local"):
-                self._run_ops(self._trunk_ops, None)
-            self._graph_head = g
-            g.replay()
-        return self.P
-
     def proposals(self, debug=False):
         """ProposalLayer on the RPN heads of the last forward(): normalised boxes [B,count,4], zero padded."""
         if self.rpn is None:
@@ -549,8 +501,7 @@ class Vgg16Plan(EncoderPlan):
         self.lib = _lib.load()
         self.math = conv_math_mode(math)
         self.winograd = (os.environ.get("DCAP_WINOGRAD", "1") != "0") if winograd is None else bool(winograd)      # all 13 layers are 3x3 / stride 1
-        self.winograd4 = os.environ.get("DCAP_WINO4", "0") == "1"
-        self._wwino, self._wwino4 = {}, {}
+        self._wwino = {}
         self.B, self.H, self.W = batch, height, width
         self.device = torch.device(device)
         self.mean_pixel = [float(v) for v in mean_pixel]
@@ -561,7 +512,6 @@ class Vgg16Plan(EncoderPlan):
         self.rpn = None
         self._external = {}
         self._w = {}
-        self._wsplit = {}
         self._upload(weights)
         self._build()
 

@@ -189,7 +189,7 @@ def gemm_bf16(A, B, out=None, out_bf16=None, a_trans=False, b_trans=False, gathe
 
 
 def conv2d(x, w_packed, kh, kw, stride, pad_t, pad_l, Ho, Wo, scale=None, shift=None, residual=None,
-           res_mode=0, relu=False, out=None, split_k=0, math=0, w_split=None, w_wino=None, w_wino4=None, _name_only=False):
+           res_mode=0, relu=False, out=None, split_k=0, math=0, w_wino=None, _name_only=False):
     """NHWC conv forward with fused epilogue; see dc_conv2d_nhwc_f32.  x [N,H,W,Cin] contiguous.  w_wino: winograd_pack(w_packed)
     of a frozen 3x3 / stride 1 / pad 1 kernel -> the layer runs in the Winograd F(2x2, 3x3) form (fp32, math=0 only)."""
     lib = _lib.load()
@@ -208,15 +208,10 @@ def conv2d(x, w_packed, kh, kw, stride, pad_t, pad_l, Ho, Wo, scale=None, shift=
     d.shift = None if shift is None else shift.data_ptr()
     d.residual = None if residual is None else _chk(residual, name="residual").data_ptr()
     d.res_mode, d.relu, d.split_k, d.math = int(res_mode), int(relu), int(split_k), int(math)
-    d.w_split = None if w_split is None else _chk(w_split, torch.int16, "w_split").data_ptr()
     if w_wino is not None:
         if not w_wino.is_contiguous() or w_wino.numel() != 16 * Cin * Cout:
             raise _lib.DcapError("conv2d: w_wino must be the contiguous winograd_pack() of this layer's kernel (16*Cin*Cout floats)")
         d.w_wino = _chk(w_wino, name="w_wino").data_ptr()
-    if w_wino4 is not None:
-        if not w_wino4.is_contiguous() or w_wino4.numel() != 36 * Cin * Cout:
-            raise _lib.DcapError("conv2d: w_wino4 must be the contiguous winograd4_pack() of this layer's kernel (36*Cin*Cout floats)")
-        d.w_wino4 = _chk(w_wino4, name="w_wino4").data_ptr()
     if _name_only:
         buf = C.create_string_buffer(128)
         check(lib.dc_conv2d_kernel_name(C.byref(d), buf, 128), "dc_conv2d_kernel_name")
@@ -229,21 +224,6 @@ def conv2d(x, w_packed, kh, kw, stride, pad_t, pad_l, Ho, Wo, scale=None, shift=
 def conv2d_kernel_name(*args, **kw):
     """The kernel template instantiation conv2d(*args, **kw) would launch (dc_conv2d_kernel_name); nothing is launched."""
     return conv2d(*args, _name_only=True, **kw)
-
-
-def winograd4_pack(w_packed, cin, cout, out=None):
-    """U = G4 g G4^T of a packed 3x3 kernel [Cout, 9*Cin] for the F(4x4, 3x3) kernel, fragment order: fp32 [36*Cin*Cout]."""
-    lib = _lib.load()
-    _chk(w_packed, name="w")
-    if not w_packed.is_contiguous() or w_packed.numel() != 9 * cin * cout:
-        raise _lib.DcapError("winograd4_pack: w must be the contiguous packed 3x3 kernel [Cout, 9*Cin]")
-    nbytes = lib.dc_conv2d_winograd4_weight_bytes(cin, cout)
-    if nbytes == 0:
-        raise _lib.DcapError("winograd4_pack: Cin and Cout must be multiples of 32")
-    if out is None:
-        out = torch.empty((nbytes // 4,), dtype=torch.float32, device=w_packed.device)
-    check(lib.dc_conv2d_winograd4_pack_f32(_ptr(w_packed), _ptr(out), cin, cout, _stream()), "dc_conv2d_winograd4_pack_f32")
-    return out
 
 
 def winograd_pack(w_packed, cin, cout, out=None):

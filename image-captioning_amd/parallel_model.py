@@ -164,6 +164,10 @@ class ParallelModel(object):
                 if m is not None and hasattr(m, "_drop_seed"):
                     base = m.__dict__.setdefault("_drop_seed_base", m._drop_seed)          # idempotent: derived from the build seed every time
                     m._drop_seed = (base ^ (self.rank * 0x9E3779B9)) & 0xFFFFFFFF
+            # ... and shuffle their proposals independently (tf.random_shuffle inside each tower's DetectionTargetLayer,
+            # dense_img_cap/dense_model.py:450-528): the rank enters the key of the joint model's detection-target sort as well
+            if hasattr(self.inner_model, "_dt_rank"):
+                self.inner_model._dt_rank = self.rank
 
     def __getattr__(self, name):
         return getattr(self.inner_model, name)

@@ -186,18 +186,11 @@ typedef struct {
                                  products: a 16-bit-mantissa product (2^-16 relative; TF32 is 2^-11) at half the MFMAs;
                                  DC_MATH_BF16 = operands rounded once to bf16, one product, fp32 accumulate -- plain bf16 compute,
                                  the arithmetic BASELINE configs[4] names (2^-9 relative per operand) */
-    const uint16_t* w_split;  /* optional with DC_MATH_BF16X3: the weights already split by dc_split_bf16x3_f32 into three bf16
-                                 planes [3][Cout][kh*kw*Cin] (same packing as w); NULL = split on the fly from w */
     const float* w_wino;      /* optional with DC_MATH_F32, forward only: the weights of a 3x3 / stride 1 / pad 1 layer transformed by
                                  dc_conv2d_winograd_pack_f32 (16 * Cin * Cout floats).  Non-NULL = run the layer in the Winograd
                                  F(2x2, 3x3) form: fp32 throughout, 16 products per 2x2 output tile instead of 36 (the minimal-filtering
                                  algorithm cuDNN picks for these layers under the reference's TF); needs Cin, Cout multiples of 32, no
                                  residual.  Layers that do not qualify ignore the field */
-    const float* w_wino4;     /* optional, like w_wino: the weights transformed by dc_conv2d_winograd4_pack_f32 (36 * Cin * Cout floats)
-                                 for the F(4x4, 3x3) form -- 36 products per 4x4 output tile instead of 144 (F(2x2,3x3): 64); fp32 error
-                                 about 1e-5 of the output scale (worst element).  Runs when given WITHOUT w_wino; given both, F(2x2,3x3) runs
-                                 (the faster kernel as measured in round 4) unless DCAP_WINO4=1 and the layer has a 32-tile x 32-channel work
-                                 item per CU */
 } dc_conv_desc;
 
 /* x = p0 + p1 + p2 with bf16 pieces rounded to nearest even: out[0..n) = p0, out[n..2n) = p1, out[2n..3n) = p2. */
@@ -218,8 +211,6 @@ int    dc_conv2d_is_pointwise(const dc_conv_desc* d);
  * feature_generation/dense_model.py:85-100, :1417-1421 are evaluated. */
 size_t dc_conv2d_winograd_weight_bytes(int Cin, int Cout);
 int    dc_conv2d_winograd_pack_f32(const float* w, float* u, int Cin, int Cout, void* stream);
-size_t dc_conv2d_winograd4_weight_bytes(int Cin, int Cout);
-int    dc_conv2d_winograd4_pack_f32(const float* w, float* u, int Cin, int Cout, void* stream);
 /* CUs the persistent Winograd grids may occupy (process-wide; a multiple of 8 -- one share per XCD; 0 restores the default:
  * DCAP_WINO_CUS or all 256).  A persistent block holds its CU for the whole launch: in a data-parallel run (parallel_model.py:58-102
  * -> one rank per GPU here) the RCCL all-reduce of another queue needs CUs of its own to overlap the encoder pass, so

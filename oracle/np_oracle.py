@@ -532,23 +532,25 @@ def nms_tf(boxes, scores, max_output_size, iou_threshold):
     ymin, ymax = np.minimum(b[:, 0], b[:, 2]), np.maximum(b[:, 0], b[:, 2])
     xmin, xmax = np.minimum(b[:, 1], b[:, 3]), np.maximum(b[:, 1], b[:, 3])
     area = (ymax - ymin) * (xmax - xmin)
-    keep = []
     thr = F32(iou_threshold)
-    for i in order:
-        if len(keep) >= max_output_size:
-            break
-        ok = True
-        for j in reversed(keep):
-            if area[i] <= 0 or area[j] <= 0:
-                continue
-            ih = np.maximum(np.minimum(ymax[i], ymax[j]) - np.maximum(ymin[i], ymin[j]), F32(0))
-            iw = np.maximum(np.minimum(xmax[i], xmax[j]) - np.maximum(xmin[i], xmin[j]), F32(0))
-            inter = ih * iw
-            if inter / (area[i] + area[j] - inter) > thr:
-                ok = False
+    cap = int(min(max_output_size, len(order)))
+    keep = np.zeros(cap, np.int64)
+    n = 0
+    # (the kept boxes are tested as one float32 vector per candidate: the same elementwise operations as the kernel's loop over them)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        for i in order:
+            if n >= cap:
                 break
-        if ok:
-            keep.append(int(i))
+            if n and area[i] > 0:
+                k = keep[:n]
+                ih = np.maximum(np.minimum(ymax[i], ymax[k]) - np.maximum(ymin[i], ymin[k]), F32(0))
+                iw = np.maximum(np.minimum(xmax[i], xmax[k]) - np.maximum(xmin[i], xmin[k]), F32(0))
+                inter = ih * iw
+                if np.any((area[k] > 0) & (inter / (area[i] + area[k] - inter) > thr)):
+                    continue
+            keep[n] = i
+            n += 1
+    keep = keep[:n]
     return np.array(keep, np.int32)
 
 

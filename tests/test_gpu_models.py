@@ -1044,47 +1044,3 @@ def test_joint_step_graph_is_dropped_and_recaptured_when_what_it_baked_changes(g
             assert seen == [True, False, True, (False, True), True], seen
         out[mode] = model.store.flat.cpu().numpy()
     np.testing.assert_array_equal(out["graph"], out["eager"])
-
-
-
-def test_joint_trunk_lookahead_changes_the_schedule_not_the_result(gpu):
-    """train_on_batch(inputs, next_images=...): the frozen ResNet trunk of the NEXT image runs at the end of this step, beside the
-    optimizer (second stream / a branch of the step's hipGraph), and the next call starts at the FPN.  Eight steps over four DIFFERENT
-    images, with the reference's dropout: weights and losses bit-equal to the same steps without look-ahead, captured and eager;
-    a look-ahead for an image the next call does NOT bring (a mismatch) falls back to the whole encoder pass."""
-    S, V, T, blocks = 128, 24, 5, 1
-    _, cfg, Wt = make_joint(S, V, T, blocks)
-    del type(cfg).RECURRENT_DROPOUT
-    from image_captioning_amd import synth
-    from image_captioning_amd.dense_model import DenseImageCapRCNN
-    steps = []
-    for k in range(8):
-        inp = joint_inputs(S, V, T, seed=8 + (k % 3))
-        inp[0] = torch.tensor(synth.images(20 + k % 4, 1, S, S), device="cuda")
-        steps.append(inp)
-    runs = {}
-    for mode in ("lookahead+graph", "lookahead+eager", "plain", "mismatch"):
-        model = DenseImageCapRCNN("training", cfg, "logs", stage4_blocks=blocks)
-        model.set_weights(Wt)
-        model.compile(1e-4)
-        model.use_step_graph = mode != "lookahead+eager"
-        losses, heads = [], 0
-        for k, inp in enumerate(steps):
-            nxt = None
-            if mode.startswith("lookahead") and k + 1 < len(steps):
-                nxt = steps[k + 1][0]
-            elif mode == "mismatch" and k + 1 < len(steps):
-                nxt = steps[(k + 2) % len(steps)][0]            # the wrong image: the next call must notice
-            had = model._trunk_ready_for is not None and inp[0] is model._trunk_ready_for
-            heads += int(had)
-            losses.append(model.train_on_batch(inp, next_images=nxt))
-        if mode.startswith("lookahead"):
-            assert heads == len(steps) - 1                      # every step but the first started at the FPN
-            if mode.endswith("graph"):
-                assert "train+prefetch" in model._graphs
-        if mode == "mismatch":
-            assert heads == 0
-        runs[mode] = (np.array(losses), model.store.flat.cpu().numpy())
-    for mode in ("lookahead+graph", "lookahead+eager", "mismatch"):
-        np.testing.assert_array_equal(runs[mode][0], runs["plain"][0])
-        np.testing.assert_array_equal(runs[mode][1], runs["plain"][1])

@@ -112,6 +112,7 @@ def test_joint_model_two_ranks_average_the_tower_gradients(tmp_path):
     grads, tower_losses = [], []
     for k in range(world):
         m = W.build()
+        m._dt_rank = k                                   # the tower's own shuffle stream (ParallelModel folds the rank into the key)
         losses = m._loss_list(m.forward_backward(per[k]))
         grads.append(m.store.flat_grad.clone())
         tower_losses.append([losses["loss"], losses["rpn_class_loss"], losses["rpn_bbox_loss"], losses["imgcap_loss"]])

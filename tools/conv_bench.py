@@ -42,9 +42,7 @@ def main():
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--filter", default="")
     ap.add_argument("--math", type=int, default=0, help="0 = fp32 MFMA, 1 = split-bf16 (3 pieces, 6 products), 2 = 2 pieces, 3 products")
-    ap.add_argument("--presplit", action="store_true", help="math 1: weights pre-split into bf16 planes")
     ap.add_argument("--winograd", action="store_true", help="math 0: 3x3 layers in the Winograd F(2x2,3x3) form (pre-transformed weights)")
-    ap.add_argument("--winograd4", action="store_true", help="with --winograd: also hand over the F(4x4,3x3) weights (the library uses them where the layer has a work item per CU)")
     args = ap.parse_args()
     dev = torch.device("cuda")
     B = args.batch
@@ -63,13 +61,11 @@ def main():
             res = torch.randn(B, Ho // 2, Ho // 2, Cout, device=dev)
         y = torch.empty(B, Ho, Ho, Cout, device=dev)
         pad = (k - 1) // 2
-        wsp = ops.split_bf16x3(w) if (args.presplit and args.math == 1) else None
         wino = ops.winograd_pack(w, Cin, Cout) if (args.winograd and k == 3 and stride == 1 and args.math == 0) else None
-        wino4 = ops.winograd4_pack(w, Cin, Cout) if (wino is not None and args.winograd4) else None
-        run = lambda: ops.conv2d(x, w, k, k, stride, pad, pad, Ho, Ho, sc, sh, res, res_mode, bool(relu), out=y, math=args.math, w_split=wsp,
-                                 w_wino=wino, w_wino4=wino4)
-        kname = ops.conv2d_kernel_name(x, w, k, k, stride, pad, pad, Ho, Ho, sc, sh, res, res_mode, bool(relu), math=args.math, w_split=wsp,
-                                       w_wino=wino, w_wino4=wino4)
+        run = lambda: ops.conv2d(x, w, k, k, stride, pad, pad, Ho, Ho, sc, sh, res, res_mode, bool(relu), out=y, math=args.math,
+                                 w_wino=wino)
+        kname = ops.conv2d_kernel_name(x, w, k, k, stride, pad, pad, Ho, Ho, sc, sh, res, res_mode, bool(relu), math=args.math,
+                                       w_wino=wino)
         for _ in range(3):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -81,7 +77,7 @@ def main():
         us = 1e3 * e0.elapsed_time(e1) / args.reps
         fl = 2.0 * B * Ho * Ho * Cout * k * k * Cin
         by = 4.0 * (x.numel() / (stride * stride if k == 1 else 1) + y.numel() + (res.numel() if res is not None else 0) + w.numel())
-        gain = 4.0 if kname.startswith("wino4_") else 2.25
+        gain = 2.25
         tag = "  [%s: %.1f TF/s executed]" % (kname, fl / gain / us / 1e6) if wino is not None else ""
         print("%-28s %8.1f us  %6.1f TF/s  %6.0f GB/s%s" % (name, us, fl / us / 1e6, by / us / 1e3, tag))
 
