@@ -134,12 +134,16 @@ class DetectionTargetsDesc(C.Structure):
                 ("rois", C.c_void_p), ("captions", C.c_void_p), ("counts", C.c_void_p)]
 
 
+class RegSegments(C.Structure):
+    _fields_ = [("start", C.c_void_p), ("coef", C.c_void_p), ("mask", C.c_void_p), ("nseg", C.c_int)]
+
+
 class AmsgradDesc(C.Structure):
     _fields_ = [("n", C.c_size_t), ("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p),
                 ("v", C.c_void_p), ("vhat", C.c_void_p),
                 ("lr_t", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("grad_scale", C.c_float), ("gnorm_sq", C.c_void_p), ("clipnorm", C.c_float),
-                ("p_bf16", C.c_void_p), ("n_bf16", C.c_size_t), ("lr_t_dev", C.c_void_p)]
+                ("p_bf16", C.c_void_p), ("n_bf16", C.c_size_t), ("lr_t_dev", C.c_void_p), ("reg", C.POINTER(RegSegments))]
 
 
 # name -> (restype, argtypes): every symbol include/dcap.h declares
@@ -158,6 +162,7 @@ SYMBOLS = {
     "dc_conv2d_bf16_tile": (C.c_int, [C.POINTER(ConvBf16Desc), C.POINTER(C.c_int)]),
     "dc_conv2d_bf16": (C.c_int, [C.POINTER(ConvBf16Desc), C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_cast_f32_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dc_cast_bf16_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_cast_f32_bf16_2d": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dc_split_bf16x3_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_conv2d_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
@@ -171,6 +176,7 @@ SYMBOLS = {
     "dc_conv2d_wgrad_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_roi_align_pyramid_bwd_f32": (C.c_int, [C.POINTER(RoiAlignDesc), C.c_void_p]),
     "dc_downsample2x_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dc_downsample2x_sum_dual_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dc_maxpool2x2s2_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dc_maxpool3x3s2_same_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dc_mold_image_padded_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]),
@@ -201,6 +207,7 @@ SYMBOLS = {
     "dc_l2_reg_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_axpy_f32": (C.c_int, [C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_relu_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dc_relu_bwd_dual_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_fold_time_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dc_colsum_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "dc_colsum_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -213,6 +220,8 @@ SYMBOLS = {
     "dc_maxpool3x3s2_same_bwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
     "dc_dropout_mask_f32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "dc_amsgrad_step_f32": (C.c_int, [C.POINTER(AmsgradDesc), C.c_void_p]),
+    "dc_reg_sumsq_workspace_bytes": (C.c_size_t, [C.c_size_t]),
+    "dc_reg_sumsq_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(RegSegments), C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 
 _lib = None

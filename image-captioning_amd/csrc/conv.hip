@@ -401,7 +401,8 @@ extern "C" int dc_scatter2_add_f32(const float* coarse, float* fine, int N, int 
     return check_launch("scatter2_add_kernel");
 }
 
-__global__ void downsample2x_sum_kernel(const float4* __restrict__ fine, float4* __restrict__ out, int N, int Ho, int Wo, int C4, int acc) {
+__global__ void downsample2x_sum_kernel(const float4* __restrict__ fine, float4* __restrict__ out, int N, int Ho, int Wo, int C4, int acc,
+                                        unsigned short* __restrict__ out_bf16) {
     const long total = (long)N * Ho * Wo * C4;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int c = (int)(idx % C4);
@@ -414,17 +415,28 @@ __global__ void downsample2x_sum_kernel(const float4* __restrict__ fine, float4*
         float4 o = make_float4((a.x + b.x) + (e.x + f.x), (a.y + b.y) + (e.y + f.y), (a.z + b.z) + (e.z + f.z), (a.w + b.w) + (e.w + f.w));
         if (acc) { const float4 q = out[idx]; o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
         out[idx] = o;
+        if (out_bf16) {                                    // the bf16 copy the lateral weight gradient reads (instead of a cast pass)
+            typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+            auto bits = [](float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); };
+            reinterpret_cast<us4*>(out_bf16)[idx] = us4{bits(o.x), bits(o.y), bits(o.z), bits(o.w)};
+        }
     }
 }
 
-extern "C" int dc_downsample2x_sum_f32(const float* fine, float* out, int N, int Ho, int Wo, int C, int accumulate, void* stream) {
+extern "C" int dc_downsample2x_sum_dual_f32(const float* fine, float* out, uint16_t* out_bf16, int N, int Ho, int Wo, int C, int accumulate,
+                                            void* stream) {
     DC_REQUIRE(fine && out && N > 0 && Ho > 0 && Wo > 0 && C > 0 && (C & 3) == 0, DC_EINVAL, "dc_downsample2x_sum: bad arguments");
-    DC_REQUIRE(aligned16(fine) && aligned16(out), DC_EALIGN, "dc_downsample2x_sum: pointers must be 16-byte aligned");
+    DC_REQUIRE(aligned16(fine) && aligned16(out) && (reinterpret_cast<uintptr_t>(out_bf16) & 7u) == 0, DC_EALIGN,
+               "dc_downsample2x_sum: pointers must be 16-byte aligned (out_bf16: 8)");
     const long total = (long)N * Ho * Wo * (C / 4);
     const int blocks = (int)std::min<long>((total + 255) / 256, (long)kNumCU * 8);
     hipLaunchKernelGGL(downsample2x_sum_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<const float4*>(fine), reinterpret_cast<float4*>(out), N, Ho, Wo, C / 4, accumulate);
+                       reinterpret_cast<const float4*>(fine), reinterpret_cast<float4*>(out), N, Ho, Wo, C / 4, accumulate, out_bf16);
     return check_launch("downsample2x_sum_kernel");
+}
+
+extern "C" int dc_downsample2x_sum_f32(const float* fine, float* out, int N, int Ho, int Wo, int C, int accumulate, void* stream) {
+    return dc_downsample2x_sum_dual_f32(fine, out, nullptr, N, Ho, Wo, C, accumulate, stream);
 }
 
 extern "C" int dc_maxpool3x3s2_same_f32(const float* x, float* y, int N, int H, int W, int C, void* stream) {

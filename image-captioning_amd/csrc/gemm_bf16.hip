@@ -145,6 +145,18 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
     for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = Epilogue::bf16_bits(x[i]);
 }
 
+// bf16 -> fp32 (exact): the gradient bucket after a bf16 all-reduce, back where the clip norm and the optimizer read it
+__global__ __launch_bounds__(256) void uncast_bf16_kernel(const unsigned short* __restrict__ x, float* __restrict__ out, size_t n) {
+    typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+    auto f = [](unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); };
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const us4 v = reinterpret_cast<const us4*>(x)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4(f(v[0]), f(v[1]), f(v[2]), f(v[3]));
+    }
+    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = f(x[i]);
+}
+
 // rows x cols fp32 (row stride ld_in) -> bf16 (row stride ld_out), columns cols..cols_out-1 zero-filled (K padding)
 __global__ __launch_bounds__(256) void cast_bf16_2d_kernel(const float* __restrict__ x, long ld_in, unsigned short* __restrict__ out, long ld_out,
                                                            int rows, int cols, int cols_out) {
@@ -265,6 +277,14 @@ extern "C" int dc_cast_f32_bf16(const float* x, uint16_t* out, size_t n, void* s
     const int blocks = (int)std::min<size_t>((n / 4 + 255) / 256 + 1, (size_t)kNumCU * 8);
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, out, n);
     return check_launch("cast_bf16_kernel");
+}
+
+extern "C" int dc_cast_bf16_f32(const uint16_t* x, float* out, size_t n, void* stream) {
+    DC_REQUIRE(x && out && n > 0, DC_EINVAL, "dc_cast_bf16_f32: bad arguments");
+    DC_REQUIRE(aligned16(out) && (reinterpret_cast<uintptr_t>(x) & 7u) == 0, DC_EALIGN, "dc_cast_bf16_f32: out 16-byte, x 8-byte aligned");
+    const int blocks = (int)std::min<size_t>((n / 4 + 255) / 256 + 1, (size_t)kNumCU * 8);
+    hipLaunchKernelGGL(uncast_bf16_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, out, n);
+    return check_launch("uncast_bf16_kernel");
 }
 
 extern "C" int dc_cast_f32_bf16_2d(const float* x, int ld_in, uint16_t* out, int ld_out, int rows, int cols, int cols_out, void* stream) {

@@ -270,6 +270,20 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__
     }
 }
 
+// contiguous rows (ld == N, N % 4 == 0): 16-byte accesses, and optionally the bf16 copy the next bf16 GEMM / convolution reads --
+// written here instead of by a cast pass that would read the fp32 result again (round 5)
+__global__ __launch_bounds__(256) void relu_bwd_vec_kernel(const float4* __restrict__ dy, const float4* __restrict__ y, float4* __restrict__ out,
+                                                           unsigned short* __restrict__ out_bf16, long n4) {
+    typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+    auto bits = [](float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); };
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 a = dy[i], b = y[i];
+        const float4 o = make_float4(b.x > 0.f ? a.x : 0.f, b.y > 0.f ? a.y : 0.f, b.z > 0.f ? a.z : 0.f, b.w > 0.f ? a.w : 0.f);
+        if (out) out[i] = o;
+        if (out_bf16) reinterpret_cast<us4*>(out_bf16)[i] = us4{bits(o.x), bits(o.y), bits(o.z), bits(o.w)};
+    }
+}
+
 __global__ __launch_bounds__(256) void fold_time_kernel(const float* __restrict__ x, int T, int B, int N, int ld, float* __restrict__ out,
                                                         int ld_out) {
     const long total = (long)B * N;
@@ -337,7 +351,86 @@ __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ x, 
     if (threadIdx.x == 0) out[0] = s / (float)n;
 }
 
-__global__ __launch_bounds__(256) void amsgrad_kernel(dc_amsgrad_desc d) {
+// Segment table of a parameter bucket in LDS (dc_reg_segments): start[] ascending, nseg <= kMaxRegSegs.
+constexpr int kMaxRegSegs = 1024;
+struct RegLds {
+    int start[kMaxRegSegs + 1];
+    float coef[kMaxRegSegs], mask[kMaxRegSegs];
+};
+__device__ __forceinline__ void reg_load(const dc_reg_segments& r, RegLds& t) {
+    for (int i = threadIdx.x; i <= r.nseg; i += blockDim.x) t.start[i] = r.start[i];
+    for (int i = threadIdx.x; i < r.nseg; i += blockDim.x) {
+        t.coef[i] = r.coef[i];
+        t.mask[i] = r.mask ? r.mask[i] : 1.f;
+    }
+    __syncthreads();
+}
+// segment of element e: the last s with start[s] <= e
+__device__ __forceinline__ int reg_find(const RegLds& t, int nseg, int e) {
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (t.start[mid] <= e) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+// (coef, mask) of the four elements 4 i .. 4 i + 3 (segments may end inside a vector: the fused RPN head's bias).  `cur` = the segment
+// of the thread's previous vector (-1: none): a thread's vectors ascend, so a short walk forward replaces the search on all but the first
+__device__ __forceinline__ void reg_vec4(const RegLds& t, int nseg, size_t i, float (&c)[4], float (&k)[4], int& cur) {
+    const int e0 = (int)(i << 2);
+    int sgm = cur;
+    if (sgm < 0 || t.start[min(sgm + 8, nseg)] <= e0) sgm = reg_find(t, nseg, e0);      // first vector, or a jump over many small segments
+    else
+        while (sgm + 1 < nseg && t.start[sgm + 1] <= e0) ++sgm;
+    cur = sgm;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        while (sgm + 1 < nseg && t.start[sgm + 1] <= e0 + j) ++sgm;
+        c[j] = t.coef[sgm];
+        k[j] = t.mask[sgm];
+    }
+}
+
+// loss partial = sum coef w^2, norm partial = sum (g mask + 2 coef w)^2: read-only, block partials in block order
+__global__ __launch_bounds__(256) void reg_sumsq_kernel(const float* __restrict__ w, const float* __restrict__ g, dc_reg_segments r, size_t n,
+                                                        float* __restrict__ part_loss, float* __restrict__ part_norm) {
+    __shared__ RegLds t;
+    __shared__ float red[4];
+    reg_load(r, t);
+    float sl = 0.f, sn = 0.f;
+    const size_t n4 = n >> 2;
+    int cur = -1;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 wv = reinterpret_cast<const float4*>(w)[i], gv = reinterpret_cast<const float4*>(g)[i];
+        float c[4], k[4];
+        reg_vec4(t, r.nseg, i, c, k, cur);
+        const float ww[4] = {wv.x, wv.y, wv.z, wv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gr = gg[j] * k[j] + 2.f * c[j] * ww[j];
+            sl += c[j] * ww[j] * ww[j];
+            sn += gr * gr;
+        }
+    }
+    for (size_t e = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const int sgm = reg_find(t, r.nseg, (int)e);
+        const float gr = g[e] * t.mask[sgm] + 2.f * t.coef[sgm] * w[e];
+        sl += t.coef[sgm] * w[e] * w[e];
+        sn += gr * gr;
+    }
+    sl = block_reduce<false>(sl, red);
+    __syncthreads();
+    sn = block_reduce<false>(sn, red);
+    if (threadIdx.x == 0) {
+        part_loss[blockIdx.x] = sl;
+        part_norm[blockIdx.x] = sn;
+    }
+}
+
+template <bool REG>
+__global__ __launch_bounds__(256) void amsgrad_kernel(dc_amsgrad_desc d, dc_reg_segments r) {
+    __shared__ RegLds t;
+    if (REG) reg_load(r, t);
     float gscale = d.grad_scale;
     if (d.gnorm_sq && d.clipnorm > 0.f) {
         const float norm = sqrtf(d.gnorm_sq[0]) * fabsf(d.grad_scale);
@@ -346,10 +439,19 @@ __global__ __launch_bounds__(256) void amsgrad_kernel(dc_amsgrad_desc d) {
     const float b1 = d.beta1, b2 = d.beta2;
     if (d.lr_t_dev) d.lr_t = d.lr_t_dev[0];
     const size_t n4 = d.n >> 2;
+    int cur = -1;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         float4 g = reinterpret_cast<const float4*>(d.g)[i];
         float4 m = reinterpret_cast<float4*>(d.m)[i], v = reinterpret_cast<float4*>(d.v)[i];
         float4 vh = reinterpret_cast<float4*>(d.vhat)[i], p = reinterpret_cast<float4*>(d.p)[i];
+        if (REG) {                                          // the regularised, masked gradient (what dc_l2_reg_f32 would have written)
+            float c[4], k[4];
+            reg_vec4(t, r.nseg, i, c, k, cur);
+            g.x = g.x * k[0] + 2.f * c[0] * p.x;
+            g.y = g.y * k[1] + 2.f * c[1] * p.y;
+            g.z = g.z * k[2] + 2.f * c[2] * p.z;
+            g.w = g.w * k[3] + 2.f * c[3] * p.w;
+        }
 #define DC_AMS(c)                                              \
     {                                                          \
         const float gg = g.c * gscale;                         \
@@ -370,7 +472,12 @@ __global__ __launch_bounds__(256) void amsgrad_kernel(dc_amsgrad_desc d) {
         }
     }
     for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (size_t)gridDim.x * 256) {
-        const float gg = d.g[i] * gscale;
+        float g0 = d.g[i];
+        if (REG) {
+            const int sgm = reg_find(t, r.nseg, (int)i);
+            g0 = g0 * t.mask[sgm] + 2.f * t.coef[sgm] * d.p[i];
+        }
+        const float gg = g0 * gscale;
         const float m = b1 * d.m[i] + (1.f - b1) * gg;
         const float v = b2 * d.v[i] + (1.f - b2) * gg * gg;
         const float vh = fmaxf(d.vhat[i], v);
@@ -436,6 +543,17 @@ extern "C" int dc_relu_bwd_f32(const float* dy, const float* y, float* out, int 
     const int blocks = (int)std::min<long>(((long)M * N + 255) / 256, (long)kNumCU * 8);
     hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dy, y, out, M, N, ld);
     return check_launch("relu_bwd_kernel");
+}
+
+extern "C" int dc_relu_bwd_dual_f32(const float* dy, const float* y, float* out, uint16_t* out_bf16, size_t n, void* stream) {
+    DC_REQUIRE(dy && y && (out || out_bf16) && n > 0 && (n & 3) == 0, DC_EINVAL, "dc_relu_bwd_dual: bad arguments (n %% 4 == 0)");
+    DC_REQUIRE(aligned16(dy) && aligned16(y) && (!out || aligned16(out)) && (!out_bf16 || (reinterpret_cast<uintptr_t>(out_bf16) & 7u) == 0), DC_EALIGN,
+               "dc_relu_bwd_dual: dy, y, out must be 16-byte aligned, out_bf16 8-byte aligned");
+    const long n4 = (long)(n >> 2);
+    const int blocks = (int)std::min<long>((n4 + 255) / 256, (long)kNumCU * 8);
+    hipLaunchKernelGGL(relu_bwd_vec_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<const float4*>(dy),
+                       reinterpret_cast<const float4*>(y), reinterpret_cast<float4*>(out), out_bf16, n4);
+    return check_launch("relu_bwd_vec_kernel");
 }
 
 extern "C" int dc_fold_time_f32(const float* x, int T, int B, int N, int ld, float* out, int ld_out, void* stream) {
@@ -528,6 +646,42 @@ extern "C" int dc_l2_reg_f32(const float* w, const float* coef, const float* mas
     if (rc || !loss) return rc;
     hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, s, partial, blocks, loss, 0);
     return check_launch("l2_reg_kernel (finish)");
+}
+
+static int reg_check(const dc_reg_segments* r, size_t n, const char* who) {
+    DC_REQUIRE(r->start && r->coef && r->nseg >= 1 && r->nseg <= kMaxRegSegs, DC_EINVAL, "%s: the segment table needs 1..%d segments, got %d", who, kMaxRegSegs,
+               r->nseg);
+    DC_REQUIRE(n < ((size_t)1 << 31), DC_EINVAL, "%s: segment offsets are 32-bit: the bucket must hold < 2^31 elements", who);
+    return DC_OK;
+}
+static int reg_sumsq_blocks(size_t n) { return (int)std::min<size_t>((n / 4 + 255) / 256 + 1, (size_t)kNumCU * opt_blocks_per_cu()); }
+
+extern "C" size_t dc_reg_sumsq_workspace_bytes(size_t n) { return n ? (size_t)2 * reg_sumsq_blocks(n) * sizeof(float) : 0; }
+
+extern "C" int dc_reg_sumsq_f32(const float* w, const float* g, const dc_reg_segments* reg, size_t n, float* loss, float* gnorm_sq, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    DC_REQUIRE(w && g && reg && n > 0 && (loss || gnorm_sq), DC_EINVAL, "dc_reg_sumsq: bad arguments");
+    DC_REQUIRE(aligned16(w) && aligned16(g), DC_EALIGN, "dc_reg_sumsq: w and g must be 16-byte aligned");
+    int rc = reg_check(reg, n, "dc_reg_sumsq");
+    if (rc) return rc;
+    const int blocks = reg_sumsq_blocks(n);
+    DC_REQUIRE(workspace && workspace_bytes >= (size_t)2 * blocks * sizeof(float), DC_EWORKSPACE, "dc_reg_sumsq: needs %zu workspace bytes",
+               (size_t)2 * blocks * sizeof(float));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(reg_sumsq_kernel, dim3(blocks), dim3(256), 0, s, w, g, *reg, n, part, part + blocks);
+    rc = check_launch("reg_sumsq_kernel");
+    if (rc) return rc;
+    if (loss) {
+        hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, s, part, blocks, loss, 0);
+        rc = check_launch("reg_sumsq_kernel (loss)");
+        if (rc) return rc;
+    }
+    if (gnorm_sq) {
+        hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, s, part + blocks, blocks, gnorm_sq, 0);
+        rc = check_launch("reg_sumsq_kernel (norm)");
+    }
+    return rc;
 }
 
 extern "C" int dc_axpy_f32(float a, const float* x, float* y, size_t n, void* stream) {
@@ -643,6 +797,12 @@ extern "C" int dc_amsgrad_step_f32(const dc_amsgrad_desc* d, void* stream) {
     DC_REQUIRE(!d->p_bf16 || ((d->n_bf16 & 3) == 0 && d->n_bf16 <= (d->n & ~(size_t)3) && (reinterpret_cast<uintptr_t>(d->p_bf16) & 7u) == 0), DC_EINVAL,
                "dc_amsgrad_step: the bf16 shadow must be 8-byte aligned and cover a multiple of 4 elements inside the vectorised part of p");
     const int blocks = (int)std::min<size_t>((d->n / 4 + 255) / 256 + 1, (size_t)kNumCU * opt_blocks_per_cu());
-    hipLaunchKernelGGL(amsgrad_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), *d);
+    if (d->reg) {
+        int rc = reg_check(d->reg, d->n, "dc_amsgrad_step");
+        if (rc) return rc;
+        hipLaunchKernelGGL(amsgrad_kernel<true>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), *d, *d->reg);
+    } else {
+        hipLaunchKernelGGL(amsgrad_kernel<false>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), *d, dc_reg_segments{});
+    }
     return check_launch("amsgrad_kernel");
 }

@@ -127,63 +127,158 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
     return ((unsigned long long)hi << 32) | lo;
 }
 
-#ifndef NMS_ROWS
-#define NMS_ROWS 24        // kept rows whose suppression masks are fetched together: the scan is one dependent round trip per batch
-#endif
-__global__ __launch_bounds__(64) void nms_scan_wave_kernel(const float4* __restrict__ boxes, const unsigned long long* __restrict__ mask, int k,
-                                                           int words, int count, float4* __restrict__ proposals, int* __restrict__ keep_out) {
-    const int b = blockIdx.x, lane = threadIdx.x;
+constexpr int NMS_ROWS = 24;  // kept rows whose suppression masks one wave fetches together
+constexpr int NMS_G = 8;       // chunks (of 64 candidates) resolved between two memory round trips
+constexpr int NMS_WAVES = 4;
+
+// OR over the 64 lanes of a wave, result uniform.  DPP row operations (quad swaps, row rotates, the two row broadcasts) instead of
+// ds_bpermute butterflies: ~12 short VALU instructions per 32-bit half, no LDS-latency round trips in the scan's dependent chain.
+__device__ __forceinline__ unsigned wave_or32(unsigned v) {
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false);       // quad_perm [1,0,3,2]
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, false);       // quad_perm [2,3,0,1]
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);      // row_ror:4
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);      // row_ror:8  -> every lane: its row's OR
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1, 3
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2, 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
+    return ((unsigned long long)wave_or32((unsigned)(v >> 32)) << 32) | wave_or32((unsigned)v);
+}
+
+// Round 5.  The scan used to pay ONE dependent global round trip per 64-candidate chunk (the kept candidates' suppression rows had to
+// be OR-ed into the removed-set before the next chunk could start): 94 chunks x ~3 us = 0.28 ms for 6000 -> 2000 on ONE wave, on the
+// joint step's critical chain.  Now:
+//   * a GROUP of NMS_G chunks is resolved by wave 0 without touching memory: besides its own word (the bits inside its chunk),
+//     candidate 64 c + lane brings the words c + 1 .. group end of its row -- a state-independent triangle of G (G + 1) / 2 words per
+//     lane, prefetched one group ahead -- and after a chunk is resolved the kept candidates' triangle words are OR-reduced over the
+//     wave into the group's pending removed-words (seven butterfly reductions per chunk at most, no memory in the chain);
+//   * the full rows of the group's kept candidates are OR-ed into the removed-set ONCE PER GROUP by all four waves (chunk i of the
+//     group by wave i % 4, NMS_ROWS rows in flight per wave); every wave keeps its own partial removed-set in registers for the whole
+//     scan, and only the G words the next group starts from are combined through LDS.
+// 12 round trips instead of 94, four waves' worth of loads in flight.  Same greedy order, same result bit for bit.
+__global__ __launch_bounds__(NMS_WAVES * 64) void nms_scan_wave_kernel(const float4* __restrict__ boxes, const unsigned long long* __restrict__ mask,
+                                                                    int k, int words, int count, float4* __restrict__ proposals,
+                                                                    int* __restrict__ keep_out) {
+    constexpr int G = NMS_G;
+    __shared__ unsigned long long s_keep[G];
+    __shared__ unsigned long long s_rem[NMS_WAVES][G];
+    __shared__ int s_done;
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned long long* M = mask + (long)b * k * words;
-    unsigned long long rem0 = 0, rem1 = 0;
-    int kept = 0;
-    auto self_bits = [&](int c) -> unsigned long long {
-        const int i = c * 64 + lane;
-        return (c < words && i < k) ? M[(long)i * words + c] : 0ull;
-    };
-    unsigned long long self = self_bits(0);
-    for (int c = 0; c < words && kept < count; ++c) {
-        const unsigned long long self_next = self_bits(c + 1);                 // independent of the scan state: prefetch
-        const unsigned long long remc = readlane64(c < 64 ? rem0 : rem1, c & 63);
-        const int left = k - c * 64;
-        unsigned long long alive = ~remc;
-        if (left < 64) alive &= (1ull << left) - 1ull;
-        unsigned long long keepmask = 0;
-        int room = count - kept;
-        while (alive != 0 && room > 0) {                                       // uniform
-            const int j = __builtin_ctzll(alive);
-            keepmask |= 1ull << j;
-            --room;
-            alive &= ~(1ull << j);
-            alive &= ~readlane64(self, j);
-        }
-        if ((keepmask >> lane) & 1ull) {
-            const int slot = kept + __builtin_popcountll(keepmask & ((1ull << lane) - 1ull));
-            proposals[(long)b * count + slot] = boxes[(long)b * k + c * 64 + lane];
-            if (keep_out) keep_out[(long)b * count + slot] = c * 64 + lane;
-        }
-        kept += __builtin_popcountll(keepmask);
-        unsigned long long km = keepmask;
-        while (km != 0) {                                                      // uniform; NMS_ROWS rows (2 loads per lane each) in flight
-            unsigned long long v0[NMS_ROWS], v1[NMS_ROWS];
+    unsigned long long rem0 = 0, rem1 = 0;                 // THIS wave's rows OR-ed so far: lane l owns words l and l + 64
+    int kept = 0;                                          // (wave 0)
+    // tri[i][d]: word (c + d) of row (64 c + lane), c = g0 + i, d = 0 .. G - 1 - i  (d = 0: the bits inside the chunk); wave 0 only
+    unsigned long long tri[G][G], nxt[G][G];
+    auto load_tri = [&](unsigned long long (&t)[G][G], int g0) {
 #pragma unroll
-            for (int u = 0; u < NMS_ROWS; ++u) {
-                v0[u] = 0; v1[u] = 0;
-                if (km != 0) {
-                    const int j = __builtin_ctzll(km);
-                    km &= km - 1ull;
-                    const unsigned long long* row = M + (long)(c * 64 + j) * words;
-                    if (lane < words) v0[u] = row[lane];
-                    if (lane + 64 < words) v1[u] = row[lane + 64];
+        for (int i = 0; i < G; ++i) {
+            const int c = g0 + i, row = c * 64 + lane;
+            const bool in = c < words && row < k;
+            const unsigned long long* r = M + (long)(in ? row : 0) * words;
+#pragma unroll
+            for (int d = 0; d < G - i; ++d) t[i][d] = (in && c + d < words) ? r[c + d] : 0ull;
+        }
+    };
+    if (wave == 0) load_tri(tri, 0);
+    unsigned long long grem[G];                            // (wave 0) removed-words of the group's chunks: complete when the chunk is reached
+#pragma unroll
+    for (int i = 0; i < G; ++i) grem[i] = 0ull;
+    for (int g0 = 0; g0 < words; g0 += G) {
+        if (wave == 0) {
+            load_tri(nxt, g0 + G);                         // state-independent: in flight while this group resolves
+            unsigned long long keepm[G];
+#pragma unroll
+            for (int i = 0; i < G; ++i) keepm[i] = 0ull;
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int c = g0 + i;
+                if (c < words && kept < count) {           // uniform
+                    const int left = k - c * 64;
+                    unsigned long long alive = ~grem[i];
+                    if (left < 64) alive &= (1ull << left) - 1ull;
+                    unsigned long long keepmask = 0;
+                    int room = count - kept;
+                    while (alive != 0 && room > 0) {       // uniform: one iteration per kept candidate, no memory in the chain
+                        const int j = __builtin_ctzll(alive);
+                        keepmask |= 1ull << j;
+                        --room;
+                        alive &= ~(1ull << j);
+                        alive &= ~readlane64(tri[i][0], j);
+                    }
+                    const bool mine = (keepmask >> lane) & 1ull;
+                    if (mine) {
+                        const int slot = kept + __builtin_popcountll(keepmask & ((1ull << lane) - 1ull));
+                        proposals[(long)b * count + slot] = boxes[(long)b * k + c * 64 + lane];
+                        if (keep_out) keep_out[(long)b * count + slot] = c * 64 + lane;
+                    }
+                    kept += __builtin_popcountll(keepmask);
+                    keepm[i] = keepmask;
+#pragma unroll
+                    for (int d = 1; d < G - i; ++d) grem[i + d] |= wave_or64(mine ? tri[i][d] : 0ull);
                 }
             }
+            if (lane < G) {
+                unsigned long long v = 0;
 #pragma unroll
-            for (int u = 0; u < NMS_ROWS; ++u) { rem0 |= v0[u]; rem1 |= v1[u]; }
+                for (int i = 0; i < G; ++i) v = lane == i ? keepm[i] : v;
+                s_keep[lane] = v;
+            }
+            if (lane == 0) s_done = (kept >= count || g0 + G >= words) ? 1 : 0;
         }
-        self = self_next;
+        __syncthreads();                                   // the group's keep masks and the stop flag are published
+        if (s_done) break;                                 // (block-uniform)
+        // the group's kept rows into the removed-sets: chunk i by wave i % NMS_WAVES
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            if ((i % NMS_WAVES) != wave) continue;
+            unsigned long long km = s_keep[i];
+            while (km != 0) {                              // wave-uniform
+                unsigned long long v0[NMS_ROWS], v1[NMS_ROWS];
+#pragma unroll
+                for (int u = 0; u < NMS_ROWS; ++u) {
+                    v0[u] = 0; v1[u] = 0;
+                    if (km != 0) {
+                        const int j = __builtin_ctzll(km);
+                        km &= km - 1ull;
+                        const unsigned long long* row = M + (long)((g0 + i) * 64 + j) * words;
+                        if (lane < words) v0[u] = row[lane];
+                        if (lane + 64 < words) v1[u] = row[lane + 64];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NMS_ROWS; ++u) { rem0 |= v0[u]; rem1 |= v1[u]; }
+            }
+        }
+        // the words the next group starts from: word g0 + G + i is owned by lane (g0 + G + i) & 63 of every wave
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int w = g0 + G + i;
+            if (lane == (w & 63)) s_rem[wave][i] = w < 64 ? rem0 : rem1;
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                unsigned long long v = 0;
+#pragma unroll
+                for (int q = 0; q < NMS_WAVES; ++q) v |= s_rem[q][i];
+                grem[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+#pragma unroll
+                for (int d = 0; d < G - i; ++d) tri[i][d] = nxt[i][d];
+        }
+        __syncthreads();                                   // s_keep / s_rem / s_done may be rewritten
     }
-    for (int r = kept + lane; r < count; r += 64) {
-        proposals[(long)b * count + r] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (keep_out) keep_out[(long)b * count + r] = -1;
+    if (wave == 0) {
+        kept = __builtin_amdgcn_readfirstlane(kept);
+        for (int r = kept + lane; r < count; r += 64) {
+            proposals[(long)b * count + r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (keep_out) keep_out[(long)b * count + r] = -1;
+        }
     }
 }
 
@@ -589,7 +684,7 @@ extern "C" int dc_proposals_f32(const dc_proposal_desc* d, void* workspace, size
     hipLaunchKernelGGL(decode_kernel, dim3((d->B * k + 255) / 256), dim3(256), 0, s, *d, vals, deltas, boxes, k);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words, d->B), dim3(64), 0, s, boxes, mask, k, words, d->nms_threshold);
     if (words <= 128)
-        hipLaunchKernelGGL(nms_scan_wave_kernel, dim3(d->B), dim3(64), 0, s, boxes, mask, k, words, d->proposal_count,
+        hipLaunchKernelGGL(nms_scan_wave_kernel, dim3(d->B), dim3(NMS_WAVES * 64), 0, s, boxes, mask, k, words, d->proposal_count,
                            reinterpret_cast<float4*>(d->proposals), d->keep_out);
     else
         hipLaunchKernelGGL(nms_scan_kernel, dim3(d->B), dim3(64), (size_t)words * 8, s, boxes, mask, k, words, d->proposal_count,

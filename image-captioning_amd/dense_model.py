@@ -628,7 +628,13 @@ class DenseImageCapRCNN(object):
                     frozen = True
             self._reg_coef = torch.tensor(coef, device=self.device)
             self._train_mask = torch.tensor(mask, device=self.device) if frozen else None
+            # the same two vectors in run-length form (a few dozen segments): what the fused optimizer pass reads instead of 2 x n floats
+            self._reg_segs = ops.RegSegmentTable(coef, mask if frozen else None, self.device)
         return self._reg_coef, self._train_mask
+
+    def _reg_segments(self):
+        self._masks()
+        return self._reg_segs
 
     # ---- one training step ------------------------------------------------------------------
     def _cast_cached(self, t, key):
@@ -638,6 +644,15 @@ class DenseImageCapRCNN(object):
         b = ops.to_bf16(t, out=self._buf(("castb", key or tuple(t.shape)), tuple(t.shape), torch.bfloat16))
         if key is not None:
             self._bf16_cache[key] = b
+        return b
+
+    def _bf16_slot(self, t, key):
+        """The buffer _cast_cached(t, key) would fill, registered as filled: for producers that write the bf16 copy of `t` themselves
+        (relu_bwd, downsample2x_sum, conv2d_bf16's second output) instead of leaving it to a cast pass.  None when nothing reads bf16."""
+        if not (self.compute_dtype == "bf16" or self.plan().fast_bf16):
+            return None
+        b = self._buf(("castb", key), tuple(t.shape), torch.bfloat16)
+        self._bf16_cache[key] = b
         return b
 
     def _wgrad(self, x, dy, k, pad, out, accumulate=False, key=None, dy_key=None):
@@ -656,7 +671,7 @@ class DenseImageCapRCNN(object):
             return ops.conv2d_wgrad_bf16(xb, dyb, k, k, 1, pad, pad, out=out, accumulate=accumulate)
         return ops.conv2d_wgrad(x, dy, k, k, 1, pad, pad, out=out, accumulate=accumulate)
 
-    def _dgrad(self, dy, wd, k, out, residual=None, key=None, dy_key=None):
+    def _dgrad(self, dy, wd, k, out, residual=None, key=None, dy_key=None, out_key=None):
         """Data gradient of a k x k / stride-1 'same' convolution = the forward convolution of dy with the rotated, transposed
         kernel `wd` (packed [Cin, k*k*Cout] fp32).  bf16 model with bf16 storage: dy and wd are cast and the product runs on
         dc_conv2d_bf16; otherwise dc_conv2d_nhwc_f32 in the plan's conv arithmetic.  residual: added (the accumulation into a
@@ -668,7 +683,8 @@ class DenseImageCapRCNN(object):
         if p.fast_bf16 and ops.conv_bf16_supported(cout):
             dyb = self._cast_cached(dy, dy_key)
             wdb = self._cast_cached(wd, None if key is None else "wd_" + key)      # the RPN's rotated kernel serves five levels
-            return ops.conv2d_bf16(dyb, wdb, k, k, 1, pad, pad, h_, w_, residual=residual, res_mode=res_mode, out=out)[0]
+            ob = None if out_key is None else self._bf16_slot(out, out_key)         # out_key: the result's bf16 copy from the same epilogue
+            return ops.conv2d_bf16(dyb, wdb, k, k, 1, pad, pad, h_, w_, residual=residual, res_mode=res_mode, out=out, out_bf16=ob)[0]
         return ops.conv2d(dy, wd, k, k, 1, pad, pad, h_, w_, residual=residual, res_mode=res_mode, out=out, math=p.math)
 
     def _images_u8(self, images):
@@ -765,7 +781,8 @@ class DenseImageCapRCNN(object):
             ops.colsum(dh.view(-1, HEAD_PAD), out=g["rpn_head/bias"], accumulate=acc)
             dsh = self._buf("dsh%d" % i, tuple(sh.shape))          # 1x1 head: its data gradient is a K = 20 GEMM on the packed weights
             ops.gemm(dh.view(-1, HEAD_PAD), w["rpn_head/kernel"], out=dsh.view(-1, 512))
-            ops.relu_bwd(dsh.view(-1, 512), sh.view(-1, 512), dsh.view(-1, 512))
+            dshb = self._bf16_slot(dsh, "dsh%d" % i)            # bf16 model: the copy the two bf16 products below read, written by the same pass
+            ops.relu_bwd(dsh.view(-1, 512), sh.view(-1, 512), dsh.view(-1, 512), out_bf16=None if dshb is None else dshb.view(-1, 512))
             self._wgrad(pm, dsh, 3, 1, g["rpn_conv_shared/kernel"], accumulate=acc, key="P%d" % i, dy_key="dsh%d" % i)
             ops.colsum(dsh.view(-1, 512), out=g["rpn_conv_shared/bias"], accumulate=acc)
             self._dgrad(dsh, wd_shared, 3, dP[i], residual=dP[i], key="rpn_shared", dy_key="dsh%d" % i)     # dP += dgrad
@@ -890,7 +907,7 @@ class DenseImageCapRCNN(object):
         p.forward(self._images_u8(images))
         return self._after_encoder(p, rpn_up, shuffle, backward, gt_caps[0], gt_norm)
 
-    def _after_encoder(self, p, rpn_up, shuffle, backward, gt_caps0, gt_norm):
+    def _after_encoder(self, p, rpn_up, shuffle, backward, gt_caps0, gt_norm, fuse_reg=False):
         """The step behind the encoder pass: proposals, detection targets, RoIAlign, head + decoder, the four losses and (backward)
         every gradient into the flat bucket.  With device-side targets (shuffle None / "rng") nothing in here depends on a host value
         that changes from step to step -- counts, stream positions and lr_t are device words of StepInputs -- so train_on_batch_device
@@ -1033,16 +1050,23 @@ class DenseImageCapRCNN(object):
             self._wgrad(p.pre[i], dP[i], 3, 1, g[name + "/kernel"], dy_key="dP%d" % i)
             ops.colsum(dP[i].view(-1, 256), out=g[name + "/bias"])
             announce(name)
-            dpre.append(self._dgrad(dP[i], wd, 3, self._buf("dpre%d" % i, tuple(dP[i].shape)), key=name, dy_key="dP%d" % i))
+            # (dpre[0] is final here: its bf16 copy comes out of the same epilogue; the coarser ones still receive the top-down sums below)
+            dpre.append(self._dgrad(dP[i], wd, 3, self._buf("dpre%d" % i, tuple(dP[i].shape)), key=name, dy_key="dP%d" % i,
+                                    out_key="dpre0" if i == 0 else None))
         for i in range(3):                                   # pre[k] = upsample(pre[k+1]) + lateral(C_k)
-            ops.downsample2x_sum(dpre[i], out=dpre[i + 1], accumulate=True)
+            ops.downsample2x_sum(dpre[i], out=dpre[i + 1], accumulate=True, out_bf16=self._bf16_slot(dpre[i + 1], "dpre%d" % (i + 1)))
         for i, cmap in enumerate(p.C):
             name = "fpn_c%dp%d" % (i + 2, i + 2)
-            self._wgrad(cmap, dpre[i], 1, 0, g[name + "/kernel"])
+            self._wgrad(cmap, dpre[i], 1, 0, g[name + "/kernel"], dy_key="dpre%d" % i)
             ops.colsum(dpre[i].view(-1, 256), out=g[name + "/bias"])
             announce(name)
         if self.backbone_from is not None:
             self._trunk_backward(p, dpre)
+        if fuse_reg and not self._reg_done:
+            # single-GPU train step: the regulariser's gradient, the trainable mask, the clip norm and losses[3] are the optimizer's
+            # passes (Adam.apply(reg=...)): flat_grad keeps the plain loss gradient and is not rewritten here
+            self._loss_scale = float(loss_rows.numel())
+            return losses
         coef, mask = self._masks()
         if self._reg_done:                                  # the ranges that did not go early (FPN / RPN, anything the decoder skipped)
             n, pos = st.flat.numel(), 0
@@ -1094,8 +1118,8 @@ class DenseImageCapRCNN(object):
         opt = self.optimizer
 
         def body():
-            losses = self._after_encoder(p, rpn_up, "rng", True, gt_caps[0], gt_norm)
-            opt.apply(self.store, grad_scale=1.0, lr_t_dev=rpn_up["lr_t"])
+            losses = self._after_encoder(p, rpn_up, "rng", True, gt_caps[0], gt_norm, fuse_reg=True)
+            opt.apply(self.store, grad_scale=1.0, lr_t_dev=rpn_up["lr_t"], reg=self._reg_segments(), reg_loss=losses[3:4])
             return losses
 
         def step():
@@ -1126,8 +1150,10 @@ class DenseImageCapRCNN(object):
                 self.step_graph_fallback = repr(e)[:200]         # queryable (bench.py reports it): the eager step is a different schedule
                 # the failed capture may have pulled the side stream in (between fork and join): it is in an invalidated-capture state,
                 # so the eager retry forks onto a fresh one
-                self._side_stream = None
                 torch.cuda.synchronize()
+                if self._side_stream is not None:
+                    ops.WORKSPACE.release(self._side_stream)
+                self._side_stream = None
                 return body()
             self._graphs[key], self._graph_out[key] = graph, out
             graph.replay()                                       # (capture records, it does not run: this is the step itself)

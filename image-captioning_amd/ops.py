@@ -4,6 +4,8 @@ All wrappers enqueue on torch's current stream and never synchronise.
 """
 import ctypes as C
 
+import numpy as np
+
 import torch
 
 from . import _lib
@@ -51,10 +53,12 @@ class no_gc_during_capture(object):
 
 class _Workspace:
     """One grow-only scratch buffer per (device, stream) (kernels never allocate).  Per STREAM since round 4: the joint step runs its
-    RPN backward on a side stream beside the proposals / decoder chain, and two streams must not scribble over one scratch buffer.  A
-    buffer created for a new stream starts at the largest size any stream of the device has asked for, so that a hipGraph capture --
-    which runs on a stream of its own, after eager steps have seen every size -- never has to grow (= free) a buffer whose address
-    earlier nodes of the same capture have baked."""
+    RPN backward on a side stream beside the proposals / decoder chain, and two streams must not scribble over one scratch buffer.
+    A buffer that is first asked for DURING a hipGraph capture (a capture runs on a stream of its own, after eager steps have seen
+    every size) starts at the largest size any stream of the device has asked for, so that the capture never has to grow (= free) a
+    buffer whose address earlier nodes have baked; outside a capture a new stream's buffer is sized by what that stream asks for
+    (round 5, ADVICE r4: side / pipeline streams no longer pin a copy of the device-wide high-water mark each).  release() drops the
+    buffers of streams the caller has retired."""
 
     def __init__(self):
         self.buf = {}
@@ -71,12 +75,18 @@ class _Workspace:
         self.hi[device] = hi
         b = self.buf.get(key)
         if b is None or b.numel() < nbytes:
-            b = torch.empty(max(hi, 1 << 20), dtype=torch.uint8, device=device)
+            want = hi if torch.cuda.is_current_stream_capturing() else nbytes + nbytes // 4
+            b = torch.empty(max(want, 1 << 20), dtype=torch.uint8, device=device)
             self.buf[key] = b
         return b, b.numel()
 
     def reserve(self, nbytes, device):
         self.get(nbytes, device)
+
+    def release(self, stream):
+        """Drop the scratch buffer of a torch.cuda.Stream the caller is done with (no captured graph may still reference it)."""
+        for key in [k for k in self.buf if k[1] == stream.cuda_stream]:
+            del self.buf[key]
 
 
 WORKSPACE = _Workspace()
@@ -120,6 +130,15 @@ def gemm(A, B, out=None, a_trans=False, b_trans=False, gather=None, scale=None, 
 
 
 BF16 = torch.bfloat16
+
+
+def from_bf16(x, out):
+    """bf16 -> fp32 (exact) into `out` (dc_cast_bf16_f32); both contiguous, one size."""
+    lib = _lib.load()
+    if not (x.is_contiguous() and out.is_contiguous()) or x.numel() != out.numel():
+        raise _lib.DcapError("from_bf16: contiguous tensors of one size")
+    check(lib.dc_cast_bf16_f32(_ptr(_chk(x, BF16, "x")), _ptr(_chk(out, name="out")), x.numel(), _stream()), "dc_cast_bf16_f32")
+    return out
 
 
 def to_bf16(x, out=None, pad_cols=None):
@@ -338,13 +357,15 @@ def wgrad_bf16_supported(x_shape, dy_shape):
     return x_shape[-1] % 128 == 0 and dy_shape[-1] % 8 == 0
 
 
-def downsample2x_sum(fine, out=None, accumulate=False):
+def downsample2x_sum(fine, out=None, accumulate=False, out_bf16=None):
+    """out (+)= the 2x2 block sums of fine [N,H,W,C] (the adjoint of UpSampling2D(2)); out_bf16: the bf16 copy of out, same pass."""
     lib = _lib.load()
     _chk(fine, name="fine")
     N, H, W, Cc = fine.shape
     if out is None:
         out = torch.empty((N, H // 2, W // 2, Cc), dtype=torch.float32, device=fine.device)
-    check(lib.dc_downsample2x_sum_f32(_ptr(fine), _ptr(out), N, H // 2, W // 2, Cc, int(accumulate), _stream()), "dc_downsample2x_sum_f32")
+    check(lib.dc_downsample2x_sum_dual_f32(_ptr(fine), _ptr(out), None if out_bf16 is None else _ptr(_chk(out_bf16, BF16, "out_bf16")), N, H // 2, W // 2, Cc,
+                                           int(accumulate), _stream()), "dc_downsample2x_sum_dual_f32")
     return out
 
 
@@ -746,10 +767,16 @@ def axpy(a, x, y):
     return y
 
 
-def relu_bwd(dy, y, out):
-    """out = dy where y > 0 else 0 (all [M,N] with one row stride)."""
+def relu_bwd(dy, y, out, out_bf16=None):
+    """out = dy where y > 0 else 0 (all [M,N] with one row stride).  out_bf16 (contiguous operands only): the bf16 copy of the result,
+    written in the same pass (dc_relu_bwd_dual_f32)."""
     lib = _lib.load()
     _chk(dy, name="dy"), _chk(y, name="y"), _chk(out, name="out")
+    if out_bf16 is not None:
+        if not (dy.is_contiguous() and y.is_contiguous() and out.is_contiguous() and out_bf16.is_contiguous()) or out_bf16.numel() != out.numel():
+            raise _lib.DcapError("relu_bwd: the bf16 copy needs contiguous operands of one size")
+        check(lib.dc_relu_bwd_dual_f32(_ptr(dy), _ptr(y), _ptr(out), _ptr(_chk(out_bf16, BF16, "out_bf16")), out.numel(), _stream()), "dc_relu_bwd_dual_f32")
+        return out
     if not (dy.stride(0) == y.stride(0) == out.stride(0)):
         raise _lib.DcapError("relu_bwd: tensors must share a row stride")
     check(lib.dc_relu_bwd_f32(_ptr(dy), _ptr(y), _ptr(out), y.shape[0], y.shape[1], y.stride(0), _stream()), "dc_relu_bwd_f32")
@@ -837,8 +864,36 @@ def maxpool3x3s2_same_bwd(x, y, dy, out=None):
     return out
 
 
+class RegSegmentTable(object):
+    """dc_reg_segments on the device: the run-length form of the per-element regulariser coefficient / trainable-mask vectors of a flat
+    parameter bucket (coef, mask: host float32 arrays of the bucket's length; mask None = everything trains)."""
+
+    def __init__(self, coef, mask, device):
+        coef = np.ascontiguousarray(coef, np.float32)
+        mask = np.ones_like(coef) if mask is None else np.ascontiguousarray(mask, np.float32)
+        n = coef.shape[0]
+        cut = np.flatnonzero((coef[1:] != coef[:-1]) | (mask[1:] != mask[:-1])) + 1
+        start = np.concatenate([[0], cut, [n]]).astype(np.int32)
+        self.n, self.nseg = n, len(start) - 1
+        self.start = torch.tensor(start, device=device)
+        self.coef = torch.tensor(coef[start[:-1]], device=device)
+        self.mask = torch.tensor(mask[start[:-1]], device=device)
+        self.c = _lib.RegSegments(self.start.data_ptr(), self.coef.data_ptr(), self.mask.data_ptr(), self.nseg)
+
+
+def reg_sumsq(w, g, segs, loss=None, gnorm_sq=None):
+    """One read-only pass: loss[0] = sum coef w^2, gnorm_sq[0] = sum (g mask + 2 coef w)^2 (dc_reg_sumsq_f32), fixed summation order."""
+    lib = _lib.load()
+    if segs.n != w.numel() or g.numel() != w.numel():
+        raise _lib.DcapError("reg_sumsq: the segment table covers %d elements, the bucket has %d" % (segs.n, w.numel()))
+    ws, wsb = WORKSPACE.get(lib.dc_reg_sumsq_workspace_bytes(w.numel()), w.device)
+    check(lib.dc_reg_sumsq_f32(_ptr(_chk(w, name="w")), _ptr(_chk(g, name="g")), C.byref(segs.c), w.numel(), None if loss is None else _ptr(loss),
+                               None if gnorm_sq is None else _ptr(gnorm_sq), _ptr(ws), wsb, _stream()), "dc_reg_sumsq_f32")
+    return loss, gnorm_sq
+
+
 def amsgrad_step(p, g, m, v, vhat, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, gnorm_sq=None, clipnorm=0.0, p_bf16=None,
-                 lr_t_dev=None):
+                 lr_t_dev=None, reg=None):
     lib = _lib.load()
     d = AmsgradDesc()
     d.n = p.numel()
@@ -851,4 +906,8 @@ def amsgrad_step(p, g, m, v, vhat, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_
         d.p_bf16, d.n_bf16 = _chk(p_bf16, BF16, "p_bf16").data_ptr(), p_bf16.numel()
     if lr_t_dev is not None:
         d.lr_t_dev = _chk(lr_t_dev, name="lr_t_dev").data_ptr()
+    if reg is not None:                                    # regulariser + trainable mask applied inside the update (RegSegmentTable)
+        if reg.n != p.numel():
+            raise _lib.DcapError("amsgrad_step: the segment table covers %d elements, the bucket has %d" % (reg.n, p.numel()))
+        d.reg = C.pointer(reg.c)
     check(lib.dc_amsgrad_step_f32(C.byref(d), _stream()), "dc_amsgrad_step_f32")

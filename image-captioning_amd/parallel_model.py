@@ -56,12 +56,23 @@ def shard(x, rank, world):
 
 class GradAllReduce(object):
     """Callable installed as model.grad_sync: sums the gradient bucket over ranks (in `buckets` chunks so
-    RCCL can pipeline them over all 7 xGMI links) and returns the scale (1/world) the optimizer applies."""
+    RCCL can pipeline them over all 7 xGMI links) and returns the scale (1/world) the optimizer applies.
 
-    def __init__(self, group=None, bucket_bytes=64 << 20):
+    dtype='bf16' (round 5; SURVEY section 5: configs[4]'s exchange is specified in bf16): every range is rounded into a persistent bf16
+    bucket as it becomes final, the bf16 slices are all-reduced -- half the bytes per link: ~150 MB instead of ~300 MB for the joint
+    model's 77 M parameters -- and the summed bf16 values go back into the fp32 gradient bucket before the clip norm and AMSGrad read
+    it (fp32 master weights, fp32 optimizer state; only the wire format changes).  Every rank receives the same bits from the
+    collective, so replicas stay bit-identical; the update differs from the fp32 exchange by bf16 rounding of the gradient
+    (tests/test_dp_gloo.py, tests/test_gpu_multirank.py).  DCAP_GRAD_DTYPE=bf16 selects it for ParallelModel."""
+
+    def __init__(self, group=None, bucket_bytes=64 << 20, dtype="f32"):
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("GradAllReduce dtype must be 'f32' or 'bf16'")
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.bucket_elems = max(1, bucket_bytes // 4)
+        self.dtype = dtype
+        self.bucket_elems = max(1, bucket_bytes // (2 if dtype == "bf16" else 4))
+        self._wire = None               # bf16: the persistent bf16 twin of the gradient bucket
 
         self._pending = []              # (work handle, lo, hi) of the ranges already on the wire this step
         self.ranks_seen = None          # world size RCCL reported after a real all-reduce (bench.py prints it)
@@ -76,9 +87,33 @@ class GradAllReduce(object):
         (bucketed against backward).  Ranges are cut into bucket_elems pieces."""
         if self.world == 1 or hi <= lo:
             return
+        src = flat_grad
+        if self.dtype == "bf16":
+            if self._wire is None or self._wire.numel() != flat_grad.numel() or self._wire.device != flat_grad.device:
+                self._wire = torch.empty(flat_grad.numel(), dtype=torch.bfloat16, device=flat_grad.device)
+            self._round(flat_grad[lo:hi], self._wire[lo:hi])
+            src = self._wire
         for o in range(lo, hi, self.bucket_elems):
             e = min(hi, o + self.bucket_elems)
-            self._pending.append((dist.all_reduce(flat_grad[o:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True), o, e))
+            self._pending.append((dist.all_reduce(src[o:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True), o, e))
+
+    @staticmethod
+    def _round(src, dst):
+        """fp32 -> bf16 (round to nearest even) of one range.  On the GPU the library's cast kernel; host tensors (the gloo tests of
+        the bucket logic run without a GPU) take torch's conversion, which rounds the same way."""
+        if src.is_cuda:
+            from . import ops
+            ops.to_bf16(src, out=dst)
+        else:
+            dst.copy_(src)
+
+    @staticmethod
+    def _widen(src, dst):
+        if src.is_cuda:
+            from . import ops
+            ops.from_bf16(src, dst)
+        else:
+            dst.copy_(src)
 
     def __call__(self, flat_grad):
         """Finish the step's exchange: reduce whatever ready() has not covered, wait for everything in flight (the
@@ -103,8 +138,21 @@ class GradAllReduce(object):
             e1.record()
             self._host_wait += time.perf_counter() - t0
             self._marks.append((e0, e1))
+        if self.dtype == "bf16":                             # the summed bf16 values back into the fp32 bucket (exact)
+            for lo, hi in self._merged(sorted((lo, hi) for _, lo, hi in self._pending)):
+                self._widen(self._wire[lo:hi], flat_grad[lo:hi])
         self._pending = []
         return 1.0 / self.world
+
+    @staticmethod
+    def _merged(ranges):
+        out = []
+        for lo, hi in ranges:
+            if out and lo <= out[-1][1]:
+                out[-1][1] = max(out[-1][1], hi)
+            else:
+                out.append([lo, hi])
+        return out
 
     def exposed_ms(self, reset=True):
         """(mean exposed all-reduce time per step on the compute stream in ms, mean host wait per step in ms, steps) since the last
@@ -137,7 +185,8 @@ class ParallelModel(object):
     the torch.distributed world size (one process per GPU).  Attribute access falls through to the
     wrapped model (the reference's __getattribute__ trick, parallel_model.py:41-46)."""
 
-    def __init__(self, keras_model, gpu_count):
+    def __init__(self, keras_model, gpu_count, grad_dtype=None):
+        """grad_dtype: 'f32' (default) or 'bf16' = the gradient exchange's wire format (GradAllReduce); DCAP_GRAD_DTYPE sets the default."""
         world = dist.get_world_size() if dist.is_initialized() else 1
         if gpu_count != world:
             raise ValueError("gpu_count=%d but %d process(es) are running: launch one process per GPU "
@@ -146,7 +195,7 @@ class ParallelModel(object):
         self.gpu_count = gpu_count
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         reserve_cus_for_collectives(world)
-        keras_model.grad_sync = GradAllReduce()
+        keras_model.grad_sync = GradAllReduce(dtype=grad_dtype or os.environ.get("DCAP_GRAD_DTYPE", "f32"))
         keras_model.is_chief = self.rank == 0          # one rank prints and writes checkpoints (the others barrier)
         keras_model._outer = self                      # the wrapped model's train() loop feeds global batches through this wrapper
         self.broadcast_weights()

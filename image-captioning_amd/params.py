@@ -120,18 +120,26 @@ class Adam:
         t = self.iterations
         return self.lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
 
-    def apply(self, store, grad_scale=1.0, lr_t_dev=None):
+    def apply(self, store, grad_scale=1.0, lr_t_dev=None, reg=None, reg_loss=None):
         """One update of every trainable weight from store.flat_grad (scaled by grad_scale, e.g.
         1/world_size after a summing all-reduce).  lr_t_dev: a float32 device word holding this step's lr_t (the caller wrote
         lr * sqrt(1 - b2^t) / (1 - b1^t) for t = iterations + 1 there): the launch then carries no per-step host value and can be
-        replayed from a captured hipGraph."""
+        replayed from a captured hipGraph.
+        reg (ops.RegSegmentTable): the joint model's L2 regulariser and trainable mask are applied INSIDE the update -- store.flat_grad
+        holds the plain loss gradient and is left alone; one read-only pass over (weights, gradient) gives the clip norm of the
+        regularised gradient and the regulariser's loss term (-> reg_loss[0]) -- instead of a pass that rewrites the gradient bucket
+        (three reads + one write) followed by a norm pass (one more read)."""
         if self._state is None:
             self._init(store)
         self.iterations += 1
         m, v, vh = self._state
         gn = None
-        if self.clipnorm:
+        if reg is not None:
+            if self.clipnorm or reg_loss is not None:
+                ops.reg_sumsq(store.flat, store.flat_grad, reg, loss=reg_loss, gnorm_sq=self._gnorm if self.clipnorm else None)
+            gn = self._gnorm if self.clipnorm else None
+        elif self.clipnorm:
             gn = ops.sumsq(store.flat_grad, out=self._gnorm)
         ops.amsgrad_step(store.flat, store.flat_grad, m, v, vh, self.lr_t(), self.beta_1, self.beta_2, self.epsilon,
                          grad_scale=grad_scale, gnorm_sq=gn, clipnorm=self.clipnorm or 0.0, p_bf16=getattr(store, "flat_bf16", None),
-                         lr_t_dev=lr_t_dev)
+                         lr_t_dev=lr_t_dev, reg=reg)

@@ -150,6 +150,9 @@ int    dc_conv2d_bf16_tile(const dc_conv_bf16_desc* d, int* split_k);
 /* fp32 -> bf16 (round to nearest even): the bf16 shadow of weights / activations that feed dc_gemm_bf16.
  * _2d: rows x cols with row strides, output columns cols..cols_out-1 zero-filled (pads K to a multiple of 8). */
 int dc_cast_f32_bf16(const float* x, uint16_t* out, size_t n, void* stream);
+/* bf16 -> fp32 (exact).  Data-parallel joint model with a bf16 gradient exchange (configs[4]'s buckets travel as bf16,
+ * half the bytes on xGMI): the all-reduced bf16 bucket goes back into the fp32 gradient bucket the clip norm and AMSGrad read. */
+int dc_cast_bf16_f32(const uint16_t* x, float* out, size_t n, void* stream);
 int dc_cast_f32_bf16_2d(const float* x, int ld_in, uint16_t* out, int ld_out, int rows, int cols, int cols_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -312,6 +315,8 @@ int dc_roi_align_pyramid_bwd_f32(const dc_roialign_desc* d, void* stream);
 /* FPN top-down backward: out[n,y,x,c] (+)= sum of the 2x2 block of fine[n,2y..2y+1,2x..2x+1,c]
  * (the gradient of UpSampling2D(2) + Add, dense_model.py:1407-1415). */
 int dc_downsample2x_sum_f32(const float* fine, float* out, int N, int Ho, int Wo, int C, int accumulate, void* stream);
+/* ... and, in the same pass, the bf16 copy of `out` that the bf16 weight-gradient GEMM of the lateral convolution reads (NULL: none). */
+int dc_downsample2x_sum_dual_f32(const float* fine, float* out, uint16_t* out_bf16, int N, int Ho, int Wo, int C, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Keras-2.1 LSTM over a whole sequence (gate blocks i,f,c,o; hard-sigmoid gates; tanh; mask carry).
@@ -515,6 +520,9 @@ int dc_axpy_f32(float a, const float* x, float* y, size_t n, void* stream);
 
 /* out = (y > 0) ? dy : 0 over [M][N] (row strides ld): backward of Activation('relu') given its output. */
 int dc_relu_bwd_f32(const float* dy, const float* y, float* out, int M, int N, int ld, void* stream);
+/* The same over n contiguous elements (n % 4 == 0) with 16-byte accesses, writing the fp32 result and / or its bf16 copy (either may be
+ * NULL): the RPN branch's d(shared) feeds bf16 convolutions, and a separate cast pass would read the fp32 result once more. */
+int dc_relu_bwd_dual_f32(const float* dy, const float* y, float* out, uint16_t* out_bf16, size_t n, void* stream);
 
 /* out[b][n] = sum_t x[t*B + b][n]  (time-major fold: the per-RoI gradient of a term that was broadcast
  * over timesteps -- RepeatVector(feature), text_generation_model.py:146). */
@@ -560,6 +568,17 @@ int dc_maxpool3x3s2_same_bwd_f32(const float* x, const float* y, const float* dy
 /* mean of loss rows: out[0] = sum(x)/n. */
 int dc_mean_f32(const float* x, size_t n, float* out, void* stream);
 
+/* Piecewise-constant per-element coefficients over a flat parameter bucket: segment s covers elements [start[s], start[s+1]) and
+ * carries coef[s] (WEIGHT_DECAY / size(tensor), 0 for BatchNorm gamma / beta and padding) and mask[s] (1 = trainable, 0 = frozen;
+ * mask NULL = everything trains).  The arrays live in DEVICE memory; start has nseg + 1 ascending entries, start[0] = 0, start[nseg] = n.
+ * Replaces the two n-element float vectors dc_l2_reg_f32 reads (2 x 300 MB per step for the joint model's 77 M parameters). */
+typedef struct {
+    const int32_t* start;
+    const float* coef;
+    const float* mask;
+    int nseg;
+} dc_reg_segments;
+
 /* ------------------------------------------------------------------------------------------------
  * keras.optimizers.Adam(amsgrad=True) fused over one flat parameter bucket
  * (text_generation_model.py:425; _v2.py:266): with g' = g * grad_scale * clip,
@@ -583,9 +602,21 @@ typedef struct {
     size_t n_bf16;            /* the shadow covers p[0 .. n_bf16) (a multiple of 4) */
     const float* lr_t_dev;    /* optional: a device word that overrides lr_t (Keras' lr_t depends on the iteration count; a captured
                                  hipGraph reads this step's value from memory the host refreshed before the replay) */
+    const dc_reg_segments* reg; /* optional (HOST pointer, read during the call): the joint model's regulariser and trainable mask applied
+                                 INSIDE this pass -- the gradient the update sees is g * mask + 2 * coef * p with per-segment constants --
+                                 instead of by a dc_l2_reg_f32 pass that rewrites the gradient bucket first; gnorm_sq must then come from
+                                 dc_reg_sumsq_f32 (the norm of that same regularised gradient).  The gradient bucket is left as it was */
 } dc_amsgrad_desc;
 
 int dc_amsgrad_step_f32(const dc_amsgrad_desc* d, void* stream);
+
+/* One READ-ONLY pass over (w, g) in front of the fused update above (round 5: replaces dc_l2_reg_f32 + dc_sumsq_f32 = three reads and
+ * one write of the bucket + one more read, by two reads): loss[0] = sum coef * w^2 (the L2 term of dense_img_cap/dense_model.py:1715-1718),
+ * gnorm_sq[0] = sum (g * mask + 2 * coef * w)^2 (what Adam(clipnorm=0.5), :1699, clips by), both as block partials in block order
+ * through `workspace`, added by one block in a fixed tree (bit-reproducible).  Either output may be NULL. */
+size_t dc_reg_sumsq_workspace_bytes(size_t n);
+int dc_reg_sumsq_f32(const float* w, const float* g, const dc_reg_segments* reg, size_t n, float* loss, float* gnorm_sq, void* workspace,
+                     size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,7 @@ def main():
     rank, world, _ = init_process_group_from_env()
     model = build()
     pm = ParallelModel(model, world)
+    assert model.grad_sync.dtype == os.environ.get("DCAP_GRAD_DTYPE", "f32")        # the wire format the test asked for
     inputs, _ = global_inputs(world)
     losses = [pm.train_on_batch(inputs) for _ in range(steps)]
     torch.cuda.synchronize()

@@ -57,6 +57,43 @@ def test_two_rank_gradient_average_equals_single_rank(tmp_path):
     assert err < 1e-12
 
 
+def _worker_bf16_exchange(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from image_captioning_amd.parallel_model import GradAllReduce, init_process_group_from_env
+    init_process_group_from_env(backend="gloo")
+    n = 40000
+    g = torch.tensor(np.random.default_rng(100 + rank).standard_normal(n).astype(np.float32) * 10.0 ** np.random.default_rng(7).uniform(-6, 1, n).astype(np.float32))
+    out = {}
+    for dtype in ("f32", "bf16"):
+        flat = g.clone()
+        sync = GradAllReduce(bucket_bytes=1 << 14, dtype=dtype)
+        sync.ready(flat, 30000, 36000)                    # layer groups announce their ranges as their backward finishes: out of order,
+        sync.ready(flat, 4000, 12000)                     # several buckets each; the final call covers the rest
+        assert sync(flat) == 1.0 / world and not sync._pending
+        out[dtype] = flat.numpy().copy()
+    np.save(os.path.join(out_dir, "bf16_rank%d.npy" % rank), np.stack([out["f32"], out["bf16"], g.numpy()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bf16_gradient_exchange_two_ranks(tmp_path):
+    """GradAllReduce(dtype='bf16') (configs[4]'s gradient buckets travel as bf16): every element of the bucket is
+    exchanged exactly once whatever the order of the ready() calls, both replicas end with the same bits, the result is the bf16 sum of
+    the bf16-rounded tower gradients -- within bf16 rounding (2^-8 relative per value) of the fp32 exchange."""
+    world = 2
+    mp.spawn(_worker_bf16_exchange, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / ("bf16_rank%d.npy" % k)) for k in range(world)]
+    np.testing.assert_array_equal(r[0][0], r[1][0])
+    np.testing.assert_array_equal(r[0][1], r[1][1])                       # replicas: bit-identical
+    f32, b16 = r[0][0].astype(np.float64), r[0][1].astype(np.float64)
+    g0, g1 = r[0][2].astype(np.float64), r[1][2].astype(np.float64)
+    np.testing.assert_allclose(f32, g0 + g1, rtol=1e-6, atol=0)
+    bf = lambda a: torch.tensor(a, dtype=torch.float32).to(torch.bfloat16).to(torch.float64).numpy()
+    np.testing.assert_array_equal(b16, bf(bf(g0) + bf(g1)))               # what a bf16 wire carries
+    scale = np.abs(g0) + np.abs(g1)
+    assert np.all(np.abs(b16 - (g0 + g1)) <= 3 * 2.0 ** -8 * scale + 1e-30)
+
+
 def test_shard_is_tf_split():
     from image_captioning_amd.parallel_model import shard
     x = np.arange(12).reshape(6, 2)

@@ -530,6 +530,56 @@ def test_amsgrad_trajectory(ops, clip):
     close(vh, Vh, 1e-5)
 
 
+def test_amsgrad_with_the_regulariser_inside_the_update(ops):
+    """dc_reg_sumsq_f32 + dc_amsgrad_step_f32(reg=segments) (round 5: the joint model's L2 term, trainable mask and clip norm without
+    rewriting the gradient bucket) against the float64 oracle -- g' = g mask + 2 coef w, clip by the global norm of g', AMSGrad -- and
+    against the three-pass path it replaces (dc_l2_reg_f32, dc_sumsq_f32, dc_amsgrad_step_f32).  Segments end inside float4 vectors
+    (the fused RPN head's bias: 6 + 12 + 2 elements) and the bucket length is no multiple of 4."""
+    rng = np.random.default_rng(9)
+    bounds = [0, 6, 18, 20, 1021, 1024, 5000, 5003, 9001, 10007]
+    n = bounds[-1]
+    coef = np.zeros(n, np.float32)
+    mask = np.ones(n, np.float32)
+    for s_, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
+        coef[lo:hi] = 0.0 if s_ % 3 == 2 else 1e-4 / (hi - lo)
+        mask[lo:hi] = 0.0 if s_ in (3, 6) else 1.0
+    for use_mask in (True, False):
+        mk = mask if use_mask else None
+        segs = ops.RegSegmentTable(coef, mk, "cuda")
+        assert segs.nseg <= len(bounds) - 1 and segs.n == n
+        p0 = rng.standard_normal(n)
+        pa, pb = dev(p0), dev(p0)
+        st_a = [torch.zeros(n, device="cuda") for _ in range(3)]
+        st_b = [torch.zeros(n, device="cuda") for _ in range(3)]
+        P, Mm, Vv, Vh = p0.astype(np.float32).astype(np.float64), 0.0, 0.0, 0.0
+        loss, gn = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+        for t in range(1, 5):
+            g = rng.standard_normal(n) * (0.5 ** t)
+            g32 = g.astype(np.float32).astype(np.float64)
+            gr = g32 * (1.0 if mk is None else mk) + 2.0 * coef.astype(np.float64) * P
+            want_loss = float((coef.astype(np.float64) * P * P).sum())
+            (gc,), _ = O.clip_by_global_norm([gr], 0.5)
+            lr_t = 1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+            # fused: the gradient bucket is read twice and never written
+            ga = dev(g)
+            keep = ga.clone()
+            ops.reg_sumsq(pa, ga, segs, loss=loss, gnorm_sq=gn)
+            assert abs(float(loss.item()) - want_loss) < 1e-5 * max(want_loss, 1e-12)
+            assert abs(float(gn.item()) - float((gr * gr).sum())) < 1e-5 * float((gr * gr).sum())
+            ops.amsgrad_step(pa, ga, *st_a, lr_t, gnorm_sq=gn, clipnorm=0.5, reg=segs)
+            assert torch.equal(ga, keep)
+            # the path it replaces
+            gb = dev(g)
+            ops.l2_reg(pb, dev(coef), gb, mask=None if mk is None else dev(mk))
+            ops.amsgrad_step(pb, gb, *st_b, lr_t, gnorm_sq=ops.sumsq(gb), clipnorm=0.5)
+            P, Mm, Vv, Vh = O.amsgrad_step(P, gc, Mm, Vv, Vh, t)
+        close(pa, P, 1e-6)
+        close(st_a[2], Vh, 1e-5)
+        assert float((pa - pb).abs().max()) < 1e-6 * float(pb.abs().max())
+    with pytest.raises(Exception):
+        ops.amsgrad_step(pa[:100], ga[:100], *[t_[:100] for t_ in st_a], 1e-3, reg=segs)       # a table for another bucket
+
+
 def test_subsample2(ops):
     x = np.random.default_rng(0).standard_normal((2, 8, 6, 8))
     close(ops.subsample2(dev(x)), O.subsample2(x), 1e-7)

@@ -85,8 +85,12 @@ def test_configs3_shaped_step_two_ranks_at_the_full_per_rank_size(tmp_path):
     assert np.abs(r[0]["flat"] - single).max() < 2e-5 * np.abs(single).max()
 
 
-def test_joint_model_two_ranks_average_the_tower_gradients(tmp_path):
-    """The joint model (configs[4]'s model at a small size) under ParallelModel, one image per rank: after a step every replica
+@pytest.mark.parametrize("grad_dtype", ["f32", "bf16"])
+def test_joint_model_two_ranks_average_the_tower_gradients(tmp_path, grad_dtype):
+    """grad_dtype = 'bf16': the same step with the gradient exchange in bf16 buckets (DCAP_GRAD_DTYPE / GradAllReduce(dtype='bf16'),
+    SURVEY section 5: configs[4]'s wire format): replicas still bit-identical; the weights differ from the fp32 exchange's by the bf16
+    rounding of the summed gradient only (a small fraction of one AMSGrad step).
+    The joint model (configs[4]'s model at a small size) under ParallelModel, one image per rank: after a step every replica
     holds the same weights, and they are the weights a single process gets from the MEAN of the two images' gradient buckets
     (the reference's mean-of-tower-means, parallel_model.py:58-102) through the same clip + AMSGrad update."""
     if not torch.cuda.is_available():
@@ -99,7 +103,7 @@ def test_joint_model_two_ranks_average_the_tower_gradients(tmp_path):
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   DCAP_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   DCAP_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0", DCAP_GRAD_DTYPE=grad_dtype)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dp_joint_worker.py"), str(tmp_path), str(steps)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
@@ -126,4 +130,7 @@ def test_joint_model_two_ranks_average_the_tower_gradients(tmp_path):
     assert moved > 0
     diff = np.abs(r[0]["flat"] - single).max()
     print("joint 2-rank vs averaged single process: max |dw| = %.3e of a %.3e update" % (diff, moved))
+    if grad_dtype == "bf16":
+        assert moved > 0 and diff < 0.1 * moved, (diff, moved)          # same update up to the wire's rounding; not the fp32 bits
+        return
     assert moved > 0 and diff == 0.0      # bit-equal (round 2: 2e-3 of the update -- RoIAlign's backward was an atomic scatter then; it is a fixed-order gather now)
