@@ -44,7 +44,7 @@ class ConvDesc(C.Structure):
                 ("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p),
                 ("scale", C.c_void_p), ("shift", C.c_void_p),
                 ("residual", C.c_void_p), ("res_mode", C.c_int),
-                ("relu", C.c_int), ("split_k", C.c_int), ("accumulate", C.c_int), ("math", C.c_int), ("w_wino", C.c_void_p)]
+                ("relu", C.c_int), ("split_k", C.c_int), ("accumulate", C.c_int), ("math", C.c_int), ("w_wino", C.c_void_p), ("w_wino_b3", C.c_void_p)]
 
 
 class ConvWgradBf16Desc(C.Structure):
@@ -171,6 +171,8 @@ SYMBOLS = {
     "dc_conv2d_is_pointwise": (C.c_int, [C.POINTER(ConvDesc)]),
     "dc_conv2d_winograd_weight_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "dc_conv2d_winograd_pack_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "dc_conv2d_winograd_b3_weight_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "dc_conv2d_winograd_pack_b3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dc_conv2d_kernel_name": (C.c_int, [C.POINTER(ConvDesc), C.c_char_p, C.c_size_t]),
     "dc_conv2d_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "dc_conv2d_wgrad_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p]),

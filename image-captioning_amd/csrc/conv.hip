@@ -259,7 +259,7 @@ extern "C" int dc_conv2d_kernel_name(const dc_conv_desc* d, char* buf, size_t bu
         return DC_OK;
     }
     if (!stem && conv_winograd_supported(d)) {
-        snprintf(buf, buf_bytes, "wino%d_kernel", conv_winograd_tiles(d));
+        snprintf(buf, buf_bytes, "wino%d%s_kernel", conv_winograd_tiles(d), conv_winograd_split_bf16(d) ? "b" : "");
         return DC_OK;
     }
     const bool pw = !stem && conv_is_pointwise(d);

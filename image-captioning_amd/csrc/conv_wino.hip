@@ -26,7 +26,7 @@
 //     item, the input patch staged ONCE per 32 channels by LDS-DMA, no V image -- every wave makes its own MFMA fragments straight
 //     from the patch --, persistent blocks, vector-memory instructions issued one per MFMA: 639 us.  64-tile items (512 threads,
 //     one block per CU) where every CU gets one, 32-tile items (256 threads, two blocks per CU) for the small layers.
-#include "igemm_core.h"
+#include "igemm_bf16s.h"
 #include <algorithm>
 
 namespace dcap {
@@ -71,6 +71,44 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
             for (int b = 0; b < 4; ++b) {
                 const int xi = 4 * a + b;
                 u[((((long)(xi * NTG + ntg) * KC + kc) * 2 + j) * 64 + (h * 32 + i)) * 4 + e] = r[b];
+            }
+        }
+    }
+}
+
+// The same U for the split-bf16 kernels (wino_body<.., true>): every element as three bf16 pieces (x = p0 + p1 + p2, rounded to
+// nearest even, remainders exact) in the fragment order of v_mfma_f32_32x32x16_bf16: ushort index
+//   (((((xi * NTG + ntg) * KC16 + kc) * 3 + piece) * 64 + lane) * 8 + jj),  lane = 32 h + i  <->  cout = 32 ntg + i, cin = 16 kc + 8 h + jj
+__global__ void wino_pack_b3_kernel(const float* __restrict__ w, unsigned short* __restrict__ u, int Cin, int Cout) {
+    const long total = (long)Cin * Cout;
+    const int NTG = Cout / 32, KC = Cin / 16;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int cin = (int)(idx % Cin), cout = (int)(idx / Cin);
+        float g[3][3];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = w[((long)cout * 9 + t) * Cin + cin];
+        float gg[4][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            gg[0][c] = g[0][c];
+            gg[1][c] = 0.5f * (g[0][c] + g[1][c] + g[2][c]);
+            gg[2][c] = 0.5f * (g[0][c] - g[1][c] + g[2][c]);
+            gg[3][c] = g[2][c];
+        }
+        const int ntg = cout >> 5, i = cout & 31, kc = cin >> 4, kk = cin & 15, h = kk >> 3, jj = kk & 7;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float r[4] = {gg[a][0], 0.5f * (gg[a][0] + gg[a][1] + gg[a][2]), 0.5f * (gg[a][0] - gg[a][1] + gg[a][2]), gg[a][2]};
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int xi = 4 * a + b;
+                float x = r[b];
+#pragma unroll
+                for (int piece = 0; piece < 3; ++piece) {
+                    const unsigned short pb = __builtin_bit_cast(unsigned short, (__bf16)x);
+                    x -= __uint_as_float((unsigned)pb << 16);
+                    u[((((long)(xi * NTG + ntg) * KC + kc) * 3 + piece) * 64 + (h * 32 + i)) * 8 + jj] = pb;
+                }
             }
         }
     }
@@ -128,7 +166,31 @@ struct Cfg {
 };
 }
 
-template <int HALVES>
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// eight fp32 values (channels 8 h + 0..3 in va, 8 h + 4..7 in vb) -> the three bf16x8 pieces of an MFMA operand fragment
+__device__ __forceinline__ void split8(const f4& va, const f4& vb, u32x4& p0, u32x4& p1, u32x4& p2) {
+    unsigned a0, a1, a2, b0, b1, b2, c0, c1, c2, d0, d1, d2;
+    split_pair(va[0], va[1], a0, a1, a2);
+    split_pair(va[2], va[3], b0, b1, b2);
+    split_pair(vb[0], vb[1], c0, c1, c2);
+    split_pair(vb[2], vb[3], d0, d1, d2);
+    p0 = u32x4{a0, b0, c0, d0};
+    p1 = u32x4{a1, b1, c1, d1};
+    p2 = u32x4{a2, b2, c2, d2};
+}
+__device__ __forceinline__ f32x16 mfma_b(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// B3 = true (round 5): the 16 products per tile on the BF16 matrix pipe in split arithmetic -- U pre-split once per frozen weight into
+// three bf16 pieces (wino_pack_b3_kernel), the transformed patch values V split in registers, six v_mfma_f32_32x32x16_bf16 products
+// per fp32 product (p0 q0 + p0 q1 + p1 q0 + p0 q2 + p1 q1 + p2 q0, small terms first, fp32 accumulation: the arithmetic of
+// DC_MATH_BF16X3, igemm_bf16s.h, which holds the fp32 kernel's tolerances).  Per 16-channel chunk and wave: 24 MFMAs of 32 cycles
+// instead of 32 of 64 (the fp32 matrix pipe's floor per 32-channel pair 3.41 us -> 1.28); the patch staging, the transform, the
+// output transform and the persistent item walk are the fp32 kernel's.  A lane's fragment of a K = 16 MFMA is its 8 channels
+// 8 h .. 8 h + 7 of the chunk: the values of the fp32 kernel's steps j = 0 and j = 1 side by side.
+template <int HALVES, bool B3>
 __device__ __forceinline__ void wino_body(const Args& a) {
     using namespace wp;
     typedef Cfg<HALVES> C;
@@ -147,6 +209,7 @@ __device__ __forceinline__ void wino_body(const Args& a) {
     int nb, img, gyi, gxi;
     unsigned doff[NDMA];
     const f4* ubase;
+    const u32x4* ubase3;                                   // B3: 16 bytes per lane, fragment (b, kc, piece) at b * ustep3 + (3 kc + piece) * 64
     auto setup = [&](int item) {
         const int bid = xcd_remap(item, total);            // gridDim.x % 8 == 0: item % 8 is this block's XCD for every item it takes
         nb = bid / a.groups;
@@ -165,6 +228,7 @@ __device__ __forceinline__ void wino_body(const Args& a) {
             doff[n] = in ? (unsigned)(((((long)img * a.H + iy) * a.W + ix) * a.Cin + 4 * c8) * 4) : kOobOffset;
         }
         ubase = a.u + lane + (((long)(4 * wa) * NTG + nb) * KC << 7);
+        ubase3 = reinterpret_cast<const u32x4*>(a.u) + lane + (((long)(4 * wa) * NTG + nb) * KC * 3 << 6);
     };
     auto issue_dma_pieces = [&](int pair, int buf, int n0, int n1) {
 #pragma unroll
@@ -183,6 +247,13 @@ __device__ __forceinline__ void wino_body(const Args& a) {
         }
     };
     auto load_u = [&](f4 (&dst)[4][2], int kc) { load_u_part(dst, kc, 0, 4); };
+    const long ustep3 = (long)NTG * KC * 3 << 6;
+    auto load_u3 = [&](u32x4 (&dst)[3], int kc, int b) {
+        const u32x4* p = ubase3 + b * ustep3 + ((long)kc * 3 << 6);
+        dst[0] = p[0];
+        dst[1] = p[64];
+        dst[2] = p[128];
+    };
 
     // ---- fragment geometry: lane (tile i of this wave's half, k-half h); transform row wa combines patch rows r1, r2
     const int fi = lane & 31, fh = lane >> 5;
@@ -219,7 +290,13 @@ __device__ __forceinline__ void wino_body(const Args& a) {
     setup(item);
     issue_dma(0, 0);
     f4 ub[2][4][2];
-    load_u(ub[0], 0);
+    u32x4 u3[4][3];                                        // B3: the chunk's U fragments, refilled in place one chunk ahead
+    if constexpr (B3) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) load_u3(u3[b], 0, b);
+    } else {
+        load_u(ub[0], 0);
+    }
     for (;;) {
         f32x16 acc[4];
 #pragma unroll
@@ -230,6 +307,41 @@ __device__ __forceinline__ void wino_body(const Args& a) {
             constexpr bool more = decltype(more_c)::value;      // a pair p + 1 of this item exists: request its patch
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the patch (and its U fragments) have landed
             __syncthreads();                               // every wave's have; every wave is done with the other buffer
+            if constexpr (B3) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    f4 d0[2][4], d1[2][4];
+                    read_d(d0, 2 * half);
+                    read_d(d1, 2 * half + 1);
+                    if constexpr (more) issue_dma_pieces(p + 1, (p + 1) & 1, 3 * half, 3 * half + 3);
+                    f4 t0[4], t1[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        t0[c] = d0[1][c] * sgn + d0[0][c];          // row wa of B^T d, channels 8 h + 0..3 and 8 h + 4..7
+                        t1[c] = d1[1][c] * sgn + d1[0][c];
+                    }
+                    const int kc_next = min(2 * p + half + 1, KC - 1);                   // (the last one re-reads: uniform counts)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const f4 va = b == 0 ? t0[0] - t0[2] : (b == 1 ? t0[1] + t0[2] : (b == 2 ? t0[2] - t0[1] : t0[1] - t0[3]));
+                        const f4 vb = b == 0 ? t1[0] - t1[2] : (b == 1 ? t1[1] + t1[2] : (b == 2 ? t1[2] - t1[1] : t1[1] - t1[3]));
+                        u32x4 q0, q1, q2;
+                        split8(va, vb, q0, q1, q2);
+                        acc[b] = mfma_b(u3[b][0], q2, acc[b]);      // small terms first
+                        acc[b] = mfma_b(u3[b][1], q1, acc[b]);
+                        acc[b] = mfma_b(u3[b][2], q0, acc[b]);
+                        acc[b] = mfma_b(u3[b][1], q0, acc[b]);
+                        acc[b] = mfma_b(u3[b][0], q1, acc[b]);
+                        acc[b] = mfma_b(u3[b][0], q0, acc[b]);
+                        load_u3(u3[b], kc_next, b);                // in place: this position's fragments of the next chunk, four positions ahead
+                    }
+                }
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) paddr[rr][c] ^= (unsigned)BUF;
+                return;
+            }
             // four steps of 16 MFMAs.  The patch reads of step st + 1 are issued at the top of step st, ahead of its first eight MFMAs;
             // the transform of step st + 1 is VALU work placed beside the last eight.  The scheduling fences keep the compiler from
             // sinking the reads to just before their use (it did: every step then opened with an exposed LDS round trip).
@@ -302,7 +414,12 @@ __device__ __forceinline__ void wino_body(const Args& a) {
         if (next < total) {
             setup(next);
             issue_dma(0, 0);
-            load_u(ub[0], 0);
+            if constexpr (B3) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) load_u3(u3[b], 0, b);
+            } else {
+                load_u(ub[0], 0);
+            }
         }
         // output transform.  In registers: the column half (A applied to this wave's row a): s[qx] from M[a][0..3]; through LDS (the
         // SECOND buffer: the first is being filled): the row half across the four waves of a tile half.  Plane 2 a + qx of half th.
@@ -342,19 +459,24 @@ __device__ __forceinline__ void wino_body(const Args& a) {
     }
 }
 
-__global__ __launch_bounds__(512, 1) void wino64_kernel(Args a) { wino_body<2>(a); }
-__global__ __launch_bounds__(256, 2) void wino32_kernel(Args a) { wino_body<1>(a); }
+__global__ __launch_bounds__(512, 1) void wino64_kernel(Args a) { wino_body<2, false>(a); }
+__global__ __launch_bounds__(256, 2) void wino32_kernel(Args a) { wino_body<1, false>(a); }
+__global__ __launch_bounds__(512, 1) void wino64b_kernel(Args a) { wino_body<2, true>(a); }
+__global__ __launch_bounds__(256, 2) void wino32b_kernel(Args a) { wino_body<1, true>(a); }
 
 }  // namespace wino
 
-static bool wino_shape_ok(const dc_conv_desc* d, const float* u) {
+static bool wino_shape_ok(const dc_conv_desc* d, const void* u) {
     return u != nullptr && d->math == DC_MATH_F32 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 &&
            d->Ho == d->H && d->Wo == d->W && d->Cin % 32 == 0 && d->Cout % 32 == 0 && d->res_mode == 0 && d->split_k <= 1 && aligned16(d->y) &&
            aligned16(u) && (!d->scale || aligned16(d->scale)) && (!d->shift || aligned16(d->shift)) &&
            (size_t)d->N * d->H * d->W * d->Cin * sizeof(float) < (1ull << 31);      // one buffer resource, 32-bit offsets: larger inputs take the direct kernels
 }
 
-bool conv_winograd_supported(const dc_conv_desc* d) { return wino_shape_ok(d, d->w_wino); }
+// w_wino_b3 (the split-bf16 products) wins when both are given
+static bool wino_b3(const dc_conv_desc* d) { return wino_shape_ok(d, d->w_wino_b3); }
+bool conv_winograd_supported(const dc_conv_desc* d) { return wino_b3(d) || wino_shape_ok(d, d->w_wino); }
+bool conv_winograd_split_bf16(const dc_conv_desc* d) { return wino_b3(d); }
 
 // tiles per work item: 64 where every CU still gets an item, else 32.  DCAP_WINO_TILES = 32 / 64 forces one (tests).
 static int wino_force() {
@@ -387,7 +509,8 @@ int conv_winograd_tiles(const dc_conv_desc* d) {
 int conv2d_winograd(const dc_conv_desc* d, hipStream_t s) {
     wino::Args a;
     a.x = d->x;
-    a.u = reinterpret_cast<const f4*>(d->w_wino);
+    const bool b3 = wino_b3(d);
+    a.u = b3 ? reinterpret_cast<const f4*>(d->w_wino_b3) : reinterpret_cast<const f4*>(d->w_wino);
     a.y = d->y;
     a.scale = d->scale;
     a.shift = d->shift;
@@ -412,7 +535,13 @@ int conv2d_winograd(const dc_conv_desc* d, hipStream_t s) {
     const long full = big ? kNumCU : 2 * kNumCU;
     const long slots = items >= 8 * full ? (big ? persistent_cus() : 2 * persistent_cus()) : full;
     const unsigned grid = items >= slots ? (unsigned)slots : (unsigned)std::max<long>(8, items / 8 * 8);
-    if (big) {
+    if (b3 && big) {
+        DC_ENSURE_DYN_LDS(wino::wino64b_kernel, wino::wp::Cfg<2>::LDS_BYTES);
+        hipLaunchKernelGGL(wino::wino64b_kernel, dim3(grid), dim3(wino::wp::Cfg<2>::NT), wino::wp::Cfg<2>::LDS_BYTES, s, a);
+    } else if (b3) {
+        DC_ENSURE_DYN_LDS(wino::wino32b_kernel, wino::wp::Cfg<1>::LDS_BYTES);
+        hipLaunchKernelGGL(wino::wino32b_kernel, dim3(grid), dim3(wino::wp::Cfg<1>::NT), wino::wp::Cfg<1>::LDS_BYTES, s, a);
+    } else if (big) {
         DC_ENSURE_DYN_LDS(wino::wino64_kernel, wino::wp::Cfg<2>::LDS_BYTES);
         hipLaunchKernelGGL(wino::wino64_kernel, dim3(grid), dim3(wino::wp::Cfg<2>::NT), wino::wp::Cfg<2>::LDS_BYTES, s, a);
     } else {
@@ -439,6 +568,21 @@ extern "C" int dc_conv2d_winograd_pack_f32(const float* w, float* u, int Cin, in
     const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(wino::wino_pack_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w, u, Cin, Cout);
     return check_launch("dc_conv2d_winograd_pack_f32");
+}
+
+extern "C" size_t dc_conv2d_winograd_b3_weight_bytes(int Cin, int Cout) {
+    if (Cin <= 0 || Cout <= 0 || Cin % 32 || Cout % 32) return 0;
+    return (size_t)16 * Cin * Cout * 3 * sizeof(uint16_t);
+}
+
+extern "C" int dc_conv2d_winograd_pack_b3(const float* w, uint16_t* u, int Cin, int Cout, void* stream) {
+    DC_REQUIRE(w && u, DC_EINVAL, "dc_conv2d_winograd_pack_b3: null pointer");
+    DC_REQUIRE(Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0, DC_EINVAL, "dc_conv2d_winograd_pack_b3: Cin and Cout must be multiples of 32");
+    DC_REQUIRE(aligned16(u), DC_EALIGN, "dc_conv2d_winograd_pack_b3: u must be 16-byte aligned");
+    const long total = (long)Cin * Cout;
+    const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(wino::wino_pack_b3_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w, u, Cin, Cout);
+    return check_launch("dc_conv2d_winograd_pack_b3");
 }
 
 extern "C" int dc_set_persistent_cus(int n) {

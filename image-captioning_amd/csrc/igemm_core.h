@@ -893,6 +893,7 @@ bool conv_pw_stream_supported(const dc_conv_desc* d, const Epilogue& ep);
 int conv2d_pointwise_stream(const dc_conv_desc* d, const Epilogue& ep, int M, int N, hipStream_t s);
 // conv_wino.hip: 3x3 / stride 1 / pad 1 layers with pre-transformed frozen weights in the Winograd F(2x2, 3x3) form
 bool conv_winograd_supported(const dc_conv_desc* d);
+bool conv_winograd_split_bf16(const dc_conv_desc* d);
 int conv_winograd_tiles(const dc_conv_desc* d);
 int conv2d_winograd(const dc_conv_desc* d, hipStream_t s);
 

@@ -208,7 +208,7 @@ def gemm_bf16(A, B, out=None, out_bf16=None, a_trans=False, b_trans=False, gathe
 
 
 def conv2d(x, w_packed, kh, kw, stride, pad_t, pad_l, Ho, Wo, scale=None, shift=None, residual=None,
-           res_mode=0, relu=False, out=None, split_k=0, math=0, w_wino=None, _name_only=False):
+           res_mode=0, relu=False, out=None, split_k=0, math=0, w_wino=None, w_wino_b3=None, _name_only=False):
     """NHWC conv forward with fused epilogue; see dc_conv2d_nhwc_f32.  x [N,H,W,Cin] contiguous.  w_wino: winograd_pack(w_packed)
     of a frozen 3x3 / stride 1 / pad 1 kernel -> the layer runs in the Winograd F(2x2, 3x3) form (fp32, math=0 only)."""
     lib = _lib.load()
@@ -231,6 +231,10 @@ def conv2d(x, w_packed, kh, kw, stride, pad_t, pad_l, Ho, Wo, scale=None, shift=
         if not w_wino.is_contiguous() or w_wino.numel() != 16 * Cin * Cout:
             raise _lib.DcapError("conv2d: w_wino must be the contiguous winograd_pack() of this layer's kernel (16*Cin*Cout floats)")
         d.w_wino = _chk(w_wino, name="w_wino").data_ptr()
+    if w_wino_b3 is not None:
+        if not w_wino_b3.is_contiguous() or w_wino_b3.numel() != 48 * Cin * Cout:
+            raise _lib.DcapError("conv2d: w_wino_b3 must be the contiguous winograd_pack_b3() of this layer's kernel (48*Cin*Cout bf16)")
+        d.w_wino_b3 = _chk(w_wino_b3, torch.int16, "w_wino_b3").data_ptr()
     if _name_only:
         buf = C.create_string_buffer(128)
         check(lib.dc_conv2d_kernel_name(C.byref(d), buf, 128), "dc_conv2d_kernel_name")
@@ -243,6 +247,22 @@ def conv2d(x, w_packed, kh, kw, stride, pad_t, pad_l, Ho, Wo, scale=None, shift=
 def conv2d_kernel_name(*args, **kw):
     """The kernel template instantiation conv2d(*args, **kw) would launch (dc_conv2d_kernel_name); nothing is launched."""
     return conv2d(*args, _name_only=True, **kw)
+
+
+def winograd_pack_b3(w_packed, cin, cout, out=None):
+    """U = G g G^T of a packed 3x3 kernel [Cout, 9*Cin], every element as three bf16 pieces, in the fragment order of the split-bf16
+    Winograd kernel: int16 [48*Cin*Cout] (dc_conv2d_winograd_pack_b3)."""
+    lib = _lib.load()
+    _chk(w_packed, name="w")
+    if not w_packed.is_contiguous() or w_packed.numel() != 9 * cin * cout:
+        raise _lib.DcapError("winograd_pack_b3: w must be the contiguous packed 3x3 kernel [Cout, 9*Cin]")
+    nbytes = lib.dc_conv2d_winograd_b3_weight_bytes(cin, cout)
+    if nbytes == 0:
+        raise _lib.DcapError("winograd_pack_b3: Cin and Cout must be multiples of 32")
+    if out is None:
+        out = torch.empty((nbytes // 2,), dtype=torch.int16, device=w_packed.device)
+    check(lib.dc_conv2d_winograd_pack_b3(_ptr(w_packed), _ptr(out), cin, cout, _stream()), "dc_conv2d_winograd_pack_b3")
+    return out
 
 
 def winograd_pack(w_packed, cin, cout, out=None):

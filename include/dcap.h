@@ -194,6 +194,10 @@ typedef struct {
                                  F(2x2, 3x3) form: fp32 throughout, 16 products per 2x2 output tile instead of 36 (the minimal-filtering
                                  algorithm cuDNN picks for these layers under the reference's TF); needs Cin, Cout multiples of 32, no
                                  residual.  Layers that do not qualify ignore the field */
+    const uint16_t* w_wino_b3; /* optional, like w_wino (and preferred when both are given): the same transformed weights split into three bf16
+                                 pieces per element by dc_conv2d_winograd_pack_b3 (16 * Cin * Cout * 3 bf16).  The 16 products per tile then
+                                 run on the BF16 matrix pipe in split arithmetic -- six bf16 MFMA products per fp32 product, fp32
+                                 accumulation: DC_MATH_BF16X3's fp32-grade arithmetic -- transforms in fp32 as before */
 } dc_conv_desc;
 
 /* x = p0 + p1 + p2 with bf16 pieces rounded to nearest even: out[0..n) = p0, out[n..2n) = p1, out[2n..3n) = p2. */
@@ -214,6 +218,8 @@ int    dc_conv2d_is_pointwise(const dc_conv_desc* d);
  * feature_generation/dense_model.py:85-100, :1417-1421 are evaluated. */
 size_t dc_conv2d_winograd_weight_bytes(int Cin, int Cout);
 int    dc_conv2d_winograd_pack_f32(const float* w, float* u, int Cin, int Cout, void* stream);
+size_t dc_conv2d_winograd_b3_weight_bytes(int Cin, int Cout);
+int    dc_conv2d_winograd_pack_b3(const float* w, uint16_t* u, int Cin, int Cout, void* stream);
 /* CUs the persistent Winograd grids may occupy (process-wide; a multiple of 8 -- one share per XCD; 0 restores the default:
  * DCAP_WINO_CUS or all 256).  A persistent block holds its CU for the whole launch: in a data-parallel run (parallel_model.py:58-102
  * -> one rank per GPU here) the RCCL all-reduce of another queue needs CUs of its own to overlap the encoder pass, so

@@ -163,10 +163,13 @@ WINO_CASES = [
 ]
 
 
+@pytest.mark.parametrize("products", ["f32", "b3"])
 @pytest.mark.parametrize("case", WINO_CASES)
-def test_conv2d_winograd_matches_oracle_and_direct(ops, case):
+def test_conv2d_winograd_matches_oracle_and_direct(ops, case, products):
     """dc_conv_desc.w_wino: a 3x3 / stride 1 / 'same' layer in the Winograd F(2x2, 3x3) form (fp32 transforms, fp32 MFMA, 16 products
-    per 2x2 tile instead of 36) against the float64 oracle at the direct kernel's own tolerance, and against the direct kernel."""
+    per 2x2 tile instead of 36) against the float64 oracle at the direct kernel's own tolerance, and against the direct kernel.
+    products = 'b3' (dc_conv_desc.w_wino_b3, round 5): the same form with the products on the BF16 matrix pipe in split arithmetic
+    (U pre-split into three bf16 pieces, V split in registers, six MFMA products per fp32 product) -- held to the SAME tolerance."""
     from image_captioning_amd.packing import pack_conv_kernel
     N, H, W, Cin, Cout, relu, affine = case
     rng = np.random.default_rng(sum(int(v) * (i + 3) for i, v in enumerate(case)))
@@ -179,14 +182,20 @@ def test_conv2d_winograd_matches_oracle_and_direct(ops, case):
     if relu:
         y = np.maximum(y, 0)
     wp = dev(pack_conv_kernel(w))
-    u = ops.winograd_pack(wp, Cin, Cout)
-    assert u.shape == (16 * Cin * Cout,)
+    if products == "b3":
+        u = ops.winograd_pack_b3(wp, Cin, Cout)
+        assert u.shape == (48 * Cin * Cout,) and u.dtype == torch.int16
+        kw = dict(w_wino_b3=u)
+    else:
+        u = ops.winograd_pack(wp, Cin, Cout)
+        assert u.shape == (16 * Cin * Cout,)
+        kw = dict(w_wino=u)
     args = (dev(x), wp, 3, 3, 1, 1, 1, H, W, None if sc is None else dev(sc), None if sh is None else dev(sh), None, 0, relu)
     out = torch.full((N, H, W, Cout), float("nan"), device="cuda")
-    got = ops.conv2d(*args, out=out, w_wino=u)
+    got = ops.conv2d(*args, out=out, **kw)
     th, tw = (H + 1) // 2, (W + 1) // 2
     big = N * ((th + 7) // 8) * ((tw + 7) // 8) * (Cout // 32) >= 256
-    assert ops.conv2d_kernel_name(*args, w_wino=u) == ("wino64_kernel" if big else "wino32_kernel")
+    assert ops.conv2d_kernel_name(*args, **kw) == ("wino64" if big else "wino32") + ("b" if products == "b3" else "") + "_kernel"
     close(got, y, 2e-5)
     direct = ops.conv2d(*args)
     assert not ops.conv2d_kernel_name(*args).startswith("wino")

@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--filter", default="")
     ap.add_argument("--math", type=int, default=0, help="0 = fp32 MFMA, 1 = split-bf16 (3 pieces, 6 products), 2 = 2 pieces, 3 products")
     ap.add_argument("--winograd", action="store_true", help="math 0: 3x3 layers in the Winograd F(2x2,3x3) form (pre-transformed weights)")
+    ap.add_argument("--b3", action="store_true", help="with --winograd: the products on the bf16 matrix pipe in split arithmetic (w_wino_b3)")
     args = ap.parse_args()
     dev = torch.device("cuda")
     B = args.batch
@@ -62,10 +63,11 @@ def main():
         y = torch.empty(B, Ho, Ho, Cout, device=dev)
         pad = (k - 1) // 2
         wino = ops.winograd_pack(w, Cin, Cout) if (args.winograd and k == 3 and stride == 1 and args.math == 0) else None
+        wb3 = ops.winograd_pack_b3(w, Cin, Cout) if (wino is not None and args.b3) else None
         run = lambda: ops.conv2d(x, w, k, k, stride, pad, pad, Ho, Ho, sc, sh, res, res_mode, bool(relu), out=y, math=args.math,
-                                 w_wino=wino)
+                                 w_wino=wino, w_wino_b3=wb3)
         kname = ops.conv2d_kernel_name(x, w, k, k, stride, pad, pad, Ho, Ho, sc, sh, res, res_mode, bool(relu), math=args.math,
-                                       w_wino=wino)
+                                       w_wino=wino, w_wino_b3=wb3)
         for _ in range(3):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
