@@ -46,8 +46,21 @@ WINOGRAD_GAIN = 2.25            # direct 3x3: 36 products per 2x2 output tile an
 
 
 def winograd_gain(kernel):
-    """Direct-form FLOPs / FLOPs the matrix pipe executes for the layers that run on `kernel` (dc_conv2d_kernel_name's spelling)."""
-    return WINOGRAD_GAIN if kernel.startswith("wino") else 1.0
+    """Direct-form FLOPs / FLOPs the matrix pipe executes for the layers that run on `kernel` (dc_conv2d_kernel_name's spelling).
+    wino64b / wino32b (round 5): the 16 products per tile as SIX bf16 MFMA products each (split arithmetic): 6 / 2.25 of the direct
+    form's count, on the bf16 pipe."""
+    if kernel.startswith("wino"):
+        return WINOGRAD_GAIN / 6.0 if split_bf16_kernel(kernel) else WINOGRAD_GAIN
+    return 1.0
+
+
+def split_bf16_kernel(kernel):
+    return kernel.startswith("wino") and kernel.split("_")[0].endswith("b")
+
+
+def pipe_peak(kernel):
+    """The matrix-pipe peak a conv kernel's executed FLOPs are priced against (TFLOP/s)."""
+    return PEAK_BF16_MFMA_TFLOPS if split_bf16_kernel(kernel) else PEAK_F32_MFMA_TFLOPS
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
@@ -498,7 +511,7 @@ class E2E(object):
         # HBM bytes per launch: from the committed rocprofv3 PMC passes of this same command (tools/pmc_traffic.py: separate --pmc
         # passes, FETCH_SIZE / WRITE_SIZE with the guide's gfx950 corrections) -- counters cannot be read from inside the process
         traffic, traffic_src = None, None
-        for tname in (("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json") if args.backbone == "resnet101" else ()):
+        for tname in (("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json") if args.backbone == "resnet101" else ()):
             tpath = os.path.join(ROOT, "profiles", tname)
             if traffic is None and os.path.exists(tpath):
                 for name, rec in json.load(open(tpath)).items():
@@ -510,8 +523,10 @@ class E2E(object):
         # (it may exceed the peak: that is what the algorithm is for, and it is not a roofline fraction).
         wino = dom.startswith("wino")
         alg_b = g["bytes"] / g["launches"]
-        out = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-               "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "algorithmic_bytes": alg_b,
+        peak = pipe_peak(dom)
+        pipe_s = sum(v["flops"] / (pipe_peak(k) * 1e12) for k, v in groups.items())      # seconds of matrix-pipe time at each kernel's own peak
+        out = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+               "frac": achieved / peak, "traffic": traffic, "algorithmic_bytes": alg_b,
                "traffic_ratio": (traffic / alg_b) if traffic else None,
                "traffic_source": traffic_src,
                "measured": main + " (HIP events on the launch stream"
@@ -520,20 +535,27 @@ class E2E(object):
                "avg_launch_us": 1e3 * g["ms"] / g["launches"],
                "all_conv": {"gflop_per_step": plan.flops / 1e9, "ms_per_step": conv_ms, "tflops": plan.flops / (conv_ms * 1e-3) / 1e12,
                             "mfma_gflop_per_step": sum(v["flops"] for v in groups.values()) / 1e9,
-                            "mfma_frac": sum(v["flops"] for v in groups.values()) / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
-               "kernels": {k: dict({"launches": v["launches"], "ms": round(v["ms"], 4), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)},
+                            "mfma_frac": pipe_s / (conv_ms * 1e-3),
+                            "mfma_frac_note": "matrix-pipe time at each kernel's own peak (fp32 MFMA 157.3 TF; the split-bf16 Winograd kernels' six "
+                                              "bf16 products per fp32 product against 2500 TF) / measured time"},
+               "kernels": {k: dict({"launches": v["launches"], "ms": round(v["ms"], 4), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                    "frac_of_its_pipe": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / pipe_peak(k), 3)},
                                    **({"tflops_direct_form": round(v["alg"] / (v["ms"] * 1e-3) / 1e12, 2)} if v["alg"] != v["flops"] else {}))
                            for k, v in groups.items()}}
         if wino:
             out["achieved_direct_form"] = g["alg"] / (g["ms"] * 1e-3) / 1e12
             out["gflop_per_launch_direct_form"] = g["alg"] / g["launches"] / 1e9
-            out["note"] = ("Winograd F(2x2,3x3), fp32 transforms and products: executed MFMA FLOPs = direct-form FLOPs / %.2f; frac = executed / peak"
-                           % winograd_gain(dom))
+            if split_bf16_kernel(dom):
+                out["note"] = ("Winograd F(2x2,3x3), fp32 transforms, the 16 products per tile as six bf16 MFMA products each (split arithmetic, fp32 "
+                               "accumulate: fp32-grade): executed bf16 MFMA FLOPs = direct-form FLOPs x 6 / 2.25; frac = executed / 2500 TF (dense bf16)")
+            else:
+                out["note"] = ("Winograd F(2x2,3x3), fp32 transforms and products: executed MFMA FLOPs = direct-form FLOPs / %.2f; frac = executed / peak"
+                               % winograd_gain(dom))
         if main == "pipeline":
             gi = res["isolated"][0][dom]
             ai = gi["flops"] / (gi["ms"] * 1e-3) / 1e12
             iso_ms = sum(v["ms"] for v in res["isolated"][0].values())
-            out["isolated"] = {"achieved": ai, "frac": ai / PEAK_F32_MFMA_TFLOPS, "avg_launch_us": 1e3 * gi["ms"] / gi["launches"],
+            out["isolated"] = {"achieved": ai, "frac": ai / peak, "avg_launch_us": 1e3 * gi["ms"] / gi["launches"],
                                "all_conv_ms_per_step": iso_ms, "all_conv_tflops": plan.flops / (iso_ms * 1e-3) / 1e12}
         return out
 

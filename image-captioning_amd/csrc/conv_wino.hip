@@ -42,7 +42,7 @@ struct Args {
     const float* shift;
     int N, H, W, Cin, Cout, relu;
     int gy, gx, groups;       // tile groups per image (rows, columns), in all
-    unsigned x_bytes;
+    unsigned x_bytes, u_bytes;
 };
 
 // U in fragment order, K in chunks of 16: f4 index ((((xi * NTG + ntg) * KC16 + kc) * 2 + j) * 64 + lane), lane = 32 h + i,
@@ -209,7 +209,7 @@ __device__ __forceinline__ void wino_body(const Args& a) {
     int nb, img, gyi, gxi;
     unsigned doff[NDMA];
     const f4* ubase;
-    const u32x4* ubase3;                                   // B3: 16 bytes per lane, fragment (b, kc, piece) at b * ustep3 + (3 kc + piece) * 64
+    unsigned ubyte3;                                       // B3: byte offset of this wave row's fragments for the item (block-uniform)
     auto setup = [&](int item) {
         const int bid = xcd_remap(item, total);            // gridDim.x % 8 == 0: item % 8 is this block's XCD for every item it takes
         nb = bid / a.groups;
@@ -228,7 +228,7 @@ __device__ __forceinline__ void wino_body(const Args& a) {
             doff[n] = in ? (unsigned)(((((long)img * a.H + iy) * a.W + ix) * a.Cin + 4 * c8) * 4) : kOobOffset;
         }
         ubase = a.u + lane + (((long)(4 * wa) * NTG + nb) * KC << 7);
-        ubase3 = reinterpret_cast<const u32x4*>(a.u) + lane + (((long)(4 * wa) * NTG + nb) * KC * 3 << 6);
+        ubyte3 = (unsigned)((4 * wa) * NTG + nb) * (unsigned)KC * 3072u;
     };
     auto issue_dma_pieces = [&](int pair, int buf, int n0, int n1) {
 #pragma unroll
@@ -247,12 +247,15 @@ __device__ __forceinline__ void wino_body(const Args& a) {
         }
     };
     auto load_u = [&](f4 (&dst)[4][2], int kc) { load_u_part(dst, kc, 0, 4); };
-    const long ustep3 = (long)NTG * KC * 3 << 6;
+    // B3: U through a buffer resource -- the lane's offset (16 lane) is a fixed VGPR, everything else (item, position, chunk, piece) one
+    // block-uniform SGPR offset: no address VALU beside the loads
+    const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<f4*>(a.u), 0, (int)a.u_bytes, 0x00020000);
+    const unsigned ustep3 = (unsigned)NTG * KC * 3 * 1024u;                  // bytes: xi -> xi + 1
     auto load_u3 = [&](u32x4 (&dst)[3], int kc, int b) {
-        const u32x4* p = ubase3 + b * ustep3 + ((long)kc * 3 << 6);
-        dst[0] = p[0];
-        dst[1] = p[64];
-        dst[2] = p[128];
+        const unsigned so = __builtin_amdgcn_readfirstlane(ubyte3 + (unsigned)b * ustep3 + (unsigned)kc * 3072u);
+        dst[0] = __builtin_bit_cast(u32x4, buf_f4s(rsrc_u, (unsigned)lane * 16u, so));
+        dst[1] = __builtin_bit_cast(u32x4, buf_f4s(rsrc_u, (unsigned)lane * 16u, so + 1024u));
+        dst[2] = __builtin_bit_cast(u32x4, buf_f4s(rsrc_u, (unsigned)lane * 16u, so + 2048u));
     };
 
     // ---- fragment geometry: lane (tile i of this wave's half, k-half h); transform row wa combines patch rows r1, r2
@@ -308,33 +311,55 @@ __device__ __forceinline__ void wino_body(const Args& a) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the patch (and its U fragments) have landed
             __syncthreads();                               // every wave's have; every wave is done with the other buffer
             if constexpr (B3) {
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    f4 d0[2][4], d1[2][4];
-                    read_d(d0, 2 * half);
-                    read_d(d1, 2 * half + 1);
-                    if constexpr (more) issue_dma_pieces(p + 1, (p + 1) & 1, 3 * half, 3 * half + 3);
-                    f4 t0[4], t1[4];
+                // Eight position steps q = 4 half + b per pair.  Step q issues the six MFMAs of position b on the operands prepared during
+                // step q - 1 and, BETWEEN them (one MFMA : nine VALU, sched_group_barrier -- a 32x32x16 MFMA holds the vector issue for 8 of
+                // its 32 cycles, so the six dependent MFMAs of a position leave room for ~36 VALU instructions that would otherwise run
+                // after them), prepares position q + 1: the column combination of t (8 VALU) and the three-piece split (44).  The second
+                // half's patch rows are read during steps 1 and 2 and combined at the top of step 3; the next pair's patch goes out one
+                // DMA piece per step; U fragments are refilled in place right behind their MFMAs, four steps ahead of their use.
+                f4 dA[2][4], dB[2][4], t0[4], t1[4];
+                u32x4 V[2][3];
+                auto make_t = [&]() {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        t0[c] = d0[1][c] * sgn + d0[0][c];          // row wa of B^T d, channels 8 h + 0..3 and 8 h + 4..7
-                        t1[c] = d1[1][c] * sgn + d1[0][c];
+                        t0[c] = dA[1][c] * sgn + dA[0][c];          // row wa of B^T d, channels 8 h + 0..3 and 8 h + 4..7
+                        t1[c] = dB[1][c] * sgn + dB[0][c];
                     }
-                    const int kc_next = min(2 * p + half + 1, KC - 1);                   // (the last one re-reads: uniform counts)
+                };
+                auto prep = [&](u32x4 (&dst)[3], int b) {
+                    const f4 va = b == 0 ? t0[0] - t0[2] : (b == 1 ? t0[1] + t0[2] : (b == 2 ? t0[2] - t0[1] : t0[1] - t0[3]));
+                    const f4 vb = b == 0 ? t1[0] - t1[2] : (b == 1 ? t1[1] + t1[2] : (b == 2 ? t1[2] - t1[1] : t1[1] - t1[3]));
+                    split8(va, vb, dst[0], dst[1], dst[2]);
+                };
+                read_d(dA, 0);
+                read_d(dB, 1);
+                make_t();
+                prep(V[0], 0);
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const f4 va = b == 0 ? t0[0] - t0[2] : (b == 1 ? t0[1] + t0[2] : (b == 2 ? t0[2] - t0[1] : t0[1] - t0[3]));
-                        const f4 vb = b == 0 ? t1[0] - t1[2] : (b == 1 ? t1[1] + t1[2] : (b == 2 ? t1[2] - t1[1] : t1[1] - t1[3]));
-                        u32x4 q0, q1, q2;
-                        split8(va, vb, q0, q1, q2);
-                        acc[b] = mfma_b(u3[b][0], q2, acc[b]);      // small terms first
-                        acc[b] = mfma_b(u3[b][1], q1, acc[b]);
-                        acc[b] = mfma_b(u3[b][2], q0, acc[b]);
-                        acc[b] = mfma_b(u3[b][1], q0, acc[b]);
-                        acc[b] = mfma_b(u3[b][0], q1, acc[b]);
-                        acc[b] = mfma_b(u3[b][0], q0, acc[b]);
-                        load_u3(u3[b], kc_next, b);                // in place: this position's fragments of the next chunk, four positions ahead
+                for (int q = 0; q < 8; ++q) {
+                    const int half = q >> 2, b = q & 3;
+                    if (q == 1) read_d(dA, 2);
+                    if (q == 2) read_d(dB, 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (more) if (q < NDMA) issue_dma_pieces(p + 1, (p + 1) & 1, q, q + 1);
+                    const u32x4 (&vq)[3] = V[q & 1];
+                    acc[b] = mfma_b(u3[b][0], vq[2], acc[b]);       // small terms first
+                    acc[b] = mfma_b(u3[b][1], vq[1], acc[b]);
+                    acc[b] = mfma_b(u3[b][2], vq[0], acc[b]);
+                    acc[b] = mfma_b(u3[b][1], vq[0], acc[b]);
+                    acc[b] = mfma_b(u3[b][0], vq[1], acc[b]);
+                    acc[b] = mfma_b(u3[b][0], vq[0], acc[b]);
+                    if (q == 3) make_t();                           // (the first half's t is dead: position 3 was prepared during step 2)
+                    if (q < 7) prep(V[(q + 1) & 1], (q + 1) & 3);
+                    load_u3(u3[b], min(2 * p + half + 1, KC - 1), b);          // (the last chunk re-reads: uniform counts)
+#pragma unroll
+                    for (int m = 0; m < 6; ++m) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // one vector-memory instruction (the DMA piece), where there is one
+                        if (q == 3) __builtin_amdgcn_sched_group_barrier(0x002, 15, 0);
+                        else __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr)
@@ -521,6 +546,7 @@ int conv2d_winograd(const dc_conv_desc* d, hipStream_t s) {
     // 32 or more 1024 x 1024 images does not fit -- split the batch
     DC_REQUIRE(x_bytes < (1ull << 31), DC_EINVAL, "dc_conv2d (winograd): the input tensor has %zu bytes, the kernel addresses < 2 GiB", x_bytes);
     a.x_bytes = (unsigned)x_bytes;
+    a.u_bytes = (unsigned)((size_t)16 * d->Cin * d->Cout * (b3 ? 6 : 4));
     const bool big = conv_winograd_tiles(d) == 64;
     a.gy = (th + (big ? 8 : 4) - 1) / (big ? 8 : 4);
     a.gx = (tw + 7) / 8;

@@ -54,7 +54,7 @@ class EncoderPlan:
 
     def __init__(self, weights, batch, height, width, device, stage4_blocks=22,
                  mean_pixel=(123.7, 116.8, 103.9), use_graph=True, rpn=None, external=None, math=None, external_bn=None, train_stages=(),
-                 winograd=None):
+                 winograd=None, wino_products=None):
         """rpn: None (GT-RoI variant: the RPN is never evaluated) or a dict with the config values the
         proposal path needs: scales, ratios, strides, anchor_stride, bbox_std, nms_threshold, proposal_count and
         optionally head_channels (the fused class+bbox head padded to a multiple of 4 channels for the wgrad kernel).
@@ -80,6 +80,13 @@ class EncoderPlan:
         # F(2x2, 3x3) form -- fp32 transforms, fp32 MFMA, 16 products per 2x2 output tile instead of 36 (csrc/conv_wino.hip); their
         # kernels are transformed once here.  winograd=False / DCAP_WINOGRAD=0: the direct implicit GEMM everywhere.
         self.winograd = (os.environ.get("DCAP_WINOGRAD", "1") != "0") if winograd is None else bool(winograd)
+        # ... and their 16 products per tile run on the BF16 matrix pipe in split arithmetic (round 5: U pre-split into three bf16 pieces
+        # once, V split in registers, six bf16 MFMA products per fp32 product, fp32 accumulation -- DC_MATH_BF16X3's fp32-grade arithmetic,
+        # held to the fp32 kernel's tolerances at kernel level and at full depth): wino_products = 'b3' (default) | 'f32' (fp32 MFMA
+        # products; DCAP_WINO_PRODUCTS overrides the default)
+        self.wino_products = wino_products or os.environ.get("DCAP_WINO_PRODUCTS", "b3")
+        if self.wino_products not in ("b3", "f32"):
+            raise ValueError("wino_products must be 'b3' or 'f32'")
         self._wwino = {}
         self._twin = {}
         self._wb = {}
@@ -212,8 +219,11 @@ class EncoderPlan:
             # 2.25x fewer of them, faster than six (three) bf16 products per direct-form product --, the 1x1 / strided / residual layers
             # keep the split arithmetic on the bf16 matrix pipe.
             if name not in self._wwino:
-                self._wwino[name] = ops.winograd_pack(wp, Cin, Cout)
-            d.w_wino = self._wwino[name].data_ptr()
+                self._wwino[name] = (ops.winograd_pack_b3 if self.wino_products == "b3" else ops.winograd_pack)(wp, Cin, Cout)
+            if self.wino_products == "b3":
+                d.w_wino_b3 = self._wwino[name].data_ptr()
+            else:
+                d.w_wino = self._wwino[name].data_ptr()
             d.math = _lib.MATH_F32
         self._ws_bytes = max(self._ws_bytes, self.lib.dc_conv2d_workspace_bytes(C.byref(d)))
         self._ops.append(("conv", d, name))
@@ -361,7 +371,7 @@ class EncoderPlan:
             if op[0] != "conv":
                 continue
             d, s = op[1], self._specs[op[2]]
-            wbytes = (16 if op[2] in self._wwino else s.k * s.k) * d.Cin * s.cout * 4
+            wbytes = ((16 * (6 if self.wino_products == "b3" else 4)) if op[2] in self._wwino else s.k * s.k * 4) * d.Cin * s.cout
             b = 4.0 * d.N * d.H * d.W * d.Cin + 4.0 * d.N * d.Ho * d.Wo * d.Cout + wbytes
             if d.res_mode == 1:
                 b += 4.0 * d.N * d.Ho * d.Wo * d.Cout
@@ -493,7 +503,8 @@ class Vgg16Plan(EncoderPlan):
     The first convolution reads the RGBX image zero-padded to 32 channels (the implicit-GEMM loader wants Cin % 32 == 0)."""
     feat_channels = 512
 
-    def __init__(self, weights, batch, height, width, device, mean_pixel=(123.7, 116.8, 103.9), use_graph=True, math=None, winograd=None):
+    def __init__(self, weights, batch, height, width, device, mean_pixel=(123.7, 116.8, 103.9), use_graph=True, math=None, winograd=None,
+                 wino_products=None):
         from .layers import vgg16_convs
         import os
         if height % 16 or width % 16:
@@ -501,6 +512,7 @@ class Vgg16Plan(EncoderPlan):
         self.lib = _lib.load()
         self.math = conv_math_mode(math)
         self.winograd = (os.environ.get("DCAP_WINOGRAD", "1") != "0") if winograd is None else bool(winograd)      # all 13 layers are 3x3 / stride 1
+        self.wino_products = wino_products or os.environ.get("DCAP_WINO_PRODUCTS", "b3")
         self._wwino = {}
         self.B, self.H, self.W = batch, height, width
         self.device = torch.device(device)

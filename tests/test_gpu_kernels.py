@@ -220,9 +220,11 @@ def _wino_items_per_block(N, H, W, Cout):
     return items, items / 256.0
 
 
+@pytest.mark.parametrize("products", ["b3", "f32"])
 @pytest.mark.parametrize("case", WINO_PERSISTENT_CASES)
-def test_conv2d_winograd_persistent_multi_item_blocks_at_benchmark_shapes(ops, case):
-    """The kernel behind the headline number on the code path the headline runs: wino64_kernel with >= 2 work items per persistent
+def test_conv2d_winograd_persistent_multi_item_blocks_at_benchmark_shapes(ops, case, products):
+    """The kernel behind the headline number on the code path the headline runs (products = 'b3': wino64b_kernel, the split-bf16
+    products the encoder plan uses by default since round 5; 'f32': wino64_kernel): >= 2 work items per persistent
     block (next-item patch prefetch, M image in buffer 1 while buffer 0 refills, even / odd KP).  Whole tensor against the direct
     implicit-GEMM kernel (2e-5), and against the float64 oracle on windows that straddle image corners, image edges, the
     16-pixel item boundaries and the image-0 / image-1 seam, over ALL output channels (every slice of every sampled item)."""
@@ -234,11 +236,11 @@ def test_conv2d_winograd_persistent_multi_item_blocks_at_benchmark_shapes(ops, c
     w = torch.randn(Cout, 9 * Cin, device="cuda", generator=g) / (9 * Cin) ** 0.5            # packed [Cout][tap][Cin]
     sc = torch.rand(Cout, device="cuda", generator=g) + 0.5
     sh = torch.randn(Cout, device="cuda", generator=g)
-    u = ops.winograd_pack(w, Cin, Cout)
+    kw = dict(w_wino_b3=ops.winograd_pack_b3(w, Cin, Cout)) if products == "b3" else dict(w_wino=ops.winograd_pack(w, Cin, Cout))
     args = (x, w, 3, 3, 1, 1, 1, H, W, sc, sh, None, 0, True)
-    assert ops.conv2d_kernel_name(*args, w_wino=u) == "wino64_kernel"
+    assert ops.conv2d_kernel_name(*args, **kw) == ("wino64b_kernel" if products == "b3" else "wino64_kernel")
     out = torch.full((N, H, W, Cout), float("nan"), device="cuda")
-    got = ops.conv2d(*args, out=out, w_wino=u)
+    got = ops.conv2d(*args, out=out, **kw)
     assert bool(torch.isfinite(got).all())
     direct = ops.conv2d(*args)
     assert not ops.conv2d_kernel_name(*args).startswith("wino")

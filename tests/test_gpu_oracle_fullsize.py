@@ -80,17 +80,20 @@ def encoder_oracle(gpu):
     return W, img, rois, feat, [np.asarray(m) for m in maps[4:]]
 
 
-@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+@pytest.mark.parametrize("math", ["f32", "f32-wino-f32", "bf16x3"])
 def test_configs2_encoder_at_1024px_22_blocks_matches_the_float64_oracle(gpu, encoder_oracle, math):
     """P2..P5 and the 32 RoI features of ONE 1024 x 1024 image through the whole ResNet-101 + FPN (22 stage-4 blocks) against the float64
-    oracle.  Default plan: fp32 MFMA products, the 37 frozen 3x3 / stride-1 layers in the Winograd F(2x2,3x3) form; bf16x3: the split
-    arithmetic.  Tolerance 2e-4 of each map's scale -- the same as the 256 px / 2-block test: depth did not cost accuracy (measured:
+    oracle.  Default plan ('f32'): fp32 MFMA products on the 1x1 / strided layers, the 37 frozen 3x3 / stride-1 layers in the Winograd
+    F(2x2,3x3) form with their products on the bf16 pipe in split arithmetic (wino_products='b3', round 5); 'f32-wino-f32': the same
+    layers with fp32 MFMA products (round 3/4's default); bf16x3: the split arithmetic everywhere.  Tolerance 2e-4 of each map's scale -- the same as the 256 px / 2-block test: depth did not cost accuracy (measured:
     see MEASURED / DESIGN.md section 3b)."""
     from image_captioning_amd.encoder import EncoderPlan
     W, img, rois, want_feat, want_maps = encoder_oracle
-    plan = EncoderPlan(W, 1, 1024, 1024, "cuda", mean_pixel=MEAN, math=math)
-    if math == "f32":
+    plan = EncoderPlan(W, 1, 1024, 1024, "cuda", mean_pixel=MEAN, math=math.split("-")[0], wino_products="f32" if math.endswith("wino-f32") else None)
+    if math.startswith("f32"):
         assert len(plan._wwino) == 3 + 4 + 23 + 3 + 4
+        kernels = {k for (_, _, _, _, _, k) in plan.conv_table() if k.startswith("wino")}
+        assert kernels == ({"wino64_kernel", "wino32_kernel"} if math.endswith("wino-f32") else {"wino64b_kernel", "wino32b_kernel"}), kernels
     for rep in range(3):                                    # eager, capture, replay: the replay is what is compared
         P = plan.forward(torch.as_tensor(img).cuda())
     errs = {}
