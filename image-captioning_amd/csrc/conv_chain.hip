@@ -1,0 +1,235 @@
+// conv_chain.hip -- two chained pointwise convolutions in ONE launch (round 5): the last convolution of a ResNet bottleneck
+// (`2c`: 1x1, Cin -> 4 Cin, + shortcut, ReLU) and the first of the next block (`2a`: 1x1, 4 Cin -> Cin, ReLU)
+// (feature_generation/dense_model.py:85-100: identity_block's branch2c / the next block's branch2a, fp32, frozen BN folded).
+//
+// Why: at the benchmark's two images a stage-4 `2c` + `2a` pair is 2 x 27.3 us of fp32 MFMA work that ran as 44 + 38.5 us -- each
+// launch pays its prologue, its epilogue traffic (the 32 MB residual read and the 32 MB output write of `2c` after its MFMAs) and a
+// one-round tail, and `2a` re-reads from L2 / HBM what `2c` just wrote (DESIGN section 10 sized it).
+// Here a block owns 32 pixels for both layers: it computes their 32 x N1 rows of `2c`, keeps them in LDS (128 KiB for N1 = 1024),
+// writes them out once, and contracts them straight away with the `2a` weights -- the intermediate never comes back from memory,
+// the residual rows are requested before the first MFMA and are in registers when the epilogue needs them, the output stores drain
+// behind the second layer's MFMAs.
+//
+// Structure: 512 threads = 8 waves (two per SIMD: one wave's vector-memory issue and waits run in the other's MFMA shadow -- the
+// first version, four waves with 512 registers each, lost 18 % to exactly that), ONE block per CU, grid = pixels / 32.  Both layers put the output
+// CHANNELS on the MFMA's rows (A operand = weights) and the 32 pixels on its columns (B operand = activations from LDS), so a lane
+// ends with four consecutive channels of its pixel per accumulator quad (16-byte epilogue accesses, the Winograd kernels' trick).
+//   weights: packed once per frozen kernel in FRAGMENT order (dc_pw_chain_pack_f32): f4 index ((cb * K/8 + g) * 64 + lane),
+//     lane = 32 h + i, component e  <->  w[cout = 32 cb + i][k = 8 g + 4 h + e]: one wave-load = 1 KiB contiguous, four MFMAs
+//     (v_mfma_f32_32x32x2_f32: step e contracts the k pair {8 g + e, 8 g + 4 + e}), loaded through a buffer resource with a
+//     block-uniform SGPR offset (no address VALU beside the MFMAs), three (layer 1) / fifteen (layer 2) groups ahead;
+//   activations: the 32 x K1 input rows and then the 32 x N1 intermediate rows sit in LDS with row stride K + 4 floats (lane p reads
+//     16 bytes at row p: the 16 lanes of a read group hit 16 different bank quads); one ds_read_b128 feeds 4 x CB MFMAs.
+// Layer 1: wave w owns the column blocks w * CB1 .. + CB1 - 1 (CB1 = N1 / 256: 4 accumulator tiles for N1 = 1024), layer 2 the
+// column block w (N2 / 32 <= 8 blocks).
+#include "igemm_core.h"
+#include <algorithm>
+
+namespace dcap {
+namespace chain {
+
+struct Args {
+    const float* x;
+    const f4* w1;
+    const float* scale1;
+    const float* shift1;
+    const float* residual;
+    float* y;
+    const f4* w2;
+    const float* scale2;
+    const float* shift2;
+    float* z;
+    int M, K1, relu1, relu2;
+    unsigned w1_bytes, w2_bytes;
+};
+
+__global__ void chain_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int N, int K) {
+    const long total = (long)N * K;
+    const int NG = K >> 3;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int cout = (int)(idx / K), k = (int)(idx - (long)cout * K);
+        const int cb = cout >> 5, i = cout & 31, g = k >> 3, h = (k >> 2) & 1, e = k & 3;
+        out[(((long)cb * NG + g) * 64 + (h * 32 + i)) * 4 + e] = w[idx];
+    }
+}
+
+// CB1 = column blocks (of 32 channels) per wave in layer 1 = N1 / 256; NB2 = column blocks of layer 2 = N2 / 32 (<= 8: one per wave)
+template <int CB1, int NB2>
+__global__ __launch_bounds__(512, 1) void pw_chain_kernel(Args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = 512, NW = 8;
+    constexpr int N1 = CB1 * 32 * NW, N2 = NB2 * 32, LDY = N1 + 4, NG2 = N1 / 8;
+    static_assert(NB2 <= NW, "layer 2: one column block per wave");
+    constexpr int RQ = N1 / 4;                             // float4 per intermediate row
+    constexpr int RPT = 32 * RQ / NT;                      // float4 of the 32 x N1 tile per thread (row-major walk)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * 32;
+    const int K1 = a.K1, LDX = K1 + 4, NG1 = K1 >> 3;
+
+    // ---- the block's 32 input rows into LDS; the residual rows into registers (in flight during layer 1)
+    const int xq = K1 >> 2;
+    for (int idx = tid; idx < 32 * xq; idx += NT) {
+        const int r = idx / xq, c4 = idx - r * xq;
+        const int row = min(m0 + r, a.M - 1);
+        *reinterpret_cast<f4*>(smem + r * LDX + 4 * c4) = *reinterpret_cast<const f4*>(a.x + (long)row * K1 + 4 * c4);
+    }
+    f4 resv[RPT];
+    if (a.residual) {
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const int idx = j * NT + tid, r = idx / RQ, c4 = idx - r * RQ;
+            resv[j] = *reinterpret_cast<const f4*>(a.residual + (long)min(m0 + r, a.M - 1) * N1 + 4 * c4);
+        }
+    }
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f4*>(a.w1), 0, (int)a.w1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f4*>(a.w2), 0, (int)a.w2_bytes, 0x00020000);
+
+    // ---- layer 1: acc[cb] (channels x pixels) += W1 fragment x input fragment
+    f32x16 acc[CB1];
+#pragma unroll
+    for (int cb = 0; cb < CB1; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+    auto ldw1 = [&](f4 (&dst)[CB1], int g) {
+#pragma unroll
+        for (int cb = 0; cb < CB1; ++cb) dst[cb] = buf_f4s(rsrc1, lane16, (unsigned)(((wave * CB1 + cb) * NG1 + g) * 1024));
+    };
+    constexpr int R1 = 4;                                  // fragments requested R1 - 1 groups (48 MFMAs of this wave at CB1 = 4) ahead
+    f4 wa[R1][CB1];
+#pragma unroll
+    for (int u = 0; u < R1 - 1; ++u) ldw1(wa[u], min(u, NG1 - 1));
+    __syncthreads();                                       // the input rows are in LDS
+    const float* xrow = smem + p * LDX + 4 * h;            // (LDX % 4 == 0: 16-byte aligned fragment reads)
+    f4 xb = *reinterpret_cast<const f4*>(__builtin_assume_aligned(xrow, 16));
+    for (int g = 0; g < NG1; g += R1) {                    // K1 % 32 == 0
+#pragma unroll
+        for (int u = 0; u < R1; ++u) {
+            // (the fences pin the order the loop is written in: the compiler otherwise gathers a whole iteration's loads into one burst
+            // right in front of their first use, and the wave then sits out an L2 round trip per iteration)
+            ldw1(wa[(u + R1 - 1) % R1], min(g + u + R1 - 1, NG1 - 1));       // the last ones re-read: uniform counts
+            const f4 xn = *reinterpret_cast<const f4*>(__builtin_assume_aligned(xrow + 8 * min(g + u + 1, NG1 - 1), 16));   // next group's activations
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int cb = 0; cb < CB1; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[u][cb][e], xb[e], acc[cb], 0, 0, 0);
+            xb = xn;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- epilogue 1: scale / shift into the LDS image of the intermediate rows (it takes the input rows' place), then one row-major
+    // pass adds the residual, applies the ReLU, rewrites the image and stores the rows (1 KiB contiguous per wave-instruction)
+    __syncthreads();                                       // every wave is done with the input rows
+#pragma unroll
+    for (int cb = 0; cb < CB1; ++cb)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int c0 = (wave * CB1 + cb) * 32 + 8 * gq + 4 * h;
+            f4 v = {acc[cb][4 * gq], acc[cb][4 * gq + 1], acc[cb][4 * gq + 2], acc[cb][4 * gq + 3]};
+            if (a.scale1) v = v * *reinterpret_cast<const f4*>(a.scale1 + c0);
+            v = v + *reinterpret_cast<const f4*>(a.shift1 + c0);
+            *reinterpret_cast<f4*>(smem + p * LDY + c0) = v;
+        }
+    // layer 2's first weight fragments: requested before the pass below, so that they are there when it ends
+    constexpr int R2 = 16;                                 // R2 - 1 groups (60 MFMAs of this wave) ahead
+    const bool active2 = wave < NB2;                       // (N2 = 128: four column blocks, waves 4..7 sit layer 2 out)
+    f4 wb[R2];
+    auto ldw2 = [&](f4& dst, int g) { dst = buf_f4s(rsrc2, lane16, (unsigned)((wave * NG2 + g) * 1024)); };
+    if (active2) {
+#pragma unroll
+        for (int u = 0; u < R2 - 1; ++u) ldw2(wb[u], u);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+        const int idx = j * NT + tid, r = idx / RQ, c4 = idx - r * RQ;
+        f4 v = *reinterpret_cast<const f4*>(smem + r * LDY + 4 * c4);
+        if (a.residual) v = v + resv[j];
+        if (a.relu1) v = f4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+        *reinterpret_cast<f4*>(smem + r * LDY + 4 * c4) = v;
+        if (m0 + r < a.M) *reinterpret_cast<f4*>(a.y + (long)(m0 + r) * N1 + 4 * c4) = v;
+    }
+    __syncthreads();                                       // the intermediate rows are final in LDS
+    if (!active2) return;
+    // ---- layer 2: acc2 += W2 fragment x intermediate fragment (from LDS)
+    f32x16 acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+    const float* yrow = smem + p * LDY + 4 * h;
+    f4 yb = *reinterpret_cast<const f4*>(__builtin_assume_aligned(yrow, 16));
+    for (int g = 0; g < NG2; g += R2) {                    // NG2 = N1 / 8 is a multiple of 16
+#pragma unroll
+        for (int u = 0; u < R2; ++u) {
+            ldw2(wb[(u + R2 - 1) % R2], min(g + u + R2 - 1, NG2 - 1));
+            const f4 yn = *reinterpret_cast<const f4*>(__builtin_assume_aligned(yrow + 8 * min(g + u + 1, NG2 - 1), 16));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[u][e], yb[e], acc2, 0, 0, 0);
+            yb = yn;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (m0 + p < a.M) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int c0 = wave * 32 + 8 * gq + 4 * h;
+            f4 v = {acc2[4 * gq], acc2[4 * gq + 1], acc2[4 * gq + 2], acc2[4 * gq + 3]};
+            if (a.scale2) v = v * *reinterpret_cast<const f4*>(a.scale2 + c0);
+            v = v + *reinterpret_cast<const f4*>(a.shift2 + c0);
+            if (a.relu2) v = f4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+            *reinterpret_cast<f4*>(a.z + (long)(m0 + p) * N2 + c0) = v;
+        }
+    }
+}
+
+template <int CB1, int NB2>
+static int launch(const Args& a, hipStream_t s) {
+    constexpr size_t lds = (size_t)32 * (CB1 * 256 + 4) * sizeof(float);
+    DC_ENSURE_DYN_LDS((&pw_chain_kernel<CB1, NB2>), 160 * 1024);
+    hipLaunchKernelGGL((pw_chain_kernel<CB1, NB2>), dim3((a.M + 31) / 32), dim3(512), lds, s, a);
+    return check_launch("pw_chain_kernel");
+}
+
+}  // namespace chain
+}  // namespace dcap
+
+using namespace dcap;
+
+extern "C" int dc_pw_chain_supported(int K1, int N1, int N2) {
+    return (K1 >= 32 && K1 % 32 == 0 && K1 <= N1 && ((N1 == 1024 && N2 == 256) || (N1 == 512 && N2 == 128))) ? 1 : 0;
+}
+
+extern "C" int dc_pw_chain_pack_f32(const float* w, float* out, int N, int K, void* stream) {
+    DC_REQUIRE(w && out && N > 0 && K > 0 && N % 32 == 0 && K % 8 == 0, DC_EINVAL, "dc_pw_chain_pack: N %% 32 == 0 and K %% 8 == 0");
+    DC_REQUIRE(aligned16(out), DC_EALIGN, "dc_pw_chain_pack: out must be 16-byte aligned");
+    const long total = (long)N * K;
+    hipLaunchKernelGGL(chain::chain_pack_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, static_cast<hipStream_t>(stream), w, out, N, K);
+    return check_launch("dc_pw_chain_pack_f32");
+}
+
+extern "C" int dc_pw_chain_kernel_name(const dc_pw_chain_desc* d, char* buf, size_t buf_bytes) {
+    DC_REQUIRE(d && buf && buf_bytes >= 32, DC_EINVAL, "dc_pw_chain_kernel_name: bad arguments");
+    snprintf(buf, buf_bytes, "pw_chain_kernel<%d, %d>", d->N1 / 256, d->N2 / 32);
+    return DC_OK;
+}
+
+extern "C" int dc_pw_chain_f32(const dc_pw_chain_desc* d, void* stream) {
+    DC_REQUIRE(d && d->x && d->w1 && d->shift1 && d->y && d->w2 && d->shift2 && d->z && d->M > 0, DC_EINVAL, "dc_pw_chain: bad arguments");
+    DC_REQUIRE(dc_pw_chain_supported(d->K1, d->N1, d->N2), DC_EINVAL,
+               "dc_pw_chain: (K1, N1, N2) = (%d, %d, %d) is not a covered shape (K1 %% 32 == 0; N1 -> N2 = 1024 -> 256 or 512 -> 128)", d->K1, d->N1, d->N2);
+    DC_REQUIRE(aligned16(d->x) && aligned16(d->w1) && aligned16(d->w2) && aligned16(d->y) && aligned16(d->z) && aligned16(d->shift1) && aligned16(d->shift2) &&
+                   (!d->scale1 || aligned16(d->scale1)) && (!d->scale2 || aligned16(d->scale2)) && (!d->residual || aligned16(d->residual)),
+               DC_EALIGN, "dc_pw_chain: every pointer must be 16-byte aligned");
+    chain::Args a;
+    a.x = d->x; a.w1 = reinterpret_cast<const f4*>(d->w1); a.scale1 = d->scale1; a.shift1 = d->shift1; a.residual = d->residual; a.y = d->y;
+    a.w2 = reinterpret_cast<const f4*>(d->w2); a.scale2 = d->scale2; a.shift2 = d->shift2; a.z = d->z;
+    a.M = d->M; a.K1 = d->K1; a.relu1 = d->relu1; a.relu2 = d->relu2;
+    a.w1_bytes = (unsigned)((size_t)d->N1 * d->K1 * 4);
+    a.w2_bytes = (unsigned)((size_t)d->N2 * d->N1 * 4);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (d->N1 == 1024) return chain::launch<4, 8>(a, s);
+    return chain::launch<2, 4>(a, s);
+}

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops
-from ._lib import ConvBf16Desc, ConvDesc, check
+from ._lib import ConvBf16Desc, ConvDesc, PwChainDesc, check
 from .layers import ConvSpec, resnet_fpn_convs
 from .packing import fold_bn, pack_conv_kernel, pack_stem_kernel
 
@@ -54,7 +54,7 @@ class EncoderPlan:
 
     def __init__(self, weights, batch, height, width, device, stage4_blocks=22,
                  mean_pixel=(123.7, 116.8, 103.9), use_graph=True, rpn=None, external=None, math=None, external_bn=None, train_stages=(),
-                 winograd=None, wino_products=None):
+                 winograd=None, wino_products=None, pw_chain=None):
         """rpn: None (GT-RoI variant: the RPN is never evaluated) or a dict with the config values the
         proposal path needs: scales, ratios, strides, anchor_stride, bbox_std, nms_threshold, proposal_count and
         optionally head_channels (the fused class+bbox head padded to a multiple of 4 channels for the wgrad kernel).
@@ -87,6 +87,10 @@ class EncoderPlan:
         self.wino_products = wino_products or os.environ.get("DCAP_WINO_PRODUCTS", "b3")
         if self.wino_products not in ("b3", "f32"):
             raise ValueError("wino_products must be 'b3' or 'f32'")
+        # math = 'f32', frozen stages 3 and 4: a bottleneck's last 1x1 convolution (+ shortcut + ReLU) and the next block's first run as ONE
+        # launch that keeps the 4x-wide intermediate rows in LDS (csrc/conv_chain.hip, round 5).  pw_chain=False / DCAP_PW_CHAIN=0: two launches.
+        self.pw_chain = (os.environ.get("DCAP_PW_CHAIN", "1") != "0") if pw_chain is None else bool(pw_chain)
+        self._wchain = {}
         self._wwino = {}
         self._twin = {}
         self._wb = {}
@@ -231,6 +235,29 @@ class EncoderPlan:
             self._ops.append(("cast", y, self._bf(y)))
         self.flops += 2.0 * N * Ho * Wo * Cout * s.k * s.k * s.cin
 
+    def _chain_ok(self, name_c, name_a, mid, cout):
+        sc, sa = self._specs[name_c], self._specs[name_a]
+        return (self.pw_chain and self.math == _lib.MATH_F32 and not self.fast_bf16 and sc.k == 1 and sa.k == 1 and sc.stride == 1 and sa.stride == 1
+                and name_c not in self._external and name_a not in self._external and ops.pw_chain_supported(mid, cout, mid))
+
+    def _chain(self, name_c, x, y, residual, name_a, z):
+        """One launch for conv `name_c` (1x1, x -> y, + residual, ReLU) followed by conv `name_a` (1x1, y -> z, ReLU): dc_pw_chain_f32."""
+        (w1, sc1, sh1), (w2, sc2, sh2) = self._w[name_c], self._w[name_a]
+        for n, w in ((name_c, w1), (name_a, w2)):
+            if n not in self._wchain:
+                self._wchain[n] = ops.pw_chain_pack(w)
+        N, H, W, K1 = x.shape
+        d = PwChainDesc()
+        d.M, d.K1, d.N1, d.N2 = N * H * W, K1, y.shape[3], z.shape[3]
+        d.x, d.w1, d.shift1, d.y = x.data_ptr(), self._wchain[name_c].data_ptr(), sh1.data_ptr(), y.data_ptr()
+        d.scale1 = None if sc1 is None else sc1.data_ptr()
+        d.residual = None if residual is None else residual.data_ptr()
+        d.w2, d.shift2, d.z = self._wchain[name_a].data_ptr(), sh2.data_ptr(), z.data_ptr()
+        d.scale2 = None if sc2 is None else sc2.data_ptr()
+        d.relu1 = d.relu2 = 1
+        self._ops.append(("chain", d, name_c + "+" + name_a))
+        self.flops += 2.0 * d.M * (d.K1 * d.N1 + d.N1 * d.N2)
+
     def _build(self):
         B, H, W = self.B, self.H, self.W
         self._ops, self._ws_bytes, self.flops, self._bufs = [], 0, 0.0, []
@@ -257,6 +284,7 @@ class EncoderPlan:
                 pp = [self._buf(h, w, cout), self._buf(h, w, cout)]
             final = self._buf(h, w, cout)
             self.saved[s] = []
+            pending = None                                  # the previous block's deferred 2c: it runs chained with this block's 2a
             for i, blk in enumerate(blocks):
                 cn = "res%d%s_branch" % (s, blk)
                 if keep:
@@ -266,13 +294,22 @@ class EncoderPlan:
                     self.saved[s].append(dict(name=cn, x=x, m1=m1, m2=m2, sc=sc, out=out, stride=stride if i == 0 else 1))
                 else:
                     out = final if i == len(blocks) - 1 else pp[i & 1]
-                self._conv(cn + "2a", x, m1, f32=keep, bf16=True)                # read by the next convolution only (and by a backward pass)
+                if pending is not None:                                            # previous 2c (-> x) and this 2a (x -> m1) in one launch
+                    self._chain(pending[0], pending[1], x, pending[2], cn + "2a", m1)
+                    pending = None
+                else:
+                    self._conv(cn + "2a", x, m1, f32=keep, bf16=True)            # read by the next convolution only (and by a backward pass)
                 self._conv(cn + "2b", m1, m2, f32=keep, bf16=True)
+                res = x
                 if i == 0:
                     self._conv(cn + "1", x, sc, relu=False)                        # read as a residual only
-                    self._conv(cn + "2c", m2, out, residual=sc, res_mode=1, bf16=True)
+                    res = sc
+                nxt = "res%d%s_branch2a" % (s, blocks[i + 1]) if i + 1 < len(blocks) else None
+                if nxt is not None and not keep and self._chain_ok(cn + "2c", nxt, mid, cout):
+                    # m2 is rewritten only by the next block's 2b, which runs behind the chained launch: it may read it
+                    pending = (cn + "2c", m2, res)
                 else:
-                    self._conv(cn + "2c", m2, out, residual=x, res_mode=1, bf16=True)   # fp32 for the next residual add, bf16 for the next conv
+                    self._conv(cn + "2c", m2, out, residual=res, res_mode=1, bf16=True)   # fp32 for the next residual add, bf16 for the next conv
                 x = out
             return x
 
@@ -332,6 +369,10 @@ class EncoderPlan:
                 rc = lib.dc_conv2d_nhwc_f32(C.byref(op[1]), wsp, wsb, stream)
                 if rc:
                     check(rc, "dc_conv2d_nhwc_f32(%s)" % op[2])
+            elif kind == "chain":
+                rc = lib.dc_pw_chain_f32(C.byref(op[1]), stream)
+                if rc:
+                    check(rc, "dc_pw_chain_f32(%s)" % op[2])
             elif kind == "bconv":
                 rc = lib.dc_conv2d_bf16(C.byref(op[1]), wsp, wsb, stream)
                 if rc:
@@ -353,6 +394,11 @@ class EncoderPlan:
         template instantiation the library launches for the layer (dc_conv2d_kernel_name)."""
         rows = []
         for op in self._ops:
+            if op[0] == "chain":
+                d, buf = op[1], C.create_string_buffer(64)
+                check(self.lib.dc_pw_chain_kernel_name(C.byref(d), buf, 64), "dc_pw_chain_kernel_name")
+                rows.append((op[2], 2.0 * d.M * (d.K1 * d.N1 + d.N1 * d.N2), 32, d.N1, 1, buf.value.decode()))
+                continue
             if op[0] != "conv":
                 continue
             d, bm, bn, sk = op[1], C.c_int(), C.c_int(), C.c_int()
@@ -368,6 +414,10 @@ class EncoderPlan:
         the kernel reads) + the residual / upsample-add operand: what `roofline.algorithmic_bytes` in bench.py sums (fp32 plans)."""
         out = {}
         for op in self._ops:
+            if op[0] == "chain":                              # input + intermediate (written once) + shortcut + output + both kernels
+                d = op[1]
+                out[op[2]] = 4.0 * (d.M * (d.K1 + (2 if d.residual else 1) * d.N1 + d.N2) + d.K1 * d.N1 + d.N1 * d.N2)
+                continue
             if op[0] != "conv":
                 continue
             d, s = op[1], self._specs[op[2]]
@@ -389,7 +439,7 @@ class EncoderPlan:
         lib = self.lib
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         wsp, wsb = C.c_void_p(self._ws.data_ptr()), self._ws.numel()
-        convs = [op for op in self._ops if op[0] == "conv"]
+        convs = [op for op in self._ops if op[0] in ("conv", "chain")]
         acc = [0.0] * len(convs)
         for _ in range(reps):
             self._run_ops()
@@ -400,7 +450,7 @@ class EncoderPlan:
             for op in convs:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                rc = lib.dc_conv2d_nhwc_f32(C.byref(op[1]), wsp, wsb, stream)
+                rc = lib.dc_pw_chain_f32(C.byref(op[1]), stream) if op[0] == "chain" else lib.dc_conv2d_nhwc_f32(C.byref(op[1]), wsp, wsb, stream)
                 e1.record()
                 if rc:
                     check(rc, "dc_conv2d_nhwc_f32(%s)" % op[2])
@@ -537,6 +587,29 @@ class Vgg16Plan(EncoderPlan):
                 k = np.concatenate([k, np.zeros((s.k, s.k, 29, s.cout), np.float32)], axis=2)
             self._w[s.name] = (torch.tensor(pack_conv_kernel(k), device=dev), None,
                                torch.tensor(np.asarray(W[s.name + "/bias"], np.float32), device=dev))
+
+    def _chain_ok(self, name_c, name_a, mid, cout):
+        sc, sa = self._specs[name_c], self._specs[name_a]
+        return (self.pw_chain and self.math == _lib.MATH_F32 and not self.fast_bf16 and sc.k == 1 and sa.k == 1 and sc.stride == 1 and sa.stride == 1
+                and name_c not in self._external and name_a not in self._external and ops.pw_chain_supported(mid, cout, mid))
+
+    def _chain(self, name_c, x, y, residual, name_a, z):
+        """One launch for conv `name_c` (1x1, x -> y, + residual, ReLU) followed by conv `name_a` (1x1, y -> z, ReLU): dc_pw_chain_f32."""
+        (w1, sc1, sh1), (w2, sc2, sh2) = self._w[name_c], self._w[name_a]
+        for n, w in ((name_c, w1), (name_a, w2)):
+            if n not in self._wchain:
+                self._wchain[n] = ops.pw_chain_pack(w)
+        N, H, W, K1 = x.shape
+        d = PwChainDesc()
+        d.M, d.K1, d.N1, d.N2 = N * H * W, K1, y.shape[3], z.shape[3]
+        d.x, d.w1, d.shift1, d.y = x.data_ptr(), self._wchain[name_c].data_ptr(), sh1.data_ptr(), y.data_ptr()
+        d.scale1 = None if sc1 is None else sc1.data_ptr()
+        d.residual = None if residual is None else residual.data_ptr()
+        d.w2, d.shift2, d.z = self._wchain[name_a].data_ptr(), sh2.data_ptr(), z.data_ptr()
+        d.scale2 = None if sc2 is None else sc2.data_ptr()
+        d.relu1 = d.relu2 = 1
+        self._ops.append(("chain", d, name_c + "+" + name_a))
+        self.flops += 2.0 * d.M * (d.K1 * d.N1 + d.N1 * d.N2)
 
     def _build(self):
         B, H, W = self.B, self.H, self.W

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (ConvBf16Desc, AmsgradDesc, DetectionTargetsDesc, BnReluDesc, ConvDesc, ConvWgradBf16Desc, GemmBf16Desc, VocabCeDesc, ProposalDesc, RpnLossDesc, GemmDesc, LstmBwdDesc, LstmFwdDesc, RoiAlignDesc,
+from ._lib import (PwChainDesc, ConvBf16Desc, AmsgradDesc, DetectionTargetsDesc, BnReluDesc, ConvDesc, ConvWgradBf16Desc, GemmBf16Desc, VocabCeDesc, ProposalDesc, RpnLossDesc, GemmDesc, LstmBwdDesc, LstmFwdDesc, RoiAlignDesc,
                    SoftmaxCeDesc, check)
 
 
@@ -247,6 +247,50 @@ def conv2d(x, w_packed, kh, kw, stride, pad_t, pad_l, Ho, Wo, scale=None, shift=
 def conv2d_kernel_name(*args, **kw):
     """The kernel template instantiation conv2d(*args, **kw) would launch (dc_conv2d_kernel_name); nothing is launched."""
     return conv2d(*args, _name_only=True, **kw)
+
+
+def pw_chain_supported(k1, n1, n2):
+    return bool(_lib.load().dc_pw_chain_supported(int(k1), int(n1), int(n2)))
+
+
+def pw_chain_pack(w_packed, out=None):
+    """A packed 1x1 kernel [Cout, Cin] in the fragment order dc_pw_chain_f32 reads (same size)."""
+    lib = _lib.load()
+    _chk(w_packed, name="w")
+    if w_packed.dim() != 2 or not w_packed.is_contiguous():
+        raise _lib.DcapError("pw_chain_pack: w must be the contiguous packed 1x1 kernel [Cout, Cin]")
+    if out is None:
+        out = torch.empty_like(w_packed)
+    check(lib.dc_pw_chain_pack_f32(_ptr(w_packed), _ptr(out), w_packed.shape[0], w_packed.shape[1], _stream()), "dc_pw_chain_pack_f32")
+    return out
+
+
+def pw_chain(x, w1f, shift1, w2f, shift2, scale1=None, scale2=None, residual=None, relu1=True, relu2=True, y=None, z=None):
+    """y = act1((x W1^T) scale1 + shift1 [+ residual]); z = act2((y W2^T) scale2 + shift2) in one launch (dc_pw_chain_f32).
+    x [M, K1] (any leading dims), w1f / w2f: pw_chain_pack() of the packed kernels [N1, K1] / [N2, N1].  Returns (y, z)."""
+    lib = _lib.load()
+    K1 = x.shape[-1]
+    M = x.numel() // K1
+    N1, N2 = w1f.shape[0], w2f.shape[0]
+    if w1f.shape[1] != K1 or w2f.shape[1] != N1:
+        raise _lib.DcapError("pw_chain: kernel shapes do not chain: x [.., %d], w1 %s, w2 %s" % (K1, tuple(w1f.shape), tuple(w2f.shape)))
+    if y is None:
+        y = torch.empty(tuple(x.shape[:-1]) + (N1,), dtype=torch.float32, device=x.device)
+    if z is None:
+        z = torch.empty(tuple(x.shape[:-1]) + (N2,), dtype=torch.float32, device=x.device)
+    for t in (x, y, z) + (() if residual is None else (residual,)):
+        if not t.is_contiguous():
+            raise _lib.DcapError("pw_chain: tensors must be contiguous")
+    d = PwChainDesc()
+    d.M, d.K1, d.N1, d.N2 = M, K1, N1, N2
+    d.x, d.w1, d.shift1, d.y = _chk(x, name="x").data_ptr(), _chk(w1f, name="w1").data_ptr(), _chk(shift1, name="shift1").data_ptr(), _chk(y, name="y").data_ptr()
+    d.w2, d.shift2, d.z = _chk(w2f, name="w2").data_ptr(), _chk(shift2, name="shift2").data_ptr(), _chk(z, name="z").data_ptr()
+    d.scale1 = None if scale1 is None else _chk(scale1, name="scale1").data_ptr()
+    d.scale2 = None if scale2 is None else _chk(scale2, name="scale2").data_ptr()
+    d.residual = None if residual is None else _chk(residual, name="residual").data_ptr()
+    d.relu1, d.relu2 = int(relu1), int(relu2)
+    check(lib.dc_pw_chain_f32(C.byref(d), _stream()), "dc_pw_chain_f32")
+    return y, z
 
 
 def winograd_pack_b3(w_packed, cin, cout, out=None):

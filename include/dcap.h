@@ -220,6 +220,34 @@ size_t dc_conv2d_winograd_weight_bytes(int Cin, int Cout);
 int    dc_conv2d_winograd_pack_f32(const float* w, float* u, int Cin, int Cout, void* stream);
 size_t dc_conv2d_winograd_b3_weight_bytes(int Cin, int Cout);
 int    dc_conv2d_winograd_pack_b3(const float* w, uint16_t* u, int Cin, int Cout, void* stream);
+/* Two chained pointwise (1x1, stride 1) convolutions in one launch (csrc/conv_chain.hip, round 5): y = act1((x W1^T) * scale1 + shift1
+ * [+ residual]) is written out AND contracted on the spot with the second kernel, z = act2((y W2^T) * scale2 + shift2) -- the last
+ * convolution of a ResNet bottleneck (branch2c + shortcut + ReLU) and the first of the next block (branch2a + ReLU):
+ * feature_generation/dense_model.py:85-100, :120-139, frozen BatchNorm folded into scale / shift like dc_conv2d_nhwc_f32.  fp32 operands,
+ * exact fp32 MFMA products.  x [M][K1], y / residual [M][N1], z [M][N2] row-major (NHWC pixels = rows); w1 / w2: the packed kernels
+ * [N][K] re-ordered ONCE by dc_pw_chain_pack_f32 (same size).  Shapes: dc_pw_chain_supported (K1 % 32 == 0; N1 -> N2 = 1024 -> 256 or
+ * 512 -> 128).  No workspace. */
+typedef struct {
+    int M, K1, N1, N2;
+    const float* x;
+    const float* w1;
+    const float* scale1;      /* NULL = 1 */
+    const float* shift1;
+    const float* residual;    /* NULL = none */
+    int relu1;
+    float* y;
+    const float* w2;
+    const float* scale2;
+    const float* shift2;
+    int relu2;
+    float* z;
+} dc_pw_chain_desc;
+int dc_pw_chain_supported(int K1, int N1, int N2);
+int dc_pw_chain_pack_f32(const float* w, float* out, int N, int K, void* stream);
+int dc_pw_chain_f32(const dc_pw_chain_desc* d, void* stream);
+/* Profiling aid: rocprof's spelling of the kernel instantiation dc_pw_chain_f32 launches for `d` (buf_bytes >= 32). */
+int dc_pw_chain_kernel_name(const dc_pw_chain_desc* d, char* buf, size_t buf_bytes);
+
 /* CUs the persistent Winograd grids may occupy (process-wide; a multiple of 8 -- one share per XCD; 0 restores the default:
  * DCAP_WINO_CUS or all 256).  A persistent block holds its CU for the whole launch: in a data-parallel run (parallel_model.py:58-102
  * -> one rank per GPU here) the RCCL all-reduce of another queue needs CUs of its own to overlap the encoder pass, so

@@ -293,6 +293,45 @@ def test_conv2d_winograd_forced_kernels_in_a_child_process(ops, force):
     assert ("wino64_kernel" if force == "64" else "wino32_kernel") in r.stdout
 
 
+@pytest.mark.parametrize("case", [(8192, 256, 1024, 256, True, True), (1000, 256, 1024, 256, True, False), (4096, 128, 512, 128, True, True),
+                                  (77, 64, 512, 128, False, True), (33, 1024, 1024, 256, False, False)])
+def test_pw_chain_two_pointwise_convolutions_in_one_launch(ops, case):
+    """dc_pw_chain_f32 (round 5): a bottleneck's last convolution (1x1 + folded BN + shortcut + ReLU) and the next block's first (1x1 +
+    folded BN + ReLU) in one launch -- both outputs against the float64 oracle at the convolution kernels' tolerance and against the two
+    separate dc_conv2d_nhwc_f32 launches the plan used to make.  Cases: the stage-4 shape at two images (256 blocks = one per CU), a
+    ragged pixel count (the last block has 8 rows), the stage-3 shape, tiny M, K1 = N1."""
+    M, K1, N1, N2, res, sc = case
+    rng = np.random.default_rng(M + K1 + N1)
+    x = rng.standard_normal((M, K1))
+    w1 = rng.standard_normal((N1, K1)) / np.sqrt(K1)
+    w2 = rng.standard_normal((N2, N1)) / np.sqrt(N1)
+    s1, h1 = (rng.uniform(0.5, 1.5, N1) if sc else None), rng.standard_normal(N1)
+    s2, h2 = (rng.uniform(0.5, 1.5, N2) if sc else None), rng.standard_normal(N2)
+    r = rng.standard_normal((M, N1)) if res else None
+    y = x @ w1.T * (1.0 if s1 is None else s1) + h1
+    if r is not None:
+        y = y + r
+    y = np.maximum(y, 0)
+    z = np.maximum(y @ w2.T * (1.0 if s2 is None else s2) + h2, 0)
+    assert ops.pw_chain_supported(K1, N1, N2) and not ops.pw_chain_supported(K1, 256, 64) and not ops.pw_chain_supported(K1 + 16, N1, N2)
+    xd, w1d, w2d = dev(x), dev(w1), dev(w2)
+    w1f, w2f = ops.pw_chain_pack(w1d), ops.pw_chain_pack(w2d)
+    yo = torch.full((M, N1), float("nan"), device="cuda")
+    zo = torch.full((M, N2), float("nan"), device="cuda")
+    gy, gz = ops.pw_chain(xd, w1f, dev(h1), w2f, dev(h2), scale1=None if s1 is None else dev(s1), scale2=None if s2 is None else dev(s2),
+                          residual=None if r is None else dev(r), y=yo, z=zo)
+    close(gy, y, 2e-5)
+    close(gz, z, 2e-5)
+    # the two launches it replaces (M pixels as one image row)
+    x4 = xd.view(1, 1, M, K1)
+    y2 = ops.conv2d(x4, w1d, 1, 1, 1, 0, 0, 1, M, None if s1 is None else dev(s1), dev(h1), None if r is None else dev(r).view(1, 1, M, N1), 1 if res else 0, True)
+    z2 = ops.conv2d(y2, w2d, 1, 1, 1, 0, 0, 1, M, None if s2 is None else dev(s2), dev(h2), None, 0, True)
+    close(gy, y2.view(M, N1).cpu().numpy().astype(np.float64), 2e-5)
+    close(gz, z2.view(M, N2).cpu().numpy().astype(np.float64), 2e-5)
+    with pytest.raises(Exception):
+        ops.pw_chain(xd, w1f, dev(h1), ops.pw_chain_pack(dev(rng.standard_normal((64, N1)))), dev(h2[:64]))     # N2 = 64: not a covered shape
+
+
 def test_conv2d_winograd_falls_back_where_the_form_does_not_apply(ops):
     """w_wino on a layer the Winograd kernel does not cover (a residual, a stride, another arithmetic): the direct kernels run."""
     from image_captioning_amd.packing import pack_conv_kernel
