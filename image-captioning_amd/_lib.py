@@ -233,6 +233,7 @@ SYMBOLS = {
     "dc_maxpool3x3s2_same_bwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
     "dc_dropout_mask_f32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "dc_amsgrad_step_f32": (C.c_int, [C.POINTER(AmsgradDesc), C.c_void_p]),
+    "dc_zero_fill": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "dc_reg_sumsq_workspace_bytes": (C.c_size_t, [C.c_size_t]),
     "dc_reg_sumsq_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(RegSegments), C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }

@@ -700,6 +700,11 @@ extern "C" int dc_reg_sumsq_f32(const float* w, const float* g, const dc_reg_seg
     return rc;
 }
 
+extern "C" int dc_zero_fill(void* p, size_t bytes, void* stream) {
+    DC_REQUIRE(p && bytes > 0, DC_EINVAL, "dc_zero_fill: bad arguments");
+    return zero_fill_async(p, bytes, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int dc_axpy_f32(float a, const float* x, float* y, size_t n, void* stream) {
     DC_REQUIRE(x && y && n > 0, DC_EINVAL, "dc_axpy: bad arguments");
     const int blocks = (int)std::min<size_t>((n + 255) / 256, (size_t)kNumCU * 8);

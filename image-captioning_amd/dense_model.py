@@ -762,13 +762,18 @@ class DenseImageCapRCNN(object):
         st = self.store
         w, g = st.w, st.grad
         maps = list(p.P) + [p.P6]
-        dP = [self._buf("dP%d" % i, tuple(m.shape)) for i, m in enumerate(maps)]
-        for t in dP:
-            t.zero_()
+        # dP2..dP6 and the five head gradients start from zero: ten tensors cut from ONE buffer, zeroed by ONE launch of the library's
+        # zero-fill kernel (they were ten torch fill launches)
+        shapes = [tuple(m.shape) for m in maps] + [tuple(h.shape) for h in p.rpn_heads]
+        sizes = [(int(np.prod(sh)) + 3) // 4 * 4 for sh in shapes]
+        pool = self._buf("rpn_bwd_zero", (sum(sizes),))
+        ops.zero_fill(pool)
+        cuts, off = [], 0
+        for sh, n in zip(shapes, sizes):
+            cuts.append(pool[off:off + int(np.prod(sh))].view(sh))
+            off += n
+        dP, dheads = cuts[:len(maps)], cuts[len(maps):]
         # ---- RPN losses and their gradients w.r.t. the fused head outputs (selection and counts: this step's StepInputs views)
-        dheads = [self._buf("dhead%d" % i, tuple(h.shape)) for i, h in enumerate(p.rpn_heads)]
-        for t in dheads:
-            t.zero_()
         ops.rpn_loss_grad(p.rpn_heads, dheads, rpn_up["lvl"], rpn_up["idx"], rpn_up["mt"], rpn_up["deltas"], rpn_up["cap"], losses[0:2],
                           anchors_per_loc=self.A, counts_dev=rpn_up["counts"])
 
@@ -839,7 +844,7 @@ class DenseImageCapRCNN(object):
                 d_out = dxc
             else:                                            # the 1x1 / stride-2 entry convolutions read every other pixel of x
                 d_out = self._buf(("tb_dx", tuple(x.shape)), tuple(x.shape))
-                d_out.zero_()
+                ops.zero_fill(d_out)
                 ops.scatter2_add(dxc, d_out)
             # (the next, earlier block turns d_out into its ds before it writes its own dxc, which may be this very buffer)
         return d_out
@@ -873,7 +878,7 @@ class DenseImageCapRCNN(object):
             x64 = ops.mold_image_padded(p.images, p.mean_pixel, self._buf("tb_x64", tuple(p.images.shape[:3]) + (64,)))   # Cin % 64 == 0 for the wgrad kernel
             gw = ops.conv2d_wgrad(x64, dacc, 7, 7, 2, 3, 3, out=self._buf("tb_gw_stem", (64, 49 * 64)))
             gk = g["conv1/kernel"].view(64, 7, 8, 4)                       # the stem's packed layout (pads stay zero)
-            gk.zero_()
+            ops.zero_fill(g["conv1/kernel"])
             gk[:, :, :7, :3].copy_(gw.view(64, 7, 7, 64)[..., :3])
 
     @property
@@ -1000,7 +1005,7 @@ class DenseImageCapRCNN(object):
             # RPN losses need the heads only (their gradient goes to scratch), the regulariser the weights only
             scratch = [self._buf("dhead%d" % i, tuple(h.shape)) for i, h in enumerate(p.rpn_heads)]
             for t in scratch:
-                t.zero_()
+                ops.zero_fill(t)
             ops.rpn_loss_grad(p.rpn_heads, scratch, rpn_up["lvl"], rpn_up["idx"], rpn_up["mt"], rpn_up["deltas"], rpn_up["cap"], losses[0:2],
                               anchors_per_loc=self.A, counts_dev=rpn_up["counts"])
             coef, _ = self._masks()

@@ -825,6 +825,15 @@ def set_persistent_cus(n):
     return int(lib.dc_get_persistent_cus())
 
 
+def zero_fill(t):
+    """t[...] = 0 by the library's zero-fill kernel (contiguous tensor of 4-byte-multiple size): no torch fill launch on the product path."""
+    lib = _lib.load()
+    if not t.is_contiguous() or not t.is_cuda:
+        raise _lib.DcapError("zero_fill: a contiguous GPU tensor")
+    check(lib.dc_zero_fill(_ptr(t), t.numel() * t.element_size(), _stream()), "dc_zero_fill")
+    return t
+
+
 def axpy(a, x, y):
     lib = _lib.load()
     check(lib.dc_axpy_f32(float(a), _ptr(_chk(x, name="x")), _ptr(_chk(y, name="y")), x.numel(), _stream()), "dc_axpy_f32")

@@ -599,6 +599,10 @@ int dc_mul_f32(const float* a, const float* b, float* out, size_t n, void* strea
  * first maximum (row-major, as TF's MaxPoolGrad) is this pixel.  x [N,H,W,C], y / dy [N,ceil(H/2),ceil(W/2),C]. */
 int dc_maxpool3x3s2_same_bwd_f32(const float* x, const float* y, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
 
+/* bytes of zeros at p (pointer and size multiples of 4): a kernel, not a memset node -- a captured hipMemsetAsync node faulted on its
+ * second replay on this runtime (round 4), so the library and its callers zero buffers with this. */
+int dc_zero_fill(void* p, size_t bytes, void* stream);
+
 /* mean of loss rows: out[0] = sum(x)/n. */
 int dc_mean_f32(const float* x, size_t n, float* out, void* stream);
 

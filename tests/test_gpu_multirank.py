@@ -131,6 +131,12 @@ def test_joint_model_two_ranks_average_the_tower_gradients(tmp_path, grad_dtype)
     diff = np.abs(r[0]["flat"] - single).max()
     print("joint 2-rank vs averaged single process: max |dw| = %.3e of a %.3e update" % (diff, moved))
     if grad_dtype == "bf16":
-        assert moved > 0 and diff < 0.1 * moved, (diff, moved)          # same update up to the wire's rounding; not the fp32 bits
+        # the same update up to the wire's rounding, not the fp32 bits: in the L2 norm (AMSGrad's first step is lr * g / (|g| + eps), so an
+        # element whose gradient is of the order of eps = 1e-7 moves by a large fraction of a step when its gradient is rounded to 8 bits:
+        # single elements may differ by tenths of a step, the update as a whole by a fraction of a percent)
+        upd = (single - start).astype(np.float64)
+        dl2 = float(np.linalg.norm(r[0]["flat"].astype(np.float64) - single) / np.linalg.norm(upd))
+        print("bf16 wire: relative L2 difference of the update %.3e" % dl2)
+        assert moved > 0 and dl2 < 2e-2 and diff < 0.5 * moved, (dl2, diff, moved)
         return
     assert moved > 0 and diff == 0.0      # bit-equal (round 2: 2e-3 of the update -- RoIAlign's backward was an atomic scatter then; it is a fixed-order gather now)
