@@ -277,19 +277,17 @@ __device__ __forceinline__ void ce_epilogue256(b256::f32x4 (&acc)[8][4], float* 
                         g[j] = ce.keras_sparse ? gs * p[nt][j] * ((unclipped(p[nt][j]) ? invS : 0.f) - (hit ? tq : 0.f) - c) : gs * (p[nt][j] - (hit ? 1.f : 0.f));
                         if (!cv[nt]) g[j] = 0.f;               // columns V .. lddl-1 of the gradient are the zero K padding of the GEMMs that read it
                     }
-                    if (rv) cs[nt] += g;
-                    if (ce.dl_f32) {
-                        if (rv && col[nt] < ce.lddl)               // lddl % 4 == 0
-                            *reinterpret_cast<f32x4*>(ce.dl_f32 + (long)row * ce.lddl + col[nt]) = g;
-                    } else {
-                        // bf16 gradient (round 5): the tile is staged in the (now free) operand LDS -- 256 rows x 512 bytes, the 8-byte
-                        // chunk c of row r at c ^ ((r & 15) << 2): the 16 rows x 4 chunks a wave writes per instruction hit 64 different
-                        // bank pairs -- and copied out below in whole 512-byte rows; the direct form stored 8 bytes per lane in 32-byte
-                        // row segments (0.44 ms for the 300 MB of the joint model's gradient against 0.30 ms for the pass that stores nothing)
-                        typedef unsigned short us4 __attribute__((ext_vector_type(4)));
-                        const int chunk = (col[nt] - n0) >> 2;
-                        *reinterpret_cast<us4*>(reinterpret_cast<char*>(lds) + lr * 512 + ((chunk ^ ((lr & 15) << 2)) << 3)) =
-                            us4{Epilogue::bf16_bits(g[0]), Epilogue::bf16_bits(g[1]), Epilogue::bf16_bits(g[2]), Epilogue::bf16_bits(g[3])};
+                    if (rv) {
+                        cs[nt] += g;
+                        if (col[nt] < ce.lddl) {                   // lddl % 4 == 0
+                            if (ce.dl_f32) {
+                                *reinterpret_cast<f32x4*>(ce.dl_f32 + (long)row * ce.lddl + col[nt]) = g;
+                            } else {
+                                typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+                                *reinterpret_cast<us4*>(ce.dl_bf16 + (long)row * ce.lddl + col[nt]) =
+                                    us4{Epilogue::bf16_bits(g[0]), Epilogue::bf16_bits(g[1]), Epilogue::bf16_bits(g[2]), Epilogue::bf16_bits(g[3])};
+                            }
+                        }
                     }
                 }
             }
@@ -308,20 +306,7 @@ __device__ __forceinline__ void ce_epilogue256(b256::f32x4 (&acc)[8][4], float* 
             }
             *reinterpret_cast<float2*>(ce.stats + ((long)(m0 + tid) * ce.tiles_n + tile_n) * 2) = r;
         }
-    } else {
-      if (ce.dl_bf16) {
-        __syncthreads();                                             // the tile is complete in LDS
-        typedef unsigned short us4 __attribute__((ext_vector_type(4)));
-        const int ccol = n0 + 4 * lane;                              // this lane's 8-byte chunk of every row: 64 lanes = one 512-byte row
-#pragma unroll 4
-        for (int r = wave; r < 256; r += 8) {                        // wave-uniform rows
-            if (m0 + r < ce.M && ccol < ce.lddl)
-                *reinterpret_cast<us4*>(ce.dl_bf16 + (long)(m0 + r) * ce.lddl + ccol) =
-                    *reinterpret_cast<const us4*>(reinterpret_cast<const char*>(lds) + r * 512 + ((lane ^ ((r & 15) << 2)) << 3));
-        }
-        __syncthreads();                                             // (the bias-gradient partials below reuse the LDS)
-      }
-      if (ce.dbias_part) {
+    } else if (ce.dbias_part) {
         float* red = lds;                                            // [2 wave groups][256 tile columns]
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
@@ -336,7 +321,6 @@ __device__ __forceinline__ void ce_epilogue256(b256::f32x4 (&acc)[8][4], float* 
             }
         __syncthreads();
         if (tid < 256 && n0 + tid < ce.V) ce.dbias_part[(long)tile_m * ce.V + n0 + tid] = red[tid] + red[256 + tid];
-      }
     }
 }
 
