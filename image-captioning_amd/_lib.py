@@ -138,7 +138,7 @@ class PwChainDesc(C.Structure):
     _fields_ = [("M", C.c_int), ("K1", C.c_int), ("N1", C.c_int), ("N2", C.c_int),
                 ("x", C.c_void_p), ("w1", C.c_void_p), ("scale1", C.c_void_p), ("shift1", C.c_void_p), ("residual", C.c_void_p),
                 ("relu1", C.c_int), ("y", C.c_void_p), ("w2", C.c_void_p), ("scale2", C.c_void_p), ("shift2", C.c_void_p),
-                ("relu2", C.c_int), ("z", C.c_void_p)]
+                ("relu2", C.c_int), ("z", C.c_void_p), ("w1_b3", C.c_void_p), ("w2_b3", C.c_void_p)]
 
 
 class RegSegments(C.Structure):
@@ -180,6 +180,7 @@ SYMBOLS = {
     "dc_conv2d_winograd_pack_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dc_pw_chain_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "dc_pw_chain_pack_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "dc_pw_chain_pack_b3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dc_pw_chain_f32": (C.c_int, [C.POINTER(PwChainDesc), C.c_void_p]),
     "dc_pw_chain_kernel_name": (C.c_int, [C.POINTER(PwChainDesc), C.c_char_p, C.c_size_t]),
     "dc_conv2d_winograd_b3_weight_bytes": (C.c_size_t, [C.c_int, C.c_int]),

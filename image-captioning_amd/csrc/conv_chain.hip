@@ -22,7 +22,7 @@
 //     16 bytes at row p: the 16 lanes of a read group hit 16 different bank quads); one ds_read_b128 feeds 4 x CB MFMAs.
 // Layer 1: wave w owns the column blocks w * CB1 .. + CB1 - 1 (CB1 = N1 / 256: 4 accumulator tiles for N1 = 1024), layer 2 the
 // column block w (N2 / 32 <= 8 blocks).
-#include "igemm_core.h"
+#include "igemm_bf16s.h"
 #include <algorithm>
 
 namespace dcap {
@@ -53,8 +53,53 @@ __global__ void chain_pack_kernel(const float* __restrict__ w, float* __restrict
     }
 }
 
+// Split-bf16 variant of the pack (pw_chain_kernel<.., true>): every weight as three bf16 pieces (x = p0 + p1 + p2, round to nearest even,
+// exact remainders) in the fragment order of v_mfma_f32_32x32x16_bf16: ushort index
+//   ((((cb * K/16 + g) * 3 + piece) * 64 + lane) * 8 + jj),  lane = 32 h + i  <->  w[cout = 32 cb + i][k = 16 g + 8 h + jj]
+__global__ void chain_pack_b3_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int N, int K) {
+    const long total = (long)N * K;
+    const int NG = K >> 4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int cout = (int)(idx / K), k = (int)(idx - (long)cout * K);
+        const int cb = cout >> 5, i = cout & 31, g = k >> 4, h = (k >> 3) & 1, jj = k & 7;
+        float x = w[idx];
+#pragma unroll
+        for (int piece = 0; piece < 3; ++piece) {
+            const unsigned short pb = __builtin_bit_cast(unsigned short, (__bf16)x);
+            x -= __uint_as_float((unsigned)pb << 16);
+            out[((((long)cb * NG + g) * 3 + piece) * 64 + (h * 32 + i)) * 8 + jj] = pb;
+        }
+    }
+}
+
+__device__ __forceinline__ void split8(const f4& va, const f4& vb, u32x4& p0, u32x4& p1, u32x4& p2) {
+    unsigned a0, a1, a2, b0, b1, b2, c0, c1, c2, d0, d1, d2;
+    split_pair(va[0], va[1], a0, a1, a2);
+    split_pair(va[2], va[3], b0, b1, b2);
+    split_pair(vb[0], vb[1], c0, c1, c2);
+    split_pair(vb[2], vb[3], d0, d1, d2);
+    p0 = u32x4{a0, b0, c0, d0};
+    p1 = u32x4{a1, b1, c1, d1};
+    p2 = u32x4{a2, b2, c2, d2};
+}
+__device__ __forceinline__ f32x16 mfma_b(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// six products of the three-piece split, small terms first (igemm_bf16s.h's order): fp32-grade
+__device__ __forceinline__ f32x16 mfma_b3(const u32x4 (&w)[3], const u32x4 (&q)[3], f32x16 c) {
+    c = mfma_b(w[0], q[2], c);
+    c = mfma_b(w[1], q[1], c);
+    c = mfma_b(w[2], q[0], c);
+    c = mfma_b(w[1], q[0], c);
+    c = mfma_b(w[0], q[1], c);
+    return mfma_b(w[0], q[0], c);
+}
+
 // CB1 = column blocks (of 32 channels) per wave in layer 1 = N1 / 256; NB2 = column blocks of layer 2 = N2 / 32 (<= 8: one per wave)
-template <int CB1, int NB2>
+// B3: both layers' products on the BF16 matrix pipe in split arithmetic (weights pre-split into three bf16 pieces by
+// dc_pw_chain_pack_b3, activations split in registers as they leave LDS; six v_mfma_f32_32x32x16_bf16 products per fp32 product, fp32
+// accumulation: DC_MATH_BF16X3's arithmetic) -- per 16 channels and column block 6 MFMAs of 32 cycles where the fp32 form issues 8 of 64.
+template <int CB1, int NB2, bool B3>
 __global__ __launch_bounds__(512, 1) void pw_chain_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = 512, NW = 8;
@@ -76,13 +121,16 @@ __global__ __launch_bounds__(512, 1) void pw_chain_kernel(Args a) {
         *reinterpret_cast<f4*>(smem + r * LDX + 4 * c4) = *reinterpret_cast<const f4*>(a.x + (long)row * K1 + 4 * c4);
     }
     f4 resv[RPT];
-    if (a.residual) {
+    auto load_res = [&]() {
+        if (a.residual) {
 #pragma unroll
-        for (int j = 0; j < RPT; ++j) {
-            const int idx = j * NT + tid, r = idx / RQ, c4 = idx - r * RQ;
-            resv[j] = *reinterpret_cast<const f4*>(a.residual + (long)min(m0 + r, a.M - 1) * N1 + 4 * c4);
+            for (int j = 0; j < RPT; ++j) {
+                const int idx = j * NT + tid, r = idx / RQ, c4 = idx - r * RQ;
+                resv[j] = *reinterpret_cast<const f4*>(a.residual + (long)min(m0 + r, a.M - 1) * N1 + 4 * c4);
+            }
         }
-    }
+    };
+    if constexpr (!B3) load_res();                         // (B3: its deeper weight ring needs the registers; the rows are requested behind layer 1's loop)
     const unsigned lane16 = (unsigned)lane * 16u;
     const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f4*>(a.w1), 0, (int)a.w1_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f4*>(a.w2), 0, (int)a.w2_bytes, 0x00020000);
@@ -97,6 +145,46 @@ __global__ __launch_bounds__(512, 1) void pw_chain_kernel(Args a) {
 #pragma unroll
         for (int cb = 0; cb < CB1; ++cb) dst[cb] = buf_f4s(rsrc1, lane16, (unsigned)(((wave * CB1 + cb) * NG1 + g) * 1024));
     };
+    if constexpr (B3) {
+        // groups of 16 channels: the lane's eight activations (channels 16 g + 8 h .. + 7 of its pixel) -> three bf16x8 pieces -> for every
+        // column block three weight fragments (48 bytes per lane) and six MFMAs.  Weight ring: R groups, requested R - 1 groups ahead.
+        const int NGB = K1 >> 4;
+        constexpr int R = 3;
+        u32x4 wr[R][CB1][3];
+        auto ldwb = [&](u32x4 (&dst)[CB1][3], int g) {
+#pragma unroll
+            for (int cb = 0; cb < CB1; ++cb) {
+                const unsigned so = (unsigned)(((wave * CB1 + cb) * NGB + g) * 3072);
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) dst[cb][pc] = __builtin_bit_cast(u32x4, buf_f4s(rsrc1, lane16, so + 1024u * pc));
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < R - 1; ++u) ldwb(wr[u], min(u, NGB - 1));
+        __syncthreads();                                   // the input rows are in LDS
+        const float* xrow = smem + p * LDX + 8 * h;
+        f4 xa = *reinterpret_cast<const f4*>(__builtin_assume_aligned(xrow, 16)), xc = *reinterpret_cast<const f4*>(__builtin_assume_aligned(xrow + 4, 16));
+        for (int g = 0; g < NGB; g += R) {                 // K1 % 48 == 0 is not required: the tail groups re-run clamped loads but
+#pragma unroll
+            for (int u = 0; u < R; ++u) {                  // only groups < NGB issue MFMAs (uniform branch)
+                if (g + u < NGB) {
+                    ldwb(wr[(u + R - 1) % R], min(g + u + R - 1, NGB - 1));
+                    const int gn = min(g + u + 1, NGB - 1);
+                    const f4 na = *reinterpret_cast<const f4*>(__builtin_assume_aligned(xrow + 16 * gn, 16));
+                    const f4 nc = *reinterpret_cast<const f4*>(__builtin_assume_aligned(xrow + 16 * gn + 4, 16));
+                    u32x4 q[3];
+                    split8(xa, xc, q[0], q[1], q[2]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int cb = 0; cb < CB1; ++cb) acc[cb] = mfma_b3(wr[u][cb], q, acc[cb]);
+                    xa = na;
+                    xc = nc;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        load_res();
+    } else {
     constexpr int R1 = 4;                                  // fragments requested R1 - 1 groups (48 MFMAs of this wave at CB1 = 4) ahead
     f4 wa[R1][CB1];
 #pragma unroll
@@ -120,6 +208,7 @@ __global__ __launch_bounds__(512, 1) void pw_chain_kernel(Args a) {
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    }
     // ---- epilogue 1: scale / shift into the LDS image of the intermediate rows (it takes the input rows' place), then one row-major
     // pass adds the residual, applies the ReLU, rewrites the image and stores the rows (1 KiB contiguous per wave-instruction)
     __syncthreads();                                       // every wave is done with the input rows
@@ -134,30 +223,66 @@ __global__ __launch_bounds__(512, 1) void pw_chain_kernel(Args a) {
             *reinterpret_cast<f4*>(smem + p * LDY + c0) = v;
         }
     // layer 2's first weight fragments: requested before the pass below, so that they are there when it ends
-    constexpr int R2 = 16;                                 // R2 - 1 groups (60 MFMAs of this wave) ahead
     const bool active2 = wave < NB2;                       // (N2 = 128: four column blocks, waves 4..7 sit layer 2 out)
+    f32x16 acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+    auto finish_pass = [&]() {                             // residual + ReLU over the LDS image, the intermediate rows out to memory
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const int idx = j * NT + tid, r = idx / RQ, c4 = idx - r * RQ;
+            f4 v = *reinterpret_cast<const f4*>(smem + r * LDY + 4 * c4);
+            if (a.residual) v = v + resv[j];
+            if (a.relu1) v = f4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+            *reinterpret_cast<f4*>(smem + r * LDY + 4 * c4) = v;
+            if (m0 + r < a.M) *reinterpret_cast<f4*>(a.y + (long)(m0 + r) * N1 + 4 * c4) = v;
+        }
+        __syncthreads();                                   // the intermediate rows are final in LDS
+    };
+    if constexpr (B3) {
+        constexpr int NGB2 = N1 / 16, R = 8;               // seven groups (42 MFMAs of this wave + their splits) ahead
+        u32x4 wr[R][3];
+        auto ldwb = [&](u32x4 (&dst)[3], int g) {
+            const unsigned so = (unsigned)((wave * NGB2 + g) * 3072);
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) dst[pc] = __builtin_bit_cast(u32x4, buf_f4s(rsrc2, lane16, so + 1024u * pc));
+        };
+        if (active2) {
+#pragma unroll
+            for (int u = 0; u < R - 1; ++u) ldwb(wr[u], u);
+        }
+        finish_pass();
+        if (!active2) return;
+        const float* yrow = smem + p * LDY + 8 * h;
+        f4 ya = *reinterpret_cast<const f4*>(__builtin_assume_aligned(yrow, 16)), yc = *reinterpret_cast<const f4*>(__builtin_assume_aligned(yrow + 4, 16));
+        for (int g = 0; g < NGB2; g += R) {                // NGB2 = N1 / 16 is a multiple of 8
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                ldwb(wr[(u + R - 1) % R], min(g + u + R - 1, NGB2 - 1));
+                const int gn = min(g + u + 1, NGB2 - 1);
+                const f4 na = *reinterpret_cast<const f4*>(__builtin_assume_aligned(yrow + 16 * gn, 16));
+                const f4 nc = *reinterpret_cast<const f4*>(__builtin_assume_aligned(yrow + 16 * gn + 4, 16));
+                u32x4 q[3];
+                split8(ya, yc, q[0], q[1], q[2]);
+                __builtin_amdgcn_sched_barrier(0);
+                acc2 = mfma_b3(wr[u], q, acc2);
+                ya = na;
+                yc = nc;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {
+    constexpr int R2 = 16;                                 // R2 - 1 groups (60 MFMAs of this wave) ahead
     f4 wb[R2];
     auto ldw2 = [&](f4& dst, int g) { dst = buf_f4s(rsrc2, lane16, (unsigned)((wave * NG2 + g) * 1024)); };
     if (active2) {
 #pragma unroll
         for (int u = 0; u < R2 - 1; ++u) ldw2(wb[u], u);
     }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < RPT; ++j) {
-        const int idx = j * NT + tid, r = idx / RQ, c4 = idx - r * RQ;
-        f4 v = *reinterpret_cast<const f4*>(smem + r * LDY + 4 * c4);
-        if (a.residual) v = v + resv[j];
-        if (a.relu1) v = f4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-        *reinterpret_cast<f4*>(smem + r * LDY + 4 * c4) = v;
-        if (m0 + r < a.M) *reinterpret_cast<f4*>(a.y + (long)(m0 + r) * N1 + 4 * c4) = v;
-    }
-    __syncthreads();                                       // the intermediate rows are final in LDS
+    finish_pass();
     if (!active2) return;
     // ---- layer 2: acc2 += W2 fragment x intermediate fragment (from LDS)
-    f32x16 acc2;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
     const float* yrow = smem + p * LDY + 4 * h;
     f4 yb = *reinterpret_cast<const f4*>(__builtin_assume_aligned(yrow, 16));
     for (int g = 0; g < NG2; g += R2) {                    // NG2 = N1 / 8 is a multiple of 16
@@ -172,6 +297,7 @@ __global__ __launch_bounds__(512, 1) void pw_chain_kernel(Args a) {
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    }
     if (m0 + p < a.M) {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
@@ -185,11 +311,11 @@ __global__ __launch_bounds__(512, 1) void pw_chain_kernel(Args a) {
     }
 }
 
-template <int CB1, int NB2>
+template <int CB1, int NB2, bool B3>
 static int launch(const Args& a, hipStream_t s) {
     constexpr size_t lds = (size_t)32 * (CB1 * 256 + 4) * sizeof(float);
-    DC_ENSURE_DYN_LDS((&pw_chain_kernel<CB1, NB2>), 160 * 1024);
-    hipLaunchKernelGGL((pw_chain_kernel<CB1, NB2>), dim3((a.M + 31) / 32), dim3(512), lds, s, a);
+    DC_ENSURE_DYN_LDS((&pw_chain_kernel<CB1, NB2, B3>), 160 * 1024);
+    hipLaunchKernelGGL((pw_chain_kernel<CB1, NB2, B3>), dim3((a.M + 31) / 32), dim3(512), lds, s, a);
     return check_launch("pw_chain_kernel");
 }
 
@@ -210,26 +336,35 @@ extern "C" int dc_pw_chain_pack_f32(const float* w, float* out, int N, int K, vo
     return check_launch("dc_pw_chain_pack_f32");
 }
 
+extern "C" int dc_pw_chain_pack_b3(const float* w, uint16_t* out, int N, int K, void* stream) {
+    DC_REQUIRE(w && out && N > 0 && K > 0 && N % 32 == 0 && K % 16 == 0, DC_EINVAL, "dc_pw_chain_pack_b3: N %% 32 == 0 and K %% 16 == 0");
+    DC_REQUIRE(aligned16(out), DC_EALIGN, "dc_pw_chain_pack_b3: out must be 16-byte aligned");
+    const long total = (long)N * K;
+    hipLaunchKernelGGL(chain::chain_pack_b3_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, static_cast<hipStream_t>(stream), w, out, N, K);
+    return check_launch("dc_pw_chain_pack_b3");
+}
+
 extern "C" int dc_pw_chain_kernel_name(const dc_pw_chain_desc* d, char* buf, size_t buf_bytes) {
-    DC_REQUIRE(d && buf && buf_bytes >= 32, DC_EINVAL, "dc_pw_chain_kernel_name: bad arguments");
-    snprintf(buf, buf_bytes, "pw_chain_kernel<%d, %d>", d->N1 / 256, d->N2 / 32);
+    DC_REQUIRE(d && buf && buf_bytes >= 40, DC_EINVAL, "dc_pw_chain_kernel_name: bad arguments");
+    snprintf(buf, buf_bytes, "pw_chain_kernel<%d, %d, %s>", d->N1 / 256, d->N2 / 32, (d->w1_b3 && d->w2_b3) ? "true" : "false");
     return DC_OK;
 }
 
 extern "C" int dc_pw_chain_f32(const dc_pw_chain_desc* d, void* stream) {
-    DC_REQUIRE(d && d->x && d->w1 && d->shift1 && d->y && d->w2 && d->shift2 && d->z && d->M > 0, DC_EINVAL, "dc_pw_chain: bad arguments");
+    const bool b3 = d && d->w1_b3 && d->w2_b3;
+    DC_REQUIRE(d && d->x && (b3 || (d->w1 && d->w2)) && d->shift1 && d->y && d->shift2 && d->z && d->M > 0, DC_EINVAL, "dc_pw_chain: bad arguments");
     DC_REQUIRE(dc_pw_chain_supported(d->K1, d->N1, d->N2), DC_EINVAL,
                "dc_pw_chain: (K1, N1, N2) = (%d, %d, %d) is not a covered shape (K1 %% 32 == 0; N1 -> N2 = 1024 -> 256 or 512 -> 128)", d->K1, d->N1, d->N2);
-    DC_REQUIRE(aligned16(d->x) && aligned16(d->w1) && aligned16(d->w2) && aligned16(d->y) && aligned16(d->z) && aligned16(d->shift1) && aligned16(d->shift2) &&
+    DC_REQUIRE(aligned16(d->x) && aligned16(b3 ? (const void*)d->w1_b3 : (const void*)d->w1) && aligned16(b3 ? (const void*)d->w2_b3 : (const void*)d->w2) && aligned16(d->y) && aligned16(d->z) && aligned16(d->shift1) && aligned16(d->shift2) &&
                    (!d->scale1 || aligned16(d->scale1)) && (!d->scale2 || aligned16(d->scale2)) && (!d->residual || aligned16(d->residual)),
                DC_EALIGN, "dc_pw_chain: every pointer must be 16-byte aligned");
     chain::Args a;
-    a.x = d->x; a.w1 = reinterpret_cast<const f4*>(d->w1); a.scale1 = d->scale1; a.shift1 = d->shift1; a.residual = d->residual; a.y = d->y;
-    a.w2 = reinterpret_cast<const f4*>(d->w2); a.scale2 = d->scale2; a.shift2 = d->shift2; a.z = d->z;
+    a.x = d->x; a.w1 = b3 ? reinterpret_cast<const f4*>(d->w1_b3) : reinterpret_cast<const f4*>(d->w1); a.scale1 = d->scale1; a.shift1 = d->shift1; a.residual = d->residual; a.y = d->y;
+    a.w2 = b3 ? reinterpret_cast<const f4*>(d->w2_b3) : reinterpret_cast<const f4*>(d->w2); a.scale2 = d->scale2; a.shift2 = d->shift2; a.z = d->z;
     a.M = d->M; a.K1 = d->K1; a.relu1 = d->relu1; a.relu2 = d->relu2;
-    a.w1_bytes = (unsigned)((size_t)d->N1 * d->K1 * 4);
-    a.w2_bytes = (unsigned)((size_t)d->N2 * d->N1 * 4);
+    a.w1_bytes = (unsigned)((size_t)d->N1 * d->K1 * (b3 ? 6 : 4));
+    a.w2_bytes = (unsigned)((size_t)d->N2 * d->N1 * (b3 ? 6 : 4));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (d->N1 == 1024) return chain::launch<4, 8>(a, s);
-    return chain::launch<2, 4>(a, s);
+    if (b3) return d->N1 == 1024 ? chain::launch<4, 8, true>(a, s) : chain::launch<2, 4, true>(a, s);
+    return d->N1 == 1024 ? chain::launch<4, 8, false>(a, s) : chain::launch<2, 4, false>(a, s);
 }

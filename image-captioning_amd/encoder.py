@@ -243,16 +243,21 @@ class EncoderPlan:
     def _chain(self, name_c, x, y, residual, name_a, z):
         """One launch for conv `name_c` (1x1, x -> y, + residual, ReLU) followed by conv `name_a` (1x1, y -> z, ReLU): dc_pw_chain_f32."""
         (w1, sc1, sh1), (w2, sc2, sh2) = self._w[name_c], self._w[name_a]
+        b3 = self.wino_products == "b3"                       # the split-bf16 products, like the Winograd layers
         for n, w in ((name_c, w1), (name_a, w2)):
             if n not in self._wchain:
-                self._wchain[n] = ops.pw_chain_pack(w)
+                self._wchain[n] = (ops.pw_chain_pack_b3 if b3 else ops.pw_chain_pack)(w)
         N, H, W, K1 = x.shape
         d = PwChainDesc()
         d.M, d.K1, d.N1, d.N2 = N * H * W, K1, y.shape[3], z.shape[3]
-        d.x, d.w1, d.shift1, d.y = x.data_ptr(), self._wchain[name_c].data_ptr(), sh1.data_ptr(), y.data_ptr()
+        d.x, d.shift1, d.y = x.data_ptr(), sh1.data_ptr(), y.data_ptr()
+        if b3:
+            d.w1_b3, d.w2_b3 = self._wchain[name_c].data_ptr(), self._wchain[name_a].data_ptr()
+        else:
+            d.w1, d.w2 = self._wchain[name_c].data_ptr(), self._wchain[name_a].data_ptr()
         d.scale1 = None if sc1 is None else sc1.data_ptr()
         d.residual = None if residual is None else residual.data_ptr()
-        d.w2, d.shift2, d.z = self._wchain[name_a].data_ptr(), sh2.data_ptr(), z.data_ptr()
+        d.shift2, d.z = sh2.data_ptr(), z.data_ptr()
         d.scale2 = None if sc2 is None else sc2.data_ptr()
         d.relu1 = d.relu2 = 1
         self._ops.append(("chain", d, name_c + "+" + name_a))
@@ -596,16 +601,21 @@ class Vgg16Plan(EncoderPlan):
     def _chain(self, name_c, x, y, residual, name_a, z):
         """One launch for conv `name_c` (1x1, x -> y, + residual, ReLU) followed by conv `name_a` (1x1, y -> z, ReLU): dc_pw_chain_f32."""
         (w1, sc1, sh1), (w2, sc2, sh2) = self._w[name_c], self._w[name_a]
+        b3 = self.wino_products == "b3"                       # the split-bf16 products, like the Winograd layers
         for n, w in ((name_c, w1), (name_a, w2)):
             if n not in self._wchain:
-                self._wchain[n] = ops.pw_chain_pack(w)
+                self._wchain[n] = (ops.pw_chain_pack_b3 if b3 else ops.pw_chain_pack)(w)
         N, H, W, K1 = x.shape
         d = PwChainDesc()
         d.M, d.K1, d.N1, d.N2 = N * H * W, K1, y.shape[3], z.shape[3]
-        d.x, d.w1, d.shift1, d.y = x.data_ptr(), self._wchain[name_c].data_ptr(), sh1.data_ptr(), y.data_ptr()
+        d.x, d.shift1, d.y = x.data_ptr(), sh1.data_ptr(), y.data_ptr()
+        if b3:
+            d.w1_b3, d.w2_b3 = self._wchain[name_c].data_ptr(), self._wchain[name_a].data_ptr()
+        else:
+            d.w1, d.w2 = self._wchain[name_c].data_ptr(), self._wchain[name_a].data_ptr()
         d.scale1 = None if sc1 is None else sc1.data_ptr()
         d.residual = None if residual is None else residual.data_ptr()
-        d.w2, d.shift2, d.z = self._wchain[name_a].data_ptr(), sh2.data_ptr(), z.data_ptr()
+        d.shift2, d.z = sh2.data_ptr(), z.data_ptr()
         d.scale2 = None if sc2 is None else sc2.data_ptr()
         d.relu1 = d.relu2 = 1
         self._ops.append(("chain", d, name_c + "+" + name_a))

@@ -265,14 +265,31 @@ def pw_chain_pack(w_packed, out=None):
     return out
 
 
+def pw_chain_pack_b3(w_packed, out=None):
+    """A packed 1x1 kernel [Cout, Cin] as three bf16 pieces per element in the fragment order of the split-bf16 chain kernel:
+    int16 [Cout, 3 * Cin] (dc_pw_chain_pack_b3)."""
+    lib = _lib.load()
+    _chk(w_packed, name="w")
+    if w_packed.dim() != 2 or not w_packed.is_contiguous():
+        raise _lib.DcapError("pw_chain_pack_b3: w must be the contiguous packed 1x1 kernel [Cout, Cin]")
+    if out is None:
+        out = torch.empty((w_packed.shape[0], 3 * w_packed.shape[1]), dtype=torch.int16, device=w_packed.device)
+    check(lib.dc_pw_chain_pack_b3(_ptr(w_packed), _ptr(out), w_packed.shape[0], w_packed.shape[1], _stream()), "dc_pw_chain_pack_b3")
+    return out
+
+
 def pw_chain(x, w1f, shift1, w2f, shift2, scale1=None, scale2=None, residual=None, relu1=True, relu2=True, y=None, z=None):
     """y = act1((x W1^T) scale1 + shift1 [+ residual]); z = act2((y W2^T) scale2 + shift2) in one launch (dc_pw_chain_f32).
-    x [M, K1] (any leading dims), w1f / w2f: pw_chain_pack() of the packed kernels [N1, K1] / [N2, N1].  Returns (y, z)."""
+    x [M, K1] (any leading dims), w1f / w2f: pw_chain_pack() of the packed kernels [N1, K1] / [N2, N1] (fp32 MFMA products), or both
+    pw_chain_pack_b3() (int16 [N, 3 K]: the products on the bf16 pipe in split arithmetic).  Returns (y, z)."""
     lib = _lib.load()
     K1 = x.shape[-1]
     M = x.numel() // K1
     N1, N2 = w1f.shape[0], w2f.shape[0]
-    if w1f.shape[1] != K1 or w2f.shape[1] != N1:
+    b3 = w1f.dtype == torch.int16
+    if b3 != (w2f.dtype == torch.int16):
+        raise _lib.DcapError("pw_chain: both kernels in the same form (pw_chain_pack or pw_chain_pack_b3)")
+    if w1f.shape[1] != (3 if b3 else 1) * K1 or w2f.shape[1] != (3 if b3 else 1) * N1:
         raise _lib.DcapError("pw_chain: kernel shapes do not chain: x [.., %d], w1 %s, w2 %s" % (K1, tuple(w1f.shape), tuple(w2f.shape)))
     if y is None:
         y = torch.empty(tuple(x.shape[:-1]) + (N1,), dtype=torch.float32, device=x.device)
@@ -283,8 +300,12 @@ def pw_chain(x, w1f, shift1, w2f, shift2, scale1=None, scale2=None, residual=Non
             raise _lib.DcapError("pw_chain: tensors must be contiguous")
     d = PwChainDesc()
     d.M, d.K1, d.N1, d.N2 = M, K1, N1, N2
-    d.x, d.w1, d.shift1, d.y = _chk(x, name="x").data_ptr(), _chk(w1f, name="w1").data_ptr(), _chk(shift1, name="shift1").data_ptr(), _chk(y, name="y").data_ptr()
-    d.w2, d.shift2, d.z = _chk(w2f, name="w2").data_ptr(), _chk(shift2, name="shift2").data_ptr(), _chk(z, name="z").data_ptr()
+    d.x, d.shift1, d.y = _chk(x, name="x").data_ptr(), _chk(shift1, name="shift1").data_ptr(), _chk(y, name="y").data_ptr()
+    d.shift2, d.z = _chk(shift2, name="shift2").data_ptr(), _chk(z, name="z").data_ptr()
+    if b3:
+        d.w1_b3, d.w2_b3 = _chk(w1f, torch.int16, "w1").data_ptr(), _chk(w2f, torch.int16, "w2").data_ptr()
+    else:
+        d.w1, d.w2 = _chk(w1f, name="w1").data_ptr(), _chk(w2f, name="w2").data_ptr()
     d.scale1 = None if scale1 is None else _chk(scale1, name="scale1").data_ptr()
     d.scale2 = None if scale2 is None else _chk(scale2, name="scale2").data_ptr()
     d.residual = None if residual is None else _chk(residual, name="residual").data_ptr()

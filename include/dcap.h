@@ -241,11 +241,15 @@ typedef struct {
     const float* shift2;
     int relu2;
     float* z;
+    const uint16_t* w1_b3;    /* optional, BOTH or neither (then w1 / w2 may be NULL): the kernels split into three bf16 pieces per element by */
+    const uint16_t* w2_b3;    /* dc_pw_chain_pack_b3 (3 * N * K bf16): both layers' products on the BF16 matrix pipe in split arithmetic (six
+                                 bf16 MFMA products per fp32 product, fp32 accumulation: fp32-grade, DC_MATH_BF16X3's arithmetic) */
 } dc_pw_chain_desc;
 int dc_pw_chain_supported(int K1, int N1, int N2);
 int dc_pw_chain_pack_f32(const float* w, float* out, int N, int K, void* stream);
+int dc_pw_chain_pack_b3(const float* w, uint16_t* out, int N, int K, void* stream);
 int dc_pw_chain_f32(const dc_pw_chain_desc* d, void* stream);
-/* Profiling aid: rocprof's spelling of the kernel instantiation dc_pw_chain_f32 launches for `d` (buf_bytes >= 32). */
+/* Profiling aid: rocprof's spelling of the kernel instantiation dc_pw_chain_f32 launches for `d` (buf_bytes >= 40). */
 int dc_pw_chain_kernel_name(const dc_pw_chain_desc* d, char* buf, size_t buf_bytes);
 
 /* CUs the persistent Winograd grids may occupy (process-wide; a multiple of 8 -- one share per XCD; 0 restores the default:

@@ -293,13 +293,15 @@ def test_conv2d_winograd_forced_kernels_in_a_child_process(ops, force):
     assert ("wino64_kernel" if force == "64" else "wino32_kernel") in r.stdout
 
 
+@pytest.mark.parametrize("products", ["b3", "f32"])
 @pytest.mark.parametrize("case", [(8192, 256, 1024, 256, True, True), (1000, 256, 1024, 256, True, False), (4096, 128, 512, 128, True, True),
-                                  (77, 64, 512, 128, False, True), (33, 1024, 1024, 256, False, False)])
-def test_pw_chain_two_pointwise_convolutions_in_one_launch(ops, case):
+                                  (77, 64, 512, 128, False, True), (33, 1024, 1024, 256, False, False), (200, 160, 512, 128, True, True)])
+def test_pw_chain_two_pointwise_convolutions_in_one_launch(ops, case, products):
     """dc_pw_chain_f32 (round 5): a bottleneck's last convolution (1x1 + folded BN + shortcut + ReLU) and the next block's first (1x1 +
     folded BN + ReLU) in one launch -- both outputs against the float64 oracle at the convolution kernels' tolerance and against the two
     separate dc_conv2d_nhwc_f32 launches the plan used to make.  Cases: the stage-4 shape at two images (256 blocks = one per CU), a
-    ragged pixel count (the last block has 8 rows), the stage-3 shape, tiny M, K1 = N1."""
+    ragged pixel count (the last block has 8 rows), the stage-3 shape, tiny M, K1 = N1, a K1 whose 16-channel groups do not fill the
+    weight ring (10 groups).  products = 'b3': both layers on the bf16 pipe in split arithmetic (dc_pw_chain_pack_b3) -- SAME tolerance."""
     M, K1, N1, N2, res, sc = case
     rng = np.random.default_rng(M + K1 + N1)
     x = rng.standard_normal((M, K1))
@@ -315,7 +317,9 @@ def test_pw_chain_two_pointwise_convolutions_in_one_launch(ops, case):
     z = np.maximum(y @ w2.T * (1.0 if s2 is None else s2) + h2, 0)
     assert ops.pw_chain_supported(K1, N1, N2) and not ops.pw_chain_supported(K1, 256, 64) and not ops.pw_chain_supported(K1 + 16, N1, N2)
     xd, w1d, w2d = dev(x), dev(w1), dev(w2)
-    w1f, w2f = ops.pw_chain_pack(w1d), ops.pw_chain_pack(w2d)
+    pack = ops.pw_chain_pack_b3 if products == "b3" else ops.pw_chain_pack
+    w1f, w2f = pack(w1d), pack(w2d)
+    assert w1f.dtype == (torch.int16 if products == "b3" else torch.float32)
     yo = torch.full((M, N1), float("nan"), device="cuda")
     zo = torch.full((M, N2), float("nan"), device="cuda")
     gy, gz = ops.pw_chain(xd, w1f, dev(h1), w2f, dev(h2), scale1=None if s1 is None else dev(s1), scale2=None if s2 is None else dev(s2),
@@ -329,7 +333,7 @@ def test_pw_chain_two_pointwise_convolutions_in_one_launch(ops, case):
     close(gy, y2.view(M, N1).cpu().numpy().astype(np.float64), 2e-5)
     close(gz, z2.view(M, N2).cpu().numpy().astype(np.float64), 2e-5)
     with pytest.raises(Exception):
-        ops.pw_chain(xd, w1f, dev(h1), ops.pw_chain_pack(dev(rng.standard_normal((64, N1)))), dev(h2[:64]))     # N2 = 64: not a covered shape
+        ops.pw_chain(xd, w1f, dev(h1), pack(dev(rng.standard_normal((64, N1)))), dev(h2[:64]))     # N2 = 64: not a covered shape
 
 
 def test_conv2d_winograd_falls_back_where_the_form_does_not_apply(ops):
