@@ -51,11 +51,15 @@ def winograd_gain(kernel):
     form's count, on the bf16 pipe."""
     if kernel.startswith("wino"):
         return WINOGRAD_GAIN / 6.0 if split_bf16_kernel(kernel) else WINOGRAD_GAIN
-    return 1.0
+    return 1.0 / 6.0 if split_bf16_kernel(kernel) else 1.0      # pw_chain_kernel<.., true>: six bf16 products per fp32 product
 
 
 def split_bf16_kernel(kernel):
-    return kernel.startswith("wino") and kernel.split("_")[0].endswith("b")
+    """Kernels whose products run on the bf16 matrix pipe in split arithmetic (fp32-grade): wino64b / wino32b and the chained pointwise
+    kernel's `true` instantiations."""
+    if kernel.startswith("wino"):
+        return kernel.split("_")[0].endswith("b")
+    return kernel.startswith("pw_chain_kernel") and kernel.rstrip(">").rstrip().endswith("true")
 
 
 def pipe_peak(kernel):
@@ -521,7 +525,7 @@ class E2E(object):
         # construction).  For the Winograd F(2x2,3x3) kernels that is the layers' direct-form FLOPs / 2.25 -- 16 products per
         # 2x2 output tile and channel pair instead of 36 --; the direct-form rate the layers are credited with is `achieved_direct_form`
         # (it may exceed the peak: that is what the algorithm is for, and it is not a roofline fraction).
-        wino = dom.startswith("wino")
+        wino = dom.startswith("wino") or split_bf16_kernel(dom)
         alg_b = g["bytes"] / g["launches"]
         peak = pipe_peak(dom)
         pipe_s = sum(v["flops"] / (pipe_peak(k) * 1e12) for k, v in groups.items())      # seconds of matrix-pipe time at each kernel's own peak
@@ -542,10 +546,17 @@ class E2E(object):
                                     "frac_of_its_pipe": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / pipe_peak(k), 3)},
                                    **({"tflops_direct_form": round(v["alg"] / (v["ms"] * 1e-3) / 1e12, 2)} if v["alg"] != v["flops"] else {}))
                            for k, v in groups.items()}}
+        if split_bf16_kernel(dom):                             # for context: the same launches priced as the fp32 products they stand for
+            eq = g["alg"] / (WINOGRAD_GAIN if dom.startswith("wino") else 1.0)
+            out["fp32_equivalent"] = {"achieved": eq / (g["ms"] * 1e-3) / 1e12, "frac_of_fp32_mfma_peak": eq / (g["ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                      "note": "fp32 products the kernel's bf16 products replace (one per six), over the same time, against the 157.3 TF fp32 pipe"}
         if wino:
             out["achieved_direct_form"] = g["alg"] / (g["ms"] * 1e-3) / 1e12
             out["gflop_per_launch_direct_form"] = g["alg"] / g["launches"] / 1e9
-            if split_bf16_kernel(dom):
+            if split_bf16_kernel(dom) and not dom.startswith("wino"):
+                out["note"] = ("two chained 1x1 convolutions, every fp32 product as six bf16 MFMA products (split arithmetic, fp32 accumulate: "
+                               "fp32-grade): executed bf16 MFMA FLOPs = direct-form FLOPs x 6; frac = executed / 2500 TF (dense bf16)")
+            elif split_bf16_kernel(dom):
                 out["note"] = ("Winograd F(2x2,3x3), fp32 transforms, the 16 products per tile as six bf16 MFMA products each (split arithmetic, fp32 "
                                "accumulate: fp32-grade): executed bf16 MFMA FLOPs = direct-form FLOPs x 6 / 2.25; frac = executed / 2500 TF (dense bf16)")
             else:
