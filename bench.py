@@ -30,6 +30,7 @@ Rank 0 prints ONE JSON line (see the driver contract) with extra objects:
 """
 import argparse
 import json
+import math
 import os
 import subprocess
 import sys
@@ -737,8 +738,17 @@ def joint_roofline(args, dev, inner):
     g = groups[dom]
     ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
     tot_fl, tot_ms = sum(v["flops"] for v in groups.values()), sum(v["ms"] for v in groups.values())
+    # HBM bytes per launch of the dominant kernel: from the committed rocprofv3 PMC passes of `bench.py --config joint` (tools/collect_profiles.sh
+    # -> tools/pmc_traffic.py: separate --pmc passes, FETCH_SIZE / WRITE_SIZE with the guide's gfx950 corrections)
+    traffic, traffic_src = None, None
+    for tname in ("r05_joint_pmc_traffic.json",):
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if os.path.exists(tpath):
+            for name, rec in json.load(open(tpath)).items():
+                if ("::" + dom + "(") in name or name.startswith("dcap::" + dom) or name.startswith("void dcap::" + dom):
+                    traffic, traffic_src = rec["hbm_bytes_per_launch_corrected"], "profiles/" + tname
     out = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS,
-           "traffic": None, "measured": "HIP events around every dc_conv2d_bf16 launch of the forward plan (eager replay, alone on the chip)",
+           "traffic": traffic, "traffic_source": traffic_src, "measured": "HIP events around every dc_conv2d_bf16 launch of the forward plan (eager replay, alone on the chip)",
            "launches_per_step": g["launches"], "gflop_per_launch": g["flops"] / g["launches"] / 1e9, "avg_launch_us": 1e3 * g["ms"] / g["launches"],
            "forward_bf16_convs": {"gflop_per_step": tot_fl / 1e9, "ms_per_step": tot_ms, "tflops": tot_fl / (tot_ms * 1e-3) / 1e12},
            "kernels": {k: {"launches": v["launches"], "split_k_layers": v["split_k_layers"], "ms": round(v["ms"], 4),
@@ -827,7 +837,15 @@ def main():
                        "decoder_dtype": args.joint_dtype, "recurrent_dropout": args.joint_dropout, "conv_math": inner.conv_math_name, "losses": [float(v) for v in losses],
                        "rccl_ranks": ranks_seen, "dist_backend": backend, "persistent_cus": persistent_cus,
                        "allreduce_exposed_ms_per_step": None if ar is None else round(ar[0], 4),
-                       "allreduce_host_wait_ms_per_step": None if ar is None else round(ar[1], 4)},
+                       "allreduce_host_wait_ms_per_step": None if ar is None else round(ar[1], 4),
+                       # which schedule the timed steps ran: one GPU replays the step behind the encoder as ONE captured
+                       # hipGraph with the RPN backward on a second branch; a data-parallel step issues the same launches eagerly, its
+                       # collectives from Python as each layer group's backward has been enqueued (they cannot sit inside the capture)
+                       "step_path": ("eager, data-parallel: per-layer-group all-reduce issued from Python behind each group's backward"
+                                     if world > 1 else ("captured hipGraph + RPN backward on a second branch" if inner.use_step_graph and "train" in inner._graphs
+                                                        else "eager, single stream pair")),
+                       "step_graph_fallback": inner.step_graph_fallback,
+                       "grad_wire_dtype": getattr(getattr(inner, "grad_sync", None), "dtype", None) if world > 1 else None},
         }
         if rank == 0 and not args.no_roofline and args.joint_dtype == "bf16" and inner.conv_math_name == "bf16":
             inner.grad_sync = None
@@ -879,9 +897,9 @@ def main():
         # Round 4: in both modes the 3x3 layers with frozen weights run the fp32 Winograd kernel like the headline; the split arithmetic
         # applies to the 1x1 / strided / stem layers.
         labels = {"bf16x3": "1x1 / strided / stem layers: 3-piece bf16 split of both operands, 6 MFMA products, fp32 accumulate (fp32-grade: same "
-                            "test tolerances as f32); 3x3 layers: the headline's fp32 Winograd kernel",
+                            "test tolerances as f32); 3x3 layers: the headline's Winograd kernel",
                   "bf16x2": "1x1 / strided / stem layers: 2-piece bf16 split, 3 MFMA products, fp32 accumulate (2^-16 products; features within "
-                            "1e-3 of the oracle); 3x3 layers: the headline's fp32 Winograd kernel"}
+                            "1e-3 of the oracle); 3x3 layers: the headline's Winograd kernel"}
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-alt-math",
                "--no-cpu-baseline", "--no-other-configs", "--images-per-gpu", str(B), "--rois", str(R), "--tokens", str(T),
                "--vocab", str(V), "--image-size", str(S), "--stage4-blocks", str(args.stage4_blocks)] + (["--no-pipeline"] if args.no_pipeline else [])

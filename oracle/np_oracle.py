@@ -704,14 +704,20 @@ def sparse_cce_keras_with_grad(target_ids, probs, weights):
     idx = np.asarray(target_ids).astype(np.int64)
     w = np.asarray(weights, F64)
     q = np.clip(p, KERAS_EPS, 1.0 - KERAS_EPS)
-    u = ((p >= KERAS_EPS) & (p <= 1.0 - KERAS_EPS)).astype(F64)
+    inside = (p >= KERAS_EPS) & (p <= 1.0 - KERAS_EPS)                  # u: where the clip has a gradient
     S = q.sum(-1)
     qt = np.take_along_axis(q, idx[..., None], -1)[..., 0]
+    del q
     loss = -np.log(qt) + np.log(S)
-    g = u / S[..., None]
-    ut = np.take_along_axis(u, idx[..., None], -1)[..., 0]
-    np.put_along_axis(g, idx[..., None], np.take_along_axis(g, idx[..., None], -1) - (ut / qt)[..., None], -1)
-    dz = p * (g - (g * p).sum(-1, keepdims=True))
+    ut = np.take_along_axis(inside, idx[..., None], -1)[..., 0].astype(F64)
+    # g = u / S - [k == t] u_t / q_t ;  dz = p * (g - sum(g p)).  Written on one work array (the [rows, V] temporaries are what this
+    # function costs at V = 50 000): gp_sum = sum(u p) / S - u_t p_t / q_t
+    pt = np.take_along_axis(p, idx[..., None], -1)[..., 0]
+    gp_sum = np.where(inside, p, 0.0).sum(-1) / S - ut * pt / qt
+    dz = inside / S[..., None]                                            # g without the target term
+    dz -= gp_sum[..., None]
+    dz *= p
+    np.put_along_axis(dz, idx[..., None], np.take_along_axis(dz, idx[..., None], -1) - (pt * ut / qt)[..., None], -1)
     return loss * w, dz * w[..., None]
 
 
