@@ -236,17 +236,32 @@ def gpu_configs1(dev, steps=30):
     rng = np.random.default_rng(5)
     feat = torch.tensor(rng.standard_normal((B, 7, 7, 256)).astype(np.float32), device=dev)
     tb = SampleTables.from_samples(_prefix_batch(rng, B, T, V), rng.integers(3, V, B), dev)
-    for _ in range(3):
-        dec.train_step(feat, tb)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = dec.train_step(feat, tb)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    def timed(fn, n):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n, out
+    dt, loss = timed(lambda: dec.train_step(feat, tb), steps)                # the model's default: eager (GPU-bound at this batch)
+    final = float(loss.item())
+    dec.use_step_graph = True
+    dt_graph, _ = timed(lambda: dec.train_step(feat, tb), steps)
+    captured = any(cs.graph is not None for cs in dec._steps.values())
+    U, E, u = dec.WORD_UNITS, dec.E, 256
+    fwd_frozen = 2.0 * B * (7 * 7 * 256 * 1024 + 1024 * 1024)                                   # RoI head (frozen: forward only)
+    fwd_train = 2.0 * B * (T * (E + U) * 4 * U + (1024 + U + u) * 4 * u + u * V)                # word LSTM, inject LSTM, Dense(V)
+    gf = (fwd_frozen + 3.0 * fwd_train) / 1e9
     return {"workload": "BASELINE configs[1]: text_generation_model_v2.py inject decoder as written, 64 (prefix -> next word) samples on "
                         "precomputed RoI features, V=10000, window 10, train step, fp32", "value": B / dt, "unit": "samples/s",
-            "ms_per_step": 1e3 * dt, "steps": steps, "final_loss": float(loss.item())}
+            "ms_per_step": 1e3 * dt, "steps": steps, "final_loss": final,
+            "step_path": "eager (the default of CaptionModelV2: GPU-bound at this batch)",
+            "graph_replay_ms_per_step": 1e3 * dt_graph if captured else None,
+            "roofline": {"bound": "mfma", "gflop_per_step": gf, "achieved": gf / dt / 1e3, "peak": 157.3, "unit": "TFLOP/s", "frac": gf / dt / 1e3 / 157.3,
+                         "note": "a dependent chain of ~65 kernels of 5-20 us (10 + 1 LSTM steps forward, as many backward, each a launch): "
+                                 "latency-bound, neither the MFMA pipe nor HBM is near a limit; every kernel runs >= 10 us, so replaying the step from a hipGraph (opt-in, use_step_graph) gains nothing"}}
 
 
 def gpu_configs0(dev, steps=30):
@@ -278,7 +293,26 @@ def gpu_configs0(dev, steps=30):
             loss = model.train_step(feat, caps, tgt)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        out["recurrent_dropout_%.1f" % rate] = {"value": B / dt, "ms_per_step": 1e3 * dt, "final_loss": float(loss.item())}
+        captured = any(cs.graph is not None for cs in model._steps.values())
+        final = float(loss.item())
+        for _ in range(3):
+            model._train_step_eager(feat, caps, tgt)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model._train_step_eager(feat, caps, tgt)
+        torch.cuda.synchronize()
+        dt_eager = (time.perf_counter() - t0) / steps
+        out["recurrent_dropout_%.1f" % rate] = {"value": B / dt, "ms_per_step": 1e3 * dt, "final_loss": final,
+                                                "step_path": "captured hipGraph replay (step_graph.py)" if captured else "eager",
+                                                "eager_ms_per_step": 1e3 * dt_eager}
+    u, E = 512, model.E
+    fwd = 2.0 * B * (7 * 7 * 256 * 1024 + 1024 * 1024) + 2.0 * B * T * ((E + 1024 + u) * 4 * u + 2 * u * 4 * u + u * 1024 + 1024 * V)
+    gf = 3.0 * fwd / 1e9                                                                          # trainable head: everything trains
+    dt0 = out["recurrent_dropout_0.2"]["ms_per_step"] / 1e3
+    out["roofline"] = {"bound": "mfma", "gflop_per_step": gf, "achieved": gf / dt0 / 1e3, "peak": 157.3, "unit": "TFLOP/s", "frac": gf / dt0 / 1e3 / 157.3,
+                       "note": "B = 8: a dependent chain of ~130 small kernels (2 x 10 LSTM steps each way, head, vocabulary layer): latency-bound; "
+                               "the replayed graph removes the host's launch cost, what is left is kernel latency"}
     out["value"] = out["recurrent_dropout_0.2"]["value"]              # the reference's training default
     out["ms_per_step"] = out["recurrent_dropout_0.2"]["ms_per_step"]
     return out

@@ -25,7 +25,7 @@ import re
 import numpy as np
 import torch
 
-from . import ops, synth, utils
+from . import ops, step_graph, synth, utils
 from .encoder import EncoderPlan, fuse_rpn_head
 from .layers import resnet_fpn_convs
 from .modified_dense_model import load_weight_file, save_weight_file
@@ -238,51 +238,16 @@ def data_generator(dataset, config, shuffle=True, augment=True, batch_size=1, rn
 # the model
 # ------------------------------------------------------------------------------------------------
 
-class StepInputs(object):
+class StepInputs(step_graph.PackedInputs):
     """Everything the host contributes to one joint train step, packed into ONE buffer of 4-byte words and moved with ONE asynchronous
-    copy at the start of the step: the RPN selection (counts, level / index / match of the non-neutral anchors, target deltas -- fixed
-    capacity, the image's own counts travel as words), the normalised GT boxes, the GT captions and the step scalars (Keras' lr_t,
-    the dropout-mask and detection-target stream positions).  The device side is a persistent buffer whose views the kernels read
-    (fixed addresses: a captured hipGraph replays them); the host side is a small ring of page-locked buffers, each guarded by the
-    event of its last copy, so the host never waits for the device and never rewrites a buffer whose copy is still queued."""
-    SLOTS = 4
+    copy at the start of the step (step_graph.PackedInputs): the RPN selection (counts, level / index / match of the non-neutral anchors,
+    target deltas -- fixed capacity, the image's own counts travel as words), the normalised GT boxes, the GT captions and the step
+    scalars (Keras' lr_t, the dropout-mask and detection-target stream positions)."""
 
     def __init__(self, device, cap, n_gt, T):
         self.cap, self.n_gt, self.T = cap, n_gt, T
-        sizes = [("counts", 2), ("lvl", cap), ("idx", cap), ("mt", cap), ("deltas", 4 * cap), ("gt", 4 * n_gt), ("gtc", n_gt * T), ("scalars", 4)]
-        self.off, pos = {}, 0
-        for k, n in sizes:
-            self.off[k] = (pos, n)
-            pos += (n + 3) // 4 * 4                         # 16-byte aligned parts
-        self.words = pos
-        self.dev = torch.zeros(pos, dtype=torch.int32, device=device)
-        self.pins = [torch.zeros(pos, dtype=torch.int32, pin_memory=True) for _ in range(self.SLOTS)]
-        self.events = [None] * self.SLOTS
-        self.k = 0
-
-    def view(self, key, dtype=torch.int32):
-        o, n = self.off[key]
-        v = self.dev[o:o + n]
-        return v if dtype == torch.int32 else v.view(dtype)
-
-    def upload(self, parts):
-        """parts: {key: numpy array (int32 or float32)}; missing keys keep zeros."""
-        k = self.k
-        self.k = (k + 1) % self.SLOTS
-        if self.events[k] is not None:
-            self.events[k].synchronize()                    # (four steps old: complete long ago unless the host runs far ahead)
-        host = self.pins[k].numpy()
-        host[:] = 0
-        for key, a in parts.items():
-            o, n = self.off[key]
-            a = np.ascontiguousarray(a).reshape(-1)
-            if a.size > n:
-                raise ValueError("%s: %d words do not fit the %d reserved" % (key, a.size, n))
-            host[o:o + a.size] = a.view(np.int32) if a.dtype != np.int32 else a
-        self.dev.copy_(self.pins[k], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self.events[k] = ev
+        step_graph.PackedInputs.__init__(self, device, [("counts", 2), ("lvl", cap), ("idx", cap), ("mt", cap), ("deltas", 4 * cap), ("gt", 4 * n_gt),
+                                                         ("gtc", n_gt * T), ("scalars", 4)])
 
 
 class DenseImageCapRCNN(object):
@@ -317,7 +282,7 @@ class DenseImageCapRCNN(object):
         if 6 * self.A > HEAD_PAD:
             raise ValueError("at most 3 anchors per location")
         self._seed = int(seed)
-        self.use_step_graph = os.environ.get("DCAP_JOINT_GRAPH", "1") != "0"
+        self.use_step_graph = step_graph.enabled()        # DCAP_STEP_GRAPH=0: every step eagerly
         self.use_side_stream = True                          # RPN backward beside the proposals / decoder-forward chain (False: serial order)
         self._side_stream = None
         self.step_graph_fallback = None                      # set to the error text when a step-graph capture failed and the model went eager

@@ -51,6 +51,11 @@ class KerasLikeModel(object):
 
     def compile(self, optimizer, loss=None):
         self.optimizer, self.loss = optimizer, loss
+        self._invalidate_graphs()              # captured train steps hold the previous optimizer's state tensors
+
+    def _invalidate_graphs(self):
+        """Drop the captured train steps (step_graph.CapturedStep per batch shape): something they baked has moved."""
+        self._steps = {}
 
     @property
     def trainable_weights(self):
@@ -83,6 +88,7 @@ class KerasLikeModel(object):
     def _weights_changed(self):
         """Master weights were rewritten from outside the optimizer (load_weights, ParallelModel's broadcast): re-cast the bf16
         operand copies the bf16 GEMMs read (compute_dtype='bf16'); sub-classes also re-derive what they fold from weights."""
+        self._invalidate_graphs()
         self.store.refresh_shadow()
 
     def summary(self):

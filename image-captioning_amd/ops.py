@@ -83,6 +83,11 @@ class _Workspace:
     def reserve(self, nbytes, device):
         self.get(nbytes, device)
 
+    def current(self, device=None):
+        """The scratch buffer of the current stream (or None): a captured graph keeps a reference to the one its launches point into."""
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        return self.buf.get((device, torch.cuda.current_stream(device).cuda_stream))
+
     def release(self, stream):
         """Drop the scratch buffer of a torch.cuda.Stream the caller is done with (no captured graph may still reference it)."""
         for key in [k for k in self.buf if k[1] == stream.cuda_stream]:

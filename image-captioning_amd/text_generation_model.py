@@ -18,7 +18,7 @@ import os
 import numpy as np
 import torch
 
-from . import ops, synth
+from . import ops, step_graph, synth
 from .config import Config
 from .keras_like import KerasLikeModel, ModelCheckpoint, CSVLogger  # noqa: F401
 from .params import ParamStore, Adam  # noqa: F401
@@ -212,6 +212,7 @@ class CaptionModelV1(KerasLikeModel):
             st.enable_bf16_shadow(own)                    # GEMM kernels only: biases, BN parameters and the recurrences stay fp32
         self.grad_sync = None
         self._bufs = {}
+        self._steps = {}                          # captured train steps by batch shape (step_graph.CapturedStep)
         self._drop_seed, self._drop_step = (seed + 77) & 0xFFFFFFFF, 0
         self._drop_offset_dev = None
         self._rec_masks = (None, None)           # device masks of the current train step (lstm1, lstm2) or None
@@ -225,6 +226,7 @@ class CaptionModelV1(KerasLikeModel):
 
     def compile(self, optimizer, loss=None):
         self.optimizer, self.loss = optimizer, loss
+        self._invalidate_graphs()              # captured train steps hold the previous optimizer's state tensors
 
     def _prefix_rows(self, training):
         if self.dropout_rows not in ("roi", "prefix"):
@@ -472,9 +474,67 @@ class CaptionModelV1(KerasLikeModel):
                 return self._mm(dacc, self._wview(conv + '/kernel'), key='dX', b_trans=True).f
         return None
 
+    MAX_STEP_GRAPHS = 4        # batch shapes kept as captured graphs; further shapes run eagerly
+
     def train_step(self, feat, caps, targets):
+        """forward + roi_caption_loss + backward + (all-reduce) + AMSGrad; the loss as a DEVICE scalar (no sync).
+        One GPU, one mask set per RoI: the whole step is replayed from a hipGraph captured on the third call with the same batch
+        shape (step_graph.py); captions, targets, lr_t and the dropout stream position travel in ONE upload, the features in one copy."""
         if self.optimizer is None:
             raise RuntimeError("compile(optimizer, loss) first")
+        world = 1 if self.grad_sync is None else getattr(self.grad_sync, "world", None)
+        caps = np.asarray(caps)
+        B, T = caps.shape
+        key = (tuple(feat.shape), B, T)
+        steps = self._steps
+        cs = steps.get(key)
+        if world != 1 or not step_graph.enabled() or self._prefix_rows(True) or (cs is None and len(steps) >= self.MAX_STEP_GRAPHS):
+            return self._train_step_eager(feat, caps, targets)
+        opt = self.optimizer
+        N = T * B
+        if cs is None:
+            cs = steps[key] = step_graph.CapturedStep()
+            cs.feat = torch.empty(tuple(feat.shape), dtype=torch.float32, device=self.device)
+            cs.inputs = step_graph.PackedInputs(self.device, [("ids_tm", N), ("targets", N), ("mask", (N + 3) // 4), ("scalars", 4)])
+        ids = caps.astype(np.int32)                        # Embedding casts float ids to int32 (_tables)
+        scal = np.zeros(4, np.int32)
+        scal[0:1] = step_graph.lr_word(opt).view(np.int32)
+        scal[1:2] = np.array([(2 * (self._drop_step + 1)) & 0xFFFFFFFF], np.uint32).view(np.int32)      # this step's masks (lstm l: + l)
+        cs.inputs.upload({"ids_tm": ids.T, "targets": np.asarray(targets, np.int32).T, "mask": (ids != 0).T.astype(np.uint8), "scalars": scal})
+        cs.feat.copy_(self._dev_feat(feat))
+        sc = cs.inputs.view("scalars")
+        lr_dev, drop_dev = sc[0:1].view(torch.float32), sc[1:2]
+        tables = (cs.inputs.view("ids_tm"), cs.inputs.bytes_view("mask", N), cs.inputs.view("targets"), None, B, T)
+        dropout = float(self.recurrent_dropout or 0.0) > 0.0
+
+        def body():
+            self._drop_offset_dev = drop_dev if dropout else None
+            try:
+                loss_rows, _ = self._forward_train(cs.feat, None, want_grad=True, device_tables=tables)
+            finally:
+                self._drop_offset_dev = None              # a later eager step draws from the host counter again
+            loss = ops.mean(loss_rows, out=self._buf('loss', (1,)))
+            self._backward()
+            opt.apply(self.store, grad_scale=1.0, lr_t_dev=lr_dev)
+            cs.rec_masks = self._rec_masks
+            return loss
+
+        def restore(v):
+            opt.iterations, self._drop_step = v
+
+        def bump():                                          # what the captured Python did once: the host-side counters
+            opt.iterations += 1
+            self._rec_masks = cs.rec_masks                   # (last_rec_masks: this shape's mask buffers, redrawn by the replay)
+            if dropout:
+                self._drop_step += 1
+
+        own, self._bufs = self._bufs, cs.bufs                # this shape's private scratch buffers (see CapturedStep)
+        try:
+            return cs.run(body, lambda: (opt.iterations, self._drop_step), restore, bump)
+        finally:
+            self._bufs = own
+
+    def _train_step_eager(self, feat, caps, targets):
         loss_rows, _ = self._forward_train(feat, caps, targets, want_grad=True)
         loss = ops.mean(loss_rows, out=self._buf('loss', (1,)))
         self._backward()

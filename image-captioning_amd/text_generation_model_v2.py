@@ -15,7 +15,7 @@ import os
 import numpy as np
 import torch
 
-from . import ops, synth, utils
+from . import ops, step_graph, synth, utils
 from .config import Config
 from .keras_like import KerasLikeModel, ModelCheckpoint, CSVLogger  # noqa: F401  (re-exported for scripts)
 from .layers import V2_WORD_LSTM
@@ -281,10 +281,16 @@ def train_on_dataset(model, features_model, dataset, images_per_step, rois_per_i
 # --------------------------------------------------------------------------------------------------
 
 class SampleTables(object):
-    """Host-built int32 index tables, uploaded once per batch:
+    """Host-built int32 index tables, ONE packed device tensor per batch (one upload; a captured train step copies it into its
+    persistent buffer with one device-to-device copy):
     ids_tm [T*Bw] time-major tokens of the Bw word sequences, mask (ids != 0),
     roi_idx [N] row of the RoI feature, hrow_idx [N] row of h_seq (-1: the empty prefix -> zeros),
     inv_hrow [T*Bw] sample fed by each h row (-1: none), targets [N]."""
+
+    @staticmethod
+    def layout(T, Bw, N):
+        """[(part, words)] of the packed tensor; every part starts 16-byte aligned (step_graph.PackedInputs' rule)."""
+        return [("ids_tm", T * Bw), ("roi_idx", N), ("hrow_idx", N), ("inv_hrow", T * Bw), ("targets", N), ("mask", (T * Bw + 3) // 4)]
 
     def __init__(self, ids_tm, Bw, T, roi_idx, hrow_idx, targets, device):
         ids_tm = np.ascontiguousarray(ids_tm, np.int32)
@@ -295,10 +301,33 @@ class SampleTables(object):
         if len(np.unique(hr[used])) != int(used.sum()):
             raise ValueError("an LSTM state row may feed at most one sample")
         inv[hr[used]] = np.nonzero(used)[0].astype(np.int32)
-        up = lambda a, dt=torch.int32: torch.tensor(np.ascontiguousarray(a), dtype=dt, device=device)
-        self.ids_tm, self.mask = up(ids_tm), up(ids_tm != 0, torch.uint8)
-        self.roi_idx, self.hrow_idx, self.inv_hrow = up(roi_idx), up(hr), up(inv)
-        self.targets = up(targets)
+        parts = {"ids_tm": ids_tm, "roi_idx": np.asarray(roi_idx, np.int32), "hrow_idx": hr, "inv_hrow": inv,
+                 "targets": np.asarray(targets, np.int32), "mask": (ids_tm != 0).astype(np.uint8)}
+        off, pos = {}, 0
+        for k, n in self.layout(T, Bw, self.N):
+            off[k] = (pos, n)
+            pos += (n + 3) // 4 * 4
+        host = np.zeros(max(pos, 4), np.int32)
+        for k, a in parts.items():
+            o, n = off[k]
+            if a.dtype == np.uint8:
+                host[o:o + n].view(np.uint8)[:a.size] = a
+            else:
+                host[o:o + a.size] = a
+        self._bind(torch.tensor(host, dtype=torch.int32, device=device), off)
+
+    def _bind(self, packed, off):
+        self.packed, self._off = packed, off
+        cut = lambda k: packed[off[k][0]:off[k][0] + off[k][1]]
+        self.ids_tm, self.roi_idx, self.hrow_idx, self.inv_hrow, self.targets = (cut(k) for k in ("ids_tm", "roi_idx", "hrow_idx", "inv_hrow", "targets"))
+        self.mask = cut("mask").view(torch.uint8)[:self.T * self.Bw]
+
+    def like(self, packed):
+        """The same tables read from another packed tensor of this layout (a captured step's persistent copy)."""
+        tb = object.__new__(SampleTables)
+        tb.Bw, tb.T, tb.N = self.Bw, self.T, self.N
+        tb._bind(packed, self._off)
+        return tb
 
     @staticmethod
     def from_samples(words, targets, device):
@@ -360,6 +389,7 @@ class CaptionModelV2(KerasLikeModel):
 
     # frozen head: fold BN once (float64 on the host)
     def _weights_changed(self):
+        self._invalidate_graphs()                 # (the folded head below lives in new tensors: captured steps hold the old ones)
         self.store.refresh_shadow()
         w = {k: v.detach().cpu().numpy() for k, v in self.store.w.items() if k.startswith('mrcnn_class')}
         dev = self.device
@@ -454,10 +484,52 @@ class CaptionModelV2(KerasLikeModel):
             lo, hi = self.store.layer_range(layer)
             self.grad_sync.ready(self.store.flat_grad, lo, hi)
 
+    MAX_STEP_GRAPHS = 4        # batch shapes kept as captured graphs; further shapes run eagerly
+    # Replaying the step from a captured hipGraph is OPT-IN for this model: at the reference's batch (64 samples, 1024 units) every kernel
+    # runs 10 us or longer, the eager step is already GPU-bound (0.70 ms) and the replay's three input copies make it 0.73 ms
+    # (bench.py other_configs.configs1_gpu reports both).  The v1 decoder at B = 8 is launch-bound and replays by default.
+    use_step_graph = False
+
     def train_step(self, feat, tb):
-        """forward + backward + (all-reduce) + AMSGrad; returns the loss as a DEVICE scalar (no sync)."""
+        """forward + backward + (all-reduce) + AMSGrad; returns the loss as a DEVICE scalar (no sync).
+        use_step_graph (one GPU): the whole step is replayed from a hipGraph captured on the third call with the same batch shape
+        (step_graph.py); the batch reaches it through two device-to-device copies (features, packed tables) and one word (lr_t)."""
         if self.optimizer is None:
             raise RuntimeError("compile(optimizer, loss) first")
+        world = 1 if self.grad_sync is None else getattr(self.grad_sync, "world", None)
+        key = (tuple(feat.shape), tb.N, tb.T, tb.Bw)
+        steps = self._steps
+        cs = steps.get(key)
+        if world != 1 or not self.use_step_graph or not step_graph.enabled() or (cs is None and len(steps) >= self.MAX_STEP_GRAPHS):
+            return self._train_step_eager(feat, tb)
+        opt = self.optimizer
+        if cs is None:
+            cs = steps[key] = step_graph.CapturedStep()
+            cs.feat = torch.empty(tuple(feat.shape), dtype=torch.float32, device=self.device)
+            cs.tb = tb.like(torch.empty_like(tb.packed))
+            cs.scalars = step_graph.PackedInputs(self.device, [("lr_t", 1)])
+        cs.feat.copy_(self._dev_feat(feat))
+        cs.tb.packed.copy_(tb.packed)
+        cs.scalars.upload({"lr_t": step_graph.lr_word(opt)})
+        lr_dev = cs.scalars.view("lr_t", torch.float32)
+
+        def body():
+            loss_rows, _ = self._forward(cs.feat, cs.tb, want_grad=True)
+            loss = ops.mean(loss_rows, out=self._buf('loss', (1,)))
+            self._backward()
+            opt.apply(self.store, grad_scale=1.0, lr_t_dev=lr_dev)
+            return loss
+
+        def bump():
+            opt.iterations += 1
+
+        own, self._bufs = self._bufs, cs.bufs                # this shape's private scratch buffers (see CapturedStep)
+        try:
+            return cs.run(body, lambda: opt.iterations, lambda v: setattr(opt, "iterations", v), bump)
+        finally:
+            self._bufs = own
+
+    def _train_step_eager(self, feat, tb):
         loss_rows, _ = self._forward(feat, tb, want_grad=True)
         loss = ops.mean(loss_rows, out=self._buf('loss', (1,)))
         self._backward()

@@ -265,6 +265,77 @@ def test_v1_recurrent_dropout_default_is_seeded_and_matches_the_oracle_given_its
     assert all(np.array_equal(a, b) for a, b in zip(again.last_rec_masks, model.last_rec_masks))
 
 
+def _run_v2_steps(monkeypatch, graph, inject=True):
+    """Seven train steps of the v2 decoder over two alternating batch shapes, a predict() in between; DCAP_STEP_GRAPH on or off."""
+    from image_captioning_amd import synth
+    from image_captioning_amd.text_generation_model_v2 import SampleTables
+    monkeypatch.setenv("DCAP_STEP_GRAPH", "1" if graph else "0")
+    V, Tw = 400, 6
+    model, _ = make_v2(V, inject, Tw)
+    model.use_step_graph = True                             # (opt-in for this model: the as-written batch is GPU-bound either way)
+    rng = np.random.default_rng(4)
+    losses = []
+    for step in range(7):
+        R = 6 if step % 3 != 2 else 4                      # shape A: steps 0 1 3 4 6 (captured on its third call); shape B: steps 2 5
+        feat = torch.tensor(rng.standard_normal((R, 7, 7, 256)).astype(np.float32), device="cuda")
+        caps = synth.captions_v2(10 + step, R, 5, V, full=True)
+        losses.append(model.train_on_captions(feat, SampleTables.from_captions(caps, "cuda")))
+        losses[-1] = float(losses[-1].item())
+        if step == 3:
+            model.predict([feat.cpu().numpy(), np.zeros((R, Tw), np.int32)])   # other buffer shapes in between: the graph keeps its own
+    captured = sorted(k[0][0] for k, cs in model._steps.items() if cs.graph is not None)
+    return losses, {k: v.cpu().numpy() for k, v in model.store.w.items()}, model.optimizer.iterations, captured
+
+
+@pytest.mark.parametrize("inject", [True, False])
+def test_v2_captured_train_step_is_bit_equal_to_the_eager_step(gpu, monkeypatch, inject):
+    """CaptionModelV2.train_step replayed from a hipGraph (step_graph.py: third call with a batch shape captures, later calls
+    replay; the batch arrives through two device copies and one word) against DCAP_STEP_GRAPH=0: every loss and every weight after
+    seven steps identical bit for bit, Keras' iteration counter advanced by the replays."""
+    le, we, ite, cap_e = _run_v2_steps(monkeypatch, False, inject)
+    lg, wg, itg, cap_g = _run_v2_steps(monkeypatch, True, inject)
+    assert cap_e == [] and cap_g == [6]                     # shape A was captured, shape B (two calls) was still warming up
+    assert ite == itg == 7
+    assert le == lg
+    for k in we:
+        assert np.array_equal(we[k], wg[k]), k
+
+
+def _run_v1_steps(monkeypatch, graph, rate):
+    from image_captioning_amd import synth
+    from image_captioning_amd.text_generation_model import caption_targets
+    monkeypatch.setenv("DCAP_STEP_GRAPH", "1" if graph else "0")
+    V, T, B = 200, 6, 4
+    model, _, _ = make_v1(V, T, B)
+    model.recurrent_dropout = rate
+    rng = np.random.default_rng(8)
+    losses, masks = [], []
+    for step in range(6):
+        feat = rng.standard_normal((B, 7, 7, 256)).astype(np.float32)
+        caps = synth.captions_v1(30 + step, B, T, V, lmin=1, lmax=4)
+        losses.append(model.train_on_batch([feat, caps], caption_targets(caps, V)))
+        masks.append(None if model.last_rec_masks is None else model.last_rec_masks[1].copy())
+    n_graphs = sum(cs.graph is not None for cs in model._steps.values())
+    return losses, masks, {k: v.cpu().numpy() for k, v in model.store.w.items()}, (model.optimizer.iterations, model._drop_step), n_graphs
+
+
+@pytest.mark.parametrize("rate", [0.0, 0.2])
+def test_v1_captured_train_step_is_bit_equal_to_the_eager_step(gpu, monkeypatch, rate):
+    """CaptionModelV1.train_step (BASELINE configs[0]'s step) replayed from a hipGraph against the eager step: losses, weights and
+    -- with the reference's recurrent_dropout -- the masks of every step identical (a replay draws fresh masks: the stream position is
+    a device word of the step's one upload), host counters advanced."""
+    le, me, we, ce, ne = _run_v1_steps(monkeypatch, False, rate)
+    lg, mg, wg, cg, ng = _run_v1_steps(monkeypatch, True, rate)
+    assert ne == 0 and ng == 1 and ce == cg == (6, 6 if rate else 0)
+    assert le == lg
+    for a, b in zip(me, mg):
+        assert (a is None and b is None) or np.array_equal(a, b)
+    if rate:
+        assert not np.array_equal(mg[4], mg[5])            # two replays, two different mask draws
+    for k in we:
+        assert np.array_equal(we[k], wg[k]), k
+
+
 def test_v1_recurrent_dropout_per_prefix_rows_match_the_as_written_graph(gpu):
     """dropout_rows='prefix': every (RoI, prefix) row of the TimeDistributed batch gets its own masks, as Keras draws them
     (text_generation_model.py:179-187, :141-142); the LSTMs run over the B*T zero-padded prefixes.  Loss and every gradient equal
@@ -963,7 +1034,7 @@ def test_joint_train_step_as_a_captured_graph_equals_the_eager_step(gpu):
     whose per-step inputs (RPN selection and counts, GT boxes / captions, lr_t, dropout and sampling stream positions) are device
     words refreshed by one asynchronous copy.  Seven steps on inputs that CHANGE every step (other GT boxes, other selected
     anchors, other counts) with the reference's recurrent_dropout = 0.2: weights and losses bit-equal to the same model stepping
-    eagerly (DCAP_JOINT_GRAPH=0's path), and the RoI sample differs from step to step."""
+    eagerly (DCAP_STEP_GRAPH=0's path), and the RoI sample differs from step to step."""
     S, V, T, blocks = 128, 24, 5, 1
     _, cfg, Wt = make_joint(S, V, T, blocks)
     del type(cfg).RECURRENT_DROPOUT
