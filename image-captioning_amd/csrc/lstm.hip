@@ -82,6 +82,7 @@ __global__ void lstm_gate_bwd_kernel(const float* __restrict__ z_t, const float*
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
 // The weights: the first version of this kernel read U_rec in place: a block's 32 columns are 4 gate segments of 8 floats,
@@ -106,20 +107,14 @@ __global__ __launch_bounds__(256) void lstm_pack_urec_kernel(const float* __rest
 // NW/2.. publish, waves 0..NW/2-1 add theirs on top): 16.9 KB at <1,8> and <2,4> -- in the training pipeline this kernel runs
 // beside the encoder's convolutions, whose two resident blocks leave ~19 KB of a CU's LDS; with 33.8 KB its blocks could only
 // start at conv-kernel boundaries (78-100 us per step in the pipeline against 18 us alone).
-// MASKED (Keras recurrent_dropout in the training phase, round 4): h_{t-1} enters gate g through its own mask m_g, so the product is
-// four products (h * m_g) U_g.  The A operand then comes from FOUR pre-masked copies hm_prev [4][B][U] (written by the previous
-// step's epilogue -- or by lstm_mask_rows_kernel for the first step --, double-buffered: other blocks still read this step's copies
-// while a block's epilogue writes the next step's), one accumulator tile per gate against the same 32-column B fragment, of which a
-// lane keeps the tile of the gate its column belongs to (columns 8 g .. 8 g + 7 of the block are gate g's units).  Four times the
-// MFMAs of the plain step -- irrelevant: the step is latency-bound -- and ONE launch per timestep instead of six.
-template <int RT, int NW, bool MASKED = false>
+// (The recurrent-dropout variant of the step is lstm_step_masked_kernel below.)
+template <int RT, int NW>
 __global__ __launch_bounds__(NW * 64) void lstm_step_fused_kernel(float* __restrict__ z_t, const float* __restrict__ Upk,
                                                                   const float* __restrict__ h_prev, const float* __restrict__ c_prev,
                                                                   const uint8_t* __restrict__ mask_t, float* __restrict__ h_t,
-                                                                  float* __restrict__ c_t, int B, int U, const float* __restrict__ hm_prev = nullptr,
-                                                                  const float* __restrict__ rec_masks = nullptr, float* __restrict__ hm_next = nullptr) {
+                                                                  float* __restrict__ c_t, int B, int U) {
     constexpr int HALF = NW / 2, THREADS = NW * 64, ITEMS = RT * 256, IT = (ITEMS + THREADS - 1) / THREADS;
-    constexpr int NG = MASKED ? 4 : 1;
+    constexpr int NG = 1;
     __shared__ float part[HALF][RT * 32][33];
     // In the training pipeline these waves share their SIMDs with the encoder's convolution waves, which issue 64-clock fp32 MFMAs
     // back to back.  The recurrence is the decoder's serial chain and a step's MFMA work is tiny: ask for the issue slots first.
@@ -133,18 +128,17 @@ __global__ __launch_bounds__(NW * 64) void lstm_step_fused_kernel(float* __restr
     const int nch = kq / 8;                                                   // 8 k values per chunk (4 MFMAs of K = 2)
     f32x16_t acc[NG][RT];
     const float* ap[NG][RT];
-    const long gstride = (long)B * U;                                         // MASKED: between the masked copies of h
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[g][rt][r] = 0.f;
-            ap[g][rt] = (MASKED ? hm_prev + g * gstride : h_prev) + (long)min(r0 + 32 * rt + i, B - 1) * U + kbeg + 4 * h;
+            ap[g][rt] = h_prev + (long)min(r0 + 32 * rt + i, B - 1) * U + kbeg + 4 * h;
         }
     const long kstride = (long)(U / 8) * 32;                                  // floats between consecutive k rows of Upk
     const float* bp = Upk + (long)(kbeg + 4 * h) * kstride + (long)ub * 32 + i;
-    constexpr int PF = MASKED ? 4 : 8;                            // (four A streams: a shallower ring keeps the registers)
+    constexpr int PF = 8;
     f4_t a[PF][NG][RT];
     float b[PF][4];
 #pragma unroll
@@ -202,19 +196,9 @@ __global__ __launch_bounds__(NW * 64) void lstm_step_fused_kernel(float* __restr
             }
         }
     }
-    // this lane's column i = 8 gate + unit: of the four gate tiles it keeps its own gate's
     f32x16_t mine[RT];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        if constexpr (MASKED) {
-            const int gsel = i >> 3;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                mine[rt][r] = gsel == 0 ? acc[0][rt][r] : (gsel == 1 ? acc[1][rt][r] : (gsel == 2 ? acc[2][rt][r] : acc[NG - 1][rt][r]));
-        } else {
-            mine[rt] = acc[0][rt];
-        }
-    }
+    for (int rt = 0; rt < RT; ++rt) mine[rt] = acc[0][rt];
     if (wave >= HALF) {                                // round 1: the upper waves publish their K share's partial tiles
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -249,15 +233,132 @@ __global__ __launch_bounds__(NW * 64) void lstm_step_fused_kernel(float* __restr
         const float ig = hard_sigmoid(zg[0]), fg = hard_sigmoid(zg[1]), gg = tanhf(zg[2]), og = hard_sigmoid(zg[3]);
         const float cn = fg * gcp[q] + ig * gg;
         const float hn = og * tanhf(cn);
-        const float hv = gmk[q] ? hn : ghp[q];
-        h_t[o] = hv;
+        h_t[o] = gmk[q] ? hn : ghp[q];
         c_t[o] = gmk[q] ? cn : gcp[q];
-        if constexpr (MASKED) {
-            if (hm_next) {                             // the next step's A operands: h_t through the four gate masks
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused forward timestep WITH recurrent-dropout masks (round 5; U % 32 == 0).  The masked step above kept the plain step's block
+// (32 rows x 8 units x 4 gates = one 32-column MFMA tile) and computed that tile once per gate, because every gate has its own A
+// operand h * m_g: 4 x the MFMAs for the same output, 6.8 us of matrix-pipe time per block at U = 512 (18.4 us per step against 7.5
+// for the plain step -- the comment that called it irrelevant was wrong).  Here a wave owns ONE gate: block = 16 RT rows x 16 units,
+// waves = 4 gates x 2 halves of K, v_mfma_f32_16x16x4_f32 tiles (the backward step's shape), so no product is computed twice:
+// U / 8 MFMAs of 32 cycles per wave.  The masks are applied to the A fragments in registers (h and m_g each one 16-byte load per
+// four MFMAs): no pre-masked copies of h, no mask kernel in front of the first step, no four extra stores per element in the epilogue.
+// B operand: UpkT[gate * U + unit][k] = U_rec[k][gate * U + unit] (lstm_pack_urec_t_kernel, once per call): a lane reads 16 bytes along k.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_pack_urec_t_kernel(const float* __restrict__ U_rec, float* __restrict__ UpkT, int U) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, k0 = blockIdx.y * 32;            // columns of U_rec (gate * U + unit), rows k
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = U_rec[(long)(k0 + r) * (4L * U) + c0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) UpkT[(long)(c0 + r) * U + k0 + tx] = tile[tx][r];
+}
+
+template <int RT>
+__global__ __launch_bounds__(512) void lstm_step_masked_kernel(float* __restrict__ z_t, const float* __restrict__ UpkT, const float* __restrict__ h_prev,
+                                                               const float* __restrict__ c_prev, const uint8_t* __restrict__ mask_t,
+                                                               float* __restrict__ h_t, float* __restrict__ c_t, int B, int U,
+                                                               const float* __restrict__ rec_masks) {
+    constexpr int NW = 8, THREADS = NW * 64, ITEMS = RT * 256, IT = (ITEMS + THREADS - 1) / THREADS;
+    __shared__ float part[NW][RT * 16][17];
+    __builtin_amdgcn_s_setprio(3);                       // see lstm_step_fused_kernel
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gate = wave & 3, kp = wave >> 2;
+    const int u0 = blockIdx.x * 16, r0 = blockIdx.y * (RT * 16);
+    const int m = lane & 15, kk = lane >> 4;
+    const int kq = U / 2, kbeg = kp * kq, nch = kq / 16;            // 16 k values per chunk (4 MFMAs of K = 4)
+    const long gs = (long)B * U;
+    const float* bp = UpkT + ((long)gate * U + u0 + m) * U + kbeg + 4 * kk;
+    const float* ap[RT];
+    const float* mp[RT];
+    f32x4_t acc[RT];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) hm_next[g * gstride + o] = hv * rec_masks[g * gstride + o];
+    for (int rt = 0; rt < RT; ++rt) {
+        const long o = (long)min(r0 + 16 * rt + m, B - 1) * U + kbeg + 4 * kk;
+        ap[rt] = h_prev + o;
+        mp[rt] = rec_masks + gate * gs + o;
+        acc[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    constexpr int PF = (RT == 1) ? 16 : 8;               // U = 512: the wave's whole K share is requested before the first MFMA (one latency, not two)
+    f4_t a[PF][RT], mk[PF][RT], b[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        const int c = min(p, nch - 1);
+        b[p] = *reinterpret_cast<const f4_t*>(bp + 16 * c);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            a[p][rt] = *reinterpret_cast<const f4_t*>(ap[rt] + 16 * c);
+            mk[p][rt] = *reinterpret_cast<const f4_t*>(mp[rt] + 16 * c);
+        }
+    }
+    // the gate phase's operands: issued now, consumed after the K loop
+    float gz[IT][4], ghp[IT], gcp[IT];
+    bool gmk[IT];
+#pragma unroll
+    for (int q = 0; q < IT; ++q) {
+        const int e = tid + q * THREADS, row = e >> 4, uu = e & 15;
+        const int brow = min(r0 + row, B - 1);
+        const float* zrow = z_t + (long)brow * 4 * U + u0 + uu;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gz[q][g] = zrow[(long)g * U];
+        const long o = (long)brow * U + u0 + uu;
+        ghp[q] = h_prev[o];
+        gcp[q] = c_prev[o];
+        gmk[q] = mask_t ? (mask_t[brow] != 0) : true;
+    }
+    for (int c0 = 0; c0 < nch; c0 += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            f4_t x[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) x[rt] = a[p][rt] * mk[p][rt];
+            const f4_t y = b[p];
+            if (c0 + PF < nch) {                                // block-uniform: the next ring of chunks (clamped at the end)
+                const int cn = min(c0 + p + PF, nch - 1);
+                b[p] = *reinterpret_cast<const f4_t*>(bp + 16 * cn);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    a[p][rt] = *reinterpret_cast<const f4_t*>(ap[rt] + 16 * cn);
+                    mk[p][rt] = *reinterpret_cast<const f4_t*>(mp[rt] + 16 * cn);
+                }
+            }
+            if (c0 + p < nch) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[rt].x, y.x, acc[rt], 0, 0, 0);
+                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[rt].y, y.y, acc[rt], 0, 0, 0);
+                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[rt].z, y.z, acc[rt], 0, 0, 0);
+                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[rt].w, y.w, acc[rt], 0, 0, 0);
+                }
             }
         }
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave][16 * rt + 4 * kk + r][m] = acc[rt][r];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < IT; ++q) {
+        const int e = tid + q * THREADS, row = e >> 4, uu = e & 15;
+        const int brow = r0 + row;
+        if (e >= ITEMS || brow >= B) continue;
+        float zg[4];
+        float* zrow = z_t + (long)brow * 4 * U + u0 + uu;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            zg[g] = gz[q][g] + (part[g][row][uu] + part[4 + g][row][uu]);       // the two halves of K
+            zrow[(long)g * U] = zg[g];
+        }
+        const long o = (long)brow * U + u0 + uu;
+        const float ig = hard_sigmoid(zg[0]), fg = hard_sigmoid(zg[1]), gg = tanhf(zg[2]), og = hard_sigmoid(zg[3]);
+        const float cn = fg * gcp[q] + ig * gg;
+        const float hn = og * tanhf(cn);
+        h_t[o] = gmk[q] ? hn : ghp[q];
+        c_t[o] = gmk[q] ? cn : gcp[q];
     }
 }
 
@@ -270,7 +371,6 @@ __global__ __launch_bounds__(NW * 64) void lstm_step_fused_kernel(float* __restr
 // threads finish the gate math for their (row, unit).  Every (row, unit) belongs to one thread of one block, so the carried
 // dh/dc state is updated in place.
 // ------------------------------------------------------------------------------------------------
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 template <int RT, int NW>
 __global__ __launch_bounds__(NW * 64) void lstm_bwd_step_fused_kernel(const float* __restrict__ z_t, const float* __restrict__ c_prev,
@@ -485,8 +585,8 @@ extern "C" size_t dc_lstm_seq_workspace_bytes(int B, int T, int U) {
     }
     const size_t drop = align_up(g) + 2 * align_up((size_t)B * U * sizeof(float)) + align_up((size_t)4 * B * U * sizeof(float)) +
                         align_up((size_t)4 * (size_t)std::max(T - 1, 1) * B * U * sizeof(float)) + 1024;
-    // fused masked forward steps: the repacked U_rec + TWO sets of four masked copies of h
-    const size_t drop_fused = align_up(g) + align_up((size_t)4 * U * U * sizeof(float)) + 2 * align_up((size_t)4 * B * U * sizeof(float)) + 1024;
+    // fused masked forward steps: the transposed U_rec (the masks are applied to the A fragments in registers: no copies of h)
+    const size_t drop_fused = align_up(g) + align_up((size_t)4 * U * U * sizeof(float)) + 1024;
     return std::max(std::max(std::max(fwd, bwd), drop), drop_fused);
 }
 
@@ -500,30 +600,24 @@ extern "C" int dc_lstm_seq_fwd_f32(const dc_lstm_fwd_desc* d, void* workspace, s
     const bool fused = (U & 31) == 0 && d->T > 1;   // (else: per-step GEMM + gate kernel, with masks a mask kernel + four per-gate GEMMs)
     int frt = ((U / 8) * ((B + 31) / 32) <= 2 * kNumCU) ? 1 : 2;      // 32- or 64-row blocks
     int fnw = (frt == 2 && (U & 63) == 0) ? 8 : 4;                     // measured: 4 waves at 32 rows, 8 at 64
-    if (d->rec_masks && frt == 2) fnw = 4;          // the masked step keeps four gate tiles: <2, 8> would spill (297 VGPRs), <2, 4> fits
     float* Upk = nullptr;
     float* hm = nullptr;                            // dropout: [4][B][U] masked copies of h_{t-1}, at the END of the workspace
     void* gws = workspace;
     size_t gws_bytes = workspace_bytes;
-    float* hm2[2] = {nullptr, nullptr};             // fused masked steps: the double-buffered masked copies
     size_t tail = 0;                                // bytes taken from the END of the workspace
-    if (d->rec_masks) {
+    if (d->rec_masks && !fused) {                   // (the fused masked step masks its A fragments in registers: no copies)
         const size_t hm_bytes = align_up((size_t)4 * n * sizeof(float));
         char* end = static_cast<char*>(workspace) + workspace_bytes / 256 * 256;
         hm = reinterpret_cast<float*>(end - hm_bytes);
         tail = hm_bytes + (workspace_bytes - workspace_bytes / 256 * 256);
-        hm2[0] = hm;
-        if (fused) {
-            hm2[1] = reinterpret_cast<float*>(end - 2 * hm_bytes);
-            tail += hm_bytes;
-        }
         gws_bytes = workspace_bytes - tail;
     }
     if (fused) {                                   // line-contiguous copy of the recurrent weights at the END of the workspace (below the masked copies)
         const size_t pack_bytes = align_up((size_t)4 * U * U * sizeof(float));
         Upk = reinterpret_cast<float*>(static_cast<char*>(workspace) + (workspace_bytes - tail - pack_bytes) / 256 * 256);
         const long total = (long)4 * U * U;
-        hipLaunchKernelGGL(lstm_pack_urec_kernel, dim3((int)std::min<long>((total + 255) / 256, (long)kNumCU * 8)), dim3(256), 0, s, d->U_rec, Upk, U);
+        if (d->rec_masks) hipLaunchKernelGGL(lstm_pack_urec_t_kernel, dim3(4 * U / 32, U / 32), dim3(256), 0, s, d->U_rec, Upk, U);       // [4U][U]: k contiguous
+        else hipLaunchKernelGGL(lstm_pack_urec_kernel, dim3((int)std::min<long>((total + 255) / 256, (long)kNumCU * 8)), dim3(256), 0, s, d->U_rec, Upk, U);
         int rc = check_launch("lstm_pack_urec_kernel");
         if (rc) return rc;
     }
@@ -536,21 +630,12 @@ extern "C" int dc_lstm_seq_fwd_f32(const dc_lstm_fwd_desc* d, void* workspace, s
             float* h_t = d->h_seq + (long)t * n;
             float* c_t = d->c_seq + (long)t * n;
             const dim3 grid(U / 8, (B + 32 * frt - 1) / (32 * frt));
-            if (d->rec_masks) {
-                if (t == 1) {                           // h_0 through the four masks (later steps: the previous step's epilogue)
-                    hipLaunchKernelGGL(lstm_mask_rows_kernel, dim3(std::min(blocks, kNumCU * 8)), dim3(256), 0, s, hp, d->rec_masks, hm2[1], (long)B, B, U);
-                    int rc = check_launch("lstm_mask_rows_kernel");
-                    if (rc) return rc;
-                }
-                const float* hm_prev = hm2[t & 1];       // written for step t: by the mask kernel (t = 1) or by step t - 1
-                float* hm_next = (t + 1 < d->T) ? hm2[(t + 1) & 1] : nullptr;
-#define LAUNCH_FWD_STEP_M(RT_, NW_) hipLaunchKernelGGL((lstm_step_fused_kernel<RT_, NW_, true>), grid, dim3(NW_ * 64), 0, s, z_t, Upk, hp, cp, mk, h_t, c_t, B, U, hm_prev, d->rec_masks, hm_next)
-                if (frt == 1 && fnw == 8) LAUNCH_FWD_STEP_M(1, 8);
-                else if (frt == 1) LAUNCH_FWD_STEP_M(1, 4);
-                else if (fnw == 8) LAUNCH_FWD_STEP_M(2, 8);
-                else LAUNCH_FWD_STEP_M(2, 4);
-#undef LAUNCH_FWD_STEP_M
-                int rc = check_launch("lstm_step_fused_kernel (masked)");
+            if (d->rec_masks) {                        // recurrent dropout: one wave per gate, masks applied to the A fragments (lstm_step_masked_kernel)
+                const bool two = (U / 16) * ((B + 15) / 16) > kNumCU;              // 32-row blocks once 16-row blocks no longer fit the chip at once (measured: B = 200)
+                const dim3 gridm(U / 16, (B + (two ? 31 : 15)) / (two ? 32 : 16));
+                if (two) hipLaunchKernelGGL((lstm_step_masked_kernel<2>), gridm, dim3(512), 0, s, z_t, Upk, hp, cp, mk, h_t, c_t, B, U, d->rec_masks);
+                else hipLaunchKernelGGL((lstm_step_masked_kernel<1>), gridm, dim3(512), 0, s, z_t, Upk, hp, cp, mk, h_t, c_t, B, U, d->rec_masks);
+                int rc = check_launch("lstm_step_masked_kernel");
                 if (rc) return rc;
                 continue;
             }

@@ -455,13 +455,15 @@ def test_lstm_seq_forward_backward(ops, B, T, I, U, masked):
     close(ops.gemm(dz, dev(W), b_trans=True).view(T, B, I).permute(1, 0, 2), dx, 5e-5)   # dx = dz kernel^T
 
 
-@pytest.mark.parametrize("B,T,I,U", [(6, 5, 16, 32), (64, 10, 64, 512), (200, 4, 32, 128), (300, 3, 16, 512), (5, 3, 8, 24), (200, 15, 16, 512)])
+@pytest.mark.parametrize("B,T,I,U", [(6, 5, 16, 32), (64, 10, 64, 512), (200, 4, 32, 128), (300, 3, 16, 512), (5, 3, 8, 24), (200, 15, 16, 512),
+                                     (64, 3, 16, 1024), (8, 10, 16, 512)])
 def test_lstm_recurrent_dropout_matches_oracle(ops, B, T, I, U):
     """Keras recurrent_dropout in the training phase: given the four per-gate masks, forward states and every gradient of the
-    recurrence equal the oracle's (which finite differences pin, tests/test_oracle_kat.py).  Round 4: ONE fused launch per timestep
-    in both directions with masks too (forward: four pre-masked copies of h, double-buffered, one accumulator tile per gate;
-    backward: the K = 4U split falls on gate boundaries, the masks apply where the partial tiles meet); the cases cover 32- and
-    64-row forward blocks (B = 300 at U = 512), 4 and 8 K-waves, and a U that is no multiple of 16 (the per-gate GEMM path)."""
+    recurrence equal the oracle's (which finite differences pin, tests/test_oracle_kat.py).  ONE fused launch per timestep
+    in both directions with masks too (forward, round 5: lstm_step_masked_kernel -- a wave per gate and K half, 16 x 16 tiles, the masks
+    applied to the h fragments in registers; backward: the K = 4U split falls on gate boundaries, the masks apply where the partial tiles
+    meet); the cases cover 16- and 32-row forward blocks (B = 300 at U = 512), ragged row tiles, U = 1024, BASELINE configs[0]'s own
+    shape (8 x 10 x 512) and a U that is no multiple of 16 (the per-gate GEMM path)."""
     rng = np.random.default_rng(B + T + U)
     x = rng.standard_normal((B, T, I))
     W = rng.standard_normal((I, 4 * U)) / np.sqrt(I)
