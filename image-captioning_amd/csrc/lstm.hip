@@ -598,7 +598,7 @@ extern "C" int dc_lstm_seq_fwd_f32(const dc_lstm_fwd_desc* d, void* workspace, s
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int B = d->B, U = d->U, n = B * U, blocks = (n + 255) / 256;
     const bool fused = (U & 31) == 0 && d->T > 1;   // (else: per-step GEMM + gate kernel, with masks a mask kernel + four per-gate GEMMs)
-    int frt = ((U / 8) * ((B + 31) / 32) <= 2 * kNumCU) ? 1 : 2;      // 32- or 64-row blocks
+    int frt = ((U / 8) * ((B + 31) / 32) <= 2 * kNumCU) ? 1 : 2;      // 32- or 64-row blocks (measured again in round 5 at 200 x 512: 12.3 vs 13.2 us)
     int fnw = (frt == 2 && (U & 63) == 0) ? 8 : 4;                     // measured: 4 waves at 32 rows, 8 at 64
     float* Upk = nullptr;
     float* hm = nullptr;                            // dropout: [4][B][U] masked copies of h_{t-1}, at the END of the workspace
