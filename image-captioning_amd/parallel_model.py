@@ -180,13 +180,22 @@ class GradAllReduce(object):
         return self.ranks_seen
 
 
+def default_grad_dtype(keras_model):
+    """The gradient exchange's wire format when the caller names none: DCAP_GRAD_DTYPE if set, else bf16 buckets for a model whose
+    compute dtype is bf16 (BASELINE configs[4]; SURVEY section 5: "flat fp32 (bf16 in configs[4]) buckets") and fp32 otherwise."""
+    env = os.environ.get("DCAP_GRAD_DTYPE")
+    if env:
+        return env
+    return "bf16" if getattr(keras_model, "compute_dtype", "f32") == "bf16" else "f32"
+
+
 class ParallelModel(object):
     """ParallelModel(keras_model, gpu_count): same constructor as the reference.  gpu_count must equal
     the torch.distributed world size (one process per GPU).  Attribute access falls through to the
     wrapped model (the reference's __getattribute__ trick, parallel_model.py:41-46)."""
 
     def __init__(self, keras_model, gpu_count, grad_dtype=None):
-        """grad_dtype: 'f32' (default) or 'bf16' = the gradient exchange's wire format (GradAllReduce); DCAP_GRAD_DTYPE sets the default."""
+        """grad_dtype: 'f32' or 'bf16' = the gradient exchange's wire format (GradAllReduce); default: default_grad_dtype(keras_model)."""
         world = dist.get_world_size() if dist.is_initialized() else 1
         if gpu_count != world:
             raise ValueError("gpu_count=%d but %d process(es) are running: launch one process per GPU "
@@ -195,7 +204,7 @@ class ParallelModel(object):
         self.gpu_count = gpu_count
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         reserve_cus_for_collectives(world)
-        keras_model.grad_sync = GradAllReduce(dtype=grad_dtype or os.environ.get("DCAP_GRAD_DTYPE", "f32"))
+        keras_model.grad_sync = GradAllReduce(dtype=grad_dtype or default_grad_dtype(keras_model))
         keras_model.is_chief = self.rank == 0          # one rank prints and writes checkpoints (the others barrier)
         keras_model._outer = self                      # the wrapped model's train() loop feeds global batches through this wrapper
         self.broadcast_weights()

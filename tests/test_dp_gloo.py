@@ -252,3 +252,21 @@ def test_eight_rank_shard_and_bucket_coverage_at_configs3_layout(tmp_path):
     world = 8
     mp.spawn(_worker_configs3, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert int(np.load(tmp_path / "ok.npy")[0]) == 1
+
+
+def test_default_gradient_wire_format_follows_the_models_compute_dtype(monkeypatch):
+    """ParallelModel(grad_dtype=None): bf16 buckets for the bf16 joint model (configs[4]), fp32 for fp32 models (configs[3]),
+    DCAP_GRAD_DTYPE overrides both."""
+    from image_captioning_amd.parallel_model import default_grad_dtype
+
+    class M(object):
+        pass
+    f, b = M(), M()
+    b.compute_dtype = "bf16"
+    f.compute_dtype = "f32"
+    monkeypatch.delenv("DCAP_GRAD_DTYPE", raising=False)
+    assert default_grad_dtype(f) == "f32" and default_grad_dtype(b) == "bf16" and default_grad_dtype(M()) == "f32"
+    monkeypatch.setenv("DCAP_GRAD_DTYPE", "f32")
+    assert default_grad_dtype(b) == "f32"
+    monkeypatch.setenv("DCAP_GRAD_DTYPE", "bf16")
+    assert default_grad_dtype(f) == "bf16"
