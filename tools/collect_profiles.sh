@@ -46,6 +46,11 @@ python3 $root/tools/conv_bench.py --reps 50 2>&1 | grep -v amdgpu.ids > $out/con
  echo "== the same layers, Winograd F(2x2,3x3) with fp32 MFMA products (rounds 3-4)"; python3 $root/tools/conv_bench.py --filter 3x3 --winograd --reps 50 2>&1 | grep -v amdgpu.ids
  echo "== the same layers, direct implicit GEMM"; python3 $root/tools/conv_bench.py --filter 3x3 --reps 50 2>&1 | grep -v amdgpu.ids) > $out/winograd_bench.txt
 (echo "== fp32 products (wino64_kernel)"; python3 $root/tools/wino_fit.py 2>&1 | grep -v amdgpu.ids; echo "== split-bf16 products (wino64b_kernel)"; python3 $root/tools/wino_fit.py --b3 2>&1 | grep -v amdgpu.ids) > $out/winograd_fit.txt
+python3 $root/tools/chain_bench.py 2>&1 | grep -v amdgpu.ids > $out/chain_bench.txt
+for m in l2_shared_stream vmem_mfma_overlap coissue_bf16; do
+  if [ ! -x $root/tools/micro/$m ]; then /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o $root/tools/micro/$m $root/tools/micro/$m.hip; fi
+  timeout -k 10 120 $root/tools/micro/$m > $out/micro_$m.txt 2>&1 || true
+done
 rocprofv3 --kernel-trace --stats -d $out/dec -o dec -- python3 $root/tools/decoder_bench.py --captions 64 --steps 50 > $out/dec.log 2>&1
 python3 $root/tools/prof_summary.py $out/dec/dec_results.db $out/decoder_kernels.csv 53
 rm -rf $out/dec
