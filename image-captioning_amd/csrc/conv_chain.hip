@@ -24,7 +24,6 @@
 // column block w (N2 / 32 <= 8 blocks).
 #include "igemm_bf16s.h"
 #include <algorithm>
-#include <type_traits>
 
 namespace dcap {
 namespace chain {
@@ -165,50 +164,24 @@ __global__ __launch_bounds__(512, 1) void pw_chain_kernel(Args a) {
         __syncthreads();                                   // the input rows are in LDS
         const float* xrow = smem + p * LDX + 8 * h;
         f4 xa = *reinterpret_cast<const f4*>(__builtin_assume_aligned(xrow, 16)), xc = *reinterpret_cast<const f4*>(__builtin_assume_aligned(xrow + 4, 16));
-        // the six products of the split, small terms first (igemm_bf16s.h's order): weight piece / activation piece of product t
-        constexpr int PW[6] = {0, 1, 2, 1, 0, 0}, PQ[6] = {2, 1, 0, 0, 1, 0};
-        auto group = [&](auto uc, int gabs) {              // one 16-channel group; uc = its (static) ring slot
-            constexpr int u = decltype(uc)::value;
-            const int gl = min(gabs + R - 1, NGB - 1);     // (the last groups re-request the last fragments: uniform counts)
-            const int gn = min(gabs + 1, NGB - 1);
-            const f4 na = *reinterpret_cast<const f4*>(__builtin_assume_aligned(xrow + 16 * gn, 16));
-            const f4 nc = *reinterpret_cast<const f4*>(__builtin_assume_aligned(xrow + 16 * gn + 4, 16));
-            u32x4 q[3];
-            split8(xa, xc, q[0], q[1], q[2]);
-            __builtin_amdgcn_sched_barrier(0);
-            // ONE weight load (of the group R - 1 ahead) behind every two MFMAs, pinned there: issued as a burst in front of the
-            // group's MFMAs the same loads cost 2.5 x the MFMA time (tools/micro/vmem_mfma_overlap.hip: 1797 ns against 878 for
-            // 24 MFMAs : 12 loads on two waves of a SIMD).  Products outermost: consecutive MFMAs hit different accumulators.
-            u32x4 (&nx)[CB1][3] = wr[(u + R - 1) % R];
+        for (int g = 0; g < NGB; g += R) {                 // K1 % 48 == 0 is not required: the tail groups re-run clamped loads but
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+            for (int u = 0; u < R; ++u) {                  // only groups < NGB issue MFMAs (uniform branch)
+                if (g + u < NGB) {
+                    ldwb(wr[(u + R - 1) % R], min(g + u + R - 1, NGB - 1));
+                    const int gn = min(g + u + 1, NGB - 1);
+                    const f4 na = *reinterpret_cast<const f4*>(__builtin_assume_aligned(xrow + 16 * gn, 16));
+                    const f4 nc = *reinterpret_cast<const f4*>(__builtin_assume_aligned(xrow + 16 * gn + 4, 16));
+                    u32x4 q[3];
+                    split8(xa, xc, q[0], q[1], q[2]);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int cb = 0; cb < CB1; ++cb) {
-                    acc[cb] = mfma_b(wr[u][cb][PW[t]], q[PQ[t]], acc[cb]);
-                    const int mi = t * CB1 + cb;               // 6 CB1 MFMAs, 3 CB1 loads: one load per two MFMAs
-                    if (mi & 1) {
-                        const int li = mi >> 1, lcb = li / 3, lpc = li - 3 * lcb;
-                        nx[lcb][lpc] = __builtin_bit_cast(u32x4, buf_f4s(rsrc1, lane16, (unsigned)(((wave * CB1 + lcb) * NGB + gl) * 3072) + 1024u * lpc));
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                    for (int cb = 0; cb < CB1; ++cb) acc[cb] = mfma_b3(wr[u][cb], q, acc[cb]);
+                    xa = na;
+                    xc = nc;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-            xa = na;
-            xc = nc;
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        static_assert(R == 3, "the group calls below are written out for a ring of three");
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        using I2 = std::integral_constant<int, 2>;
-        int g = 0;
-        for (; g + R <= NGB; g += R) {                     // steady state: no branch inside (the compiler's vmcnt then allows the two
-            group(I0{}, g);                                // groups in flight; with the tail test inside the loop it waited for all but 4 loads)
-            group(I1{}, g + 1);
-            group(I2{}, g + 2);
-        }
-        if (g < NGB) {                                     // K1 / 16 is not a multiple of three: one or two groups left
-            group(I0{}, g);
-            if (g + 1 < NGB) group(I1{}, g + 1);
+            }
         }
         load_res();
     } else {
@@ -283,41 +256,22 @@ __global__ __launch_bounds__(512, 1) void pw_chain_kernel(Args a) {
         if (!active2) return;
         const float* yrow = smem + p * LDY + 8 * h;
         f4 ya = *reinterpret_cast<const f4*>(__builtin_assume_aligned(yrow, 16)), yc = *reinterpret_cast<const f4*>(__builtin_assume_aligned(yrow + 4, 16));
-        f32x16 acc2b;                                      // odd groups: two accumulation chains instead of one dependent chain of 6 NGB2 MFMAs
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2b[r] = 0.f;
         for (int g = 0; g < NGB2; g += R) {                // NGB2 = N1 / 16 is a multiple of 8
 #pragma unroll
             for (int u = 0; u < R; ++u) {
-                const int gl = min(g + u + R - 1, NGB2 - 1);
-                const unsigned so = (unsigned)((wave * NGB2 + gl) * 3072);
-                u32x4 (&nx)[3] = wr[(u + R - 1) % R];
+                ldwb(wr[(u + R - 1) % R], min(g + u + R - 1, NGB2 - 1));
                 const int gn = min(g + u + 1, NGB2 - 1);
                 const f4 na = *reinterpret_cast<const f4*>(__builtin_assume_aligned(yrow + 16 * gn, 16));
                 const f4 nc = *reinterpret_cast<const f4*>(__builtin_assume_aligned(yrow + 16 * gn + 4, 16));
                 u32x4 q[3];
                 split8(ya, yc, q[0], q[1], q[2]);
                 __builtin_amdgcn_sched_barrier(0);
-                f32x16& ac = (u & 1) ? acc2b : acc2;
-                // one weight load (seven groups ahead) behind every two MFMAs (see layer 1)
-                ac = mfma_b(wr[u][0], q[2], ac);
-                ac = mfma_b(wr[u][1], q[1], ac);
-                nx[0] = __builtin_bit_cast(u32x4, buf_f4s(rsrc2, lane16, so));
-                __builtin_amdgcn_sched_barrier(0);
-                ac = mfma_b(wr[u][2], q[0], ac);
-                ac = mfma_b(wr[u][1], q[0], ac);
-                nx[1] = __builtin_bit_cast(u32x4, buf_f4s(rsrc2, lane16, so + 1024u));
-                __builtin_amdgcn_sched_barrier(0);
-                ac = mfma_b(wr[u][0], q[1], ac);
-                ac = mfma_b(wr[u][0], q[0], ac);
-                nx[2] = __builtin_bit_cast(u32x4, buf_f4s(rsrc2, lane16, so + 2048u));
+                acc2 = mfma_b3(wr[u], q, acc2);
                 ya = na;
                 yc = nc;
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[r] += acc2b[r];
     } else {
     constexpr int R2 = 16;                                 // R2 - 1 groups (60 MFMAs of this wave) ahead
     f4 wb[R2];
