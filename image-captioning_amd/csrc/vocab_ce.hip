@@ -12,7 +12,11 @@
 //               gradient scale;
 //   pass CLIP   (keras_sparse only) K.sparse_categorical_crossentropy clips the probabilities to [1e-7, 1-1e-7] and
 //               renormalises: S = sum clip(p), UP = sum of the unclipped p, per row and tile; a row kernel combines them
-//               into the loss row and the two row constants of the gradient;
+//               into the loss row and the two row constants of the gradient.  LAZY since round 5: the STATS pass also keeps the
+//               smallest logit of every row, so the row kernel knows which rows have a probability outside the clip range at all
+//               (p is monotone in z: the smallest and the largest p of a row decide); a row tile without such a row leaves the
+//               CLIP pass before its GEMM (S = UP = 1 there: nothing is clipped, the row's probabilities sum to s / s) -- with
+//               50 000 words and ordinary logits that is every tile, and the step runs two GEMM passes instead of three;
 //   pass DL     recomputes the tile and writes d(loss)/d(logits) (fp32, or bf16 as the operand of the bf16 weight /
 //               data gradient GEMMs) plus per-tile column sums (the bias gradient, combined in a fixed order).
 // The recomputation costs one extra GEMM pass (two for keras_sparse); in exchange nothing of size rows x V is written
@@ -24,12 +28,15 @@ namespace dcap {
 
 enum { CE_STATS = 0, CE_CLIP = 1, CE_DL = 2 };
 constexpr int CE_RI = 8;                 // floats of row info per row
+constexpr int CE_ST = 4;                 // floats of per-(row, column tile) partials: STATS (max, sum exp, min, -), CLIP (S, UP, -, -)
 
 struct CeArgs {
     int M, V, tiles_n;
     const float* bias;                   // [V] or null
     const int32_t* targets;              // [M]
-    float* stats;                        // [M][tiles_n][2]
+    float* stats;                        // [M][tiles_n][CE_ST]
+    int* needs_clip;                     // [M]: the row has a probability outside [1e-7, 1 - 1e-7] (written by ce_rows_kernel, phase 0)
+    int tile_rows;                       // rows per tile of the launched kernel (128 / 256)
     float* zt;                           // [M]
     const float* rowinfo;                // [M][CE_RI]: m, 1/s, gs, 1/S, c, tq  (see ce_rows_kernel)
     float* dl_f32;
@@ -43,6 +50,20 @@ __device__ __forceinline__ float half_max(float v) {          // over the 32 lan
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
+}
+__device__ __forceinline__ float half_min(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// CLIP pass: does any row of this block's row tile need it?  Every wave answers for itself from the same flags (a ballot: no LDS, no
+// barrier -- __syncthreads_or would add a static LDS word to kernels that ask for the full 160 KiB dynamically), so the answer is
+// block-uniform; called before the GEMM main loop.
+__device__ __forceinline__ bool ce_tile_needs_clip(const CeArgs& ce, int m0) {
+    int any = 0;
+    for (int r = threadIdx.x & 63; r < ce.tile_rows; r += 64)
+        if (m0 + r < ce.M) any |= ce.needs_clip[m0 + r];
+    return __any(any) != 0;
 }
 __device__ __forceinline__ float half_sum(float v) {
 #pragma unroll
@@ -88,8 +109,10 @@ __device__ __forceinline__ void ce_epilogue(f32x16 (&acc)[2][2], float* Cs, cons
             mx = half_max(mx);
             float s = (v0 ? __expf(z.x - mx) : 0.f) + (v1 ? __expf(z.y - mx) : 0.f) + (v2 ? __expf(z.z - mx) : 0.f) + (v3 ? __expf(z.w - mx) : 0.f);
             s = half_sum(s);
+            float mn = fminf(fminf(v0 ? z.x : INFINITY, v1 ? z.y : INFINITY), fminf(v2 ? z.z : INFINITY, v3 ? z.w : INFINITY));
+            mn = half_min(mn);
             if (rv) {
-                if (c4 == 0) *reinterpret_cast<float2*>(ce.stats + ((long)row * ce.tiles_n + tile_n) * 2) = make_float2(mx, s);
+                if (c4 == 0) *reinterpret_cast<float4*>(ce.stats + ((long)row * ce.tiles_n + tile_n) * CE_ST) = make_float4(mx, s, mn, 0.f);
                 if (t >= col && t < col + 4 && t < ce.V) ce.zt[row] = t == col ? z.x : (t == col + 1 ? z.y : (t == col + 2 ? z.z : z.w));
             }
         } else {
@@ -104,7 +127,7 @@ __device__ __forceinline__ void ce_epilogue(f32x16 (&acc)[2][2], float* Cs, cons
                           ((v3 && unclipped(p3)) ? p3 : 0.f);
                 S = half_sum(S);
                 U = half_sum(U);
-                if (rv && c4 == 0) *reinterpret_cast<float2*>(ce.stats + ((long)row * ce.tiles_n + tile_n) * 2) = make_float2(S, U);
+                if (rv && c4 == 0) *reinterpret_cast<float2*>(ce.stats + ((long)row * ce.tiles_n + tile_n) * CE_ST) = make_float2(S, U);
             } else {
                 const float gs = ri[2];
                 float g0, g1, g2, g3;
@@ -166,6 +189,9 @@ __global__ __launch_bounds__(256, 2) void vocab_ce_f32_kernel(CeA32 al, CeB32 bl
     const int tile_m = lid / ce.tiles_n, tile_n = lid % ce.tiles_n;
     const int m0 = tile_m * 128, n0 = tile_n * 128;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    if constexpr (MODE == CE_CLIP) {
+        if (!ce_tile_needs_clip(ce, m0)) return;
+    }
     f32x16 acc[2][2];
     igemm_mainloop<128, 128, CeA32, CeB32>(al, bl, smem, m0, n0, 0, K, acc, wm, wn);
     ce_epilogue<MODE>(acc, smem, ce, m0, n0, wm, wn, tile_m, tile_n);
@@ -179,6 +205,9 @@ __global__ __launch_bounds__(256, 2) void vocab_ce_bf16_kernel(BOperand a, BOper
     const int tile_m = lid / ce.tiles_n, tile_n = lid % ce.tiles_n;
     const int m0 = tile_m * 128, n0 = tile_n * 128;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    if constexpr (MODE == CE_CLIP) {
+        if (!ce_tile_needs_clip(ce, m0)) return;
+    }
     f32x16 acc[2][2];
     bgemm_mainloop<true, false>(a, b, reinterpret_cast<char*>(smem), m0, n0, 0, K, acc, wm, wn);
     ce_epilogue<MODE>(acc, smem, ce, m0, n0, wm, wn, tile_m, tile_n);
@@ -193,6 +222,7 @@ __global__ __launch_bounds__(256, 2) void vocab_ce_bf16_kernel(BOperand a, BOper
 // rows, four shuffles over the 16 row lanes and a 2-entry combine across the wave groups -- all in a fixed order.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float quad_max(float v) { return fmaxf(fmaxf(v, __shfl_xor(v, 16, 64)), fmaxf(__shfl_xor(v, 32, 64), __shfl_xor(v, 48, 64))); }
+__device__ __forceinline__ float quad_min(float v) { return fminf(fminf(v, __shfl_xor(v, 16, 64)), fminf(__shfl_xor(v, 32, 64), __shfl_xor(v, 48, 64))); }
 __device__ __forceinline__ float quad_sum(float v) {
     v += __shfl_xor(v, 16, 64);
     return v + __shfl_xor(v, 32, 64);
@@ -213,7 +243,7 @@ __device__ __forceinline__ void ce_epilogue256(b256::f32x4 (&acc)[8][4], float* 
         cv[nt] = col[nt] < ce.V;                                  // V % 4 == 0: a lane's four columns are all inside or all outside
         bias[nt] = (ce.bias && cv[nt]) ? *reinterpret_cast<const f32x4*>(ce.bias + col[nt]) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    float2* part = reinterpret_cast<float2*>(lds);               // [4 wave columns][256 tile rows]
+    float4* part = reinterpret_cast<float4*>(lds);               // [4 wave columns][256 tile rows]
     f32x4 cs[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) cs[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -236,7 +266,12 @@ __device__ __forceinline__ void ce_epilogue256(b256::f32x4 (&acc)[8][4], float* 
             for (int nt = 0; nt < 4; ++nt)
                 if (cv[nt]) sm += __expf(z[nt][0] - mx) + __expf(z[nt][1] - mx) + __expf(z[nt][2] - mx) + __expf(z[nt][3] - mx);
             sm = quad_sum(sm);
-            if (q == 0) part[wcol * 256 + lr] = make_float2(mx, sm);       // mx = -inf, sm = 0 when the wave's 64 columns lie past V
+            float mn = INFINITY;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                if (cv[nt]) mn = fminf(mn, fminf(fminf(z[nt][0], z[nt][1]), fminf(z[nt][2], z[nt][3])));
+            mn = quad_min(mn);
+            if (q == 0) part[wcol * 256 + lr] = make_float4(mx, sm, mn, 0.f);       // mx = -inf, sm = 0, mn = +inf when the wave's 64 columns lie past V
             if (rv && t < ce.V)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
@@ -265,7 +300,7 @@ __device__ __forceinline__ void ce_epilogue256(b256::f32x4 (&acc)[8][4], float* 
                         }
                 S = quad_sum(S);
                 U = quad_sum(U);
-                if (q == 0) part[wcol * 256 + lr] = make_float2(S, U);
+                if (q == 0) part[wcol * 256 + lr] = make_float4(S, U, 0.f, 0.f);
             } else {
                 const float gs = ri[2], invS = ri[3], c = ri[4], tq = ri[5];
 #pragma unroll
@@ -296,15 +331,16 @@ __device__ __forceinline__ void ce_epilogue256(b256::f32x4 (&acc)[8][4], float* 
     if constexpr (MODE != CE_DL) {
         __syncthreads();
         if (tid < 256 && m0 + tid < ce.M) {                          // one thread per tile row: combine the four wave columns in order
-            const float2 a0 = part[tid], a1 = part[256 + tid], a2 = part[512 + tid], a3 = part[768 + tid];
-            float2 r;
+            const float4 a0 = part[tid], a1 = part[256 + tid], a2 = part[512 + tid], a3 = part[768 + tid];
+            float4 r;
             if constexpr (MODE == CE_STATS) {
                 const float m = fmaxf(fmaxf(a0.x, a1.x), fmaxf(a2.x, a3.x));            // finite: column 0 of every tile is a real word
-                r = make_float2(m, a0.y * __expf(a0.x - m) + a1.y * __expf(a1.x - m) + a2.y * __expf(a2.x - m) + a3.y * __expf(a3.x - m));
+                r = make_float4(m, a0.y * __expf(a0.x - m) + a1.y * __expf(a1.x - m) + a2.y * __expf(a2.x - m) + a3.y * __expf(a3.x - m),
+                                fminf(fminf(a0.z, a1.z), fminf(a2.z, a3.z)), 0.f);
             } else {
-                r = make_float2(a0.x + a1.x + a2.x + a3.x, a0.y + a1.y + a2.y + a3.y);
+                r = make_float4(a0.x + a1.x + a2.x + a3.x, a0.y + a1.y + a2.y + a3.y, 0.f, 0.f);
             }
-            *reinterpret_cast<float2*>(ce.stats + ((long)(m0 + tid) * ce.tiles_n + tile_n) * 2) = r;
+            *reinterpret_cast<float4*>(ce.stats + ((long)(m0 + tid) * ce.tiles_n + tile_n) * CE_ST) = r;
         }
     } else if (ce.dbias_part) {
         float* red = lds;                                            // [2 wave groups][256 tile columns]
@@ -336,6 +372,9 @@ __global__ __launch_bounds__(b256::NTHREADS, 2) void vocab_ce_bf16_256_kernel(BO
     b256::Load<false, false> lb;
     la.init(a, m0, lane, wave);
     lb.init(b, n0, lane, wave);
+    if constexpr (MODE == CE_CLIP) {
+        if (!ce_tile_needs_clip(ce, m0)) return;
+    }
     b256::f32x4 acc[8][4];
     b256::mainloop(la, lb, reinterpret_cast<char*>(smem), 0, K, acc);
     ce_epilogue256<MODE>(acc, smem, ce, m0, n0, tile_m, tile_n);
@@ -351,10 +390,10 @@ __global__ __launch_bounds__(b256::NTHREADS, 2) void vocab_ce_bf16_256_kernel(BO
 __global__ __launch_bounds__(256) void ce_rows_kernel(int phase, int M, int tiles_n, const float* __restrict__ stats, const float* __restrict__ zt,
                                                       const int32_t* __restrict__ targets, int V, const float* __restrict__ row_weights,
                                                       float grad_scale, int keras_sparse, float* __restrict__ rowinfo,
-                                                      float* __restrict__ loss_rows) {
+                                                      float* __restrict__ loss_rows, int* __restrict__ needs_clip, int tile_rows) {
     const int row = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (row >= M) return;
-    const float2* st = reinterpret_cast<const float2*>(stats) + (long)row * tiles_n;
+    const float4* st = reinterpret_cast<const float4*>(stats) + (long)row * tiles_n;
     float* ri = rowinfo + (long)row * CE_RI;
     const float rw = row_weights ? row_weights[row] : 1.f;
     const int t = targets[row];
@@ -363,12 +402,15 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(int phase, int M, int tile
         for (int j = lane; j < tiles_n; j += 64) m = fmaxf(m, st[j].x);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-        float s = 0.f;
-        for (int j = lane; j < tiles_n; j += 64) { const float2 q = st[j]; s += q.y * __expf(q.x - m); }
+        float s = 0.f, mn = INFINITY;
+        for (int j = lane; j < tiles_n; j += 64) { const float4 q = st[j]; s += q.y * __expf(q.x - m); mn = fminf(mn, q.z); }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); mn = fminf(mn, __shfl_xor(mn, o, 64)); }
         if (lane != 0) return;
         const float inv_s = 1.f / s;
+        // the passes' own expression for a probability, at the row's smallest and largest logit (p is monotone in z): is anything clipped?
+        const float pmin = __expf(mn - m) * inv_s, pmax = __expf(0.f) * inv_s;
+        needs_clip[row] = (pmin >= 1e-7f && pmax <= 1.f - 1e-7f) ? 0 : 1;
         const float pt = (t >= 0 && t < V) ? __expf(zt[row] - m) * inv_s : 1.f;
         const bool live = pt >= 1e-7f && pt <= 1.f - 1e-7f;
         ri[0] = m; ri[1] = inv_s; ri[6] = pt;
@@ -378,10 +420,18 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(int phase, int M, int tile
         }
         return;
     }
-    float S = 0.f, U = 0.f;
-    for (int j = lane; j < tiles_n; j += 64) { const float2 q = st[j]; S += q.x; U += q.y; }
+    // did the CLIP pass run on this row's tile?  (the same test its blocks made)
+    const int t0 = row / tile_rows * tile_rows;
+    int any = 0;
+    for (int r = t0 + lane; r < min(t0 + tile_rows, M); r += 64) any |= needs_clip[r];
+    any = __any(any);
+    float S = 1.f, U = 1.f;                                    // no probability of the tile's rows is clipped: S = UP = sum p = s / s
+    if (any) {
+        S = 0.f; U = 0.f;
+        for (int j = lane; j < tiles_n; j += 64) { const float4 q = st[j]; S += q.x; U += q.y; }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { S += __shfl_xor(S, o, 64); U += __shfl_xor(U, o, 64); }
+        for (int o = 32; o > 0; o >>= 1) { S += __shfl_xor(S, o, 64); U += __shfl_xor(U, o, 64); }
+    }
     if (lane != 0) return;
     const float pt = ri[6];
     const bool live = pt >= 1e-7f && pt <= 1.f - 1e-7f;
@@ -400,7 +450,8 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct CePlan {
     int tiles_m, tiles_n;
-    size_t off_stats, off_zt, off_ri, off_db, total;
+    size_t off_stats, off_zt, off_ri, off_nc, off_db, total;
+    int tile_rows;
 };
 // bf16 problems whose 256-square grid covers the chip run on the large tile (bgemm256_core.h)
 static bool ce_big(const dc_vocab_ce_desc* d) { return d->bf16 && b256::prefer(d->M, d->V, d->K, 1); }
@@ -410,9 +461,11 @@ static CePlan ce_plan(const dc_vocab_ce_desc* d) {
     p.tiles_m = (d->M + T - 1) / T;
     p.tiles_n = (d->V + T - 1) / T;
     p.off_stats = 0;
-    p.off_zt = align256((size_t)d->M * p.tiles_n * 2 * sizeof(float));
+    p.tile_rows = T;
+    p.off_zt = align256((size_t)d->M * p.tiles_n * CE_ST * sizeof(float));
     p.off_ri = p.off_zt + align256((size_t)d->M * sizeof(float));
-    p.off_db = p.off_ri + align256((size_t)d->M * CE_RI * sizeof(float));
+    p.off_nc = p.off_ri + align256((size_t)d->M * CE_RI * sizeof(float));
+    p.off_db = p.off_nc + align256((size_t)d->M * sizeof(int));
     p.total = p.off_db + (d->dbias ? align256((size_t)p.tiles_m * d->V * sizeof(float)) : 0);
     return p;
 }
@@ -488,19 +541,21 @@ extern "C" int dc_vocab_ce(const dc_vocab_ce_desc* d, void* workspace, size_t wo
     ce.zt = reinterpret_cast<float*>(ws + p.off_zt);
     float* rowinfo = reinterpret_cast<float*>(ws + p.off_ri);
     ce.rowinfo = rowinfo;
+    ce.needs_clip = reinterpret_cast<int*>(ws + p.off_nc);
+    ce.tile_rows = p.tile_rows;
     ce.keras_sparse = d->keras_sparse;
     const int row_blocks = (d->M + 3) / 4;
     rc = ce_launch<CE_STATS>(d, ce, p, s);
     if (rc) return rc;
     hipLaunchKernelGGL(ce_rows_kernel, dim3(row_blocks), dim3(256), 0, s, 0, d->M, p.tiles_n, ce.stats, ce.zt, d->targets, d->V, d->row_weights,
-                       d->grad_scale, d->keras_sparse, rowinfo, d->loss_rows);
+                       d->grad_scale, d->keras_sparse, rowinfo, d->loss_rows, ce.needs_clip, p.tile_rows);
     rc = check_launch("ce_rows_kernel");
     if (rc) return rc;
     if (d->keras_sparse) {
         rc = ce_launch<CE_CLIP>(d, ce, p, s);
         if (rc) return rc;
         hipLaunchKernelGGL(ce_rows_kernel, dim3(row_blocks), dim3(256), 0, s, 1, d->M, p.tiles_n, ce.stats, ce.zt, d->targets, d->V, d->row_weights,
-                           d->grad_scale, d->keras_sparse, rowinfo, d->loss_rows);
+                           d->grad_scale, d->keras_sparse, rowinfo, d->loss_rows, ce.needs_clip, p.tile_rows);
         rc = check_launch("ce_rows_kernel");
         if (rc) return rc;
     }

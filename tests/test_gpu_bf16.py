@@ -255,6 +255,44 @@ def test_vocab_ce_masked_keras_sparse(ops, bf16, M, V, K):
     assert torch.equal(only_loss, loss)
 
 
+@pytest.mark.parametrize("bf16,M,V,K", [(False, 300, 1000, 64), (True, 300, 1000, 64), (True, 1500, 8200, 512)])
+def test_vocab_ce_keras_sparse_clip_pass_runs_only_where_a_row_needs_it(ops, bf16, M, V, K):
+    """The lazy CLIP pass (round 5): the STATS pass keeps every row's smallest logit, the row kernel marks the rows with a probability
+    outside [1e-7, 1 - 1e-7], and only row tiles holding such a row run the second GEMM pass.  Three situations against the oracle:
+    no row clipped at all (every tile skips the pass: S = UP = 1), one row tile with a clipped-low and a clipped-high row while the
+    other tiles skip, and the same on the 256-row tile."""
+    rng = np.random.default_rng(V + K + M)
+    X, W, b, t, _ = _ce_case(rng, M, V, K, bf16)
+    W *= 0.25                                                          # logits within a few units: every probability well inside the clip range
+    b *= 0.5
+    w = rng.random(M)
+    for clipped_rows in ((), (3, 140)):
+        Xc = X.copy()
+        bc = b.copy()
+        if clipped_rows:
+            lo, hi = clipped_rows
+            Xc[hi] = 400.0 * W[:, 7] / np.linalg.norm(W[:, 7])         # aligned with word 7: its probability exceeds 1 - 1e-7 (clipped high)
+            Xc[lo] *= 24.0                                             # a wide row: some probabilities fall below 1e-7 (clipped low)
+        Xd, Wd = dev(Xc), dev(W)
+        if bf16:
+            Xd, Wd = ops.to_bf16(Xd), ops.to_bf16(Wd)
+        z = (O.to_bf16(Xc) @ O.to_bf16(W) if bf16 else Xc.astype(np.float32).astype(np.float64) @ W.astype(np.float32).astype(np.float64)) + bc
+        p = O.softmax(z)
+        outside = ((p < 1e-7) | (p > 1 - 1e-7)).any(axis=1)
+        assert sorted(np.nonzero(outside)[0]) == sorted(clipped_rows)      # exactly the rows the case clips (both in the first row tile)
+        if clipped_rows:
+            assert p[clipped_rows[1]].max() > 1 - 1e-7 and p[clipped_rows[0]].max() < 1 - 1e-7 and p[clipped_rows[0]].min() < 1e-7
+        want_loss, want_d = O.sparse_cce_keras_with_grad(t, p, w)
+        Vp = (V + 7) // 8 * 8
+        loss = torch.empty(M, device="cuda")
+        dl = torch.empty((M, Vp), device="cuda")
+        db = torch.empty(V, device="cuda")
+        ops.vocab_ce(Xd, Wd, dev(bc), dev(t, torch.int32), loss_rows=loss, dlogits=dl, dbias=db, grad_scale=1.0, row_weights=dev(w), keras_sparse=True)
+        close(loss, want_loss, 3e-5)
+        close(dl[:, :V], want_d, 3e-5)
+        close(db, want_d.sum(0), 1e-4)
+
+
 @pytest.mark.parametrize("M,V,K,sparse", [(3000, 4104, 256, False), (2900, 5000, 200, False), (1500, 8200, 512, True), (3000, 50000, 1024, True)])
 def test_vocab_ce_bf16_on_the_256_tile(ops, M, V, K, sparse):
     """Problems whose 256 x 256 grid covers the chip run the three passes on the large tile (csrc/bgemm256_core.h), reductions
