@@ -311,6 +311,148 @@ __global__ __launch_bounds__(512, 1) void pw_chain_kernel(Args a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The stage-2 seam (64 -> 256 -> 64 channels at 256 x 256 pixels per image): HBM-bound -- 470 MB as two launches, 335 MB chained (the
+// 256-channel intermediate is written once and never read back) -- and both weight sets fit LDS (64 + 64 KiB), so it runs in the streaming
+// form of conv_pw.hip rather than the tile form above: no K loop, no barrier after start-up, every wave walks over 32-pixel strips on its
+// own, activations go from global memory straight into the registers that are the MFMA B operands, channels sit on the MFMA's M side.
+// The chaining costs NO data movement at all: layer 1's accumulators (after scale / shift / shortcut / ReLU in registers) ARE layer 2's
+// B operands -- lane (pixel i, half h) holds channels 8 q + 4 h + r of its pixel, which v_mfma_f32_32x32x2_f32 reads as the k pair
+// {8 q + r, 8 q + 4 + r} of that pixel when the weight side is read in the same order (one ds_read_b128 of W2 per four MFMAs).
+// 512 threads, one block per CU, fp32 MFMA products (the layer pair is bandwidth-bound: 8.6 GF against 335 MB).
+// ------------------------------------------------------------------------------------------------
+template <int K1, int N1, int N2>
+__global__ __launch_bounds__(512, 1) void pw_chain_stream_kernel(Args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int LDW1 = K1 + 4, LDW2 = N1 + 4, KH = K1 / 2, NG1 = K1 / 8, NG2 = N1 / 8;
+    float* const W1s = smem;                               // [N1][LDW1]
+    float* const W2s = W1s + N1 * LDW1;                    // [N2][LDW2]
+    float* const sc1 = W2s + N2 * LDW2;
+    float* const sh1 = sc1 + N1;
+    float* const sc2 = sh1 + N1;
+    float* const sh2 = sc2 + N2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    // weights out of the fragment order of dc_pw_chain_pack_f32 (f4 ((cb * K/8 + g) * 64 + 32 h + i) = w[32 cb + i][8 g + 4 h .. + 3]) into rows
+    for (int idx = tid; idx < N1 * (K1 / 4); idx += 512) {
+        const int c = idx / (K1 / 4), k4 = idx - c * (K1 / 4);
+        *reinterpret_cast<f4*>(&W1s[c * LDW1 + 4 * k4]) = a.w1[((c >> 5) * NG1 + (k4 >> 1)) * 64 + 32 * (k4 & 1) + (c & 31)];
+    }
+    for (int idx = tid; idx < N2 * (N1 / 4); idx += 512) {
+        const int c = idx / (N1 / 4), k4 = idx - c * (N1 / 4);
+        *reinterpret_cast<f4*>(&W2s[c * LDW2 + 4 * k4]) = a.w2[((c >> 5) * NG2 + (k4 >> 1)) * 64 + 32 * (k4 & 1) + (c & 31)];
+    }
+    for (int c = tid; c < N1; c += 512) {
+        sc1[c] = a.scale1 ? a.scale1[c] : 1.f;
+        sh1[c] = a.shift1[c];
+    }
+    for (int c = tid; c < N2; c += 512) {
+        sc2[c] = a.scale2 ? a.scale2[c] : 1.f;
+        sh2[c] = a.shift2[c];
+    }
+    __syncthreads();
+    const int strips = (a.M + 31) / 32;
+    for (int st = blockIdx.x * 8 + wave; st < strips; st += gridDim.x * 8) {
+        const int prow = st * 32 + i;
+        const bool pv = prow < a.M;
+        const int p = min(prow, a.M - 1);
+        const float* xr = a.x + (long)p * K1 + KH * h;
+        f4 xs[KH / 4];
+#pragma unroll
+        for (int j = 0; j < KH / 4; ++j) xs[j] = *reinterpret_cast<const f4*>(xr + 4 * j);
+        const float* rrow = a.residual ? a.residual + (long)p * N1 + 4 * h : nullptr;
+        float* const yrow = a.y + (long)p * N1 + 4 * h;
+        f32x16 acc2[N2 / 32];
+#pragma unroll
+        for (int nb = 0; nb < N2 / 32; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[nb][r] = 0.f;
+        for (int cb = 0; cb < N1; cb += 64) {
+            f4 r0[4], r1[4];
+            if (rrow) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    r0[q] = *reinterpret_cast<const f4*>(rrow + cb + 8 * q);
+                    r1[q] = *reinterpret_cast<const f4*>(rrow + cb + 32 + 8 * q);
+                }
+            }
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            const float* wa0 = &W1s[(cb + i) * LDW1 + KH * h];
+            const float* wa1 = wa0 + 32 * LDW1;
+#pragma unroll
+            for (int j = 0; j < KH / 4; ++j) {
+                const f4 a0 = *reinterpret_cast<const f4*>(wa0 + 4 * j);
+                const f4 a1 = *reinterpret_cast<const f4*>(wa1 + 4 * j);
+                const f4 b = xs[j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b[e], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b[e], acc1, 0, 0, 0);
+                }
+            }
+            // layer 1's epilogue in registers: quad q of lane (i, h) = channels cb (+ 32) + 8 q + 4 h .. + 3 of pixel i
+            f4 y0[4], y1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = cb + 8 * q + 4 * h;
+                f4 v0 = f4{acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]} * *reinterpret_cast<const f4*>(&sc1[c0]) + *reinterpret_cast<const f4*>(&sh1[c0]);
+                f4 v1 = f4{acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]} * *reinterpret_cast<const f4*>(&sc1[c0 + 32]) +
+                        *reinterpret_cast<const f4*>(&sh1[c0 + 32]);
+                if (rrow) { v0 += r0[q]; v1 += r1[q]; }
+                if (a.relu1) {
+                    v0 = f4{fmaxf(v0[0], 0.f), fmaxf(v0[1], 0.f), fmaxf(v0[2], 0.f), fmaxf(v0[3], 0.f)};
+                    v1 = f4{fmaxf(v1[0], 0.f), fmaxf(v1[1], 0.f), fmaxf(v1[2], 0.f), fmaxf(v1[3], 0.f)};
+                }
+                if (pv) {
+                    *reinterpret_cast<f4*>(yrow + cb + 8 * q) = v0;
+                    *reinterpret_cast<f4*>(yrow + cb + 32 + 8 * q) = v1;
+                }
+                y0[q] = v0;
+                y1[q] = v1;
+            }
+            // layer 2: those registers as the B operand (k pair {8 q + r, 8 q + 4 + r} of the lane's pixel); A = W2 rows in the same order
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int nb = 0; nb < N2 / 32; ++nb) {
+                    const float* w2r = &W2s[(nb * 32 + i) * LDW2 + cb + 8 * q + 4 * h];
+                    const f4 wa = *reinterpret_cast<const f4*>(w2r);
+                    const f4 wb = *reinterpret_cast<const f4*>(w2r + 32);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[e], y0[q][e], acc2[nb], 0, 0, 0);
+                        acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[e], y1[q][e], acc2[nb], 0, 0, 0);
+                    }
+                }
+        }
+        if (pv) {
+            float* const zrow = a.z + (long)p * N2 + 4 * h;
+#pragma unroll
+            for (int nb = 0; nb < N2 / 32; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c0 = nb * 32 + 8 * q + 4 * h;
+                    f4 v = f4{acc2[nb][4 * q], acc2[nb][4 * q + 1], acc2[nb][4 * q + 2], acc2[nb][4 * q + 3]} * *reinterpret_cast<const f4*>(&sc2[c0]) +
+                           *reinterpret_cast<const f4*>(&sh2[c0]);
+                    if (a.relu2) v = f4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+                    *reinterpret_cast<f4*>(zrow + nb * 32 + 8 * q) = v;
+                }
+        }
+    }
+}
+
+static int launch_stream_64_256_64(const Args& a, hipStream_t s) {
+    constexpr int K1 = 64, N1 = 256, N2 = 64;
+    constexpr size_t lds = ((size_t)N1 * (K1 + 4) + (size_t)N2 * (N1 + 4) + 2 * N1 + 2 * N2) * sizeof(float);
+    DC_ENSURE_DYN_LDS((&pw_chain_stream_kernel<K1, N1, N2>), 160 * 1024);
+    const int strips = (a.M + 31) / 32;
+    const int grid = std::max(1, std::min(kNumCU, (strips + 7) / 8));
+    hipLaunchKernelGGL((pw_chain_stream_kernel<K1, N1, N2>), dim3(grid), dim3(512), lds, s, a);
+    return check_launch("pw_chain_stream_kernel");
+}
+
 template <int CB1, int NB2, bool B3>
 static int launch(const Args& a, hipStream_t s) {
     constexpr size_t lds = (size_t)32 * (CB1 * 256 + 4) * sizeof(float);
@@ -325,6 +467,7 @@ static int launch(const Args& a, hipStream_t s) {
 using namespace dcap;
 
 extern "C" int dc_pw_chain_supported(int K1, int N1, int N2) {
+    if (K1 == 64 && N1 == 256 && N2 == 64) return 1;      // the stage-2 seam: streaming form (fp32 MFMA products only)
     return (K1 >= 32 && K1 % 32 == 0 && K1 <= N1 && ((N1 == 1024 && N2 == 256) || (N1 == 512 && N2 == 128))) ? 1 : 0;
 }
 
@@ -346,7 +489,8 @@ extern "C" int dc_pw_chain_pack_b3(const float* w, uint16_t* out, int N, int K, 
 
 extern "C" int dc_pw_chain_kernel_name(const dc_pw_chain_desc* d, char* buf, size_t buf_bytes) {
     DC_REQUIRE(d && buf && buf_bytes >= 40, DC_EINVAL, "dc_pw_chain_kernel_name: bad arguments");
-    snprintf(buf, buf_bytes, "pw_chain_kernel<%d, %d, %s>", d->N1 / 256, d->N2 / 32, (d->w1_b3 && d->w2_b3) ? "true" : "false");
+    if (d->N1 == 256) snprintf(buf, buf_bytes, "pw_chain_stream_kernel<%d, %d, %d>", d->K1, d->N1, d->N2);
+    else snprintf(buf, buf_bytes, "pw_chain_kernel<%d, %d, %s>", d->N1 / 256, d->N2 / 32, (d->w1_b3 && d->w2_b3) ? "true" : "false");
     return DC_OK;
 }
 
@@ -354,7 +498,8 @@ extern "C" int dc_pw_chain_f32(const dc_pw_chain_desc* d, void* stream) {
     const bool b3 = d && d->w1_b3 && d->w2_b3;
     DC_REQUIRE(d && d->x && (b3 || (d->w1 && d->w2)) && d->shift1 && d->y && d->shift2 && d->z && d->M > 0, DC_EINVAL, "dc_pw_chain: bad arguments");
     DC_REQUIRE(dc_pw_chain_supported(d->K1, d->N1, d->N2), DC_EINVAL,
-               "dc_pw_chain: (K1, N1, N2) = (%d, %d, %d) is not a covered shape (K1 %% 32 == 0; N1 -> N2 = 1024 -> 256 or 512 -> 128)", d->K1, d->N1, d->N2);
+               "dc_pw_chain: (K1, N1, N2) = (%d, %d, %d) is not a covered shape (K1 %% 32 == 0; N1 -> N2 = 1024 -> 256 or 512 -> 128; or 64 -> 256 -> 64)", d->K1, d->N1, d->N2);
+    DC_REQUIRE(d->N1 != 256 || !b3, DC_EINVAL, "dc_pw_chain: the 64 -> 256 -> 64 seam takes fp32 products (dc_pw_chain_pack_f32 weights)");
     DC_REQUIRE(aligned16(d->x) && aligned16(b3 ? (const void*)d->w1_b3 : (const void*)d->w1) && aligned16(b3 ? (const void*)d->w2_b3 : (const void*)d->w2) && aligned16(d->y) && aligned16(d->z) && aligned16(d->shift1) && aligned16(d->shift2) &&
                    (!d->scale1 || aligned16(d->scale1)) && (!d->scale2 || aligned16(d->scale2)) && (!d->residual || aligned16(d->residual)),
                DC_EALIGN, "dc_pw_chain: every pointer must be 16-byte aligned");
@@ -365,6 +510,7 @@ extern "C" int dc_pw_chain_f32(const dc_pw_chain_desc* d, void* stream) {
     a.w1_bytes = (unsigned)((size_t)d->N1 * d->K1 * (b3 ? 6 : 4));
     a.w2_bytes = (unsigned)((size_t)d->N2 * d->N1 * (b3 ? 6 : 4));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (d->N1 == 256) return chain::launch_stream_64_256_64(a, s);
     if (b3) return d->N1 == 1024 ? chain::launch<4, 8, true>(a, s) : chain::launch<2, 4, true>(a, s);
     return d->N1 == 1024 ? chain::launch<4, 8, false>(a, s) : chain::launch<2, 4, false>(a, s);
 }

@@ -243,7 +243,7 @@ class EncoderPlan:
     def _chain(self, name_c, x, y, residual, name_a, z):
         """One launch for conv `name_c` (1x1, x -> y, + residual, ReLU) followed by conv `name_a` (1x1, y -> z, ReLU): dc_pw_chain_f32."""
         (w1, sc1, sh1), (w2, sc2, sh2) = self._w[name_c], self._w[name_a]
-        b3 = self.wino_products == "b3"                       # the split-bf16 products, like the Winograd layers
+        b3 = self.wino_products == "b3" and x.shape[3] >= 128  # the split-bf16 products, like the Winograd layers (the stage-2 seam is bandwidth-bound: fp32 products)
         for n, w in ((name_c, w1), (name_a, w2)):
             if n not in self._wchain:
                 self._wchain[n] = (ops.pw_chain_pack_b3 if b3 else ops.pw_chain_pack)(w)
@@ -592,34 +592,6 @@ class Vgg16Plan(EncoderPlan):
                 k = np.concatenate([k, np.zeros((s.k, s.k, 29, s.cout), np.float32)], axis=2)
             self._w[s.name] = (torch.tensor(pack_conv_kernel(k), device=dev), None,
                                torch.tensor(np.asarray(W[s.name + "/bias"], np.float32), device=dev))
-
-    def _chain_ok(self, name_c, name_a, mid, cout):
-        sc, sa = self._specs[name_c], self._specs[name_a]
-        return (self.pw_chain and self.math == _lib.MATH_F32 and not self.fast_bf16 and sc.k == 1 and sa.k == 1 and sc.stride == 1 and sa.stride == 1
-                and name_c not in self._external and name_a not in self._external and ops.pw_chain_supported(mid, cout, mid))
-
-    def _chain(self, name_c, x, y, residual, name_a, z):
-        """One launch for conv `name_c` (1x1, x -> y, + residual, ReLU) followed by conv `name_a` (1x1, y -> z, ReLU): dc_pw_chain_f32."""
-        (w1, sc1, sh1), (w2, sc2, sh2) = self._w[name_c], self._w[name_a]
-        b3 = self.wino_products == "b3"                       # the split-bf16 products, like the Winograd layers
-        for n, w in ((name_c, w1), (name_a, w2)):
-            if n not in self._wchain:
-                self._wchain[n] = (ops.pw_chain_pack_b3 if b3 else ops.pw_chain_pack)(w)
-        N, H, W, K1 = x.shape
-        d = PwChainDesc()
-        d.M, d.K1, d.N1, d.N2 = N * H * W, K1, y.shape[3], z.shape[3]
-        d.x, d.shift1, d.y = x.data_ptr(), sh1.data_ptr(), y.data_ptr()
-        if b3:
-            d.w1_b3, d.w2_b3 = self._wchain[name_c].data_ptr(), self._wchain[name_a].data_ptr()
-        else:
-            d.w1, d.w2 = self._wchain[name_c].data_ptr(), self._wchain[name_a].data_ptr()
-        d.scale1 = None if sc1 is None else sc1.data_ptr()
-        d.residual = None if residual is None else residual.data_ptr()
-        d.shift2, d.z = sh2.data_ptr(), z.data_ptr()
-        d.scale2 = None if sc2 is None else sc2.data_ptr()
-        d.relu1 = d.relu2 = 1
-        self._ops.append(("chain", d, name_c + "+" + name_a))
-        self.flops += 2.0 * d.M * (d.K1 * d.N1 + d.N1 * d.N2)
 
     def _build(self):
         B, H, W = self.B, self.H, self.W

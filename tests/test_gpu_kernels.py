@@ -295,14 +295,22 @@ def test_conv2d_winograd_forced_kernels_in_a_child_process(ops, force):
 
 @pytest.mark.parametrize("products", ["b3", "f32"])
 @pytest.mark.parametrize("case", [(8192, 256, 1024, 256, True, True), (1000, 256, 1024, 256, True, False), (4096, 128, 512, 128, True, True),
-                                  (77, 64, 512, 128, False, True), (33, 1024, 1024, 256, False, False), (200, 160, 512, 128, True, True)])
+                                  (77, 64, 512, 128, False, True), (33, 1024, 1024, 256, False, False), (200, 160, 512, 128, True, True),
+                                  (16384, 64, 256, 64, True, True), (1003, 64, 256, 64, True, False), (40, 64, 256, 64, False, True)])
 def test_pw_chain_two_pointwise_convolutions_in_one_launch(ops, case, products):
     """dc_pw_chain_f32 (round 5): a bottleneck's last convolution (1x1 + folded BN + shortcut + ReLU) and the next block's first (1x1 +
     folded BN + ReLU) in one launch -- both outputs against the float64 oracle at the convolution kernels' tolerance and against the two
     separate dc_conv2d_nhwc_f32 launches the plan used to make.  Cases: the stage-4 shape at two images (256 blocks = one per CU), a
     ragged pixel count (the last block has 8 rows), the stage-3 shape, tiny M, K1 = N1, a K1 whose 16-channel groups do not fill the
-    weight ring (10 groups).  products = 'b3': both layers on the bf16 pipe in split arithmetic (dc_pw_chain_pack_b3) -- SAME tolerance."""
+    weight ring (10 groups).  products = 'b3': both layers on the bf16 pipe in split arithmetic (dc_pw_chain_pack_b3) -- SAME tolerance.
+    The 64 -> 256 -> 64 cases are the stage-2 seam: the streaming form (pw_chain_stream_kernel: layer 1's accumulators are layer 2's
+    B operands), fp32 products only -- two strips per wave, a ragged last strip, fewer strips than waves."""
     M, K1, N1, N2, res, sc = case
+    if N1 == 256 and products == "b3":
+        with pytest.raises(Exception):                     # the bandwidth-bound seam takes fp32 products
+            ops.pw_chain(dev(np.zeros((M, K1))), ops.pw_chain_pack_b3(dev(np.zeros((N1, K1)))), dev(np.zeros(N1)),
+                         ops.pw_chain_pack_b3(dev(np.zeros((N2, N1)))), dev(np.zeros(N2)))
+        return
     rng = np.random.default_rng(M + K1 + N1)
     x = rng.standard_normal((M, K1))
     w1 = rng.standard_normal((N1, K1)) / np.sqrt(K1)
@@ -315,7 +323,7 @@ def test_pw_chain_two_pointwise_convolutions_in_one_launch(ops, case, products):
         y = y + r
     y = np.maximum(y, 0)
     z = np.maximum(y @ w2.T * (1.0 if s2 is None else s2) + h2, 0)
-    assert ops.pw_chain_supported(K1, N1, N2) and not ops.pw_chain_supported(K1, 256, 64) and not ops.pw_chain_supported(K1 + 16, N1, N2)
+    assert ops.pw_chain_supported(K1, N1, N2) and not ops.pw_chain_supported(K1, 256, 128) and not ops.pw_chain_supported(K1 + 16, N1, N2)
     xd, w1d, w2d = dev(x), dev(w1), dev(w2)
     pack = ops.pw_chain_pack_b3 if products == "b3" else ops.pw_chain_pack
     w1f, w2f = pack(w1d), pack(w2d)
@@ -333,7 +341,7 @@ def test_pw_chain_two_pointwise_convolutions_in_one_launch(ops, case, products):
     close(gy, y2.view(M, N1).cpu().numpy().astype(np.float64), 2e-5)
     close(gz, z2.view(M, N2).cpu().numpy().astype(np.float64), 2e-5)
     with pytest.raises(Exception):
-        ops.pw_chain(xd, w1f, dev(h1), pack(dev(rng.standard_normal((64, N1)))), dev(h2[:64]))     # N2 = 64: not a covered shape
+        ops.pw_chain(xd, w1f, dev(h1), pack(dev(rng.standard_normal((96, N1)))), dev(np.zeros(96)))     # N2 = 96: not a covered shape
 
 
 def test_conv2d_winograd_falls_back_where_the_form_does_not_apply(ops):

@@ -53,6 +53,8 @@ def main():
         gf = 2.0 * M * (K1 * N1 + N1 * N2) / 1e9
         line = "%-24s %.2f GF" % (name, gf)
         for tag, pack in (("b3", ops.pw_chain_pack_b3), ("f32", ops.pw_chain_pack)):
+            if tag == "b3" and N1 == 256:                   # the stage-2 seam runs in the streaming form with fp32 products only
+                continue
             w1f, w2f = pack(w1), pack(w2)
             fns = [lambda x=x, r=r, y=y, z=z: ops.pw_chain(x, w1f, h1, w2f, h2, scale1=s1, scale2=s2, residual=r, y=y, z=z) for x, r, y, z in sets]
             us = graph_time(fns)
