@@ -52,15 +52,19 @@ def winograd_gain(kernel):
     form's count, on the bf16 pipe."""
     if kernel.startswith("wino"):
         return WINOGRAD_GAIN / 6.0 if split_bf16_kernel(kernel) else WINOGRAD_GAIN
-    return 1.0 / 6.0 if split_bf16_kernel(kernel) else 1.0      # pw_chain_kernel<.., true>: six bf16 products per fp32 product
+    if kernel.startswith("igemm_bs_kernel") and os.environ.get("DCAP_CONV_MATH", "f32") == "bf16x2":
+        return 1.0 / 3.0                                        # the two-piece split: three products
+    return 1.0 / 6.0 if split_bf16_kernel(kernel) else 1.0      # pw_chain_kernel<.., true>, igemm_bs_kernel: six bf16 products per fp32 product
 
 
 def split_bf16_kernel(kernel):
-    """Kernels whose products run on the bf16 matrix pipe in split arithmetic (fp32-grade): wino64b / wino32b and the chained pointwise
-    kernel's `true` instantiations."""
+    """Kernels whose products run on the bf16 matrix pipe in split arithmetic (fp32-grade): wino64b / wino32b, the chained pointwise
+    kernel's `true` instantiations and the direct kernels of DC_MATH_BF16X3 (igemm_bs_kernel)."""
     if kernel.startswith("wino"):
         return kernel.split("_")[0].endswith("b")
-    return kernel.startswith("pw_chain_kernel") and kernel.rstrip(">").rstrip().endswith("true")
+    if kernel.startswith("igemm_bs_kernel"):               # the direct kernels in DC_MATH_BF16X3 (split in the loop): six bf16 products per fp32 product
+        return True
+    return kernel.startswith("pw_chain_kernel<") and kernel.rstrip(">").rstrip().endswith("true")
 
 
 def pipe_peak(kernel):

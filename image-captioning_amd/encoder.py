@@ -54,7 +54,7 @@ class EncoderPlan:
 
     def __init__(self, weights, batch, height, width, device, stage4_blocks=22,
                  mean_pixel=(123.7, 116.8, 103.9), use_graph=True, rpn=None, external=None, math=None, external_bn=None, train_stages=(),
-                 winograd=None, wino_products=None, pw_chain=None):
+                 winograd=None, wino_products=None, pw_chain=None, layer_math=None):
         """rpn: None (GT-RoI variant: the RPN is never evaluated) or a dict with the config values the
         proposal path needs: scales, ratios, strides, anchor_stride, bbox_std, nms_threshold, proposal_count and
         optionally head_channels (the fused class+bbox head padded to a multiple of 4 channels for the wgrad kernel).
@@ -90,6 +90,8 @@ class EncoderPlan:
         # math = 'f32', frozen stages 3 and 4: a bottleneck's last 1x1 convolution (+ shortcut + ReLU) and the next block's first run as ONE
         # launch that keeps the 4x-wide intermediate rows in LDS (csrc/conv_chain.hip, round 5).  pw_chain=False / DCAP_PW_CHAIN=0: two launches.
         self.pw_chain = (os.environ.get("DCAP_PW_CHAIN", "1") != "0") if pw_chain is None else bool(pw_chain)
+        # per-layer choice between the fp32 pipe and split-bf16 arithmetic for the direct pointwise layers (_layer_math)
+        self.layer_math = (os.environ.get("DCAP_LAYER_MATH", "1") != "0") if layer_math is None else bool(layer_math)
         self._wchain = {}
         self._wwino = {}
         self._twin = {}
@@ -213,7 +215,7 @@ class EncoderPlan:
         d.scale = None if sc is None else sc.data_ptr()
         d.shift = sh.data_ptr()
         d.residual = None if residual is None else residual.data_ptr()
-        d.res_mode, d.relu, d.split_k, d.math = res_mode, int(relu), 0, self.math
+        d.res_mode, d.relu, d.split_k, d.math = res_mode, int(relu), 0, self._layer_math(s, name)
         use_wino = (self.winograd and self.math in (_lib.MATH_F32, _lib.MATH_BF16X3, _lib.MATH_BF16X2) and s.k == 3 and s.stride == 1 and
                     s.padding == "same" and residual is None and name not in self._external and Cin % 32 == 0 and Cout % 32 == 0 and
                     wp.shape[1] == 9 * Cin)
@@ -234,6 +236,22 @@ class EncoderPlan:
         if self.fast_bf16 and bf16:                    # a layer the bf16 kernel does not take (the stem): cast its output
             self._ops.append(("cast", y, self._bf(y)))
         self.flops += 2.0 * N * Ho * Wo * Cout * s.k * s.k * s.cin
+
+    def _layer_math(self, s, name):
+        """Arithmetic of one direct-kernel layer.  In the fp32-grade default plan (conv_math='f32') the pointwise layers that measured
+        faster in split-bf16 arithmetic (DC_MATH_BF16X3: three bf16 pieces per operand, six matrix-pipe products, fp32 accumulation --
+        the same fp32-grade result, the same test tolerances) run there: the strided projection shortcuts (res3a/4a/5a_branch1) and the
+        stride-1 layers with 128 <= Cin <= 512 and Cout >= 256 (FPN laterals C2 / C3, the un-chained 2c layers).  tools/conv_bench.py
+        --filter 1x1 [--math 1], two images: res3a_1 85 -> 61 us, res4a_1 77 -> 55, fpn_c2p2 163 -> 142, fpn_c3p3 74 -> 58, res5_2c 41 -> 38;
+        Cin >= 1024 and the strided 2a layers are faster on the fp32 pipe and stay there.  layer_math=False / DCAP_LAYER_MATH=0: one
+        arithmetic for all direct layers."""
+        if self.math != _lib.MATH_F32 or not self.layer_math or name in self._external or s.k != 1:
+            return self.math
+        if s.stride == 2 and s.cout >= 512:
+            return _lib.MATH_BF16X3
+        if s.stride == 1 and 128 <= s.cin <= 512 and s.cout >= 256:
+            return _lib.MATH_BF16X3
+        return self.math
 
     def _chain_ok(self, name_c, name_a, mid, cout):
         sc, sa = self._specs[name_c], self._specs[name_a]
@@ -569,6 +587,7 @@ class Vgg16Plan(EncoderPlan):
         self.winograd = (os.environ.get("DCAP_WINOGRAD", "1") != "0") if winograd is None else bool(winograd)      # all 13 layers are 3x3 / stride 1
         self.wino_products = wino_products or os.environ.get("DCAP_WINO_PRODUCTS", "b3")
         self._wwino = {}
+        self.layer_math = False                         # (13 3x3 layers: nothing to choose)
         self.B, self.H, self.W = batch, height, width
         self.device = torch.device(device)
         self.mean_pixel = [float(v) for v in mean_pixel]

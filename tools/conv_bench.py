@@ -28,7 +28,16 @@ SHAPES = [
     ("res5_2c 1x1 512>2048 +res", 32, 512, 2048, 1, 1, 1, 1),
     ("res5_2a 1x1 2048>512", 32, 2048, 512, 1, 1, 0, 1),
     ("res4a_1 1x1s2 512>1024", 128, 512, 1024, 1, 2, 0, 0),
+    ("res2a_1 1x1 64>256", 256, 64, 256, 1, 1, 0, 0),
+    ("res3a_1 1x1s2 256>512", 256, 256, 512, 1, 2, 0, 0),
+    ("res3a_2a 1x1s2 256>128", 256, 256, 128, 1, 2, 0, 1),
+    ("res4a_2a 1x1s2 512>256", 128, 512, 256, 1, 2, 0, 1),
+    ("res5a_1 1x1s2 1024>2048", 64, 1024, 2048, 1, 2, 0, 0),
+    ("res5a_2a 1x1s2 1024>512", 64, 1024, 512, 1, 2, 0, 1),
     ("fpn_c2p2 1x1 256>256 +up", 256, 256, 256, 1, 1, 2, 0),
+    ("fpn_c3p3 1x1 512>256 +up", 128, 512, 256, 1, 1, 2, 0),
+    ("fpn_c4p4 1x1 1024>256 +up", 64, 1024, 256, 1, 1, 2, 0),
+    ("fpn_c5p5 1x1 2048>256", 32, 2048, 256, 1, 1, 0, 0),
     ("fpn_p2 3x3 256", 256, 256, 256, 3, 1, 0, 0),
     ("fpn_p3 3x3 256", 128, 256, 256, 3, 1, 0, 0),
     ("fpn_p4 3x3 256", 64, 256, 256, 3, 1, 0, 0),
