@@ -240,12 +240,16 @@ class EncoderPlan:
     def _layer_math(self, s, name):
         """Arithmetic of one direct-kernel layer.  In the fp32-grade default plan (conv_math='f32') the pointwise layers that measured
         faster in split-bf16 arithmetic (DC_MATH_BF16X3: three bf16 pieces per operand, six matrix-pipe products, fp32 accumulation --
-        the same fp32-grade result, the same test tolerances) run there: the strided projection shortcuts (res3a/4a/5a_branch1) and the
+        the same fp32-grade result, the same test tolerances) run there: the stem, the strided projection shortcuts (res3a/4a/5a_branch1) and the
         stride-1 layers with 128 <= Cin <= 512 and Cout >= 256 (FPN laterals C2 / C3, the un-chained 2c layers).  tools/conv_bench.py
         --filter 1x1 [--math 1], two images: res3a_1 85 -> 61 us, res4a_1 77 -> 55, fpn_c2p2 163 -> 142, fpn_c3p3 74 -> 58, res5_2c 41 -> 38;
         Cin >= 1024 and the strided 2a layers are faster on the fp32 pipe and stay there.  layer_math=False / DCAP_LAYER_MATH=0: one
         arithmetic for all direct layers."""
-        if self.math != _lib.MATH_F32 or not self.layer_math or name in self._external or s.k != 1:
+        if self.math != _lib.MATH_F32 or not self.layer_math or name in self._external:
+            return self.math
+        if s.k == 7 and s.cin == 3:                        # the stem: 185 -> 122 us at two images (output within 6e-7 of the fp32 pipe's)
+            return _lib.MATH_BF16X3
+        if s.k != 1:
             return self.math
         if s.stride == 2 and s.cout >= 512:
             return _lib.MATH_BF16X3
