@@ -57,7 +57,7 @@ rm -rf $out/dec
 cd $root
 timeout -k 10 300 python3 bench.py --gpus 2 --steps 5 --warmup 2 > $out/rehearsal_2rank_selflaunch.log 2>&1 || true
 timeout -k 10 300 python3 bench.py --config joint --gpus 2 --steps 5 --warmup 2 --no-roofline > $out/rehearsal_2rank_joint.log 2>&1 || true
-DCAP_GRAD_DTYPE=bf16 timeout -k 10 300 python3 bench.py --config joint --gpus 2 --steps 5 --warmup 2 --no-roofline > $out/rehearsal_2rank_joint_bf16wire.log 2>&1 || true
+DCAP_GRAD_DTYPE=f32 timeout -k 10 300 python3 bench.py --config joint --gpus 2 --steps 5 --warmup 2 --no-roofline > $out/rehearsal_2rank_joint_f32wire.log 2>&1 || true
 bash tools/roialign_profile.sh > /dev/null 2>&1 && cp gpurun_out/roialign_profile.txt $out/roialign_hbm.txt && cp gpurun_out/roialign_hbm.json $out/roialign_hbm.json || true
 fi
 ls $out
