@@ -251,14 +251,18 @@ class EncoderPlan:
             return _lib.MATH_BF16X3
         if s.k != 1:
             return self.math
-        if s.stride == 2 and s.cout >= 512:
+        if s.stride == 2 and s.cout >= 512 and s.cout > s.cin:   # the projection shortcuts (res5a_branch2a, 1024 -> 512 strided, is faster on the fp32 pipe)
             return _lib.MATH_BF16X3
         if s.stride == 1 and 128 <= s.cin <= 512 and s.cout >= 256:
             return _lib.MATH_BF16X3
         return self.math
 
-    def _chain_ok(self, name_c, name_a, mid, cout):
+    def _chain_ok(self, name_c, name_a, mid, cout, pixels):
         sc, sa = self._specs[name_c], self._specs[name_a]
+        # the tile form (cout >= 512) is one 32-pixel block per CU: below ~3/4 of the chip's CUs the two separate launches are faster
+        # (one image per GPU, stage 4: 128 blocks -- 7 800 captions/s chained against 7 920 unchained); the streaming form has no such limit
+        if cout >= 512 and pixels < 32 * 192:
+            return False
         return (self.pw_chain and self.math == _lib.MATH_F32 and not self.fast_bf16 and sc.k == 1 and sa.k == 1 and sc.stride == 1 and sa.stride == 1
                 and name_c not in self._external and name_a not in self._external and ops.pw_chain_supported(mid, cout, mid))
 
@@ -332,7 +336,7 @@ class EncoderPlan:
                     self._conv(cn + "1", x, sc, relu=False)                        # read as a residual only
                     res = sc
                 nxt = "res%d%s_branch2a" % (s, blocks[i + 1]) if i + 1 < len(blocks) else None
-                if nxt is not None and not keep and self._chain_ok(cn + "2c", nxt, mid, cout):
+                if nxt is not None and not keep and self._chain_ok(cn + "2c", nxt, mid, cout, x.shape[0] * m2.shape[1] * m2.shape[2]):
                     # m2 is rewritten only by the next block's 2b, which runs behind the chained launch: it may read it
                     pending = (cn + "2c", m2, res)
                 else:

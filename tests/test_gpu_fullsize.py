@@ -220,14 +220,18 @@ def test_full_size_encoder_winograd_plan_tracks_the_direct_plan(ops):
     W = synth.encoder_weights(0, 22)
     img = torch.tensor(synth.images(5, 2), device="cuda")
     rois = synth.rois(3, 2, 32, 1024, 1024)
-    direct = EncoderPlan(W, 2, 1024, 1024, "cuda", winograd=False)
-    assert not direct._wwino
+    direct = EncoderPlan(W, 2, 1024, 1024, "cuda", winograd=False, pw_chain=False, layer_math=False)      # every layer on the direct fp32 kernels
+    assert not direct._wwino and all("+" not in n and not k.startswith("igemm_bs") for (n, _, _, _, _, k) in direct.conv_table())
     ref = [p.clone() for p in direct.forward(img)]
     ref_feat = direct.roi_features(rois).clone()
     del direct
     torch.cuda.empty_cache()
     wino = EncoderPlan(W, 2, 1024, 1024, "cuda", winograd=True)
     assert len(wino._wwino) == 3 + 4 + 23 + 3 + 4                                   # every 2b branch + the four FPN output layers
+    table = wino.conv_table()
+    chained = [n for (n, _, _, _, _, k) in table if "+" in n]
+    assert len(chained) == 2 + 3 + 22                                               # the default plan at two images: the seams of stages 2, 3 and 4 as one launch each
+    assert sum(k.startswith("igemm_bs") for (_, _, _, _, _, k) in table) == 11      # ... and the per-layer split-bf16 choice (stem, shortcuts, laterals, un-chained 2c)
     for rep in range(3):                                                            # eager, capture, replay: the replay is what is compared
         got = [p.clone() for p in wino.forward(img)]
     feat = wino.roi_features(rois)
