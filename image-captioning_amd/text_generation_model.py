@@ -485,7 +485,8 @@ class CaptionModelV1(KerasLikeModel):
         world = 1 if self.grad_sync is None else getattr(self.grad_sync, "world", None)
         caps = np.asarray(caps)
         B, T = caps.shape
-        key = (tuple(feat.shape), B, T)
+        # what the captured launches bake: the batch shape and whether (and at which rate) the mask kernels are part of the step
+        key = (tuple(feat.shape), B, T, float(self.recurrent_dropout or 0.0))
         steps = self._steps
         cs = steps.get(key)
         if world != 1 or not step_graph.enabled() or self._prefix_rows(True) or (cs is None and len(steps) >= self.MAX_STEP_GRAPHS):

@@ -336,6 +336,32 @@ def test_v1_captured_train_step_is_bit_equal_to_the_eager_step(gpu, monkeypatch,
         assert np.array_equal(we[k], wg[k]), k
 
 
+def test_v1_captured_step_is_keyed_on_the_dropout_rate(gpu, monkeypatch):
+    """Changing recurrent_dropout between train steps must not replay a graph captured at the other rate: the rate is part of the
+    captured step's key (with dropout the mask kernels are launches of the step)."""
+    from image_captioning_amd import synth
+    from image_captioning_amd.text_generation_model import caption_targets
+    V, T, B = 200, 6, 4
+    rng = np.random.default_rng(11)
+    feat = rng.standard_normal((B, 7, 7, 256)).astype(np.float32)
+    caps = synth.captions_v1(41, B, T, V, lmin=1, lmax=4)
+    tg = caption_targets(caps, V)
+    out = {}
+    for graph in (True, False):
+        monkeypatch.setenv("DCAP_STEP_GRAPH", "1" if graph else "0")
+        model, _, _ = make_v1(V, T, B)
+        model.recurrent_dropout = 0.2
+        losses = [model.train_on_batch([feat, caps], tg) for _ in range(4)]          # the fourth step replays the rate-0.2 graph
+        assert model.last_rec_masks is not None
+        model.recurrent_dropout = 0.0
+        losses += [model.train_on_batch([feat, caps], tg) for _ in range(2)]
+        assert model.last_rec_masks is None                                           # no mask kernels ran: not the 0.2 graph
+        model.recurrent_dropout = 0.2
+        losses.append(model.train_on_batch([feat, caps], tg))                        # back on the captured 0.2 graph, fresh masks
+        out[graph] = (losses, model.store.flat.cpu().numpy(), model._drop_step)
+    assert out[True][0] == out[False][0] and np.array_equal(out[True][1], out[False][1]) and out[True][2] == out[False][2] == 5
+
+
 def test_v1_recurrent_dropout_per_prefix_rows_match_the_as_written_graph(gpu):
     """dropout_rows='prefix': every (RoI, prefix) row of the TimeDistributed batch gets its own masks, as Keras draws them
     (text_generation_model.py:179-187, :141-142); the LSTMs run over the B*T zero-padded prefixes.  Loss and every gradient equal
