@@ -883,7 +883,7 @@ def main():
                        # hipGraph with the RPN backward on a second branch; a data-parallel step issues the same launches eagerly, its
                        # collectives from Python as each layer group's backward has been enqueued (they cannot sit inside the capture)
                        "step_path": ("eager, data-parallel: per-layer-group all-reduce issued from Python behind each group's backward"
-                                     if world > 1 else ("captured hipGraph + RPN backward on a second branch" if inner.use_step_graph and "train" in inner._graphs
+                                     if world > 1 else ("captured hipGraph + RPN backward on a second branch" if inner.use_step_graph and any(k[0] == "train" for k in inner._graphs)
                                                         else "eager, single stream pair")),
                        "step_graph_fallback": inner.step_graph_fallback,
                        "grad_wire_dtype": getattr(getattr(inner, "grad_sync", None), "dtype", None) if world > 1 else None},

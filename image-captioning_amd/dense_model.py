@@ -1095,7 +1095,7 @@ class DenseImageCapRCNN(object):
         def step():
             if not self.use_step_graph:
                 return body()
-            key = "train"
+            key = ("train", float(cm.recurrent_dropout or 0.0))      # (with dropout the mask kernels are launches of the step)
             graph = self._graphs.get(key)
             if graph is not None:
                 graph.replay()

@@ -1088,7 +1088,7 @@ def test_joint_train_step_as_a_captured_graph_equals_the_eager_step(gpu):
             losses.append(model.train_on_batch(inp))
             samples.append(model.last_targets["rois"].copy())
         if mode == "graph":
-            assert "train" in model._graphs and model.use_step_graph, "the step was not captured"
+            assert any(k[0] == "train" for k in model._graphs) and model.use_step_graph, "the step was not captured"
             assert model.optimizer.iterations == len(steps) and model.caption_model._drop_step == len(steps)
         runs[mode] = (np.array(losses), model.store.flat.cpu().numpy(), samples)
     np.testing.assert_array_equal(runs["graph"][0], runs["eager"][0])
@@ -1124,19 +1124,19 @@ def test_joint_step_graph_is_dropped_and_recaptured_when_what_it_baked_changes(g
         seen = []
         for _ in range(4):
             model.train_on_batch(base)
-        seen.append("train" in model._graphs)
+        seen.append(any(k[0] == "train" for k in model._graphs))
         model.set_trainable(model.LAYER_REGEX["caption_only"])
-        seen.append("train" in model._graphs)
+        seen.append(any(k[0] == "train" for k in model._graphs))
         model.compile(1e-4)
         for _ in range(4):
             model.train_on_batch(base)
-        seen.append("train" in model._graphs)
+        seen.append(any(k[0] == "train" for k in model._graphs))
         cap0 = model._step_in.cap
         model.train_on_batch(big)                               # the packed inputs grow: new buffer, graph dropped
-        seen.append(("train" in model._graphs, model._step_in.cap > cap0))
+        seen.append((any(k[0] == "train" for k in model._graphs), model._step_in.cap > cap0))
         for _ in range(3):
             model.train_on_batch(big)
-        seen.append("train" in model._graphs)
+        seen.append(any(k[0] == "train" for k in model._graphs))
         if mode == "graph":
             assert seen == [True, False, True, (False, True), True], seen
         out[mode] = model.store.flat.cpu().numpy()
