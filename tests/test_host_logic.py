@@ -627,3 +627,27 @@ def test_fit_generator_runs_the_generator_on_a_background_thread_like_keras():
     e = GeneratorEnqueuer(iter([1, 2, 3]), workers=1, max_queue_size=2)
     assert list(e.get()) == [1, 2, 3]                                    # a finite generator ends the stream cleanly
     e.stop()
+
+
+def test_encoder_plan_per_layer_arithmetic_rule():
+    """EncoderPlan._layer_math (host logic, no GPU): in the fp32-grade plan the stem, the projection shortcuts and the short-K pointwise
+    layers that measured faster in split-bf16 arithmetic are the ones handed to DC_MATH_BF16X3; everything else, external layers and
+    every layer of the other arithmetic modes keep the plan's arithmetic."""
+    from types import SimpleNamespace
+    from image_captioning_amd import _lib
+    from image_captioning_amd.encoder import EncoderPlan
+    from image_captioning_amd.layers import resnet_fpn_convs
+    specs = {s.name: s for s in resnet_fpn_convs(22)}
+    plan = SimpleNamespace(math=_lib.MATH_F32, layer_math=True, _external={})
+    pick = {n for n, s in specs.items() if EncoderPlan._layer_math(plan, s, n) == _lib.MATH_BF16X3}
+    assert {"conv1", "res3a_branch1", "res4a_branch1", "res5a_branch1", "fpn_c2p2", "fpn_c3p3", "res3d_branch2c", "res4w_branch2c",
+            "res5a_branch2c", "res5b_branch2c", "res5c_branch2c"} <= pick
+    # faster on the fp32 pipe (tools/conv_bench.py): deep K, the strided 2a layers, Cin = 64, every 3x3 layer
+    assert not pick & {"res4b_branch2a", "res5b_branch2a", "fpn_c4p4", "fpn_c5p5", "res3a_branch2a", "res4a_branch2a", "res5a_branch2a",
+                       "res2a_branch1", "res2a_branch2a", "res2a_branch2c", "res4b_branch2b", "fpn_p2"}
+    plan.layer_math = False
+    assert all(EncoderPlan._layer_math(plan, s, n) == _lib.MATH_F32 for n, s in specs.items())
+    plan.layer_math, plan._external = True, {"conv1": None}
+    assert EncoderPlan._layer_math(plan, specs["conv1"], "conv1") == _lib.MATH_F32               # trainable / external weights: the plan's arithmetic
+    plan.math, plan._external = _lib.MATH_BF16X2, {}
+    assert all(EncoderPlan._layer_math(plan, s, n) == _lib.MATH_BF16X2 for n, s in specs.items())
