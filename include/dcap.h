@@ -226,7 +226,8 @@ int    dc_conv2d_winograd_pack_b3(const float* w, uint16_t* u, int Cin, int Cout
  * feature_generation/dense_model.py:85-100, :120-139, frozen BatchNorm folded into scale / shift like dc_conv2d_nhwc_f32.  fp32 operands,
  * exact fp32 MFMA products.  x [M][K1], y / residual [M][N1], z [M][N2] row-major (NHWC pixels = rows); w1 / w2: the packed kernels
  * [N][K] re-ordered ONCE by dc_pw_chain_pack_f32 (same size).  Shapes: dc_pw_chain_supported (K1 % 32 == 0; N1 -> N2 = 1024 -> 256 or
- * 512 -> 128).  No workspace. */
+ * 512 -> 128: a block owns 32 pixels, the intermediate rows stay in LDS; or K1 -> N1 -> N2 = 64 -> 256 -> 64, the stage-2 seam: a
+ * streaming kernel whose layer-1 accumulators are layer 2's MFMA operands, fp32 products only).  No workspace. */
 typedef struct {
     int M, K1, N1, N2;
     const float* x;
@@ -433,8 +434,9 @@ int dc_softmax_ce_f32(const dc_softmax_ce_desc* d, void* stream);
  *   loss_rows [M] (optional), dlogits [M][lddl] (optional; float32, or bf16 when dl_bf16 -- then columns V..lddl-1 are written
  *   as zeros so the matrix can feed dc_gemm_bf16 as an operand), dbias [V] (optional, needs dlogits): column sums of dlogits,
  *   combined in a fixed order.  Semantics of loss / gradient / row_weights / keras_sparse exactly as dc_softmax_ce_f32.
- * Cost model: one GEMM pass for the loss (two with keras_sparse) plus one for the gradient, against one pass plus four
- * sweeps over a [M,V] float32 matrix unfused.
+ * Cost model: one GEMM pass for the loss plus one for the gradient, against one pass plus four sweeps over a [M,V] float32 matrix
+ * unfused; keras_sparse adds a pass that sums the clipped probabilities -- only on the row tiles that hold a probability outside
+ * [1e-7, 1 - 1e-7] (the first pass keeps every row's smallest logit; elsewhere nothing is clipped and the sums are 1).
  * ------------------------------------------------------------------------------------------------ */
 typedef struct {
     int M, V, K;
