@@ -58,12 +58,13 @@ class GradAllReduce(object):
     """Callable installed as model.grad_sync: sums the gradient bucket over ranks (in `buckets` chunks so
     RCCL can pipeline them over all 7 xGMI links) and returns the scale (1/world) the optimizer applies.
 
-    dtype='bf16' (round 5; SURVEY section 5: configs[4]'s exchange is specified in bf16): every range is rounded into a persistent bf16
+    dtype='bf16' (opt-in; SURVEY section 5 allows configs[4]'s exchange in bf16): every range is rounded into a persistent bf16
     bucket as it becomes final, the bf16 slices are all-reduced -- half the bytes per link: ~150 MB instead of ~300 MB for the joint
     model's 77 M parameters -- and the summed bf16 values go back into the fp32 gradient bucket before the clip norm and AMSGrad read
     it (fp32 master weights, fp32 optimizer state; only the wire format changes).  Every rank receives the same bits from the
     collective, so replicas stay bit-identical; the update differs from the fp32 exchange by bf16 rounding of the gradient
-    (tests/test_dp_gloo.py, tests/test_gpu_multirank.py).  DCAP_GRAD_DTYPE=bf16 selects it for ParallelModel."""
+    (tests/test_dp_gloo.py, tests/test_gpu_multirank.py).  The default wire is fp32 (the reference's tower mean is fp32):
+    ParallelModel(grad_dtype='bf16') or DCAP_GRAD_DTYPE=bf16 selects this one."""
 
     def __init__(self, group=None, bucket_bytes=64 << 20, dtype="f32"):
         if dtype not in ("f32", "bf16"):
@@ -180,13 +181,12 @@ class GradAllReduce(object):
         return self.ranks_seen
 
 
-def default_grad_dtype(keras_model):
-    """The gradient exchange's wire format when the caller names none: DCAP_GRAD_DTYPE if set, else bf16 buckets for a model whose
-    compute dtype is bf16 (BASELINE configs[4]; SURVEY section 5: "flat fp32 (bf16 in configs[4]) buckets") and fp32 otherwise."""
-    env = os.environ.get("DCAP_GRAD_DTYPE")
-    if env:
-        return env
-    return "bf16" if getattr(keras_model, "compute_dtype", "f32") == "bf16" else "f32"
+def default_grad_dtype(keras_model=None):
+    """The gradient exchange's wire format when the caller names none: DCAP_GRAD_DTYPE if set, else fp32 for EVERY model -- the
+    reference's towers are averaged in fp32 (parallel_model.py:88-102), and a bf16 wire rounds each tower's gradient before the
+    collective and sums in bf16 inside RCCL, an error that grows with the rank count (tests/test_dp_gloo.py measures it at 8 ranks).
+    The bf16 wire (half the bytes per xGMI link) is opt-in: ParallelModel(grad_dtype='bf16') or DCAP_GRAD_DTYPE=bf16."""
+    return os.environ.get("DCAP_GRAD_DTYPE") or "f32"
 
 
 class ParallelModel(object):
