@@ -239,6 +239,7 @@ SYMBOLS = {
     "dc_reg_sumsq_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(RegSegments), C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 
+ABI_VERSION = 600        # include/dcap.h: DC_ABI_VERSION (the ctypes Structures below mirror that header's layouts)
 _lib = None
 
 
@@ -260,6 +261,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    got = lib.dc_version()
+    if got // 100 != ABI_VERSION // 100:                 # descriptor layouts are per major version (include/dcap.h: DC_ABI_VERSION)
+        raise DcapError("%s is ABI version %d, these bindings are for %d: rebuild it (python __graft_entry__.py)" % (path, got, ABI_VERSION))
     _lib = lib
     return lib
 

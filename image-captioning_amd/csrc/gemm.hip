@@ -90,7 +90,7 @@ static int gemm_validate(const dc_gemm_desc* d) {
 using namespace dcap;
 
 
-extern "C" int dc_version(void) { return 1; }
+extern "C" int dc_version(void) { return DC_ABI_VERSION; }
 extern "C" const char* dc_last_error(void) { return g_err; }
 
 // K not a multiple of the 32-deep K-tile (vocabulary 50 000, T*B = 3000 caption rows, 300-d embeddings): the bulk runs on

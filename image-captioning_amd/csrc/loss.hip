@@ -2,6 +2,7 @@
 // argmax, column sums (bias gradients), reductions and the fused AMSGrad update.
 // All of these are HBM-bandwidth kernels: 16-byte accesses, wavefront (64-lane) shuffles for the
 // row reductions, one pass over the data wherever the maths allows.
+#include <type_traits>
 #include "dcap_internal.h"
 #include <algorithm>
 #include <math.h>
@@ -441,8 +442,8 @@ __global__ __launch_bounds__(256) void reg_sumsq_kernel(const float* __restrict_
 
 template <bool REG>
 __global__ __launch_bounds__(256) void amsgrad_kernel(dc_amsgrad_desc d, dc_reg_segments r) {
-    __shared__ RegLds t;
-    if (REG) reg_load(r, t);
+    __shared__ typename std::conditional<REG, RegLds, int>::type t;      // the 12 KB table only in the instantiation that reads it
+    if constexpr (REG) reg_load(r, t);
     float gscale = d.grad_scale;
     if (d.gnorm_sq && d.clipnorm > 0.f) {
         const float norm = sqrtf(d.gnorm_sq[0]) * fabsf(d.grad_scale);
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(256) void amsgrad_kernel(dc_amsgrad_desc d, dc_reg_
         float4 g = reinterpret_cast<const float4*>(d.g)[i];
         float4 m = reinterpret_cast<float4*>(d.m)[i], v = reinterpret_cast<float4*>(d.v)[i];
         float4 vh = reinterpret_cast<float4*>(d.vhat)[i], p = reinterpret_cast<float4*>(d.p)[i];
-        if (REG) {                                          // the regularised, masked gradient (what dc_l2_reg_f32 would have written)
+        if constexpr (REG) {                                // the regularised, masked gradient (what dc_l2_reg_f32 would have written)
             float c[4], k[4];
             reg_vec4(t, r.nseg, i, c, k, cur);
             g.x = g.x * k[0] + 2.f * c[0] * p.x;
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(256) void amsgrad_kernel(dc_amsgrad_desc d, dc_reg_
     }
     for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (size_t)gridDim.x * 256) {
         float g0 = d.g[i];
-        if (REG) {
+        if constexpr (REG) {
             const int sgm = reg_find(t, r.nseg, (int)i);
             g0 = g0 * t.mask[sgm] + 2.f * t.coef[sgm] * d.p[i];
         }

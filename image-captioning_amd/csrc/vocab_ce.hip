@@ -420,12 +420,12 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(int phase, int M, int tile
         }
         return;
     }
-    // did the CLIP pass run on this row's tile?  (the same test its blocks made)
-    const int t0 = row / tile_rows * tile_rows;
-    int any = 0;
-    for (int r = t0 + lane; r < min(t0 + tile_rows, M); r += 64) any |= needs_clip[r];
-    any = __any(any);
-    float S = 1.f, U = 1.f;                                    // no probability of the tile's rows is clipped: S = UP = sum p = s / s
+    // decided per ROW: a row without a clipped probability takes S = UP = 1 exactly whether or not a neighbour made its tile run the
+    // CLIP pass -- a row's loss and gradient do not depend on the batch it sits in or on the tile size (a row that needs the pass has
+    // had it: its tile's blocks tested the same flags; tile_rows only sizes that test)
+    (void)tile_rows;
+    const int any = needs_clip[row];
+    float S = 1.f, U = 1.f;                                    // no probability of this row is clipped: S = UP = sum p = s / s
     if (any) {
         S = 0.f; U = 0.f;
         for (int j = lane; j < tiles_n; j += 64) { const float4 q = st[j]; S += q.x; U += q.y; }

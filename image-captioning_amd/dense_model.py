@@ -558,7 +558,7 @@ class DenseImageCapRCNN(object):
         """Adam(lr, clipnorm=0.5, amsgrad=True); losses = the three graph losses + L2(WEIGHT_DECAY)(w)/size(w) over the
         trainable non-BN weights (:1694-1730)."""
         self.optimizer = Adam(lr=learning_rate, clipnorm=0.5, amsgrad=True)
-        self.caption_model.optimizer = self.optimizer
+        self.caption_model.compile(self.optimizer)          # (drops the caption model's own captured steps: they hold the old m / v / vhat)
         self._invalidate_graphs()
 
     def _masks(self):
@@ -598,8 +598,10 @@ class DenseImageCapRCNN(object):
         return self._reg_coef, self._train_mask
 
     def _reg_segments(self):
+        """The run-length table the fused optimizer passes read, or None when the trainable set cuts the bucket into more runs than the
+        kernels' LDS table holds (ops.RegSegmentTable.MAX_SEGMENTS): the step then takes the unfused dc_l2_reg_f32 + sumsq passes."""
         self._masks()
-        return self._reg_segs
+        return self._reg_segs if self._reg_segs.nseg <= ops.RegSegmentTable.MAX_SEGMENTS else None
 
     # ---- one training step ------------------------------------------------------------------
     def _cast_cached(self, t, key):
@@ -1088,14 +1090,15 @@ class DenseImageCapRCNN(object):
         opt = self.optimizer
 
         def body():
-            losses = self._after_encoder(p, rpn_up, "rng", True, gt_caps[0], gt_norm, fuse_reg=True)
-            opt.apply(self.store, grad_scale=1.0, lr_t_dev=rpn_up["lr_t"], reg=self._reg_segments(), reg_loss=losses[3:4])
+            segs = self._reg_segments()
+            losses = self._after_encoder(p, rpn_up, "rng", True, gt_caps[0], gt_norm, fuse_reg=segs is not None)
+            opt.apply(self.store, grad_scale=1.0, lr_t_dev=rpn_up["lr_t"], reg=segs, reg_loss=None if segs is None else losses[3:4])
             return losses
 
         def step():
             if not self.use_step_graph:
                 return body()
-            key = ("train", float(cm.recurrent_dropout or 0.0))      # (with dropout the mask kernels are launches of the step)
+            key = ("train", float(cm.recurrent_dropout or 0.0), opt.baked_key())      # (with dropout the mask kernels are launches of the step)
             graph = self._graphs.get(key)
             if graph is not None:
                 graph.replay()

@@ -153,7 +153,14 @@ class DenseImageCapRCNN(object):
         feats = self.extract_features(molded, rois)
         feats = feats.clone() if device_features else feats.cpu().numpy()
         n = self.config.POST_NMS_ROIS_INFERENCE
-        return [{"features": feats[i][:n]} for i in range(len(images))]
+        results = [{"features": feats[i][:n]} for i in range(len(images))]
+        if self.use_generated_rois:
+            # evaluate_models/modified_dense_model.py:1922-1929: the evaluation's copy also hands back the proposals the features were
+            # pooled from (normalised y1, x1, y2, x2) -- what test_score_dense_captions.generate_features reads as results[0]['rois']
+            props = self.last_proposals.cpu().numpy()
+            for i, r in enumerate(results):
+                r["rois"] = props[i][:n]
+        return results
 
     def train(self, *a, **k):
         raise NotImplementedError("joint training is a SURVEY 8(f) 'next' row")

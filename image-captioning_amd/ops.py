@@ -965,7 +965,9 @@ def maxpool3x3s2_same_bwd(x, y, dy, out=None):
 
 class RegSegmentTable(object):
     """dc_reg_segments on the device: the run-length form of the per-element regulariser coefficient / trainable-mask vectors of a flat
-    parameter bucket (coef, mask: host float32 arrays of the bucket's length; mask None = everything trains)."""
+    parameter bucket (coef, mask: host float32 arrays of the bucket's length; mask None = everything trains).  The kernels keep the
+    table in LDS: at most MAX_SEGMENTS runs (csrc/loss.hip: kMaxRegSegs); callers with more take the unfused passes."""
+    MAX_SEGMENTS = 1024
 
     def __init__(self, coef, mask, device):
         coef = np.ascontiguousarray(coef, np.float32)

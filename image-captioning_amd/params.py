@@ -111,6 +111,12 @@ class Adam:
         self.iterations = 0
         self._state = None
 
+    def baked_key(self):
+        """What a captured train step bakes of this optimizer as kernel arguments (only lr reaches a replay, through the lr_t device
+        word): part of every step-graph key, so that changing any of them after a capture takes a fresh capture instead of being
+        silently ignored."""
+        return (id(self), float(self.beta_1), float(self.beta_2), float(self.epsilon), float(self.clipnorm or 0.0))
+
     def _init(self, store):
         z = lambda: torch.zeros_like(store.flat)
         self._state = (z(), z(), z())

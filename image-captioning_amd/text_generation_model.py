@@ -486,7 +486,7 @@ class CaptionModelV1(KerasLikeModel):
         caps = np.asarray(caps)
         B, T = caps.shape
         # what the captured launches bake: the batch shape and whether (and at which rate) the mask kernels are part of the step
-        key = (tuple(feat.shape), B, T, float(self.recurrent_dropout or 0.0))
+        key = (tuple(feat.shape), B, T, float(self.recurrent_dropout or 0.0), self.optimizer.baked_key())
         steps = self._steps
         cs = steps.get(key)
         if world != 1 or not step_graph.enabled() or self._prefix_rows(True) or (cs is None and len(steps) >= self.MAX_STEP_GRAPHS):

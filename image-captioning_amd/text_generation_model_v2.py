@@ -497,7 +497,7 @@ class CaptionModelV2(KerasLikeModel):
         if self.optimizer is None:
             raise RuntimeError("compile(optimizer, loss) first")
         world = 1 if self.grad_sync is None else getattr(self.grad_sync, "world", None)
-        key = (tuple(feat.shape), tb.N, tb.T, tb.Bw)
+        key = (tuple(feat.shape), tb.N, tb.T, tb.Bw, self.optimizer.baked_key())
         steps = self._steps
         cs = steps.get(key)
         if world != 1 or not self.use_step_graph or not step_graph.enabled() or (cs is None and len(steps) >= self.MAX_STEP_GRAPHS):

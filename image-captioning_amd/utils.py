@@ -132,3 +132,69 @@ def generate_pyramid_anchors(scales, ratios, feature_shapes, feature_strides, an
     """All levels concatenated, scale i on level i (utils.py:372-389)."""
     return np.concatenate([generate_anchors(scales[i], ratios, feature_shapes[i], feature_strides[i], anchor_stride)
                            for i in range(len(scales))], axis=0)
+
+
+# ------------------------------------------------------------------------------------------------
+# Box helpers of the reference's utils namespace (dense_img_cap_separate_models/utils.py:30-184, :410-417; the dense_img_cap copy is
+# identical; evaluate_models/utils.py differs in compute_iou: see test_score_dense_captions.py).  Callers of the drop-in surface reach
+# them as `utils.<name>`; outputs equal the reference functions' own on the same inputs (tests/test_golden_reference.py).
+# ------------------------------------------------------------------------------------------------
+
+def compute_iou(box, boxes, box_area, boxes_area):
+    """IoU of one (y1,x1,y2,x2) box with an array of boxes; the areas are passed in (utils.py:30-48)."""
+    ih = np.maximum(np.minimum(box[2], boxes[:, 2]) - np.maximum(box[0], boxes[:, 0]), 0)
+    iw = np.maximum(np.minimum(box[3], boxes[:, 3]) - np.maximum(box[1], boxes[:, 1]), 0)
+    inter = iw * ih
+    return inter / (box_area + boxes_area - inter)
+
+
+def compute_overlaps(boxes1, boxes2):
+    """float64 IoU matrix [len(boxes1), len(boxes2)] (utils.py:51-67)."""
+    a1 = (boxes1[:, 2] - boxes1[:, 0]) * (boxes1[:, 3] - boxes1[:, 1])
+    a2 = (boxes2[:, 2] - boxes2[:, 0]) * (boxes2[:, 3] - boxes2[:, 1])
+    out = np.zeros((boxes1.shape[0], boxes2.shape[0]))
+    for i in range(boxes2.shape[0]):
+        out[:, i] = compute_iou(boxes2[i], boxes1, a2[i], a1)
+    return out
+
+
+def non_max_suppression(boxes, scores, threshold):
+    """Kept indices (int32) in descending score order; integer boxes are taken as float32 (utils.py:70-104)."""
+    assert boxes.shape[0] > 0
+    if boxes.dtype.kind != "f":
+        boxes = boxes.astype(np.float32)
+    area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+    ixs = scores.argsort()[::-1]
+    pick = []
+    while len(ixs) > 0:
+        i, rest = ixs[0], ixs[1:]
+        pick.append(i)
+        ixs = rest[~(compute_iou(boxes[i], boxes[rest], area[i], area[rest]) > threshold)]
+    return np.array(pick, dtype=np.int32)
+
+
+def _center_form(b):
+    h, w = b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]
+    return b[:, 0] + 0.5 * h, b[:, 1] + 0.5 * w, h, w
+
+
+def apply_box_deltas(boxes, deltas):
+    """boxes shifted by (dy, dx) of their size and scaled by exp(dh), exp(dw); float32 boxes (utils.py:107-128)."""
+    cy, cx, h, w = _center_form(boxes.astype(np.float32))
+    cy, cx = cy + deltas[:, 0] * h, cx + deltas[:, 1] * w
+    h, w = h * np.exp(deltas[:, 2]), w * np.exp(deltas[:, 3])
+    y1, x1 = cy - 0.5 * h, cx - 0.5 * w
+    return np.stack([y1, x1, y1 + h, x1 + w], axis=1)
+
+
+def box_refinement(box, gt_box):
+    """The (dy, dx, log dh, log dw) that takes box to gt_box, computed in float32 (utils.py:157-180)."""
+    cy, cx, h, w = _center_form(box.astype(np.float32))
+    gy, gx, gh, gw = _center_form(gt_box.astype(np.float32))
+    return np.stack([(gy - cy) / h, (gx - cx) / w, np.log(gh / h), np.log(gw / w)], axis=1)
+
+
+def trim_zeros(x):
+    """Rows that are not all zero (utils.py:410-417)."""
+    assert len(x.shape) == 2
+    return x[~np.all(x == 0, axis=1)]

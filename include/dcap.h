@@ -31,7 +31,11 @@ extern "C" {
 #define DC_EWORKSPACE   -3   /* workspace too small */
 #define DC_ELAUNCH      -4   /* HIP launch error (text in dc_last_error) */
 
-int         dc_version(void);            /* 100*major + minor */
+/* ABI version = 100*major + minor.  The major number changes whenever a descriptor struct's layout changes (fields removed or
+ * reordered: round 5 removed dc_conv_desc.w_split / w_wino4 and grew dc_amsgrad_desc => major 6); a caller compiled against this
+ * header checks dc_version() / 100 == DC_ABI_VERSION / 100 before the first call (image-captioning_amd/_lib.py does at load). */
+#define DC_ABI_VERSION 600
+int         dc_version(void);
 const char* dc_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------

@@ -15,7 +15,10 @@ image meta, mold/unmold, RPN target building (incl. its use of np.random), clip_
 base class, resize_image's padding/window logic (scale == 1: scipy.misc.imresize no longer exists), load_image_gt and the
 joint model's data_generator (all six input arrays), the v1 create_roi_info / data_generator batch layout (features come
 from a seeded table standing in for the Keras feature model, which is the generator's INPUT, not code under test) and the
-vocabulary helpers load_corpus / encode_word / encode_word_v2 / decode_word / decode_caption.
+vocabulary helpers load_corpus / encode_word / encode_word_v2 / decode_word / decode_caption; since round 6 also the evaluation script's
+post-processing (evaluate_models/test_score_dense_captions.py: refine_generations, unmold_generations, clip_to_window, merge_boxes,
+assign_detections_to_ground_truth, with evaluate_models/utils.py's own overlap and NMS), v2 load_sequences, and box_refinement /
+compute_overlaps of the separate-models utils.py.  NOT pinnable this way: the v2 data_generator (it calls keras' pad_sequences).
 What stays unpinned: every Keras/TF layer's arithmetic (conv, BN, LSTM, crop_and_resize, losses, optimizer).
 
 Run:  python tests/golden/make_reference_vectors.py        (needs /root/reference; the GPU box never runs this)
@@ -250,6 +253,93 @@ def main():
     out["vocab/encode_known_unknown"] = np.asarray([P.encode_word("car", w2i), P.encode_word("zebra", w2i)])
     onehots = np.eye(len(i2w))[[w2i["red"], w2i["dog"]]]
     out["vocab/decode_caption"] = np.asarray(P.decode_caption(onehots, i2w))
+
+
+    # ---- round 6: the evaluation script's NumPy post-processing (evaluate_models/test_score_dense_captions.py + its own utils.py, whose
+    # compute_iou is 2 * intersection / (area + area)), v2 load_sequences, and the separate-models copy of box_refinement / compute_iou
+    EV = "/root/reference/evaluate_models"
+    UE = functions_from(os.path.join(EV, "utils.py"), ["compute_iou", "compute_overlaps", "non_max_suppression"])
+    E = functions_from(os.path.join(EV, "test_score_dense_captions.py"), ["DenseCaptioningEvaluator"],
+                       extra_globals={"compute_overlaps": UE.compute_overlaps, "non_max_suppression": UE.non_max_suppression})
+    ev = E.DenseCaptioningEvaluator(None, None, "METEOR", None, None, None, None, "golden")
+    er = np.random.RandomState(61)
+    out["eval/iou_b1"], out["eval/iou_b2"], out["eval/overlaps"] = b1, b2, UE.compute_overlaps(b1, b2)
+    for t in (0.3, 0.5):
+        out["eval/nms_keep_%02d" % int(t * 10)] = UE.non_max_suppression(nb.copy(), ns.copy(), t)
+    out["eval/nms_int_keep"] = UE.non_max_suppression(ib, ns[:30].copy(), 0.5)
+    N, Tm1, V = 40, 5, 9
+    y, x = er.uniform(0, 0.7, N), er.uniform(0, 0.7, N)
+    rois_n = np.stack([y, x, y + er.uniform(0.05, 0.3, N), x + er.uniform(0.05, 0.3, N)], axis=1).astype(np.float32)
+    rois_n[20:30] = rois_n[:10] + er.normal(0, 0.01, (10, 4)).astype(np.float32)      # heavy overlaps
+    probs = er.dirichlet(np.ones(V) * 0.3, (N, Tm1))
+    probs[7] = probs[3]                                      # two captions with the same score
+    probs[31] = probs[12]
+    ecfg = types.SimpleNamespace(DETECTION_NMS_THRESHOLD=0.5, DETECTION_MAX_INSTANCES=12)
+    rb_, rc_ = ev.refine_generations(rois_n, probs, np.array([0, 0, 96, 128]), ecfg)
+    out["eval/refine_rois_in"], out["eval/refine_probs_in"] = rois_n, probs
+    out["eval/refine_boxes"], out["eval/refine_captions"] = rb_, rc_
+    ecfg2 = types.SimpleNamespace(DETECTION_NMS_THRESHOLD=0.3, DETECTION_MAX_INSTANCES=100)
+    rb2, rc2 = ev.refine_generations(rois_n * 128.0, probs, np.array([0, 0, 96, 128]), ecfg2)
+    out["eval/refine2_boxes"], out["eval/refine2_captions"] = rb2, rc2
+    w3 = np.array([16, 0, 112, 128])
+    out["eval/unmold_in"], out["eval/unmold_window"] = rb2, w3
+    out["eval/unmold_out"] = ev.unmold_generations(rb2.copy(), (300, 400, 3), w3)
+    cb = boxes(15, -30, 150)
+    out["eval/clip_in"], out["eval/clip_out"] = cb, ev.clip_to_window(w3, cb.copy())
+    gb = np.round(boxes(14, 0, 100)).astype(np.int64)
+    gb[5:9] = gb[:4] + er.randint(-3, 4, (4, 4))             # near-duplicates that merge
+    gb[9] = gb[0] + 1
+    caps_txt = [["caption %d" % i] for i in range(14)]
+    mb, mc = E.DenseCaptioningEvaluator.merge_boxes(gb.copy(), caps_txt, 0.7)
+    out["eval/merge_in"], out["eval/merge_boxes"] = gb, mb
+    out["eval/merge_caption_ids"] = np.asarray([-1 if j is None else j for grp in mc for j in
+                                                [int(c[0].split()[1]) for c in grp] + [None]])
+    det = [np.round(boxes(10, 0, 100)), np.round(boxes(6, 0, 100))]
+    gtb = [det[0][[1, 4, 4, 7]] + er.randint(-4, 5, (4, 4)), np.round(boxes(3, 200, 300))]        # image 1: no overlap at all
+    lp = [er.uniform(-9, -1, 10), er.uniform(-9, -1, 6)]
+    lp[0][2] = lp[0][6]
+    dcap = [["det %d" % i for i in range(10)], ["det %d" % i for i in range(6)]]
+    gcap = [[["ref %d" % i] for i in range(4)], [["ref %d" % i] for i in range(3)]]
+    rec = E.DenseCaptioningEvaluator.assign_detections_to_ground_truth(2, gtb, gcap, det, dcap, lp)
+    for i in range(2):
+        out["eval/assign%d_det" % i], out["eval/assign%d_gt" % i], out["eval/assign%d_lp" % i] = det[i], gtb[i], lp[i]
+        out["eval/assign%d_ok" % i] = np.asarray([r["ok"] for r in rec[i]])
+        out["eval/assign%d_ov" % i] = np.asarray([r["ov"] for r in rec[i]])
+        out["eval/assign%d_candidate" % i] = np.asarray([int(r["candidate"].split()[1]) for r in rec[i]])
+        out["eval/assign%d_reference" % i] = np.asarray([int(r["references"][0].split()[1]) if r["references"] else -1 for r in rec[i]])
+
+    from tqdm import tqdm
+    V2 = functions_from(os.path.join(SEP, "text_generation_model_v2.py"), ["load_sequences"], extra_globals={"tqdm": tqdm})
+
+    class ToyV2:
+        _image_ids = np.array([4, 0, 2])
+
+        def load_captions_and_rois(self, image_id):
+            r = np.random.RandomState(5000 + image_id)
+            caps = []
+            for _ in range(1 + image_id % 3):
+                ids = r.randint(1, 11, r.randint(1, 5))
+                caps.append(np.eye(11)[ids])
+            return None, np.array(caps, dtype=object) if len({len(c) for c in caps}) > 1 else np.array(caps)
+    seqs = V2.load_sequences(ToyV2())
+    out["v2_seq/count"] = np.asarray(len(seqs))
+    out["v2_seq/image_roi_next"] = np.asarray([[s_[0], s_[1], s_[3]] for s_ in seqs])
+    out["v2_seq/prefix_flat"] = np.asarray([w for s_ in seqs for w in list(s_[2]) + [-1]])
+
+    USEP = functions_from(os.path.join(SEP, "utils.py"), ["compute_iou", "compute_overlaps", "box_refinement"])
+    out["sep/overlaps"] = USEP.compute_overlaps(b1, b2)
+    out["sep/refine"] = USEP.box_refinement(b1.copy(), g)
+    ib2 = np.round(b1).astype(np.int32)
+    out["sep/refine_int_in"], out["sep/refine_int_gt"] = ib2, np.round(g).astype(np.int32)
+    out["sep/refine_int"] = USEP.box_refinement(ib2, np.round(g).astype(np.int32))
+
+    # encode_word_v2 on a word outside the vocabulary: the reference looks up '<UNK>' in a table whose key is '<unk>'
+    try:
+        P.encode_word_v2("zebra", w2i)
+        out["vocab/encode_v2_oov_raises"] = np.asarray(0)
+    except KeyError:
+        out["vocab/encode_v2_oov_raises"] = np.asarray(1)
+    out["vocab/encode_v2_known"] = P.encode_word_v2("car", w2i)
 
     np.savez_compressed(OUT, **out)
     print("wrote %s: %d arrays, %.1f KB" % (OUT, len(out), os.path.getsize(OUT) / 1024))

@@ -16,7 +16,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol(repo_root):
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.dc_version() >= 1
+    assert lib.dc_version() == _lib.ABI_VERSION == 600
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -244,3 +244,121 @@ def test_mold_inputs_matches_reference():
     np.testing.assert_allclose(molded.astype(np.float32) - GCfg.MEAN_PIXEL, G["mold_inputs/molded"], atol=0)
     np.testing.assert_array_equal(metas, G["mold_inputs/metas"])
     np.testing.assert_array_equal(windows, G["mold_inputs/windows"])
+
+
+# ---- round 6: more of the host surface pinned by the reference's own functions ------------------------------------------------
+
+def test_utils_namespace_box_helpers_match_reference():
+    """utils.compute_overlaps / non_max_suppression / apply_box_deltas / box_refinement / trim_zeros (the reference's `utils.<name>`
+    call surface), against dense_img_cap/utils.py and the identical separate-models copy."""
+    from image_captioning_amd import utils as U
+    b1, b2 = G["iou/b1"], G["iou/b2"]
+    np.testing.assert_array_equal(U.compute_overlaps(b1, b2), G["iou/out"])
+    np.testing.assert_array_equal(U.compute_overlaps(b1, b2), G["sep/overlaps"])
+    for t in (0.3, 0.5, 0.7):
+        got = U.non_max_suppression(G["nms/boxes"].copy(), G["nms/scores"].copy(), t)
+        assert got.dtype == np.int32
+        np.testing.assert_array_equal(got, G["nms/keep_%02d" % int(t * 10)])
+    np.testing.assert_array_equal(U.non_max_suppression(G["nms/int_boxes"], G["nms/scores"][:30].copy(), 0.5), G["nms/int_keep"])
+    got = U.apply_box_deltas(b1.copy(), G["deltas/in"])
+    np.testing.assert_allclose(got, G["deltas/applied"], rtol=1e-6, atol=1e-5)     # (float32 arithmetic, another order of additions)
+    for want, args in ((G["refine/out"], (b1.copy(), G["refine/gt"])), (G["sep/refine"], (b1.copy(), G["refine/gt"])),
+                       (G["sep/refine_int"], (G["sep/refine_int_in"], G["sep/refine_int_gt"]))):
+        got = U.box_refinement(*args)
+        assert got.dtype == want.dtype == np.float32
+        np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(U.trim_zeros(G["trim/in"]), G["trim/out"])
+
+
+def _evaluator():
+    from image_captioning_amd.test_score_dense_captions import DenseCaptioningEvaluator
+    return DenseCaptioningEvaluator(None, None, "METEOR", None, None, None, None, "golden")
+
+
+def test_evaluation_overlap_is_the_dice_form_and_its_nms_matches_reference():
+    from image_captioning_amd import test_score_dense_captions as E
+    np.testing.assert_array_equal(E.compute_overlaps(G["eval/iou_b1"], G["eval/iou_b2"]), G["eval/overlaps"])
+    assert not np.allclose(G["eval/overlaps"], G["iou/out"])                      # 2 I / (A + B) is not I / (A + B - I)
+    iou = G["iou/out"]
+    np.testing.assert_allclose(G["eval/overlaps"], 2 * iou / (1 + iou), rtol=1e-12)
+    for t in (0.3, 0.5):
+        np.testing.assert_array_equal(E.non_max_suppression(G["nms/boxes"].copy(), G["nms/scores"].copy(), t), G["eval/nms_keep_%02d" % int(t * 10)])
+    np.testing.assert_array_equal(E.non_max_suppression(G["nms/int_boxes"], G["nms/scores"][:30].copy(), 0.5), G["eval/nms_int_keep"])
+
+
+def test_evaluation_refine_generations_matches_reference_including_tie_order():
+    import types
+    ev = _evaluator()
+    rois, probs = G["eval/refine_rois_in"], G["eval/refine_probs_in"]
+    cfg = types.SimpleNamespace(DETECTION_NMS_THRESHOLD=0.5, DETECTION_MAX_INSTANCES=12)
+    boxes, caps = ev.refine_generations(rois, probs, np.array([0, 0, 96, 128]), cfg)
+    assert boxes.dtype == np.float32 and boxes.shape == (12, 4)                   # boxes as handed in: normalised, unclipped, unrounded
+    np.testing.assert_array_equal(boxes, G["eval/refine_boxes"])
+    np.testing.assert_array_equal(caps, G["eval/refine_captions"])
+    cfg2 = types.SimpleNamespace(DETECTION_NMS_THRESHOLD=0.3, DETECTION_MAX_INSTANCES=100)
+    boxes2, caps2 = ev.refine_generations(rois * 128.0, probs, np.array([0, 0, 96, 128]), cfg2)
+    np.testing.assert_array_equal(boxes2, G["eval/refine2_boxes"])
+    np.testing.assert_array_equal(caps2, G["eval/refine2_captions"])
+    scores = np.log(caps2.max(axis=2)).sum(axis=1)
+    assert np.all(np.diff(scores) <= 0)                                            # descending caption score
+
+
+def test_evaluation_unmold_clip_merge_and_assignment_match_reference():
+    from image_captioning_amd.test_score_dense_captions import DenseCaptioningEvaluator as DE
+    ev = _evaluator()
+    got = ev.unmold_generations(G["eval/unmold_in"].copy(), (300, 400, 3), G["eval/unmold_window"])
+    assert got.dtype == np.int32
+    np.testing.assert_array_equal(got, G["eval/unmold_out"])
+    np.testing.assert_array_equal(ev.clip_to_window(G["eval/unmold_window"], G["eval/clip_in"].copy()), G["eval/clip_out"])
+    gb = G["eval/merge_in"]
+    mb, mc = DE.merge_boxes(gb.copy(), [["caption %d" % i] for i in range(len(gb))], 0.7)
+    np.testing.assert_array_equal(mb, G["eval/merge_boxes"])
+    flat = [-1 if j is None else j for grp in mc for j in [int(c[0].split()[1]) for c in grp] + [None]]
+    np.testing.assert_array_equal(flat, G["eval/merge_caption_ids"])
+    assert len(mb) < len(gb)                                                       # something did merge
+    det = [G["eval/assign%d_det" % i] for i in range(2)]
+    gtb = [G["eval/assign%d_gt" % i] for i in range(2)]
+    lp = [G["eval/assign%d_lp" % i] for i in range(2)]
+    dcap = [["det %d" % i for i in range(len(d))] for d in det]
+    gcap = [[["ref %d" % i] for i in range(len(g))] for g in gtb]
+    rec = DE.assign_detections_to_ground_truth(2, gtb, gcap, det, dcap, lp)
+    for i in range(2):
+        np.testing.assert_array_equal([r["ok"] for r in rec[i]], G["eval/assign%d_ok" % i])
+        np.testing.assert_array_equal([r["ov"] for r in rec[i]], G["eval/assign%d_ov" % i])
+        np.testing.assert_array_equal([int(r["candidate"].split()[1]) for r in rec[i]], G["eval/assign%d_candidate" % i])
+        np.testing.assert_array_equal([int(r["references"][0].split()[1]) if r["references"] else -1 for r in rec[i]], G["eval/assign%d_reference" % i])
+    assert (G["eval/assign1_reference"] == -1).all()                               # image 1: nothing overlaps, no references
+
+
+def test_v2_load_sequences_matches_reference():
+    from image_captioning_amd.text_generation_model_v2 import load_sequences
+
+    class ToyV2:
+        _image_ids = np.array([4, 0, 2])
+
+        def load_captions_and_rois(self, image_id):
+            r = np.random.RandomState(5000 + image_id)
+            caps = []
+            for _ in range(1 + image_id % 3):
+                ids = r.randint(1, 11, r.randint(1, 5))
+                caps.append(np.eye(11)[ids])
+            return None, np.array(caps, dtype=object) if len({len(c) for c in caps}) > 1 else np.array(caps)
+    seqs = load_sequences(ToyV2())
+    assert len(seqs) == int(G["v2_seq/count"])
+    np.testing.assert_array_equal([[s[0], s[1], s[3]] for s in seqs], G["v2_seq/image_roi_next"])
+    np.testing.assert_array_equal([w for s in seqs for w in list(s[2]) + [-1]], G["v2_seq/prefix_flat"])
+    assert seqs[0][2] == [0]                                                       # every caption's first sample: the prefix [0]
+
+
+def test_encode_word_v2_out_of_vocabulary_deviation_is_the_documented_one():
+    """The reference's encode_word_v2 looks an unknown word up under '<UNK>' while load_corpus registers '<unk>': it raises KeyError
+    (the vector records that).  The product maps the word to '<unk>' (id 0), the row encode_caption_v2 then drops -- the evident
+    intent; INTEGRATION.md lists the deviation.  Known words agree exactly."""
+    from image_captioning_amd import preprocess as P
+    emb = {w: np.random.RandomState(50 + i).standard_normal(8) for i, w in enumerate(["a", "red", "car", "dog"])}
+    np.random.seed(11)
+    w2i, _, _ = P.load_corpus(["a", "red", "car", "dog"], emb, 8)
+    assert int(G["vocab/encode_v2_oov_raises"]) == 1
+    np.testing.assert_array_equal(P.encode_word_v2("car", w2i), G["vocab/encode_v2_known"])
+    oov = P.encode_word_v2("zebra", w2i)
+    assert oov[0] == 1 and oov.sum() == 1

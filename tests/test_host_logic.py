@@ -651,3 +651,34 @@ def test_encoder_plan_per_layer_arithmetic_rule():
     assert EncoderPlan._layer_math(plan, specs["conv1"], "conv1") == _lib.MATH_F32               # trainable / external weights: the plan's arithmetic
     plan.math, plan._external = _lib.MATH_BF16X2, {}
     assert all(EncoderPlan._layer_math(plan, s, n) == _lib.MATH_BF16X2 for n, s in specs.items())
+
+
+def test_evaluator_decode_rois_equals_the_reference_per_roi_loop():
+    """DenseCaptioningEvaluator.decode_rois batches the reference's loop (evaluate_models/test_score_dense_captions.py:213-224: per RoI,
+    PADDING_SIZE - 1 predict calls on the pre-padded argmax ids so far, starting from the zero word): same probabilities row by row."""
+    import types
+    from image_captioning_amd.test_score_dense_captions import DenseCaptioningEvaluator
+    from image_captioning_amd.text_generation_model_v2 import pad_sequences
+    V, T, N = 7, 5, 4
+    rng = np.random.default_rng(0)
+    table = rng.standard_normal((V, V, 3))
+
+    class Fake(object):
+        calls = 0
+
+        def predict(self, inputs):
+            feat, words = inputs
+            Fake.calls += 1
+            z = np.stack([table[w[-1], :, 0] * f[0] + table[w[-2], :, 1] + (w > 0).sum() * table[0, :, 2] for f, w in zip(feat, np.asarray(words))])
+            e = np.exp(z - z.max(axis=1, keepdims=True))
+            return e / e.sum(axis=1, keepdims=True)
+    feats = rng.standard_normal((N, 2))
+    ev = DenseCaptioningEvaluator(Fake(), None, "METEOR", None, None, None, types.SimpleNamespace(PADDING_SIZE=T), "t")
+    got = ev.decode_rois(feats)
+    assert got.shape == (N, T - 1, V) and Fake.calls == T - 1
+    for j in range(N):                                              # the reference's loop, one RoI at a time
+        prev = [np.zeros(V)]
+        for _ in range(T - 1):
+            res = Fake().predict([np.array([feats[j]]), np.array([pad_sequences([[np.argmax(c) for c in prev]], T)[0]])])
+            prev.append(res[0])
+        np.testing.assert_allclose(got[j], np.vstack(prev[1:]), rtol=1e-12)
