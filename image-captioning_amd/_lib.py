@@ -99,7 +99,7 @@ class VocabCeDesc(C.Structure):
                 ("X", C.c_void_p), ("ldx", C.c_int), ("W", C.c_void_p), ("ldw", C.c_int),
                 ("bias", C.c_void_p), ("targets", C.c_void_p), ("row_weights", C.c_void_p),
                 ("grad_scale", C.c_float), ("keras_sparse", C.c_int), ("loss_rows", C.c_void_p),
-                ("dlogits", C.c_void_p), ("lddl", C.c_int), ("dl_bf16", C.c_int), ("dbias", C.c_void_p)]
+                ("dlogits", C.c_void_p), ("lddl", C.c_int), ("dl_bf16", C.c_int), ("dbias", C.c_void_p), ("materialize_bf16", C.c_int)]
 
 
 class BnReluDesc(C.Structure):

@@ -19,6 +19,12 @@
 //               50 000 words and ordinary logits that is every tile, and the step runs two GEMM passes instead of three;
 //   pass DL     recomputes the tile and writes d(loss)/d(logits) (fp32, or bf16 as the operand of the bf16 weight /
 //               data gradient GEMMs) plus per-tile column sums (the bias gradient, combined in a fixed order).
+//   MATERIALISED bf16 logits (round 6; dc_vocab_ce_desc.materialize_bf16, the joint model's bf16 arithmetic on the 256-square tile):
+//               pass STATSZ is pass STATS on logits ROUNDED to bf16, which it also parks in the gradient's own [M][lddl] bf16
+//               buffer; the clip sums (rows that need them only) and the gradient are then ELEMENTWISE passes over that buffer, the
+//               gradient in place: one GEMM pass (307 GFLOP at 3000 x 50 000 x 1024) + 600 MB of streaming instead of two GEMM
+//               passes, the second of which spent a third of its time storing the same 300 MB from its epilogue.  Loss and
+//               gradient are those of the rounded logits (consistent with each other: every row of the gradient still sums to 0).
 // The recomputation costs one extra GEMM pass (two for keras_sparse); in exchange nothing of size rows x V is written
 // but the gradient itself.  All reductions are wavefront shuffles over the 32 lanes that share a row of the tile.
 #include "bgemm256_core.h"
@@ -26,7 +32,7 @@
 
 namespace dcap {
 
-enum { CE_STATS = 0, CE_CLIP = 1, CE_DL = 2 };
+enum { CE_STATS = 0, CE_CLIP = 1, CE_DL = 2, CE_STATSZ = 3 };
 constexpr int CE_RI = 8;                 // floats of row info per row
 constexpr int CE_ST = 4;                 // floats of per-(row, column tile) partials: STATS (max, sum exp, min, -), CLIP (S, UP, -, -)
 
@@ -255,7 +261,17 @@ __device__ __forceinline__ void ce_epilogue256(b256::f32x4 (&acc)[8][4], float* 
         f32x4 z[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) z[nt] = acc[mt][nt] + bias[nt];
-        if constexpr (MODE == CE_STATS) {
+        if constexpr (MODE == CE_STATSZ) {                     // the logits this call works with are the bf16-rounded ones: park them
+            typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const us4 zb{Epilogue::bf16_bits(z[nt][0]), Epilogue::bf16_bits(z[nt][1]), Epilogue::bf16_bits(z[nt][2]), Epilogue::bf16_bits(z[nt][3])};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) z[nt][j] = __builtin_bit_cast(float, (unsigned)zb[j] << 16);
+                if (rv && cv[nt]) *reinterpret_cast<us4*>(ce.dl_bf16 + (long)row * ce.lddl + col[nt]) = zb;
+            }
+        }
+        if constexpr (MODE == CE_STATS || MODE == CE_STATSZ) {
             float mx = -INFINITY;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
@@ -333,7 +349,7 @@ __device__ __forceinline__ void ce_epilogue256(b256::f32x4 (&acc)[8][4], float* 
         if (tid < 256 && m0 + tid < ce.M) {                          // one thread per tile row: combine the four wave columns in order
             const float4 a0 = part[tid], a1 = part[256 + tid], a2 = part[512 + tid], a3 = part[768 + tid];
             float4 r;
-            if constexpr (MODE == CE_STATS) {
+            if constexpr (MODE == CE_STATS || MODE == CE_STATSZ) {
                 const float m = fmaxf(fmaxf(a0.x, a1.x), fmaxf(a2.x, a3.x));            // finite: column 0 of every tile is a real word
                 r = make_float4(m, a0.y * __expf(a0.x - m) + a1.y * __expf(a1.x - m) + a2.y * __expf(a2.x - m) + a3.y * __expf(a3.x - m),
                                 fminf(fminf(a0.z, a1.z), fminf(a2.z, a3.z)), 0.f);
@@ -390,7 +406,8 @@ __global__ __launch_bounds__(b256::NTHREADS, 2) void vocab_ce_bf16_256_kernel(BO
 __global__ __launch_bounds__(256) void ce_rows_kernel(int phase, int M, int tiles_n, const float* __restrict__ stats, const float* __restrict__ zt,
                                                       const int32_t* __restrict__ targets, int V, const float* __restrict__ row_weights,
                                                       float grad_scale, int keras_sparse, float* __restrict__ rowinfo,
-                                                      float* __restrict__ loss_rows, int* __restrict__ needs_clip, int tile_rows) {
+                                                      float* __restrict__ loss_rows, int* __restrict__ needs_clip, int tile_rows,
+                                                      const unsigned short* __restrict__ z_bf16, long ldz) {
     const int row = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (row >= M) return;
     const float4* st = reinterpret_cast<const float4*>(stats) + (long)row * tiles_n;
@@ -426,7 +443,25 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(int phase, int M, int tile
     (void)tile_rows;
     const int any = needs_clip[row];
     float S = 1.f, U = 1.f;                                    // no probability of this row is clipped: S = UP = sum p = s / s
-    if (any) {
+    if (any && z_bf16) {
+        // materialised logits: the row's clip sums straight from the parked bf16 logits (the row's own wave, 8 logits per lane and step;
+        // V % 8 == 0).  Only rows that need the sums come here: with ordinary logits that is none of them.
+        typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+        const float m = ri[0], inv_s = ri[1];
+        const unsigned short* zr = z_bf16 + (long)row * ldz;
+        S = 0.f; U = 0.f;
+        for (int c = 8 * lane; c < V; c += 512) {
+            const us8 zb = *reinterpret_cast<const us8*>(zr + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float p = __expf(__builtin_bit_cast(float, (unsigned)zb[j] << 16) - m) * inv_s;
+                S += fminf(fmaxf(p, 1e-7f), 1.f - 1e-7f);
+                U += (p >= 1e-7f && p <= 1.f - 1e-7f) ? p : 0.f;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { S += __shfl_xor(S, o, 64); U += __shfl_xor(U, o, 64); }
+    } else if (any) {
         S = 0.f; U = 0.f;
         for (int j = lane; j < tiles_n; j += 64) { const float4 q = st[j]; S += q.x; U += q.y; }
 #pragma unroll
@@ -441,6 +476,56 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(int phase, int M, int tile
     ri[4] = U * invS - (live ? pt / qt : 0.f);
     ri[5] = live ? 1.f / qt : 0.f;
     if (loss_rows) loss_rows[row] = rw * (-logf(qt) + logf(S));
+}
+
+// Materialised logits -> gradient, IN PLACE (dl_bf16 holds the bf16 logits on entry, the bf16 gradient on exit; columns V .. lddl-1
+// become the zero K padding of the GEMMs that read it).  Block = 256 rows x 256 columns: 32 lanes x 8 columns (one 16-byte access) per
+// row, 8 row groups, 32 rows each; the column sums of the block's rows (the bias gradient's partials, [row tile][V]) meet in LDS in
+// row-group order -- fixed summation order, like the GEMM epilogue's.  HBM-bound: 4 bytes per logit.
+__global__ __launch_bounds__(256) void ce_dl_from_logits_kernel(CeArgs ce) {
+    typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+    __shared__ float red[8][256];
+    const int tid = threadIdx.x, cl = tid & 31, rg = tid >> 5;
+    const int m0 = blockIdx.y * 256, col = blockIdx.x * 256 + 8 * cl;
+    const bool inside = col < ce.lddl;                            // lddl % 8 == 0 (host-checked): a lane's 8 columns are all inside or all outside
+    float cs[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cs[j] = 0.f;
+    auto unclipped = [](float p) { return p >= 1e-7f && p <= 1.f - 1e-7f; };
+#pragma unroll 4
+    for (int rr = 0; rr < 32; ++rr) {
+        const int row = m0 + rg + 8 * rr;
+        if (row >= ce.M || !inside) continue;
+        unsigned short* zp = ce.dl_bf16 + (long)row * ce.lddl + col;
+        const us8 zb = *reinterpret_cast<const us8*>(zp);
+        const float* ri = ce.rowinfo + (long)row * CE_RI;
+        const float m = ri[0], inv_s = ri[1], gs = ri[2], invS = ri[3], c = ri[4], tq = ri[5];
+        const int t = ce.targets[row];
+        us8 gb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float g = 0.f;
+            if (col + j < ce.V) {
+                const float p = __expf(__builtin_bit_cast(float, (unsigned)zb[j] << 16) - m) * inv_s;
+                const bool hit = t == col + j;
+                g = ce.keras_sparse ? gs * p * ((unclipped(p) ? invS : 0.f) - (hit ? tq : 0.f) - c) : gs * (p - (hit ? 1.f : 0.f));
+            }
+            cs[j] += g;
+            gb[j] = Epilogue::bf16_bits(g);
+        }
+        *reinterpret_cast<us8*>(zp) = gb;
+    }
+    if (!ce.dbias_part) return;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[rg][8 * cl + j] = cs[j];
+    __syncthreads();
+    const int oc = blockIdx.x * 256 + tid;
+    if (oc < ce.V) {
+        float v = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) v += red[g][tid];
+        ce.dbias_part[(long)blockIdx.y * ce.V + oc] = v;
+    }
 }
 
 // defined in loss.hip: partial [chunks][N] -> out[N] in a fixed order
@@ -545,19 +630,39 @@ extern "C" int dc_vocab_ce(const dc_vocab_ce_desc* d, void* workspace, size_t wo
     ce.tile_rows = p.tile_rows;
     ce.keras_sparse = d->keras_sparse;
     const int row_blocks = (d->M + 3) / 4;
-    rc = ce_launch<CE_STATS>(d, ce, p, s);
+    // materialised bf16 logits: the 256-square bf16 tile with a bf16 gradient buffer whose rows take 16-byte accesses
+    const bool mat = d->materialize_bf16 && d->bf16 && d->dl_bf16 && d->dlogits && ce_big(d) && (d->lddl & 7) == 0 && (d->V & 7) == 0 &&
+                     aligned16(d->dlogits);
+    if (mat) {
+        ce.dl_bf16 = static_cast<unsigned short*>(d->dlogits);
+        ce.lddl = d->lddl;
+        rc = ce_launch<CE_STATSZ>(d, ce, p, s);
+    } else {
+        rc = ce_launch<CE_STATS>(d, ce, p, s);
+    }
     if (rc) return rc;
     hipLaunchKernelGGL(ce_rows_kernel, dim3(row_blocks), dim3(256), 0, s, 0, d->M, p.tiles_n, ce.stats, ce.zt, d->targets, d->V, d->row_weights,
-                       d->grad_scale, d->keras_sparse, rowinfo, d->loss_rows, ce.needs_clip, p.tile_rows);
+                       d->grad_scale, d->keras_sparse, rowinfo, d->loss_rows, ce.needs_clip, p.tile_rows, (const unsigned short*)nullptr, 0L);
     rc = check_launch("ce_rows_kernel");
     if (rc) return rc;
     if (d->keras_sparse) {
-        rc = ce_launch<CE_CLIP>(d, ce, p, s);
-        if (rc) return rc;
+        if (!mat) {
+            rc = ce_launch<CE_CLIP>(d, ce, p, s);
+            if (rc) return rc;
+        }
         hipLaunchKernelGGL(ce_rows_kernel, dim3(row_blocks), dim3(256), 0, s, 1, d->M, p.tiles_n, ce.stats, ce.zt, d->targets, d->V, d->row_weights,
-                           d->grad_scale, d->keras_sparse, rowinfo, d->loss_rows, ce.needs_clip, p.tile_rows);
+                           d->grad_scale, d->keras_sparse, rowinfo, d->loss_rows, ce.needs_clip, p.tile_rows,
+                           mat ? static_cast<const unsigned short*>(d->dlogits) : (const unsigned short*)nullptr, (long)d->lddl);
         rc = check_launch("ce_rows_kernel");
         if (rc) return rc;
+    }
+    if (mat) {
+        ce.dbias_part = d->dbias ? reinterpret_cast<float*>(ws + p.off_db) : nullptr;
+        hipLaunchKernelGGL(ce_dl_from_logits_kernel, dim3((d->lddl + 255) / 256, p.tiles_m), dim3(256), 0, s, ce);
+        rc = check_launch("ce_dl_from_logits_kernel");
+        if (rc || !d->dbias) return rc;
+        hipLaunchKernelGGL(colsum_finish_kernel, dim3((d->V + 15) / 16), dim3(256), 0, s, ce.dbias_part, p.tiles_m, d->V, d->dbias, 0);
+        return check_launch("colsum_finish_kernel");
     }
     if (!d->dlogits) return DC_OK;
     if (d->dl_bf16) ce.dl_bf16 = static_cast<unsigned short*>(d->dlogits);

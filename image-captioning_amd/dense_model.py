@@ -3,7 +3,7 @@ dense_img_cap/dense_model.py  (DenseImageCapRCNN :1408, build('training') :1429-
 train :1810-1888, data_generator :1260-1403, build_rpn_targets :1095-1183, detection_targets_graph :450-528,
 rpn_class_loss_graph :877-900, rpn_bbox_loss_graph :903-933, imgcap_caption_loss_graph :936-946).
 
-One train step on the GPU (IMAGES_PER_GPU = 1 like train_dense_captions.py:27):
+One train step on the GPU (IMAGES_PER_GPU images; the reference's training script uses 1, train_dense_captions.py:27):
 
   frozen ResNet-101  ->  FPN (trainable)  ->  RPN on P2..P6 (trainable)  ->  ProposalLayer (2000 boxes)
   -> detection targets (<= TRAIN_ROIS_PER_IMAGE RoIs, positives carry their GT caption)
@@ -244,10 +244,11 @@ class StepInputs(step_graph.PackedInputs):
     target deltas -- fixed capacity, the image's own counts travel as words), the normalised GT boxes, the GT captions and the step
     scalars (Keras' lr_t, the dropout-mask and detection-target stream positions)."""
 
-    def __init__(self, device, cap, n_gt, T):
-        self.cap, self.n_gt, self.T = cap, n_gt, T
-        step_graph.PackedInputs.__init__(self, device, [("counts", 2), ("lvl", cap), ("idx", cap), ("mt", cap), ("deltas", 4 * cap), ("gt", 4 * n_gt),
-                                                         ("gtc", n_gt * T), ("scalars", 4)])
+    def __init__(self, device, cap, n_gt, T, B=1):
+        """cap: selected anchors / target rows of the WHOLE batch (the images' selections travel concatenated); n_gt, T: per image."""
+        self.cap, self.n_gt, self.T, self.B = cap, n_gt, T, B
+        step_graph.PackedInputs.__init__(self, device, [("counts", 2), ("lvl", cap), ("idx", cap), ("mt", cap), ("deltas", 4 * cap), ("gt", 4 * n_gt * B),
+                                                         ("gtc", n_gt * T * B), ("scalars", 4)])
 
 
 class DenseImageCapRCNN(object):
@@ -267,8 +268,11 @@ class DenseImageCapRCNN(object):
         vocabulary layers (bf16 copies of weights / activations on the bf16 matrix pipe, fp32 master weights and
         accumulation; text_generation_model.CaptionModelV1).  conv_math selects the convolutions' arithmetic separately."""
         assert mode in ['training', 'inference']
-        if config.IMAGES_PER_GPU != 1:
-            raise ValueError("the joint model runs one image per GPU (train_dense_captions.py:27); scale out with ParallelModel")
+        # IMAGES_PER_GPU images per step and GPU (the reference's graph is batched: config.py:35, DetectionTargetLayer's batch_slice
+        # dense_model.py:531-572; its training script uses 1, train_dense_captions.py:27); ParallelModel scales out over GPUs
+        self.images_per_gpu = int(config.IMAGES_PER_GPU)
+        if self.images_per_gpu < 1:
+            raise ValueError("IMAGES_PER_GPU must be >= 1")
         h, w = config.IMAGE_SHAPE[:2]
         if h % 64 or w % 64:
             raise Exception("Image size must be dividable by 2 at least 6 times to avoid fractions when downscaling and up-scaling.")
@@ -400,7 +404,7 @@ class DenseImageCapRCNN(object):
                                        mean=w[sp.bn + "/moving_mean"], var=w[sp.bn + "/moving_variance"])
             stages = () if self.backbone_from is None else tuple(range(max(self.backbone_from, 2), 6))
             # the FPN/RPN weights change every step: the plan reads them in place from the parameter bucket
-            self._plan = EncoderPlan(self._backbone, 1, h, wd, self.device, self.stage4_blocks, cfg.MEAN_PIXEL, rpn=rpn, external=ext,
+            self._plan = EncoderPlan(self._backbone, self.images_per_gpu, h, wd, self.device, self.stage4_blocks, cfg.MEAN_PIXEL, rpn=rpn, external=ext,
                                      math=self.conv_math, external_bn=ext_bn, train_stages=stages)
         return self._plan
 
@@ -664,7 +668,11 @@ class DenseImageCapRCNN(object):
         # the generator yields molded float images (image - MEAN_PIXEL); the GPU molds from the uint8 original
         return torch.as_tensor(np.clip(np.rint(a.astype(np.float64) + np.asarray(self.config.MEAN_PIXEL, np.float64)), 0, 255).astype(np.uint8))
 
-    def _rpn_selection(self, rpn_match):
+    def _rpn_selection(self, rpn_match, image=0):
+        """Non-neutral anchors of one image as (level, index inside the level's [B, h, w, A] head tensor, match).  The heads of a batch are
+        contiguous per level, so image b's anchor i of a level is anchor b * h * w * A + i of that level's tensor: the selections of all
+        images, concatenated in image order, are ONE selection over the batched heads -- and the means of the reference's RPN losses run
+        over exactly that union (rpn_class_loss_graph / rpn_bbox_loss_graph gather over the whole batch, dense_model.py:877-933)."""
         m = np.asarray(rpn_match).reshape(-1)
         p = self.plan()
         sizes = [h.shape[1] * h.shape[2] * self.A for h in p.rpn_heads]
@@ -673,7 +681,7 @@ class DenseImageCapRCNN(object):
         idx = np.nonzero(m != 0)[0]
         bounds = np.cumsum([0] + sizes)
         level = np.searchsorted(bounds, idx, side="right") - 1
-        return level.astype(np.int32), (idx - bounds[level]).astype(np.int32), m[idx].astype(np.int32)
+        return level.astype(np.int32), (idx - bounds[level] + image * np.asarray(sizes)[level]).astype(np.int32), m[idx].astype(np.int32)
 
     def _pinned(self, key, shape, dtype=torch.float32):
         """A page-locked host buffer owned by the model (asynchronous device -> host copies land here)."""
@@ -686,19 +694,28 @@ class DenseImageCapRCNN(object):
         return b
 
     def _step_uploads(self, p, rpn_match, rpn_bbox, gt_norm, gt_caps, training):
-        """This step's host inputs -> the device, one asynchronous copy (StepInputs).  Returns the device views the step's kernels read."""
+        """This step's host inputs -> the device, one asynchronous copy (StepInputs).  Returns the device views the step's kernels read.
+        rpn_match / rpn_bbox / gt_norm / gt_caps: the generator's arrays with the image axis first (IMAGES_PER_GPU entries)."""
         cfg = self.config
-        lvl, idx, mt = self._rpn_selection(rpn_match[0])
-        tdl = np.asarray(rpn_bbox[0], np.float32).reshape(-1, 4)
+        B = self.images_per_gpu
+        sel, rows = [], []
+        for b in range(B):
+            l_, i_, m_ = self._rpn_selection(rpn_match[b], b)
+            t_ = np.asarray(rpn_bbox[b], np.float32).reshape(-1, 4)
+            npos_b = int((m_ == 1).sum())
+            if npos_b > t_.shape[0]:
+                raise ValueError("%d positive anchors but only %d target rows" % (npos_b, t_.shape[0]))
+            sel.append((l_, i_, m_))
+            rows.append(t_ if B == 1 else t_[:npos_b])       # batch_pack_graph: the images' first-count rows, concatenated
+        lvl, idx, mt = (np.concatenate([s_[k] for s_ in sel]) for k in range(3))
+        tdl = np.concatenate(rows)
         n_pos = int((mt == 1).sum())
-        if n_pos > tdl.shape[0]:
-            raise ValueError("%d positive anchors but only %d target rows" % (n_pos, tdl.shape[0]))
-        gt_norm = np.asarray(gt_norm, np.float32).reshape(-1, 4)
-        gtc = np.asarray(gt_caps).astype(np.int32)
-        cap = max(int(cfg.RPN_TRAIN_ANCHORS_PER_IMAGE), len(lvl), tdl.shape[0], 1)
+        gt_norm = np.asarray(gt_norm, np.float32).reshape(B, -1, 4)
+        gtc = np.asarray(gt_caps).astype(np.int32).reshape(B, gt_norm.shape[1], -1)
+        cap = max(B * int(cfg.RPN_TRAIN_ANCHORS_PER_IMAGE), len(lvl), tdl.shape[0], 1)
         si = self._step_in
-        if si is None or si.cap < cap or si.n_gt != gt_norm.shape[0] or si.T != gtc.shape[1]:
-            si = self._step_in = StepInputs(self.device, cap, gt_norm.shape[0], gtc.shape[1])
+        if si is None or si.cap < cap or si.n_gt != gt_norm.shape[1] or si.T != gtc.shape[2] or si.B != B:
+            si = self._step_in = StepInputs(self.device, cap, gt_norm.shape[1], gtc.shape[2], B)
             self._invalidate_graphs()                       # captured graphs hold the old views
         if training:
             self._dt_step += 1
@@ -719,8 +736,8 @@ class DenseImageCapRCNN(object):
                    "gt": gt_norm, "gtc": gtc, "scalars": scal})
         sc = si.view("scalars")
         return dict(counts=si.view("counts"), lvl=si.view("lvl"), idx=si.view("idx"), mt=si.view("mt"),
-                    deltas=si.view("deltas", torch.float32).view(si.cap, 4), gt=si.view("gt", torch.float32).view(-1, 4),
-                    gtc=si.view("gtc").view(si.n_gt, si.T), cap=si.cap, lr_t=sc[0:1].view(torch.float32), drop_offset=sc[1:2], dt_offset=sc[2:3])
+                    deltas=si.view("deltas", torch.float32).view(si.cap, 4), gt=si.view("gt", torch.float32).view(si.B, si.n_gt, 4),
+                    gtc=si.view("gtc").view(si.B, si.n_gt, si.T), cap=si.cap, lr_t=sc[0:1].view(torch.float32), drop_offset=sc[1:2], dt_offset=sc[2:3])
 
     def _rpn_backward(self, p, rpn_up, losses):
         """RPN losses (dense_model.py:1008-1075) and the backward of the RPN branch: gradients of the fused head and of the shared
@@ -742,7 +759,7 @@ class DenseImageCapRCNN(object):
         dP, dheads = cuts[:len(maps)], cuts[len(maps):]
         # ---- RPN losses and their gradients w.r.t. the fused head outputs (selection and counts: this step's StepInputs views)
         ops.rpn_loss_grad(p.rpn_heads, dheads, rpn_up["lvl"], rpn_up["idx"], rpn_up["mt"], rpn_up["deltas"], rpn_up["cap"], losses[0:2],
-                          anchors_per_loc=self.A, counts_dev=rpn_up["counts"])
+                          anchors_per_loc=self.A, counts_dev=rpn_up["counts"], batched=True)
 
         # ---- RPN backward (shared weights over the five levels: gradients accumulate)
         wd_shared = ops.conv_weight_dgrad_pack(w["rpn_conv_shared/kernel"], 3, 3, 256, out=self._buf("wd_shared", (256, 9 * 512)))
@@ -850,36 +867,43 @@ class DenseImageCapRCNN(object):
 
     @property
     def last_targets(self):
-        """The last step's detection targets as host values: dict(rois [R,4], caps [R,T], npos, nneg).  The step itself leaves them on
-        the device; reading this property is what copies them (and waits for the step)."""
+        """The last step's detection targets as host values: dict(rois [R,4], caps [R,T], npos, nneg) -- with IMAGES_PER_GPU > 1 the
+        arrays carry the image axis first ([B,R,4], [B,R,T]) and npos / nneg are int arrays [B].  The step itself leaves them on the
+        device; reading this property is what copies them (and waits for the step)."""
         t = self._last_targets
         if t is None or isinstance(t, dict):
             return t
         rois, caps, counts = t
-        c = counts.cpu().numpy()
-        return dict(rois=rois.cpu().numpy(), caps=caps.cpu().numpy(), npos=int(c[0]), nneg=int(c[1]))
+        c, r, k = counts.cpu().numpy(), rois.cpu().numpy(), caps.cpu().numpy()
+        if c.shape[0] == 1:
+            return dict(rois=r[0], caps=k[0], npos=int(c[0, 0]), nneg=int(c[0, 1]))
+        return dict(rois=r, caps=k, npos=c[:, 0].astype(int), nneg=c[:, 1].astype(int))
 
     def forward_backward(self, inputs, shuffle="rng", backward=True):
-        """Losses and gradients of one image into the flat gradient bucket (no optimizer step).
+        """Losses and gradients of one step's IMAGES_PER_GPU images into the flat gradient bucket (no optimizer step).
         Returns the device tensor [rpn_class_loss, rpn_bbox_loss, imgcap_loss, reg_loss].
         backward=False: the forward graph only (validation, Keras' test_on_batch): no gradient is computed, the gradient bucket is
         left alone, no recurrent dropout, and the detection-target sample is drawn from a generator of its own so that an
         evaluation between two train steps does not change the training run."""
         images, _meta, rpn_match, rpn_bbox, gt_caps, gt_boxes = inputs[:6]
-        if len(images) != 1:
-            raise ValueError("one image per step and GPU (IMAGES_PER_GPU = 1)")
         p = self.plan()
-        H, W = p.H, p.W
+        gt_norm = self._check_batch(p, images, gt_boxes)
         # ---- this step's host inputs go to the device FIRST (GT boxes, GT captions, the RPN selection, the step scalars: one asynchronous
         # copy, StepInputs): nothing the host contributes may sit in the middle of the step
-        gt_norm = (np.asarray(gt_boxes[0], np.float32) / np.array([H, W, H, W], np.float32)).astype(np.float32)
-        rpn_up = self._step_uploads(p, rpn_match, rpn_bbox, gt_norm, gt_caps[0], backward)
+        rpn_up = self._step_uploads(p, rpn_match, rpn_bbox, gt_norm, gt_caps, backward)
 
         # ---- forward: backbone + FPN + RPN (the plan's hipGraph), then everything behind the encoder
         p.forward(self._images_u8(images))
-        return self._after_encoder(p, rpn_up, shuffle, backward, gt_caps[0], gt_norm)
+        return self._after_encoder(p, rpn_up, shuffle, backward, gt_caps, gt_norm)
 
-    def _after_encoder(self, p, rpn_up, shuffle, backward, gt_caps0, gt_norm, fuse_reg=False):
+    def _check_batch(self, p, images, gt_boxes):
+        """The step takes exactly IMAGES_PER_GPU images (static graph, like the reference's KL.Input batch); returns the GT boxes
+        normalised by the molded image's size, float32 [B, G, 4]."""
+        if len(images) != self.images_per_gpu:
+            raise ValueError("%d image(s) handed to a model built for IMAGES_PER_GPU = %d" % (len(images), self.images_per_gpu))
+        return (np.asarray(gt_boxes, np.float32).reshape(self.images_per_gpu, -1, 4) / np.array([p.H, p.W, p.H, p.W], np.float32)).astype(np.float32)
+
+    def _after_encoder(self, p, rpn_up, shuffle, backward, gt_caps, gt_norm, fuse_reg=False):
         """The step behind the encoder pass: proposals, detection targets, RoIAlign, head + decoder, the four losses and (backward)
         every gradient into the flat bucket.  With device-side targets (shuffle None / "rng") nothing in here depends on a host value
         that changes from step to step -- counts, stream positions and lr_t are device words of StepInputs -- so train_on_batch_device
@@ -891,7 +915,7 @@ class DenseImageCapRCNN(object):
         up = lambda a, dt=torch.float32: torch.tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
         device_targets = shuffle is None or shuffle == "rng"
         gt_dev, gtc_dev = rpn_up["gt"], rpn_up["gtc"]
-        gt_caps = [gt_caps0]
+        B = self.images_per_gpu
         self._bf16_cache = {}
         losses = self._buf("losses", (4,))
         # The RPN branch's backward (RPN losses, head / shared-convolution weight gradients, data gradients into dP2..dP6: ~1.2 ms of
@@ -901,7 +925,24 @@ class DenseImageCapRCNN(object):
         # backward adds into dP.  (Captured: two branches of the step's hipGraph.  Data parallel: serial as before -- the RPN ranges'
         # all-reduce is issued from Python right behind their backward.)
         overlap_dp = self.grad_sync is not None and hasattr(self.grad_sync, "ready") and getattr(self.grad_sync, "world", 1) > 1
-        fork = backward and device_targets and not overlap_dp and self.use_side_stream
+        # Data parallel (round 6): the same fork.  The RPN ranges' regulariser pass and their all-reduce are issued from INSIDE the side
+        # stream's context right behind the RPN backward -- torch.distributed orders a collective behind the stream that is current when
+        # it is issued -- so the exchange of the RPN gradients starts while the main stream still runs proposals -> targets -> decoder.
+        fork = backward and device_targets and self.use_side_stream
+        self._reg_done = []
+        early = None
+        if backward and overlap_dp:
+            coef_, mask_ = self._masks()
+
+            def early(lo, hi):                              # regulariser gradient + mask of one layer range, then it may travel
+                ops.l2_reg(st.flat[lo:hi], coef_[lo:hi], st.flat_grad[lo:hi], mask=None if mask_ is None else mask_[lo:hi])
+                self._reg_done.append((lo, hi))
+
+        def rpn_ranges_travel():
+            for layer in ("rpn_conv_shared", "rpn_head"):
+                lo, hi = st.layer_range(layer)
+                early(lo, hi)
+                self.grad_sync.ready(st.flat_grad, lo, hi)
         maps = dP = None
         if fork:
             if self._side_stream is None:
@@ -910,6 +951,8 @@ class DenseImageCapRCNN(object):
             self._side_stream.wait_stream(cur)
             with torch.cuda.stream(self._side_stream):
                 maps, dP = self._rpn_backward(p, rpn_up, losses)
+                if overlap_dp:
+                    rpn_ranges_travel()
         proposals = p.proposals()
         R = cfg.TRAIN_ROIS_PER_IMAGE
         if device_targets:
@@ -917,28 +960,36 @@ class DenseImageCapRCNN(object):
             # from (model seed, step): reproducible, where tf.random_shuffle is not), the 1:2 sample and the caption gather.  Nothing
             # comes back to the host: counts travel as device words, every shape downstream is static (TRAIN_ROIS_PER_IMAGE rows).
             seed = None if shuffle is None else ((self._seed + (0 if backward else 1)) * 2654435761 + 12345 + self._dt_rank * 0x9E3779B9) & 0xFFFFFFFF
-            T = int(np.asarray(gt_caps[0]).shape[1])
-            rois_d, caps_d, counts_d = ops.detection_targets(
-                proposals[0], gt_dev, gtc_dev, R, cfg.ROI_POSITIVE_RATIO, seed=seed, offset=0, offset_dev=rpn_up["dt_offset"],
-                out=(self._buf("dt_rois", (R, 4)), self._buf("dt_caps", (R, T), torch.int32), self._buf("dt_counts", (2,), torch.int32)))
+            T = int(np.asarray(gt_caps).shape[-1])
+            # one launch per image (the reference's utils.batch_slice over DetectionTargetLayer, dense_model.py:531-572), each image with
+            # its own Philox key; the sampled RoIs, captions and counts of the batch are rows of ONE set of buffers
+            rois_d, caps_d, counts_d = self._buf("dt_rois", (B, R, 4)), self._buf("dt_caps", (B, R, T), torch.int32), self._buf("dt_counts", (B, 2), torch.int32)
+            for b in range(B):
+                ops.detection_targets(proposals[b], gt_dev[b], gtc_dev[b], R, cfg.ROI_POSITIVE_RATIO,
+                                      seed=None if seed is None else (seed + b * 0x85EBCA6B) & 0xFFFFFFFF, offset=0, offset_dev=rpn_up["dt_offset"],
+                                      out=(rois_d[b], caps_d[b], counts_d[b]))
             self._last_targets = (rois_d, caps_d, counts_d)
-            boxes = rois_d.view(1, R, 4)
-            feats = p.roi_features(boxes_norm=boxes, out=self._buf("feats", (1, R, cfg.POOL_SIZE, cfg.POOL_SIZE, 256)))
-            tables = ops.caption_tables(caps_d, out=(self._buf("ct_ids", (T * R,), torch.int32), self._buf("ct_mask", (T * R,), torch.uint8),
-                                                     self._buf("ct_tg", (T * R,), torch.int32), self._buf("ct_rw", (T * R,))))
+            boxes = rois_d
+            feats = p.roi_features(boxes_norm=boxes, out=self._buf("feats", (B, R, cfg.POOL_SIZE, cfg.POOL_SIZE, 256)))
+            feats = feats.view(B * R, cfg.POOL_SIZE, cfg.POOL_SIZE, 256)
+            # the caption loss is the mean over every live position of the BATCH (imgcap_caption_loss_graph gathers over all images,
+            # dense_model.py:936-946): the tables' row weights are 1 / (live positions of all B * R captions)
+            R_all = B * R
+            tables = ops.caption_tables(caps_d.view(R_all, T), out=(self._buf("ct_ids", (T * R_all,), torch.int32), self._buf("ct_mask", (T * R_all,), torch.uint8),
+                                                                    self._buf("ct_tg", (T * R_all,), torch.int32), self._buf("ct_rw", (T * R_all,))))
             if cm._prefix_rows(backward):
                 # DROPOUT_ROWS = 'prefix' (one mask per (RoI, prefix) row, as the reference's TimeDistributed graph draws them): the T-fold
                 # prefix tables are built on the host, so this non-default mode reads the sampled captions back (one synchronisation)
                 cm._drop_offset_dev = None
-                caps_h = caps_d.cpu().numpy()
+                caps_h = caps_d.view(R_all, T).cpu().numpy()
                 tg_h = caption_targets(caps_h)
                 live = (tg_h > 0).astype(np.float32)
-                loss_rows, _ = cm._forward_train(feats[0], caps_h, tg_h, want_grad=backward, row_weights=live / max(float(live.sum()), 1.0),
+                loss_rows, _ = cm._forward_train(feats, caps_h, tg_h, want_grad=backward, row_weights=live / max(float(live.sum()), 1.0),
                                                  keras_sparse=True)
             else:
                 cm._drop_offset_dev = rpn_up["drop_offset"]
                 try:
-                    loss_rows, _ = cm._forward_train(feats[0], None, want_grad=backward, keras_sparse=True, device_tables=tables + (R, T))
+                    loss_rows, _ = cm._forward_train(feats, None, want_grad=backward, keras_sparse=True, device_tables=tables + (R_all, T))
                 finally:
                     cm._drop_offset_dev = None                  # a later standalone step of the shared caption model draws from ITS counter
             if backward and not fork:
@@ -947,6 +998,8 @@ class DenseImageCapRCNN(object):
             # a caller-supplied permutation (shuffle = callable): the sample is drawn on the host, as until round 3.  The proposals start
             # their way to the host first; the RPN branch's backward is enqueued behind that copy, so the GPU works while the host samples.
             mix = shuffle
+            if B != 1:
+                raise ValueError("a caller-supplied shuffle samples on the host: one image per step only (use shuffle=None or 'rng')")
             if backward:
                 host_props = self._pinned("props", tuple(proposals[0].shape))
                 host_props.copy_(proposals[0], non_blocking=True)
@@ -958,7 +1011,7 @@ class DenseImageCapRCNN(object):
             else:
                 props_np = proposals[0].cpu().numpy()
             cm._drop_offset_dev = None
-            rois, caps, npos, nneg = detection_targets(props_np, gt_caps[0], gt_norm, cfg, mix)
+            rois, caps, npos, nneg = detection_targets(props_np, gt_caps[0], gt_norm[0], cfg, mix)
             self._last_targets = dict(rois=rois, caps=caps, npos=npos, nneg=nneg)
             boxes = up(rois[None])
             feats = p.roi_features(boxes_norm=boxes, out=self._buf("feats", (1, R, cfg.POOL_SIZE, cfg.POOL_SIZE, 256)))
@@ -974,28 +1027,19 @@ class DenseImageCapRCNN(object):
             for t in scratch:
                 ops.zero_fill(t)
             ops.rpn_loss_grad(p.rpn_heads, scratch, rpn_up["lvl"], rpn_up["idx"], rpn_up["mt"], rpn_up["deltas"], rpn_up["cap"], losses[0:2],
-                              anchors_per_loc=self.A, counts_dev=rpn_up["counts"])
+                              anchors_per_loc=self.A, counts_dev=rpn_up["counts"], batched=True)
             coef, _ = self._masks()
             ops.l2_reg(st.flat, coef, None, loss=losses[3:4])
             return losses
 
         # ---- backward: decoder + head -> RoI features -> pyramid
-        overlap = self.grad_sync is not None and hasattr(self.grad_sync, "ready") and getattr(self.grad_sync, "world", 1) > 1
-        self._reg_done = []
+        overlap = overlap_dp
         if overlap:
-            coef_, mask_ = self._masks()
-
-            def early(lo, hi):                              # regulariser gradient + mask of one layer range, then it may travel
-                ops.l2_reg(st.flat[lo:hi], coef_[lo:hi], st.flat_grad[lo:hi], mask=None if mask_ is None else mask_[lo:hi])
-                self._reg_done.append((lo, hi))
             cm.before_sync, cm.grad_sync, cm.overlap_sync = early, self.grad_sync, True
         else:
             cm.before_sync, cm.overlap_sync = None, False
-        if overlap:                                          # the RPN's gradients are final (computed beside the host's RoI sampling): they travel first
-            for layer in ("rpn_conv_shared", "rpn_head"):
-                lo, hi = st.layer_range(layer)
-                early(lo, hi)
-                self.grad_sync.ready(st.flat_grad, lo, hi)
+        if overlap and not fork:                             # serial order: the RPN's gradients are final here, they travel first
+            rpn_ranges_travel()
         # (tried and measured without gain, round 4: the decoder's weight-gradient GEMMs on the side stream beside its LSTM backward
         # chain -- 8.77 ms against 8.68 captured, 8.57 against 8.58 eager)
         dX = cm._backward(want_dx=True)
@@ -1005,7 +1049,7 @@ class DenseImageCapRCNN(object):
             # bucket's 308 MB -- on the side stream beside the RoIAlign / FPN backward: 8.59 ms against 8.58 eager, 9.07 against 8.68
             # captured -- every extra branch costs the graph replay more than the overlap returns)
         # dP already holds the RPN branch's data gradients; the RoI features' gradient is added on top (a fixed-order gather per pyramid pixel: reproducible)
-        ops.roi_align_pyramid_bwd(dP[:4], boxes, float(H * W), dX.view(1, R, cfg.POOL_SIZE, cfg.POOL_SIZE, 256), cfg.POOL_SIZE)
+        ops.roi_align_pyramid_bwd(dP[:4], boxes, float(H * W), dX.view(B, R, cfg.POOL_SIZE, cfg.POOL_SIZE, 256), cfg.POOL_SIZE)
         ops.scatter2_add(dP[4], dP[3])                       # P6 = MaxPooling2D(1, strides=2)(P5)
 
         # ---- FPN backward (data parallel: every layer's gradient range starts its all-reduce as soon as it is complete)
@@ -1080,18 +1124,16 @@ class DenseImageCapRCNN(object):
             return losses
         # ---- single GPU: [one async upload] -> [encoder hipGraph] -> [step hipGraph: proposals .. losses .. gradients .. AMSGrad]
         images, _meta, rpn_match, rpn_bbox, gt_caps, gt_boxes = inputs[:6]
-        if len(images) != 1:
-            raise ValueError("one image per step and GPU (IMAGES_PER_GPU = 1)")
         p = self.plan()
         dev = self.device
-        gt_norm = (np.asarray(gt_boxes[0], np.float32) / np.array([p.H, p.W, p.H, p.W], np.float32)).astype(np.float32)
-        rpn_up = self._step_uploads(p, rpn_match, rpn_bbox, gt_norm, gt_caps[0], True)
+        gt_norm = self._check_batch(p, images, gt_boxes)
+        rpn_up = self._step_uploads(p, rpn_match, rpn_bbox, gt_norm, gt_caps, True)
         p.forward(self._images_u8(images))
         opt = self.optimizer
 
         def body():
             segs = self._reg_segments()
-            losses = self._after_encoder(p, rpn_up, "rng", True, gt_caps[0], gt_norm, fuse_reg=segs is not None)
+            losses = self._after_encoder(p, rpn_up, "rng", True, gt_caps, gt_norm, fuse_reg=segs is not None)
             opt.apply(self.store, grad_scale=1.0, lr_t_dev=rpn_up["lr_t"], reg=segs, reg_loss=None if segs is None else losses[3:4])
             return losses
 
@@ -1169,14 +1211,17 @@ class DenseImageCapRCNN(object):
         proposals = p.proposals()
         self.last_proposals = proposals
         feats = p.roi_features(boxes_norm=proposals)
-        probs, ids, word_scores = self.caption_model.generate(feats[0], return_probabilities=return_probabilities)
-        boxes, keep = refine_generations(proposals[0].cpu().numpy(), word_scores, windows[0], self.config)
-        final, ok = unmold_generations(boxes, images[0].shape, windows[0])
-        keep = keep[ok]
-        out = {"rois": final[ok], "ids": ids[keep]}
-        if return_probabilities:
-            out["captions"] = probs[keep]
-        return [out]
+        results = []
+        for b in range(len(images)):
+            probs, ids, word_scores = self.caption_model.generate(feats[b], return_probabilities=return_probabilities)
+            boxes, keep = refine_generations(proposals[b].cpu().numpy(), word_scores, windows[b], self.config)
+            final, ok = unmold_generations(boxes, images[b].shape, windows[b])
+            keep = keep[ok]
+            out = {"rois": final[ok], "ids": ids[keep]}
+            if return_probabilities:
+                out["captions"] = probs[keep]
+            results.append(out)
+        return results
 
     # ---- training loop ----------------------------------------------------------------------
     def train(self, train_dataset, val_dataset, learning_rate, epochs, layers):

@@ -3,6 +3,7 @@ the current HIP stream and (elsewhere) torch.distributed; every arithmetic op is
 All wrappers enqueue on torch's current stream and never synchronise.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -674,10 +675,12 @@ def vocab_ce_supported(X, W):
     return K % 32 == 0 and V % 4 == 0 and V >= 4 and X.stride(0) % 4 == 0 and W.stride(0) % 4 == 0
 
 
-def vocab_ce(X, W, bias, targets, loss_rows=None, dlogits=None, dbias=None, grad_scale=1.0, row_weights=None, keras_sparse=False):
+def vocab_ce(X, W, bias, targets, loss_rows=None, dlogits=None, dbias=None, grad_scale=1.0, row_weights=None, keras_sparse=False,
+             materialize_bf16=None):
     """Fused Dense(V) + softmax + Keras cross-entropy (dc_vocab_ce): X [M,K] and W [K,V] both float32 or both bf16; the
-    [M,V] logits are never materialised.  dlogits: float32 or bf16 [M, >=V] receives d(loss)/d(logits); dbias [V] its
-    column sums."""
+    [M,V] logits are never materialised in fp32.  dlogits: float32 or bf16 [M, >=V] receives d(loss)/d(logits); dbias [V] its
+    column sums.  materialize_bf16 (default: DCAP_VOCAB_MATERIALIZE, on): bf16 operands with a bf16 dlogits buffer -- the logits are
+    rounded to bf16 and parked in that buffer by the first GEMM pass, the gradient is an in-place elementwise pass (dcap.h)."""
     lib = _lib.load()
     bf = X.dtype == BF16
     _chk(X, BF16 if bf else torch.float32, "X"), _chk(W, BF16 if bf else torch.float32, "W")
@@ -697,6 +700,9 @@ def vocab_ce(X, W, bias, targets, loss_rows=None, dlogits=None, dbias=None, grad
             raise _lib.DcapError("vocab_ce: dlogits must be a float32 or bf16 device matrix with M rows")
         d.dlogits, d.lddl, d.dl_bf16 = dlogits.data_ptr(), dlogits.stride(0), int(dlogits.dtype == BF16)
     d.dbias = None if dbias is None else _chk(dbias, name="dbias").data_ptr()
+    if materialize_bf16 is None:
+        materialize_bf16 = os.environ.get("DCAP_VOCAB_MATERIALIZE", "1") != "0"
+    d.materialize_bf16 = int(bool(materialize_bf16) and bf and dlogits is not None and dlogits.dtype == BF16)
     ws, wsb = WORKSPACE.get(lib.dc_vocab_ce_workspace_bytes(C.byref(d)), X.device)
     check(lib.dc_vocab_ce(C.byref(d), _ptr(ws), wsb, _stream()), "dc_vocab_ce")
 
@@ -763,9 +769,13 @@ def conv_weight_dgrad_pack(w_packed, kh, kw, cin, out=None):
     return out
 
 
-def rpn_loss_grad(heads, dheads, sel_level, sel_index, sel_match, target_deltas, n_pos, losses, image=0, anchors_per_loc=3, counts_dev=None):
+def rpn_loss_grad(heads, dheads, sel_level, sel_index, sel_match, target_deltas, n_pos, losses, image=0, anchors_per_loc=3, counts_dev=None,
+                  batched=False):
     """RPN class + bbox losses of image `image` and their gradients scattered into the (pre-zeroed) dheads.  counts_dev: int32 device
-    tensor {n_sel, n_pos} overriding the host counts (sel_* / target_deltas then have fixed capacities: graph-capturable)."""
+    tensor {n_sel, n_pos} overriding the host counts (sel_* / target_deltas then have fixed capacities: graph-capturable).
+    batched=True: the selection indexes the WHOLE [B, h, w, C] head tensors (image b's anchor i of a level = b * h * w * A + i, images
+    in order, target rows packed in the same order): both means then run over the batch's union of selected anchors, as the
+    reference's batched loss graphs do (dense_img_cap/dense_model.py:877-933)."""
     lib = _lib.load()
     d = RpnLossDesc()
     d.levels, d.anchors_per_loc, d.head_stride = len(heads), anchors_per_loc, heads[0].shape[-1]
@@ -773,7 +783,7 @@ def rpn_loss_grad(heads, dheads, sel_level, sel_index, sel_match, target_deltas,
         per = h.shape[1] * h.shape[2] * h.shape[3]
         d.heads[i] = h.data_ptr() + 4 * per * image
         d.dheads[i] = g.data_ptr() + 4 * per * image
-        d.Hs[i], d.Ws[i] = h.shape[1], h.shape[2]
+        d.Hs[i], d.Ws[i] = (h.shape[0] * h.shape[1] if batched else h.shape[1]), h.shape[2]      # (a batch is a taller map to the kernel's bound check)
     d.n_sel, d.n_pos = sel_level.numel(), int(n_pos)
     if d.n_sel:                                         # no selected anchor (all neutral): the kernel only zeroes the losses
         d.sel_level, d.sel_index, d.sel_match = (_chk(t, torch.int32, "sel").data_ptr() for t in (sel_level, sel_index, sel_match))

@@ -441,6 +441,7 @@ int dc_softmax_ce_f32(const dc_softmax_ce_desc* d, void* stream);
  * Cost model: one GEMM pass for the loss plus one for the gradient, against one pass plus four sweeps over a [M,V] float32 matrix
  * unfused; keras_sparse adds a pass that sums the clipped probabilities -- only on the row tiles that hold a probability outside
  * [1e-7, 1 - 1e-7] (the first pass keeps every row's smallest logit; elsewhere nothing is clipped and the sums are 1).
+ * materialize_bf16 (round 6, configs[4]'s bf16 arithmetic): one GEMM pass + one in-place elementwise pass over the bf16 [M,V] buffer.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct {
     int M, V, K;
@@ -455,6 +456,11 @@ typedef struct {
     float* loss_rows;
     void* dlogits;  int lddl;  int dl_bf16;
     float* dbias;
+    int materialize_bf16;     /* bf16 = dl_bf16 = 1 with dlogits, large problems (the 256-square tile): the first GEMM pass ROUNDS the logits to
+                                 bf16 and parks them in the dlogits buffer; statistics, loss and gradient are those of the rounded logits
+                                 (what a bf16 framework that materialises its logits computes); the clip sums and the gradient are then
+                                 elementwise passes over that buffer, in place -- ONE GEMM pass instead of two or three.  0 (default) and
+                                 every other shape: fp32 logits recomputed per pass, never stored. */
 } dc_vocab_ce_desc;
 
 size_t dc_vocab_ce_workspace_bytes(const dc_vocab_ce_desc* d);

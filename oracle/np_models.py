@@ -551,17 +551,28 @@ def joint_trainable(Wt):
 
 
 def joint_loss_and_grads(Wt, image_u8, rpn_match, rpn_bbox_target, gt_captions, gt_boxes_px, cfg, shuffle=None, stage4_blocks=22,
-                         targets_override=None, backbone_from=None):
+                         targets_override=None, backbone_from=None, term_weights=None, trunk_cache=None):
     """One training step's losses and gradients for ONE image (IMAGES_PER_GPU = 1, train_dense_captions.py:27).
+    term_weights = dict(imgcap_loss=, rpn_class_loss=, rpn_bbox_loss=, reg_loss=): every loss term AND its gradient is scaled by its
+    weight -- how joint_loss_and_grads_batch pools a batch (below).  trunk_cache: a dict that keeps the frozen ResNet's C2..C5 of this
+    image between calls (they depend on the image and the frozen weights only; a second device model checked against the same image
+    does not pay for the float64 trunk again).
     cfg: dict(mean_pixel, scales, ratios, strides, proposal_count, nms, train_rois, positive_ratio, weight_decay, T).
     targets_override = (rois [R,4] normalised, caps [R,T]) replaces the DetectionTargetLayer's sample (which carries no
     gradient): parity tests hand in the sample the device drew, since near-tied proposal scores may order differently.
     Returns (losses dict, grads dict over joint_trainable(Wt), aux dict)."""
     x = O.mold_image(image_u8[None], cfg['mean_pixel'])
     _, H, W, _ = x.shape
+    tw = dict(imgcap_loss=1.0, rpn_class_loss=1.0, rpn_bbox_loss=1.0, reg_loss=1.0)
+    tw.update(term_weights or {})
     if backbone_from is None:
-        _, C2, C3, C4, C5 = resnet_graph(x, Wt, stage4_blocks)
-        Cs = {2: C2, 3: C3, 4: C4, 5: C5}
+        if trunk_cache is not None and 'Cs' in trunk_cache:
+            Cs = trunk_cache['Cs']
+        else:
+            _, C2, C3, C4, C5 = resnet_graph(x, Wt, stage4_blocks)
+            Cs = {2: C2, 3: C3, 4: C4, 5: C5}
+            if trunk_cache is not None:
+                trunk_cache['Cs'] = Cs
     else:                                                           # train(layers="3+" | "4+" | "5+" | "all"): ResNet stages train too
         Cs, trunk_caches = resnet_graph_cached(x, Wt, stage4_blocks)
     conv = lambda t, n, pad='valid': O.conv2d_nhwc(t, Wt[n + '/kernel'], Wt[n + '/bias'], 1, pad)
@@ -594,13 +605,15 @@ def joint_loss_and_grads(Wt, image_u8, rpn_match, rpn_bbox_target, gt_captions, 
     w = (tg > 0).astype(F64)
     cnt = w.sum()
     rows_loss, dlog = O.sparse_cce_keras_with_grad(tg, cap_probs, w / max(cnt, 1.0))
-    losses = {'imgcap_loss': float(rows_loss.sum()) if cnt > 0 else 0.0}
+    losses = {'imgcap_loss': tw['imgcap_loss'] * (float(rows_loss.sum()) if cnt > 0 else 0.0)}
+    dlog = dlog * tw['imgcap_loss']
     l_cls, dlogits = O.rpn_class_loss(rpn_match, logits)
     l_box, dbbox = O.rpn_bbox_loss(rpn_bbox_target, rpn_match, bbox)
-    losses['rpn_class_loss'], losses['rpn_bbox_loss'] = l_cls, l_box
+    losses['rpn_class_loss'], losses['rpn_bbox_loss'] = tw['rpn_class_loss'] * l_cls, tw['rpn_bbox_loss'] * l_box
+    dlogits, dbbox = dlogits * tw['rpn_class_loss'], dbbox * tw['rpn_bbox_loss']
     train = joint_trainable(Wt) + (backbone_trainable(Wt, backbone_from, stage4_blocks) if backbone_from is not None else [])
     reg_keys = [k for k in train if 'gamma' not in k and 'beta' not in k]
-    losses['reg_loss'] = float(sum(cfg['weight_decay'] * (np.asarray(Wt[k], F64) ** 2).sum() / np.asarray(Wt[k]).size for k in reg_keys))
+    losses['reg_loss'] = tw['reg_loss'] * float(sum(cfg['weight_decay'] * (np.asarray(Wt[k], F64) ** 2).sum() / np.asarray(Wt[k]).size for k in reg_keys))
     losses['loss'] = sum(losses[k] for k in ('imgcap_loss', 'rpn_class_loss', 'rpn_bbox_loss', 'reg_loss'))
 
     # ---- backward
@@ -640,6 +653,38 @@ def joint_loss_and_grads(Wt, image_u8, rpn_match, rpn_bbox_target, gt_captions, 
     if backbone_from is not None:
         G.update(resnet_backward(dC, trunk_caches, Wt, backbone_from))
     for k in reg_keys:
-        G[k] = G[k] + 2.0 * cfg['weight_decay'] * np.asarray(Wt[k], F64) / np.asarray(Wt[k]).size
+        G[k] = G[k] + tw['reg_loss'] * 2.0 * cfg['weight_decay'] * np.asarray(Wt[k], F64) / np.asarray(Wt[k]).size
     aux = dict(proposals=proposals, rois=rois, caps=caps, npos=npos, nneg=nneg, count=cnt, cap_probs=cap_probs, anchors=anchors)
     return losses, {k: G[k] for k in train}, aux
+
+
+def joint_loss_and_grads_batch(Wt, images_u8, rpn_match, rpn_bbox_target, gt_captions, gt_boxes_px, cfg, targets_override, stage4_blocks=22,
+                               trunk_caches=None):
+    """The reference's BATCHED training graph (IMAGES_PER_GPU = B, dense_img_cap/config.py:35): DetectionTargetLayer slices the batch
+    (utils.batch_slice, dense_model.py:531-572), every loss gathers over ALL images before its mean --
+      rpn_class_loss   mean over the non-neutral anchors of the batch               (:877-900)
+      rpn_bbox_loss    mean over the positive anchors of the batch (x 4 coordinates) (:903-933, batch_pack_graph)
+      imgcap_loss      mean over the caption positions with target > 0 of the batch  (:936-946)
+    -- so the batch loss is NOT the mean of the per-image losses when the images' counts differ: image b's per-image mean enters
+    with the weight count_b / sum(count).  The weight regulariser is counted once.  Arguments carry the image axis first;
+    targets_override = (rois [B,R,4], caps [B,R,T]) as in joint_loss_and_grads.  Returns (losses, grads, [aux per image])."""
+    B = len(images_u8)
+    rpn_match = [np.asarray(m).reshape(-1) for m in rpn_match]
+    n_sel = np.array([(m != 0).sum() for m in rpn_match], F64)
+    n_pos = np.array([(m == 1).sum() for m in rpn_match], F64)
+    caps = [np.asarray(targets_override[1][b]) for b in range(B)]
+    n_tok = np.array([(v1_targets(c) > 0).sum() for c in caps], F64)
+    share = lambda n: n / max(n.sum(), 1.0)
+    w_cls, w_box, w_cap = share(n_sel), share(n_pos), share(n_tok)
+    losses, grads, auxes = {}, {}, []
+    for b in range(B):
+        tw = dict(imgcap_loss=w_cap[b], rpn_class_loss=w_cls[b], rpn_bbox_loss=w_box[b], reg_loss=1.0 if b == 0 else 0.0)
+        l, g, aux = joint_loss_and_grads(Wt, images_u8[b], rpn_match[b], rpn_bbox_target[b], gt_captions[b], gt_boxes_px[b], cfg,
+                                         stage4_blocks=stage4_blocks, targets_override=(targets_override[0][b], caps[b]), term_weights=tw,
+                                         trunk_cache=None if trunk_caches is None else trunk_caches[b])
+        for k, v in l.items():
+            losses[k] = losses.get(k, 0.0) + v
+        for k, v in g.items():
+            grads[k] = grads.get(k, 0.0) + v
+        auxes.append(aux)
+    return losses, grads, auxes

@@ -277,9 +277,10 @@ def cpu_baseline_step(enc_W, dec_W, image_u8, rois_px, captions, mean_pixel, win
 
 # ------------------------------------------------------------------ joint model (autograd cross-check)
 
-def joint_loss(Wt, image_u8, rpn_match, rpn_bbox_target, rois, caps, mean_pixel, ratios, weight_decay, stage4_blocks=22):
+def joint_loss(Wt, image_u8, rpn_match, rpn_bbox_target, rois, caps, mean_pixel, ratios, weight_decay, stage4_blocks=22, term_weights=None):
     """Total loss of the joint model for one image given the (non-differentiable) detection targets `rois`/`caps`:
-    imgcap sparse-CE (target > 0) + RPN class + RPN bbox + L2/size regulariser.  float64 tensors in Wt."""
+    imgcap sparse-CE (target > 0) + RPN class + RPN bbox + L2/size regulariser.  float64 tensors in Wt.
+    term_weights (dict by loss name): the total is the weighted sum -- one image's share of a pooled batch loss."""
     x = torch.tensor(image_u8[None].astype(np.float64)) - torch.tensor(np.asarray(mean_pixel, np.float64))
     H, W = image_u8.shape[:2]
     xin = x.permute(0, 3, 1, 2)
@@ -328,4 +329,7 @@ def joint_loss(Wt, image_u8, rpn_match, rpn_bbox_target, rois, caps, mean_pixel,
     for k, v in Wt.items():
         if v.requires_grad and 'gamma' not in k and 'beta' not in k:
             reg = reg + weight_decay * (v ** 2).sum() / v.numel()
-    return l_cap + l_cls + l_box + reg, dict(imgcap_loss=float(l_cap), rpn_class_loss=float(l_cls), rpn_bbox_loss=float(l_box), reg_loss=float(reg))
+    tw = dict(imgcap_loss=1.0, rpn_class_loss=1.0, rpn_bbox_loss=1.0, reg_loss=1.0)
+    tw.update(term_weights or {})
+    total = tw['imgcap_loss'] * l_cap + tw['rpn_class_loss'] * l_cls + tw['rpn_bbox_loss'] * l_box + tw['reg_loss'] * reg
+    return total, dict(imgcap_loss=float(l_cap), rpn_class_loss=float(l_cls), rpn_bbox_loss=float(l_box), reg_loss=float(reg))

@@ -216,7 +216,7 @@ def test_vocab_ce_categorical(ops, bf16, M, V, K):
     if bf16:                                                           # bf16 gradient output, K-padded with zeros
         Vp = (V + 7) // 8 * 8
         dlb = torch.full((M, Vp), 7.0, dtype=BF, device="cuda")
-        ops.vocab_ce(Xd, Wd, dev(b0), dev(t, torch.int32), dlogits=dlb, grad_scale=1.0)
+        ops.vocab_ce(Xd, Wd, dev(b0), dev(t, torch.int32), dlogits=dlb, grad_scale=1.0, materialize_bf16=False)
         got = dlb.float().cpu().numpy().astype(np.float64)
         assert np.abs(got[:, :V] - want_d * M).max() <= 2.0 ** -8 * np.abs(want_d * M).max() + 1e-6 and not got[:, V:].any()
 
@@ -324,9 +324,69 @@ def test_vocab_ce_bf16_on_the_256_tile(ops, M, V, K, sparse):
     close(db * scale, want_d.sum(0), 2e-4)
     Vp = V + 8
     dlb = torch.full((M, Vp), 7.0, dtype=BF, device="cuda")              # bf16 gradient output, K-padded with zeros
-    ops.vocab_ce(Xd, Wd, dev(b), dev(t, torch.int32), dlogits=dlb, **kw)
+    ops.vocab_ce(Xd, Wd, dev(b), dev(t, torch.int32), dlogits=dlb, materialize_bf16=False, **kw)      # fp32 logits recomputed per pass
     got = dlb.float().cpu().numpy().astype(np.float64) * scale
     assert np.abs(got[:, :V] - want_d).max() <= 2.0 ** -8 * np.abs(want_d).max() + 1e-6 and not got[:, V:].any()
+
+
+@pytest.mark.parametrize("M,V,K,sparse,clip", [(3000, 4104, 256, False, False), (1500, 8200, 512, True, False), (1500, 8200, 512, True, True),
+                                               (3000, 50000, 1024, True, False), (2900, 5000, 200, True, True)])
+def test_vocab_ce_bf16_materialised_logits(ops, M, V, K, sparse, clip):
+    """dc_vocab_ce_desc.materialize_bf16 (round 6): ONE GEMM pass rounds the logits to bf16 and parks them in the gradient's buffer, the
+    clip sums and the gradient are elementwise passes over it (in place).  Reference = the oracle applied to the bf16-ROUNDED logits:
+    loss, gradient and bias gradient are those of the rounded logits, consistent with each other (every gradient row sums to zero).
+    A logit within fp32 accumulation error of a bf16 rounding boundary may round the other way than in the float64 oracle: such an
+    entry differs by one bf16 ulp of the logit, so tolerances are 2^-7 of the row's largest |logit| on the loss and 2^-7 on gradients
+    (of the largest entry); against the recomputing flavour (fp32 logits) the same bounds hold with the rounding itself inside."""
+    rng = np.random.default_rng(V + K + M + int(clip))
+    X, W, b, t, _ = _ce_case(rng, M, V, K, True)
+    if clip:
+        b[t[0]] -= 80.0                                               # a word whose probability falls below 1e-7 in every row
+        X[5] = 400.0 * W[:, 7] / np.linalg.norm(W[:, 7])              # a row whose word 7 exceeds 1 - 1e-7
+    else:
+        W *= 0.25                                                     # ordinary logits: no probability outside the clip range (lazy pass skipped)
+        b *= 0.5
+    X[1] = 0
+    w = rng.random(M)
+    w[2] = 0.0
+    Xd, Wd = ops.to_bf16(dev(X)), ops.to_bf16(dev(W))
+    z = O.to_bf16(X) @ O.to_bf16(W) + b
+    zr = O.to_bf16(z)
+    p = O.softmax(zr)
+    if sparse:
+        want_loss, want_d = O.sparse_cce_keras_with_grad(t, p, w)
+        kw = dict(grad_scale=1.0, row_weights=dev(w), keras_sparse=True)
+        scale = 1.0
+    else:
+        want_loss, want_d = O.categorical_crossentropy(t, p), O.softmax_ce_grad_logits(t, p, np.full(M, 1.0 / M)) * M
+        kw = dict(grad_scale=1.0 / M)
+        scale = float(M)
+    Vp = V + 8
+    loss = torch.empty(M, device="cuda")
+    dlb = torch.full((M, Vp), 7.0, dtype=BF, device="cuda")
+    db = torch.empty(V, device="cuda")
+    ops.vocab_ce(Xd, Wd, dev(b), dev(t, torch.int32), loss_rows=loss, dlogits=dlb, dbias=db, materialize_bf16=True, **kw)
+    got = dlb.float().cpu().numpy().astype(np.float64) * scale
+    zmax = np.abs(z).max(axis=1)
+    wrow = w if sparse else np.ones(M)
+    lerr = np.abs(loss.cpu().numpy().astype(np.float64) - want_loss)
+    assert np.all(lerr <= 2.0 ** -7 * wrow * np.maximum(1.0, zmax) + 3e-5), float(lerr.max())
+    assert not got[:, V:].any()
+    gmax = np.abs(want_d).max()
+    assert np.abs(got[:, :V] - want_d).max() <= (2.0 ** -7 * max(1.0, float(zmax.max())) / 2 + 2.0 ** -8) * gmax + 1e-6
+    # the median row is exact to output rounding: boundary flips are rare
+    row_err = np.abs(got[:, :V] - want_d).max(axis=1)
+    assert np.median(row_err) <= 2.0 ** -8 * gmax + 1e-6
+    if not clip:                                                      # nothing clipped: a row's gradient sums to zero (to the bf16 rounding of its V outputs)
+        assert np.abs(got[:, :V].sum(axis=1)).max() <= 2.0 ** -8 * np.abs(got[:, :V]).sum(axis=1).max() + 1e-6
+    close(db * scale, got[:, :V].sum(0), 2e-3)                        # bias gradient = the column sums of the gradient it wrote (fp32 sums of pre-rounding values)
+    # against the recomputing flavour: same call, fp32 logits
+    loss2 = torch.empty(M, device="cuda")
+    dl2 = torch.full((M, Vp), 7.0, dtype=BF, device="cuda")
+    ops.vocab_ce(Xd, Wd, dev(b), dev(t, torch.int32), loss_rows=loss2, dlogits=dl2, materialize_bf16=False, **kw)
+    d = (loss - loss2).abs().cpu().numpy()
+    assert np.all(d <= 2.0 ** -7 * wrow * np.maximum(1.0, zmax) + 3e-5)
+    assert float((dlb.float() - dl2.float()).abs().max()) * scale <= (2.0 ** -7 * max(1.0, float(zmax.max())) / 2 + 2.0 ** -7) * gmax + 1e-6
 
 
 @pytest.mark.parametrize("case", [

@@ -14,7 +14,7 @@ sizes through properties.  Here the oracle itself runs at full size -- it is sec
               M.joint_loss_and_grads (losses 1e-4, gradients 5e-4), bf16 model at its bf16 tolerances
               (dense_img_cap/dense_model.py:1429-1629)
 
-The measured errors are written to gpurun_out/r05_fullsize_parity.json (copied to profiles/ by hand) and quoted in DESIGN.md."""
+The measured errors are written to gpurun_out/r06_fullsize_parity.json (copied to profiles/ by hand) and quoted in DESIGN.md."""
 import json
 import os
 import time
@@ -42,7 +42,7 @@ def gpu():
     try:                                                   # the record of what was measured (best effort: the tests do not depend on it)
         out = os.path.join(ROOT, "gpurun_out")
         os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, "r05_fullsize_parity.json"), "w") as f:
+        with open(os.path.join(out, "r06_fullsize_parity.json"), "w") as f:
             json.dump(MEASURED, f, indent=1, sort_keys=True)
     except OSError:
         pass
@@ -269,14 +269,15 @@ def test_configs0_v1_decoder_at_full_size_with_replayed_dropout_masks(gpu):
 # configs[4]: joint model at 512 x 512 x 22 blocks, 2000 -> 200 RoIs, V = 50 000
 # ---------------------------------------------------------------------------------------------
 
-def _joint_full(compute_dtype, conv_math, S=512, V=50000, T=15, blocks=22):
+def _joint_full(compute_dtype, conv_math, S=512, V=50000, T=15, blocks=22, B=1):
+    """Model, config, reference-layout weights and one step's generator inputs for B images (IMAGES_PER_GPU = B)."""
     from image_captioning_amd import synth, utils
     from image_captioning_amd.config import Config
     from image_captioning_amd.dense_model import DenseImageCapRCNN, build_rpn_targets
 
     class Cfg(Config):
         NAME = "joint"
-        IMAGES_PER_GPU = 1
+        IMAGES_PER_GPU = B
         IMAGE_MIN_DIM = S
         IMAGE_MAX_DIM = S
         PADDING_SIZE = T
@@ -296,31 +297,43 @@ def _joint_full(compute_dtype, conv_math, S=512, V=50000, T=15, blocks=22):
     model = DenseImageCapRCNN("training", cfg, "logs", stage4_blocks=blocks, compute_dtype=compute_dtype, conv_math=conv_math)
     model.set_weights(Wt)
     rng = np.random.RandomState(0)
-    img = synth.images(7, 1, S, S)
-    # ground truth = 40 of the (random-weight) RPN's own proposals, so that DetectionTargetLayer finds positive RoIs
+    img = synth.images(7, B, S, S)
+    # ground truth = some of the (random-weight) RPN's own proposals, so that DetectionTargetLayer finds positive RoIs; with B > 1 the
+    # images get DIFFERENT numbers of GT boxes, positive anchors and caption lengths: the pooled means then differ from means of means
     plan = model.plan()
     plan.forward(torch.as_tensor(img))
-    props = plan.proposals()[0].cpu().numpy().astype(np.float64) * S
-    big = props[((props[:, 2] - props[:, 0]) >= 24) & ((props[:, 3] - props[:, 1]) >= 24)]
-    boxes = np.rint(big[:40]).astype(np.int32)
-    n_gt = boxes.shape[0]
-    assert n_gt >= 8, "the random RPN produced too few usable proposals"
-    caps = synth.captions_v1(9, n_gt, T, V, lmin=3, lmax=12).astype(np.int32)
+    props_all = plan.proposals().cpu().numpy().astype(np.float64) * S
     anchors = utils.generate_pyramid_anchors(cfg.RPN_ANCHOR_SCALES, cfg.RPN_ANCHOR_RATIOS, cfg.BACKBONE_SHAPES, cfg.BACKBONE_STRIDES, 1)
-    match, deltas = build_rpn_targets(img[0].shape, anchors, caps, boxes, cfg, rng)
-    gt_caps = np.zeros((1, cfg.MAX_GT_INSTANCES, T), np.int32)
-    gt_boxes = np.zeros((1, cfg.MAX_GT_INSTANCES, 4), np.int32)
-    gt_caps[0, :n_gt], gt_boxes[0, :n_gt] = caps, boxes
-    return model, cfg, Wt, [img, np.zeros((1, 12)), match[None, :, None], deltas[None], gt_caps, gt_boxes]
+    gt_caps = np.zeros((B, cfg.MAX_GT_INSTANCES, T), np.int32)
+    gt_boxes = np.zeros((B, cfg.MAX_GT_INSTANCES, 4), np.int32)
+    matches, deltas_all = [], []
+    for b in range(B):
+        props = props_all[b]
+        big = props[((props[:, 2] - props[:, 0]) >= 24) & ((props[:, 3] - props[:, 1]) >= 24)]
+        boxes = np.rint(big[:40 if b == 0 else 12]).astype(np.int32)
+        n_gt = boxes.shape[0]
+        assert n_gt >= 8, "the random RPN produced too few usable proposals"
+        caps = synth.captions_v1(9 + b, n_gt, T, V, lmin=3, lmax=12 if b == 0 else 6).astype(np.int32)
+        match, deltas = build_rpn_targets(img[b].shape, anchors, caps, boxes, cfg, rng)
+        gt_caps[b, :n_gt], gt_boxes[b, :n_gt] = caps, boxes
+        matches.append(match[:, None])
+        deltas_all.append(deltas)
+    return model, cfg, Wt, [img, np.zeros((B, 12)), np.stack(matches), np.stack(deltas_all), gt_caps, gt_boxes]
+
+
+def _oracle_cfg(cfg):
+    return dict(mean_pixel=MEAN, scales=cfg.RPN_ANCHOR_SCALES, ratios=cfg.RPN_ANCHOR_RATIOS, strides=cfg.BACKBONE_STRIDES,
+                proposal_count=cfg.POST_NMS_ROIS_TRAINING, nms=cfg.RPN_NMS_THRESHOLD, train_rois=cfg.TRAIN_ROIS_PER_IMAGE,
+                positive_ratio=cfg.ROI_POSITIVE_RATIO, weight_decay=cfg.WEIGHT_DECAY, T=cfg.PADDING_SIZE)
+
+
+TRUNK_CACHE = {}          # the float64 ResNet maps of the configs[4] test image: computed by the first leg, reused by the second
 
 
 def _joint_oracle(Wt, cfg, inputs, targets, blocks):
     img, _, match, tdelta, gt_caps, gt_boxes = inputs
-    oc = dict(mean_pixel=MEAN, scales=cfg.RPN_ANCHOR_SCALES, ratios=cfg.RPN_ANCHOR_RATIOS, strides=cfg.BACKBONE_STRIDES,
-              proposal_count=cfg.POST_NMS_ROIS_TRAINING, nms=cfg.RPN_NMS_THRESHOLD, train_rois=cfg.TRAIN_ROIS_PER_IMAGE,
-              positive_ratio=cfg.ROI_POSITIVE_RATIO, weight_decay=cfg.WEIGHT_DECAY, T=cfg.PADDING_SIZE)
-    return M.joint_loss_and_grads(f64(Wt), img[0], match[0, :, 0], tdelta[0], gt_caps[0], gt_boxes[0], oc, stage4_blocks=blocks,
-                                  targets_override=targets)
+    return M.joint_loss_and_grads(f64(Wt), img[0], match[0, :, 0], tdelta[0], gt_caps[0], gt_boxes[0], _oracle_cfg(cfg), stage4_blocks=blocks,
+                                  targets_override=targets, trunk_cache=TRUNK_CACHE.setdefault((img.shape, blocks), {}))
 
 
 def _grads_as_reference(model):
@@ -365,5 +378,45 @@ def test_configs4_joint_step_at_512px_22_blocks_50k_vocabulary(gpu, dtype):
     worst = sorted(rec["grads"].items(), key=lambda kv: -kv[1])[:6]
     assert all(np.isfinite(v) for v in rec["grads"].values())
     assert worst[0][1] < (1e-1 if bf else 5e-4), worst
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_configs4_joint_step_two_images_per_gpu_pools_the_losses_over_the_batch(gpu):
+    """IMAGES_PER_GPU = 2 (the reference's batched graph: config.py:35, DetectionTargetLayer over utils.batch_slice
+    dense_model.py:531-572): two 512 x 512 images with DIFFERENT numbers of GT boxes / positive anchors / caption tokens in one step.
+    Losses and every gradient against M.joint_loss_and_grads_batch -- each loss the mean over the batch's union of anchors / caption
+    positions (rpn_class_loss_graph :877-900, rpn_bbox_loss_graph :903-933, imgcap_caption_loss_graph :936-946), given the RoI samples
+    the device drew; fp32: losses 1e-4, gradients 5e-4 of each tensor's largest entry.  Full depth is the one-image test's job: two
+    stage-4 blocks and V = 10 000 here keep the float64 oracle at seconds."""
+    blocks, V = 2, 10000
+    model, cfg, Wt, inputs = _joint_full("f32", None, V=V, blocks=blocks, B=2)
+    for rep in range(2):
+        losses = model._loss_list(model.forward_backward(inputs, shuffle=None))
+    tg = model.last_targets
+    assert tg['rois'].shape == (2, 200, 4) and np.all(tg['npos'] > 0) and np.all(tg['npos'] + tg['nneg'] <= 200)
+    match = inputs[2][:, :, 0]
+    want, G, auxes = M.joint_loss_and_grads_batch(f64(Wt), inputs[0], match, inputs[3], inputs[4], inputs[5], _oracle_cfg(cfg),
+                                                  (tg['rois'], tg['caps']), stage4_blocks=blocks)
+    # the pooled means are not the means of the per-image means here (the images' counts differ on purpose)
+    n_sel = (match != 0).sum(1)
+    tok = np.array([a['count'] for a in auxes])
+    assert tok[0] != tok[1] and (match == 1).sum(1)[0] != (match == 1).sum(1)[1], (tok, n_sel)
+    rec = dict(losses={}, grads={}, tokens=tok.tolist(), positives=(match == 1).sum(1).tolist())
+    for k in ('imgcap_loss', 'rpn_class_loss', 'rpn_bbox_loss', 'reg_loss', 'loss'):
+        rec["losses"][k] = (float(losses[k]), float(want[k]))
+        assert abs(losses[k] - want[k]) < 1e-4 * max(1.0, abs(want[k])), (k, losses[k], want[k])
+    got = _grads_as_reference(model)
+    for k in M.joint_trainable(Wt):
+        rec["grads"][k] = rel_err(got[k], G[k])
+    MEASURED["configs4_joint_2_images_per_gpu"] = rec
+    worst = sorted(rec["grads"].items(), key=lambda kv: -kv[1])[:6]
+    assert worst[0][1] < 5e-4, worst
+    # one captured optimizer step on the same batch: the step graph takes the batched launches too
+    model.compile(1e-3)
+    before = model.store.flat.clone()
+    for _ in range(4):
+        out = model.train_on_batch(inputs)
+    assert np.isfinite(out).all() and not torch.equal(before, model.store.flat)
     del model
     torch.cuda.empty_cache()

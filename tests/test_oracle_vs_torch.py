@@ -132,3 +132,59 @@ def test_joint_model_losses_and_gradients():
         np.testing.assert_allclose(losses[k], v, rtol=1e-9, atol=1e-12, err_msg=k)
     for k in train:
         np.testing.assert_allclose(G[k], Tt[k].grad.numpy(), rtol=1e-6, atol=1e-11, err_msg=k)
+
+
+def test_joint_batch_oracle_pools_every_loss_over_the_batch():
+    """IMAGES_PER_GPU = 2 (dense_img_cap/config.py:35): the reference's loss graphs gather over ALL images before their mean
+    (dense_model.py:877-946), so with unequal counts the batch loss is the count-weighted combination of the per-image means, not their
+    average.  M.joint_loss_and_grads_batch against torch autograd of that definition, on two 128 x 128 images with different numbers of
+    selected anchors, positive anchors and caption tokens."""
+    S, V, T = 128, 24, 5
+    Wt = dict(synth.encoder_weights(0, 1), **synth.rpn_weights(4))
+    Wt['rpn_conv_shared/kernel'] = Wt['rpn_conv_shared/kernel'] * np.float32(0.05)
+    Wt['rpn_bbox_pred/kernel'] = Wt['rpn_bbox_pred/kernel'] * np.float32(0.3)
+    Wt.update(synth.head_weights(1))
+    Wt.update(synth.v1_weights(2, V))
+    Wt['imgcap_embedding_layer/embeddings'] = synth.embedding_matrix(3, V)
+    imgs = synth.images(7, 2, S, S)
+    rng = np.random.default_rng(8)
+    gt_boxes = [np.array([[10, 12, 70, 90], [40, 30, 120, 128], [0, 0, 50, 40]], np.float32), np.array([[20, 20, 100, 110], [5, 60, 60, 120]], np.float32)]
+    gt_caps = [synth.captions_v1(9, 3, T, V, lmin=1, lmax=3), synth.captions_v1(10, 2, T, V, lmin=2, lmax=3)]
+    A = (32 * 32 + 16 * 16 + 8 * 8 + 4 * 4 + 2 * 2) * 3
+    match, tdelta = [], []
+    for n_sel, frac in ((40, 0.4), (24, 0.7)):
+        m = np.zeros(A, np.int32)
+        m[rng.choice(A, n_sel, replace=False)] = np.where(rng.random(n_sel) < frac, 1, -1)
+        match.append(m)
+        tdelta.append(rng.standard_normal((64, 4)))
+    cfg = dict(mean_pixel=[123.7, 116.8, 103.9], scales=(32, 64, 128, 256, 512), ratios=[0.5, 1, 2], strides=[4, 8, 16, 32, 64],
+               proposal_count=60, nms=0.7, train_rois=12, positive_ratio=0.33, weight_decay=1e-4, T=T)
+    # the per-image samples (the DetectionTargetLayer carries no gradient): drawn by the single-image oracle, then handed to the batch
+    singles = [M.joint_loss_and_grads(Wt, imgs[b], match[b], tdelta[b], gt_caps[b], gt_boxes[b], cfg, stage4_blocks=1) for b in range(2)]
+    rois = np.stack([s_[2]['rois'] for s_ in singles])
+    caps = np.stack([s_[2]['caps'] for s_ in singles])
+    losses, G, auxes = M.joint_loss_and_grads_batch(Wt, imgs, match, tdelta, gt_caps, gt_boxes, cfg, (rois, caps), stage4_blocks=1)
+    n_sel = np.array([(m != 0).sum() for m in match], float)
+    n_pos = np.array([(m == 1).sum() for m in match], float)
+    n_tok = np.array([a['count'] for a in auxes], float)
+    assert n_sel[0] != n_sel[1] and n_pos[0] != n_pos[1] and n_tok[0] != n_tok[1] and n_tok.min() > 0
+    train = M.joint_trainable(Wt)
+    Tt = TR.to_t(Wt, requires_grad=train)
+    total, want = 0.0, {}
+    for b in range(2):
+        share = dict(rpn_class_loss=n_sel[b] / n_sel.sum(), rpn_bbox_loss=n_pos[b] / n_pos.sum(), imgcap_loss=n_tok[b] / n_tok.sum(),
+                     reg_loss=1.0 if b == 0 else 0.0)
+        t_b, parts = TR.joint_loss(Tt, imgs[b], match[b], tdelta[b], rois[b], caps[b], cfg['mean_pixel'], cfg['ratios'], 1e-4, 1, term_weights=share)
+        total = total + t_b
+        for k, w_ in share.items():
+            want[k] = want.get(k, 0.0) + w_ * parts[k]
+    total.backward()
+    for k in ('rpn_class_loss', 'rpn_bbox_loss', 'imgcap_loss', 'reg_loss'):
+        np.testing.assert_allclose(losses[k], want[k], rtol=1e-9, atol=1e-12, err_msg=k)
+    np.testing.assert_allclose(losses['loss'], float(total), rtol=1e-9)
+    # the pooled definition, directly: per-image mean x count summed, over the total count (the caption term)
+    per = [s_[0]['imgcap_loss'] for s_ in singles]
+    np.testing.assert_allclose(losses['imgcap_loss'], (per[0] * n_tok[0] + per[1] * n_tok[1]) / n_tok.sum(), rtol=1e-9)
+    assert abs(losses['imgcap_loss'] - 0.5 * (per[0] + per[1])) > 1e-6             # ... which is not the mean of the two means
+    for k in train:                                                                 # torch autograd of the pooled total
+        np.testing.assert_allclose(G[k], Tt[k].grad.numpy(), rtol=1e-6, atol=1e-11, err_msg=k)
