@@ -879,13 +879,16 @@ class DenseImageCapRCNN(object):
             return dict(rois=r[0], caps=k[0], npos=int(c[0, 0]), nneg=int(c[0, 1]))
         return dict(rois=r, caps=k, npos=c[:, 0].astype(int), nneg=c[:, 1].astype(int))
 
-    def forward_backward(self, inputs, shuffle="rng", backward=True):
+    def forward_backward(self, inputs, shuffle="rng", backward=True, targets=None):
         """Losses and gradients of one step's IMAGES_PER_GPU images into the flat gradient bucket (no optimizer step).
         Returns the device tensor [rpn_class_loss, rpn_bbox_loss, imgcap_loss, reg_loss].
         backward=False: the forward graph only (validation, Keras' test_on_batch): no gradient is computed, the gradient bucket is
         left alone, no recurrent dropout, and the detection-target sample is drawn from a generator of its own so that an
-        evaluation between two train steps does not change the training run."""
+        evaluation between two train steps does not change the training run.
+        targets = (rois [R,4] normalised, caps [R,T]): the DetectionTargetLayer's sample handed in by the caller instead of drawn (one
+        image per step; parity tests check a second model against the oracle result of a sample another model drew)."""
         images, _meta, rpn_match, rpn_bbox, gt_caps, gt_boxes = inputs[:6]
+        self._targets_given = None if targets is None else (np.asarray(targets[0], np.float32), np.asarray(targets[1]))
         p = self.plan()
         gt_norm = self._check_batch(p, images, gt_boxes)
         # ---- this step's host inputs go to the device FIRST (GT boxes, GT captions, the RPN selection, the step scalars: one asynchronous
@@ -913,7 +916,9 @@ class DenseImageCapRCNN(object):
         dev = self.device
         H, W = p.H, p.W
         up = lambda a, dt=torch.float32: torch.tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
-        device_targets = shuffle is None or shuffle == "rng"
+        given = getattr(self, "_targets_given", None)
+        self._targets_given = None
+        device_targets = (shuffle is None or shuffle == "rng") and given is None
         gt_dev, gtc_dev = rpn_up["gt"], rpn_up["gtc"]
         B = self.images_per_gpu
         self._bf16_cache = {}
@@ -1000,7 +1005,11 @@ class DenseImageCapRCNN(object):
             mix = shuffle
             if B != 1:
                 raise ValueError("a caller-supplied shuffle samples on the host: one image per step only (use shuffle=None or 'rng')")
-            if backward:
+            if given is not None:
+                props_np = None
+                if backward:
+                    maps, dP = self._rpn_backward(p, rpn_up, losses)
+            elif backward:
                 host_props = self._pinned("props", tuple(proposals[0].shape))
                 host_props.copy_(proposals[0], non_blocking=True)
                 ev = torch.cuda.Event()
@@ -1011,7 +1020,12 @@ class DenseImageCapRCNN(object):
             else:
                 props_np = proposals[0].cpu().numpy()
             cm._drop_offset_dev = None
-            rois, caps, npos, nneg = detection_targets(props_np, gt_caps[0], gt_norm[0], cfg, mix)
+            if given is not None:
+                rois, caps = given
+                npos = int((np.asarray(caps)[:, 1:] > 0).any(axis=1).sum())
+                nneg = int((np.abs(rois).sum(axis=1) > 0).sum()) - npos
+            else:
+                rois, caps, npos, nneg = detection_targets(props_np, gt_caps[0], gt_norm[0], cfg, mix)
             self._last_targets = dict(rois=rois, caps=caps, npos=npos, nneg=nneg)
             boxes = up(rois[None])
             feats = p.roi_features(boxes_norm=boxes, out=self._buf("feats", (1, R, cfg.POOL_SIZE, cfg.POOL_SIZE, 256)))
