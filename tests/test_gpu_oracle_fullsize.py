@@ -361,6 +361,8 @@ def test_configs4_joint_step_at_512px_22_blocks_50k_vocabulary(gpu, dtype):
     # on it; the bf16 leg is handed the same sample (forward_backward(targets=)) and is held to the same oracle result.  (The oracle's
     # cost is its T-prefix decoder at 50 000 words in float64, not the trunk: sharing the trunk alone saved nothing.)
     shared = ORACLE_CACHE.get("configs4_512")
+    if bf and shared is not None:
+        inputs = shared["inputs"]                          # (_joint_full draws the ground truth from the model's OWN proposals: the legs share the fp32 leg's)
     for rep in range(2):                                   # eager plan, then captured graph
         if bf and shared is not None:
             losses = model._loss_list(model.forward_backward(inputs, targets=shared["targets"]))
@@ -374,7 +376,7 @@ def test_configs4_joint_step_at_512px_22_blocks_50k_vocabulary(gpu, dtype):
     else:
         want, G, aux = _joint_oracle(Wt, cfg, inputs, (tg['rois'], tg['caps']), blocks)
         if not bf:
-            ORACLE_CACHE["configs4_512"] = dict(targets=(tg['rois'], tg['caps']), result=(want, G, aux))
+            ORACLE_CACHE["configs4_512"] = dict(inputs=inputs, targets=(tg['rois'], tg['caps']), result=(want, G, aux))
     rec = dict(oracle_seconds=round(time.time() - t0, 1), npos=int(tg['npos']), nneg=int(tg['nneg']), losses={}, grads={})
     rec["oracle_shared_with_the_fp32_leg"] = bool(bf and shared is not None)
     if not bf:                                              # the device's own proposals reproduce the oracle's sample unless near-tied scores swapped

@@ -4,7 +4,7 @@
 # kernel summaries + step timeline, the micro-benchmarks and the 2-rank rehearsals.  Outputs under gpurun_out/profiles_<tag>/ ; copy what
 # should be judged into profiles/.
 set -e
-tag=${1:-r05}
+tag=${1:-r06}
 part=${2:-all}          # a = bench line, kernel traces, PMC passes, joint legs; b = micro-benchmarks, rehearsals; all = both
 out=$PWD/gpurun_out/profiles_$tag
 mkdir -p $out
@@ -26,6 +26,10 @@ python3 $root/bench.py --config joint --steps 10 --joint-dtype f32 --no-roofline
 tail -1 $out/joint_bench_f32.log > $out/joint_bench_f32.json
 python3 $root/bench.py --config joint --steps 10 --joint-dropout 0.2 --no-roofline > $out/joint_bench_dropout.log 2>&1
 tail -1 $out/joint_bench_dropout.log > $out/joint_bench_dropout.json
+python3 $root/bench.py --config joint --steps 10 --joint-images-per-gpu 2 --no-roofline > $out/joint_bench_2img.log 2>&1
+tail -1 $out/joint_bench_2img.log > $out/joint_bench_2img.json
+DCAP_VOCAB_MATERIALIZE=0 python3 $root/bench.py --config joint --steps 10 --no-roofline > $out/joint_bench_recompute_logits.log 2>&1
+tail -1 $out/joint_bench_recompute_logits.log > $out/joint_bench_recompute_logits.json
 rocprofv3 --kernel-trace --stats -d $out/joint -o joint -- python3 $root/bench.py --config joint --steps 10 --no-roofline > $out/joint.log 2>&1
 python3 $root/tools/prof_summary.py $out/joint/joint_results.db $out/joint_kernels.csv 13
 python3 $root/tools/prof_timeline.py $out/joint/joint_results.db $out/joint_timeline.tsv || true
@@ -57,7 +61,7 @@ rm -rf $out/dec
 cd $root
 timeout -k 10 300 python3 bench.py --gpus 2 --steps 5 --warmup 2 > $out/rehearsal_2rank_selflaunch.log 2>&1 || true
 timeout -k 10 300 python3 bench.py --config joint --gpus 2 --steps 5 --warmup 2 --no-roofline > $out/rehearsal_2rank_joint.log 2>&1 || true
-DCAP_GRAD_DTYPE=f32 timeout -k 10 300 python3 bench.py --config joint --gpus 2 --steps 5 --warmup 2 --no-roofline > $out/rehearsal_2rank_joint_f32wire.log 2>&1 || true
+DCAP_GRAD_DTYPE=bf16 timeout -k 10 300 python3 bench.py --config joint --gpus 2 --steps 5 --warmup 2 --no-roofline > $out/rehearsal_2rank_joint_bf16wire.log 2>&1 || true
 bash tools/roialign_profile.sh > /dev/null 2>&1 && cp gpurun_out/roialign_profile.txt $out/roialign_hbm.txt && cp gpurun_out/roialign_hbm.json $out/roialign_hbm.json || true
 fi
 ls $out

@@ -45,10 +45,14 @@ def main():
     for name, sparse, passes, Wx, bx in (("categorical (2 passes)", False, 2, W, b), ("keras_sparse, every row clipped (3 passes)", True, 3, W, b),
                                          ("keras_sparse, no row clipped (2 passes: lazy CLIP)", True, 2, Wn, bn)):
         kw = dict(row_weights=w, keras_sparse=True) if sparse else {}
-        ms = timed(lambda: ops.vocab_ce(X, Wx, bx, t, loss_rows=loss, dlogits=dl, dbias=db, grad_scale=1.0, **kw))
+        ms = timed(lambda: ops.vocab_ce(X, Wx, bx, t, loss_rows=loss, dlogits=dl, dbias=db, grad_scale=1.0, materialize_bf16=False, **kw))
         fwd = timed(lambda: ops.vocab_ce(X, Wx, bx, t, loss_rows=loss, **kw))
         print("%-52s train call %7.1f us = %6.1f us/pass, %6.1f TFLOP/s per pass incl. row kernels; forward-only call %7.1f us"
               % (name, ms * 1e3, ms * 1e3 / passes, passes * gf / ms, fwd * 1e3), flush=True)
+        # round 6: bf16 logits rounded and parked in the gradient's buffer by ONE GEMM pass, gradient (and clip sums) elementwise in place
+        mm = timed(lambda: ops.vocab_ce(X, Wx, bx, t, loss_rows=loss, dlogits=dl, dbias=db, grad_scale=1.0, materialize_bf16=True, **kw))
+        print("%-52s train call %7.1f us: 1 GEMM pass (%6.1f TFLOP/s over the whole call) + %.0f MB of in-place elementwise traffic"
+              % ("  ... materialised bf16 logits", mm * 1e3, gf / mm, 4.0 * M * V / 1e6), flush=True)
 
 
 if __name__ == "__main__":
