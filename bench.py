@@ -707,7 +707,9 @@ def build_joint(args, dev, rank=0, world=1):
 def run_joint(args, dev, rank, world, barrier):
     """Times args.steps joint train steps (see build_joint); returns (seconds, last losses, RoIs per step, the model)."""
     model, inner, inputs, cfg = build_joint(args, dev, rank, world)
-    for _ in range(max(args.warmup, 2)):
+    # warm-up: at least 8 steps on one GPU -- the model's automatic step-path choice needs 3 eager steps, the capture, 2 timed replays and
+    # the step that decides (dense_model.DenseImageCapRCNN._choose_step_path); none of that may sit in the timed region
+    for _ in range(max(args.warmup, 8 if world == 1 else 2)):
         out = inner.train_on_batch(inputs)
     if world > 1 and getattr(inner, "grad_sync", None) is not None and hasattr(inner.grad_sync, "exposed_ms"):
         inner.grad_sync.exposed_ms()
@@ -719,20 +721,22 @@ def run_joint(args, dev, rank, world, barrier):
     barrier()
     dt = time.perf_counter() - t0
     R = cfg.TRAIN_ROIS_PER_IMAGE * args.joint_images_per_gpu          # captions (RoIs with their targets) per step and GPU
-    inner.eager_ms_per_step = None
-    if world == 1 and inner.use_step_graph:
-        # what the data-parallel step gives up by issuing its launches from Python (its collectives cannot sit inside a
-        # capture): the SAME step, same two-stream fork, issued eagerly -- timed after the headline region, reported beside it
-        inner.use_step_graph = False
-        for _ in range(2):
+    inner.other_path_ms_per_step = None
+    if world == 1:
+        # what the data-parallel step gives up (or gains) by issuing its launches from Python (its collectives cannot
+        # sit inside a capture): the SAME step with the same two-stream fork on the OTHER path -- eager when the timed region replayed the
+        # captured graph, the graph when the model's measured choice was eager -- timed after the headline region, reported beside it
+        inner.timed_path = "graph" if (inner.use_step_graph and any(k[0] == "train" for k in inner._graphs)) else "eager"
+        inner.use_step_graph = inner.timed_path == "eager"
+        for _ in range(4):
             inner.train_on_batch(inputs)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            last = inner.train_on_batch(inputs)
+            inner.train_on_batch(inputs)
         torch.cuda.synchronize()
-        inner.eager_ms_per_step = 1e3 * (time.perf_counter() - t1) / args.steps
-        inner.use_step_graph = True
+        inner.other_path_ms_per_step = 1e3 * (time.perf_counter() - t1) / args.steps
+        inner.use_step_graph = inner.timed_path == "graph"
     return dt, out, R, inner
 
 
@@ -951,11 +955,13 @@ def main():
                        # which schedule the timed steps ran: one GPU replays the step behind the encoder as ONE captured
                        # hipGraph with the RPN backward on a second branch; a data-parallel step issues the same launches eagerly, its
                        # collectives from Python as each layer group's backward has been enqueued (they cannot sit inside the capture)
-                       "eager_same_schedule_ms_per_step": None if getattr(inner, "eager_ms_per_step", None) is None else round(inner.eager_ms_per_step, 4),
+                       "other_path_ms_per_step": None if getattr(inner, "other_path_ms_per_step", None) is None else
+                       {("eager" if getattr(inner, "timed_path", "") == "graph" else "graph"): round(inner.other_path_ms_per_step, 4)},
+                       "step_path_choice": getattr(inner, "step_path_choice", None),
                        "step_path": ("eager, data-parallel: RPN backward + its ranges' all-reduce on a second stream beside the proposals -> decoder chain; "
                                      "per-layer-group all-reduce issued from Python behind each group's backward"
-                                     if world > 1 else ("captured hipGraph + RPN backward on a second branch" if inner.use_step_graph and any(k[0] == "train" for k in inner._graphs)
-                                                        else "eager, single stream pair")),
+                                     if world > 1 else ("captured hipGraph + RPN backward on a second branch" if getattr(inner, "timed_path", "graph") == "graph"
+                                                        else "eager launches (the model's measured choice over the captured graph) + RPN backward on a second stream")),
                        "step_graph_fallback": inner.step_graph_fallback,
                        "grad_wire_dtype": getattr(getattr(inner, "grad_sync", None), "dtype", None) if world > 1 else None},
         }
@@ -993,7 +999,6 @@ def main():
                    "images_per_gpu": B, "global_batch_images": B * world, "captions_per_step": B * R * world,
                    "parallelism": "dp%d" % world, "stage4_blocks": args.stage4_blocks, "final_loss": final_loss,
                    "pipeline": "encoder(i+1) || decoder(i), 2 HIP streams" if e2e.pipe is not None else "single stream",
-                   "decoder_behind": getattr(e2e.pipe, "decoder_behind", None),
                    "rccl_ranks": ranks_seen, "dist_backend": backend, "persistent_cus": persistent_cus,
                    "allreduce_exposed_ms_per_step": None if ar is None else round(ar[0], 4),
                    "allreduce_host_wait_ms_per_step": None if ar is None else round(ar[1], 4),

@@ -286,7 +286,14 @@ class DenseImageCapRCNN(object):
         if 6 * self.A > HEAD_PAD:
             raise ValueError("at most 3 anchors per location")
         self._seed = int(seed)
-        self.use_step_graph = step_graph.enabled()        # DCAP_STEP_GRAPH=0: every step eagerly
+        # DCAP_STEP_GRAPH: 0 = every step eagerly, 1 = the captured step graph, unset / auto (round 6) = capture, then KEEP whichever of the
+        # two measured faster on this machine over the first steps (HIP events around whole steps: _choose_step_path) -- on the pool's
+        # boxes the eager step has been 1 - 2.5 % faster in two rounds of measurements (the replay of a two-branch graph costs more than
+        # issuing its launches from a host that stays ahead); a slow or busy host turns that around.  Assigning use_step_graph pins it.
+        self._use_step_graph = step_graph.enabled()
+        self._step_path_auto = os.environ.get("DCAP_STEP_GRAPH", "auto") not in ("0", "1")
+        self._path_events = {"eager": [], "graph": []}
+        self.step_path_choice = None                         # dict(eager_ms, graph_ms, kept) once the automatic choice has been made
         self.use_side_stream = True                          # RPN backward beside the proposals / decoder-forward chain (False: serial order)
         self._side_stream = None
         self.step_graph_fallback = None                      # set to the error text when a step-graph capture failed and the model went eager
@@ -307,6 +314,27 @@ class DenseImageCapRCNN(object):
         self._seed = seed
         self.set_log_dir()
         self._build(seed)
+
+    @property
+    def use_step_graph(self):
+        return self._use_step_graph
+
+    @use_step_graph.setter
+    def use_step_graph(self, value):
+        self._use_step_graph = bool(value)
+        self._step_path_auto = False                          # an explicit choice is kept
+
+    def _choose_step_path(self):
+        """Automatic mode: two eager steps and two replays have been timed (events around the whole step incl. the encoder pass): keep the
+        faster path.  Called at the start of a later step, when those events completed long ago."""
+        ev = self._path_events
+        if not self._step_path_auto or len(ev["eager"]) < 2 or len(ev["graph"]) < 2:
+            return
+        t = {k: min(a.elapsed_time(b) for a, b in v) for k, v in ev.items()}
+        self._step_path_auto = False
+        keep_graph = t["graph"] <= t["eager"]
+        self._use_step_graph = keep_graph
+        self.step_path_choice = dict(eager_ms=round(t["eager"], 4), graph_ms=round(t["graph"], 4), kept="graph" if keep_graph else "eager")
 
     # ---- construction -----------------------------------------------------------------------
     @staticmethod
@@ -1142,8 +1170,20 @@ class DenseImageCapRCNN(object):
         dev = self.device
         gt_norm = self._check_batch(p, images, gt_boxes)
         rpn_up = self._step_uploads(p, rpn_match, rpn_bbox, gt_norm, gt_caps, True)
+        self._choose_step_path()
+        timing = self._step_path_auto and self._use_step_graph
+        if timing:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         p.forward(self._images_u8(images))
         opt = self.optimizer
+
+        def timed(kind, out):
+            if timing and len(self._path_events[kind]) < 2:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                self._path_events[kind].append((e0, e1))
+            return out
 
         def body():
             segs = self._reg_segments()
@@ -1161,10 +1201,12 @@ class DenseImageCapRCNN(object):
                 opt.iterations += 1                              # what the captured Python did once: the host-side counters
                 if float(cm.recurrent_dropout or 0.0) > 0.0:
                     cm._drop_step += 1
-                return self._graph_out[key]
-            if self._graph_warm.get(key, 0) < 2:
-                self._graph_warm[key] = self._graph_warm.get(key, 0) + 1  # eager: sizes every buffer and workspace, builds the masks
-                return body()
+                return timed("graph", self._graph_out[key])
+            warm_steps = 3 if self._step_path_auto else 2        # (automatic mode: the first eager step allocates; the next two are timed)
+            if self._graph_warm.get(key, 0) < warm_steps:
+                self._graph_warm[key] = n_warm = self._graph_warm.get(key, 0) + 1  # eager: sizes every buffer and workspace, builds the masks
+                out = body()
+                return timed("eager", out) if n_warm > 1 else out
             saved = (opt.iterations, cm._drop_step)
             try:
                 torch.cuda.synchronize()

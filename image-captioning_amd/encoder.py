@@ -102,7 +102,6 @@ class EncoderPlan:
         self.stage4_blocks = stage4_blocks
         self.use_graph = bool(use_graph)
         self._graph = None
-        self._graph2 = {}               # cut index -> (graph of ops [0, cut), graph of ops [cut, end)): forward(cut_after=)
         self._warm = False
         self._specs = {s.name: s for s in resnet_fpn_convs(stage4_blocks)}
         self.rpn = rpn
@@ -523,20 +522,9 @@ class EncoderPlan:
             rows.append((op[2], 2.0 * d.N * d.Ho * d.Wo * d.Cout * d.kh * d.kw * d.Cin, a / reps, tile, int(sk.value)))
         return rows
 
-    def _cut_index(self, layer_prefix):
-        """Index of the first op BEHIND the last convolution whose name starts with `layer_prefix` (e.g. 'res3': the end of stage 3)."""
-        last = None
-        for i, op in enumerate(self._ops):
-            if op[0] in ("conv", "chain", "bconv") and any(part.startswith(layer_prefix) for part in str(op[2]).split("+")):
-                last = i
-        return None if last is None or last + 1 >= len(self._ops) else last + 1
-
-    def forward(self, images_u8=None, cut_after=None, between=None):
+    def forward(self, images_u8=None):
         """images_u8: [B,H,W,3] uint8 torch tensor (any device) or None to reuse self.images.
-        Returns (P2, P3, P4, P5), plan-owned buffers valid until the next forward().
-        cut_after (a layer-name prefix, e.g. 'res3') + between (a callable): the pass is issued as TWO captured graphs and `between()` runs
-        on the host between their launches -- the training pipeline records an event there, behind which the previous batch's decoder
-        step starts (pipeline.CaptionTrainPipeline.decoder_behind)."""
+        Returns (P2, P3, P4, P5), plan-owned buffers valid until the next forward()."""
         if images_u8 is not None:
             # host arrays arrive as pageable memory: the runtime moves one 1024x1024 image in ~64 KB pieces (48 copy kernels, 0.7 ms
             # on the compute queue).  A pinned staging buffer + one DMA was tried and measured SLOWER inside the joint step (35 vs
@@ -546,48 +534,21 @@ class EncoderPlan:
             # memory really is asynchronous, and the caller's array may be freed or refilled right away: round 3 found the training
             # pipeline reading half-overwritten images that way.  Device tensors and pinned buffers stay asynchronous.)
             self.images.copy_(images_u8, non_blocking=bool(images_u8.is_cuda or images_u8.is_pinned()))
-        cut = self._cut_index(cut_after) if cut_after else None
-        if cut is None:
-            between = None
-        elif between is None:
-            between = lambda: None
         if not self.use_graph:
-            if cut is None:
-                self._run_ops()
-            else:
-                self._run_ops(0, cut)
-                between()
-                self._run_ops(cut)
-        elif cut is not None and self._graph2.get(cut) is not None:
-            g1, g2 = self._graph2[cut]
-            g1.replay()
-            between()
-            g2.replay()
-        elif cut is None and self._graph is not None:
+            self._run_ops()
+        elif self._graph is not None:
             self._graph.replay()
         elif not self._warm:
             self._run_ops()                 # first call: eager (sets kernel attributes, sizes the workspace)
-            if between is not None:
-                between()
             self._warm = True
         else:
+            g = torch.cuda.CUDAGraph()
             # thread-local capture: the RCCL watchdog thread of a multi-GPU run polls events while this thread captures;
             # under the default (global) mode that would invalidate the capture
-            parts = [(0, None)] if cut is None else [(0, cut), (cut, None)]
-            graphs = []
-            for lo, hi in parts:
-                g = torch.cuda.CUDAGraph()
-                with ops.no_gc_during_capture(), torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    self._run_ops(lo, hi)
-                graphs.append(g)
-            if cut is None:
-                self._graph = graphs[0]
-                graphs[0].replay()
-            else:
-                self._graph2[cut] = tuple(graphs)
-                graphs[0].replay()
-                between()
-                graphs[1].replay()
+            with ops.no_gc_during_capture(), torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self._run_ops()
+            self._graph = g
+            g.replay()
         return self.P
 
     def proposals(self, debug=False):

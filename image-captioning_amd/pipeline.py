@@ -12,15 +12,11 @@ import torch
 
 
 class CaptionTrainPipeline(object):
-    def __init__(self, plan, decoder, rois_per_image, decoder_behind=None):
-        """decoder_behind (layer-name prefix, e.g. 'res3'; default DCAP_DEC_BEHIND or None): the decoder step of batch i starts only when
-        encoder pass i+1 has got behind that layer.  Measured (profiles/r06_decoder_behind.txt): the decoder's small kernels cost the
-        bandwidth-bound stem / stage-2 / stage-3 layers 0.3 ms per pass when they run beside them; beside the stage-4 chain they wait
-        for CU slots instead."""
-        import os
+    def __init__(self, plan, decoder, rois_per_image):
+        # (round 6, tried and removed: starting the decoder step only once the encoder pass has got behind stage 2 / stage 3 -- the
+        # encoder pass as two graphs with an event between them -- to keep the decoder's small kernels away from the bandwidth-bound early
+        # layers, which lose 0.3 ms per pass beside them: 6.18 / 6.15 ms against 6.18 / 6.14 without, profiles/r06_decoder_behind.txt)
         self.plan, self.dec = plan, decoder
-        self.decoder_behind = decoder_behind if decoder_behind is not None else (os.environ.get("DCAP_DEC_BEHIND") or None)
-        self.ev_mid = torch.cuda.Event()
         dev = plan.device
         self.s_enc = torch.cuda.Stream(device=dev)
         self.s_dec = torch.cuda.Stream(device=dev, priority=-1)      # its short kernels slot in between the convs
@@ -46,19 +42,13 @@ class CaptionTrainPipeline(object):
         with torch.cuda.stream(self.s_enc):
             if self.n >= 2:
                 self.s_enc.wait_event(self.ev_free[slot])
-            if self.decoder_behind and hasattr(self.plan, "_cut_index"):
-                self.plan.forward(images, cut_after=self.decoder_behind, between=lambda: self.ev_mid.record(self.s_enc))
-                self._mid_recorded = True
-            else:
-                self.plan.forward(images)
+            self.plan.forward(images)
             self.plan.roi_features(boxes_norm=boxes, out=self.feat[slot])
             self.ev_feat[slot].record(self.s_enc)
 
     def _decode(self, slot, tables):
         with torch.cuda.stream(self.s_dec):
             self.s_dec.wait_event(self.ev_feat[slot])
-            if self.decoder_behind and getattr(self, "_mid_recorded", False):
-                self.s_dec.wait_event(self.ev_mid)          # (recorded by the encoder pass enqueued just before this call)
             f = self.feat[slot]
             loss = self.dec.train_step(f.view(-1, 7, 7, self.fc), tables)
             self.ev_free[slot].record(self.s_dec)
