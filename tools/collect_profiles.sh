@@ -5,12 +5,12 @@
 # should be judged into profiles/.
 set -e
 tag=${1:-r06}
-part=${2:-all}          # a = bench line, kernel traces, PMC passes, joint legs; b = micro-benchmarks, rehearsals; all = both
+part=${2:-all}          # a1 = bench line, kernel trace, PMC passes; a2 = joint legs; a = a1 + a2; b = micro-benchmarks, rehearsals; all = everything
 out=$PWD/gpurun_out/profiles_$tag
 mkdir -p $out
 root=$PWD
 cd /tmp && export TMPDIR=/tmp
-if [ "$part" = "a" ] || [ "$part" = "all" ]; then
+if [ "$part" = "a1" ] || [ "$part" = "a" ] || [ "$part" = "all" ]; then
 python3 $root/bench.py --steps 20 --warmup 3 --layer-table $out/conv_layers.tsv > $out/bench.log 2>&1
 tail -1 $out/bench.log > $out/bench.json
 rocprofv3 --kernel-trace --stats -d $out/trace -o bench -- python3 $root/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --no-alt-math --no-other-configs > $out/trace.log 2>&1
@@ -19,6 +19,8 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $roo
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $root/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-alt-math --no-other-configs --no-pipeline > $out/pmc_write.log 2>&1
 python3 $root/tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write $out/pmc_traffic.json
 rm -rf $out/trace $out/pmc_fetch $out/pmc_write
+fi
+if [ "$part" = "a2" ] || [ "$part" = "a" ] || [ "$part" = "all" ]; then
 # joint model: bench line (bf16 as specified, fp32, the reference's dropout), kernel summary + step timeline (captured graph and eager)
 python3 $root/bench.py --config joint --steps 20 > $out/joint_bench.log 2>&1
 tail -1 $out/joint_bench.log > $out/joint_bench.json
