@@ -523,27 +523,39 @@ __global__ __launch_bounds__(256) void topk_compact_kernel(const float* __restri
 
 // k <= TK_LDS_MAX, round 6: a RANK sort over several workgroups instead of the one-workgroup bitonic network (91 barrier-separated stages
 // for 8192 slots: 72 us on the joint step's serial chain).  The candidates' 64-bit words are unique (key, then ~index), so a
-// candidate's position in the descending order is the number of candidates above it: every block stages all k words in LDS (48 KB at
-// k = 6000), a thread owns one candidate and walks the list two words per 16-byte broadcast read, then writes its unpacked (index,
-// score) at its rank.  Same output as the network, bit for bit; ~3000 iterations of a compare instead of 91 x 4 exchanges + barriers.
+// candidate's position in the descending order is the number of candidates above it: every workgroup stages all k words in LDS (48 KB at
+// k = 6000) and ranks 32 candidates, eight lanes each (188 workgroups at k = 6000), then writes each candidate's unpacked (index, score)
+// at its rank.  Same output as the network, bit for bit.  (A first version with one lane per candidate -- 3000 dependent iterations
+// of a 64-bit compare per thread, 24 workgroups -- took the network's 71 us: the walk is VALU- and LDS-latency-bound per thread.)
 __global__ __launch_bounds__(256) void topk_ranksort_kernel(const unsigned long long* __restrict__ cand, long cand_stride, int k,
                                                             int* __restrict__ vals, float* __restrict__ keys, long out_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     const int b = blockIdx.y;
     const unsigned long long* in = cand + (long)b * cand_stride;
-    for (int i = threadIdx.x; i < k; i += 256) sk[i] = in[i];
+    const int pairs = (k + 1) >> 1;
+    for (int i = threadIdx.x; i < 2 * pairs; i += 256) sk[i] = i < k ? in[i] : 0ull;      // (odd k: a 0 word, below every real one)
     __syncthreads();
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= k) return;
-    const unsigned long long mine = sk[i];
+    // 32 candidates per workgroup, EIGHT lanes per candidate: each lane counts the candidates above `mine` in an eighth of the list,
+    // four independent 16-byte reads in flight; the eight partial counts meet by three shuffles
+    const int i = blockIdx.x * 32 + (threadIdx.x >> 3), part = threadIdx.x & 7;
+    const unsigned long long mine = i < k ? sk[i] : ~0ull;
+    const int per = (pairs + 7) >> 3, j0 = part * per, j1 = min(pairs, j0 + per);
     int rank = 0;
-    const int k2 = k & ~1;
-    for (int j = 0; j < k2; j += 2) {
-        const u64x2 pr = *reinterpret_cast<const u64x2*>(&sk[j]);
-        rank += (pr[0] > mine ? 1 : 0) + (pr[1] > mine ? 1 : 0);
+    int j = j0;
+    for (; j + 4 <= j1; j += 4) {
+        const u64x2 a = *reinterpret_cast<const u64x2*>(&sk[2 * j]), c = *reinterpret_cast<const u64x2*>(&sk[2 * j + 2]);
+        const u64x2 e = *reinterpret_cast<const u64x2*>(&sk[2 * j + 4]), g = *reinterpret_cast<const u64x2*>(&sk[2 * j + 6]);
+        rank += (a[0] > mine) + (a[1] > mine) + (c[0] > mine) + (c[1] > mine) + (e[0] > mine) + (e[1] > mine) + (g[0] > mine) + (g[1] > mine);
     }
-    if (k & 1) rank += sk[k - 1] > mine ? 1 : 0;
+    for (; j < j1; ++j) {
+        const u64x2 a = *reinterpret_cast<const u64x2*>(&sk[2 * j]);
+        rank += (a[0] > mine) + (a[1] > mine);
+    }
+    rank += __shfl_xor(rank, 1, 64);
+    rank += __shfl_xor(rank, 2, 64);
+    rank += __shfl_xor(rank, 4, 64);
+    if (i >= k || part != 0) return;
     vals[(long)b * out_stride + rank] = (int)(0xFFFFFFFFu - (unsigned)(mine & 0xFFFFFFFFull));
     const unsigned key = (unsigned)(mine >> 32), bits = key ^ ((key >> 31) ? 0x80000000u : 0xFFFFFFFFu);
     keys[(long)b * out_stride + rank] = __uint_as_float(bits);
@@ -595,7 +607,7 @@ static int topk_select(const float* scores, int B, int A_total, int k, TopkState
     if (rc) return rc;
     if (P <= TK_LDS_MAX) {
         DC_ENSURE_DYN_LDS(&topk_ranksort_kernel, TK_LDS_MAX * 8);
-        hipLaunchKernelGGL(topk_ranksort_kernel, dim3((k + 255) / 256, B), dim3(256), (size_t)((k + 1) & ~1) * 8, s, cand, (long)P, k, vals, keys, (long)A_total);
+        hipLaunchKernelGGL(topk_ranksort_kernel, dim3((k + 31) / 32, B), dim3(256), (size_t)((k + 1) & ~1) * 8, s, cand, (long)P, k, vals, keys, (long)A_total);
         return check_launch("topk_ranksort_kernel");
     }
     const dim3 sgrid(std::min((P / 2 + 255) / 256, kNumCU * 4), B);
@@ -716,7 +728,7 @@ extern "C" int dc_proposals_f32(const dc_proposal_desc* d, void* workspace, size
 constexpr int DT_MAX_PROPOSALS = 4096, DT_MAX_GT = 512, DT_THREADS = 1024;
 
 __global__ __launch_bounds__(DT_THREADS) void detection_targets_kernel(dc_detection_targets_desc d) {
-    __shared__ __attribute__((aligned(16))) unsigned long long v[DT_MAX_PROPOSALS];       // (class << 62) | (key << 16 ...) see below
+    __shared__ __attribute__((aligned(16))) unsigned long long v[DT_MAX_PROPOSALS + 2];   // (class << 62) | (key << 16 ...) see below
     __shared__ float4 gbox[DT_MAX_GT];
     __shared__ unsigned short best_g[DT_MAX_PROPOSALS];
     __shared__ int wave_nz[DT_THREADS / 64];
@@ -780,57 +792,52 @@ __global__ __launch_bounds__(DT_THREADS) void detection_targets_kernel(dc_detect
     const int npos = min(total_pos, d.max_positive);
     const int want_neg = (int)(d.inv_ratio * (float)npos) - npos;          // tf.cast(r * tf.cast(positive_count, tf.float32), tf.int32) - positive_count
     const int nneg = max(0, min(min(total_neg, want_neg), d.n_rois - npos));
-    // ---- zero fill, then the selected rows on top (disjoint rows: no ordering issue after the barrier)
+    // ---- zero fill (workgroup 0) and the selected rows (every workgroup its own proposals): disjoint rows, no ordering issue
     const int T = d.T;
-    for (int r = tid; r < d.n_rois; r += DT_THREADS)
-        if (r >= npos + nneg) reinterpret_cast<float4*>(d.rois)[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int e = tid; e < d.n_rois * T; e += DT_THREADS)
-        if (e / T >= npos) d.captions[e] = 0;
-    if (tid == 0) { d.counts[0] = npos; d.counts[1] = nneg; }
-    // ---- ranks: number of (class, key, index) triples below mine.  A thread owns up to four proposals (tid + k * DT_THREADS) and ranks
-    // them in ONE walk over v[], two keys per 16-byte LDS read (every lane reads the same address: a broadcast) -- the walk was one pass
-    // of N iterations per owned proposal with an 8-byte read each (round 6: 112 -> ~30 us at 2000 proposals, on the step's serial chain).
-    constexpr int OWN = DT_MAX_PROPOSALS / DT_THREADS;
-    unsigned long long mine[OWN];
-    int rank[OWN];
-#pragma unroll
-    for (int k = 0; k < OWN; ++k) {
-        const int i = tid + k * DT_THREADS;
-        mine[k] = i < N ? v[i] : 0ull;                       // (0: below every real entry's own value is impossible -- rank stays 0, unused)
-        rank[k] = 0;
-    }
-    const int own = (N + DT_THREADS - 1) / DT_THREADS;       // block-uniform: owned slots that hold a proposal for some thread
+    // ---- ranks: number of (class, key, index) triples below mine.  Round 6: the launch is ceil(N / 256) workgroups; every one of them
+    // has built the same v[] above (the class / key pass is 8 us of redundant work), and ranks ITS 256 proposals with FOUR lanes per
+    // proposal, each lane walking a quarter of the list with independent 16-byte LDS reads in flight (the one-workgroup walk of rounds 4-5
+    // was N iterations per thread behind one LDS latency each: 112 us at 2000 proposals, on the step's serial chain).
+    const int own_i = blockIdx.x * (DT_THREADS / 4) + (tid >> 2), part = tid & 3;
+    const bool have = own_i < N;
+    const unsigned long long mine = have ? v[own_i] : 0ull;
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    const int N2 = N & ~1;
-    for (int j = 0; j < N2; j += 2) {
-        const u64x2 pr = *reinterpret_cast<const u64x2*>(&v[j]);
-#pragma unroll
-        for (int k = 0; k < OWN; ++k)
-            if (k < own) rank[k] += (pr[0] < mine[k] ? 1 : 0) + (pr[1] < mine[k] ? 1 : 0);
+    const int pairs = (N + 1) >> 1;                          // v[N] is written as ~0 below when N is odd: above every real entry
+    if ((N & 1) && tid == 0) v[N] = ~0ull;
+    __syncthreads();
+    const int per = (pairs + 3) >> 2, j0 = part * per, j1 = min(pairs, j0 + per);
+    int rank = 0;
+    int j = j0;
+    for (; j + 4 <= j1; j += 4) {
+        const u64x2 a = *reinterpret_cast<const u64x2*>(&v[2 * j]), b = *reinterpret_cast<const u64x2*>(&v[2 * j + 2]);
+        const u64x2 c = *reinterpret_cast<const u64x2*>(&v[2 * j + 4]), e = *reinterpret_cast<const u64x2*>(&v[2 * j + 6]);
+        rank += (a[0] < mine) + (a[1] < mine) + (b[0] < mine) + (b[1] < mine) + (c[0] < mine) + (c[1] < mine) + (e[0] < mine) + (e[1] < mine);
     }
-    if (N & 1) {
-        const unsigned long long last = v[N - 1];
-#pragma unroll
-        for (int k = 0; k < OWN; ++k)
-            if (k < own) rank[k] += last < mine[k] ? 1 : 0;
+    for (; j < j1; ++j) {
+        const u64x2 a = *reinterpret_cast<const u64x2*>(&v[2 * j]);
+        rank += (a[0] < mine) + (a[1] < mine);
     }
-#pragma unroll
-    for (int k = 0; k < OWN; ++k) {
-        const int i = tid + k * DT_THREADS;
-        if (i >= N) continue;
-        const int cls = (int)(mine[k] >> 62);
-        if (cls == 2) continue;
-        int r = rank[k];
-        if (cls == 0) {
-            if (r < npos) {
-                reinterpret_cast<float4*>(d.rois)[r] = props[i];
-                const int32_t* src = d.gt_captions + (long)best_g[i] * T;
-                for (int t = 0; t < T; ++t) d.captions[(long)r * T + t] = src[t];
-            }
-        } else {
-            r -= total_pos;
-            if (r < nneg) reinterpret_cast<float4*>(d.rois)[npos + r] = props[i];
+    rank += __shfl_xor(rank, 1, 64);
+    rank += __shfl_xor(rank, 2, 64);
+    if (blockIdx.x == 0) {                                   // zero fill + counts: once (rows the selected proposals do not touch)
+        for (int r = tid; r < d.n_rois; r += DT_THREADS)
+            if (r >= npos + nneg) reinterpret_cast<float4*>(d.rois)[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = tid; e < d.n_rois * T; e += DT_THREADS)
+            if (e / T >= npos) d.captions[e] = 0;
+        if (tid == 0) { d.counts[0] = npos; d.counts[1] = nneg; }
+    }
+    if (!have || part != 0) return;
+    const int cls = (int)(mine >> 62);
+    if (cls == 2) return;
+    if (cls == 0) {
+        if (rank < npos) {
+            reinterpret_cast<float4*>(d.rois)[rank] = props[own_i];
+            const int32_t* src = d.gt_captions + (long)best_g[own_i] * T;
+            for (int t = 0; t < T; ++t) d.captions[(long)rank * T + t] = src[t];
         }
+    } else {
+        rank -= total_pos;
+        if (rank < nneg) reinterpret_cast<float4*>(d.rois)[npos + rank] = props[own_i];
     }
 }
 
@@ -872,7 +879,8 @@ extern "C" int dc_detection_targets_f32(const dc_detection_targets_desc* d, void
                DC_EINVAL, "dc_detection_targets: needs 1..%d proposals, 0..%d GT boxes, n_rois > 0, 0 <= max_positive <= n_rois", DT_MAX_PROPOSALS,
                DT_MAX_GT);
     DC_REQUIRE(aligned16(d->proposals) && aligned16(d->gt_boxes) && aligned16(d->rois), DC_EALIGN, "dc_detection_targets: boxes must be 16-byte aligned");
-    hipLaunchKernelGGL(detection_targets_kernel, dim3(1), dim3(DT_THREADS), 0, static_cast<hipStream_t>(stream), *d);
+    hipLaunchKernelGGL(detection_targets_kernel, dim3((d->n_proposals + DT_THREADS / 4 - 1) / (DT_THREADS / 4)), dim3(DT_THREADS), 0,
+                       static_cast<hipStream_t>(stream), *d);
     return check_launch("detection_targets_kernel");
 }
 
