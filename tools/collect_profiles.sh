@@ -33,7 +33,7 @@ tail -1 $out/joint_bench_2img.log > $out/joint_bench_2img.json
 DCAP_VOCAB_MATERIALIZE=0 python3 $root/bench.py --config joint --steps 10 --no-roofline > $out/joint_bench_recompute_logits.log 2>&1
 tail -1 $out/joint_bench_recompute_logits.log > $out/joint_bench_recompute_logits.json
 rocprofv3 --kernel-trace --stats -d $out/joint -o joint -- python3 $root/bench.py --config joint --steps 10 --no-roofline > $out/joint.log 2>&1
-python3 $root/tools/prof_summary.py $out/joint/joint_results.db $out/joint_kernels.csv 13
+python3 $root/tools/prof_summary.py $out/joint/joint_results.db $out/joint_kernels.csv 32   # 8 warm-up + 10 timed + 4 + 10 steps on the other path
 python3 $root/tools/prof_timeline.py $out/joint/joint_results.db $out/joint_timeline.tsv || true
 rm -rf $out/joint
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/jf -- python3 $root/bench.py --config joint --steps 3 --warmup 2 --no-roofline > $out/joint_pmc_fetch.log 2>&1
