@@ -1141,3 +1141,91 @@ def test_joint_step_graph_is_dropped_and_recaptured_when_what_it_baked_changes(g
             assert seen == [True, False, True, (False, True), True], seen
         out[mode] = model.store.flat.cpu().numpy()
     np.testing.assert_array_equal(out["graph"], out["eager"])
+
+
+def test_joint_model_two_images_per_gpu_small(gpu, tmp_path):
+    """IMAGES_PER_GPU = 2 at 128 px (the 512-px oracle comparison is tests/test_gpu_oracle_fullsize.py): losses and gradients pooled over
+    the batch against M.joint_loss_and_grads_batch with images whose counts differ; the captured optimizer step equals the eager one
+    bit for bit; train() runs the batched generator end to end; batched inference returns per image what a one-image model returns."""
+    from image_captioning_amd import synth, utils
+    from image_captioning_amd.dense_model import DenseImageCapRCNN
+    S, V, T, blocks = 128, 24, 5, 1
+    _, cfg, Wt = make_joint(S, V, T, blocks)
+    cfg.IMAGES_PER_GPU, cfg.BATCH_SIZE = 2, 2
+    one = joint_inputs(S, V, T, seed=8)
+    two = joint_inputs(S, V, T, seed=9)                      # image 1: the same picture (its proposals meet the GT boxes), but two GT boxes
+    two[5][0, 0] = 0                                          # instead of three, other captions, another anchor selection and target rows
+    two[4][0, 0] = 0
+    two[4][0, 1] = [1, 7, 2, 0, 0][:T]
+    two[4][0, 2] = [1, 9, 11, 13, 2][:T]
+    inputs = [np.concatenate([a, b]) for a, b in zip(one, two)]
+    model = DenseImageCapRCNN("training", cfg, "logs", stage4_blocks=blocks)
+    model.set_weights(Wt)
+    for rep in range(2):
+        losses = model._loss_list(model.forward_backward(inputs, shuffle=None))
+    tg = model.last_targets
+    assert tg['rois'].shape[0] == 2 and np.all(tg['npos'] > 0), tg['npos']
+    oc = dict(mean_pixel=MEAN, scales=cfg.RPN_ANCHOR_SCALES, ratios=cfg.RPN_ANCHOR_RATIOS, strides=cfg.BACKBONE_STRIDES,
+              proposal_count=cfg.POST_NMS_ROIS_TRAINING, nms=cfg.RPN_NMS_THRESHOLD, train_rois=cfg.TRAIN_ROIS_PER_IMAGE,
+              positive_ratio=cfg.ROI_POSITIVE_RATIO, weight_decay=cfg.WEIGHT_DECAY, T=cfg.PADDING_SIZE)
+    want, G, auxes = M.joint_loss_and_grads_batch({k: np.asarray(v, np.float64) for k, v in Wt.items()}, inputs[0], inputs[2][:, :, 0], inputs[3],
+                                                  inputs[4], inputs[5], oc, (tg['rois'], tg['caps']), stage4_blocks=blocks)
+    for k in ('imgcap_loss', 'rpn_class_loss', 'rpn_bbox_loss', 'reg_loss', 'loss'):
+        assert abs(losses[k] - want[k]) < 1e-4 * max(1.0, abs(want[k])), (k, losses[k], want[k])
+    got = joint_grads_as_reference(model)
+    worst = {k: rel_err(got[k], G[k]) for k in M.joint_trainable(Wt)}
+    assert max(worst.values()) < 5e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    # eager and captured optimizer steps on the batch: bit-equal weights
+    flats = {}
+    for mode in ("eager", "graph"):
+        m = DenseImageCapRCNN("training", cfg, "logs", stage4_blocks=blocks)
+        m.set_weights(Wt)
+        m.compile(1e-4)
+        m.use_step_graph = mode == "graph"
+        for _ in range(5):
+            m.train_on_batch(inputs)
+        if mode == "graph":
+            assert any(k[0] == "train" for k in m._graphs)
+        flats[mode] = m.store.flat.clone()
+    assert torch.equal(flats["eager"], flats["graph"])
+    # batched inference == two one-image passes
+    cfg.POST_NMS_ROIS_INFERENCE, cfg.DETECTION_MAX_INSTANCES = 40, 10
+    inf2 = DenseImageCapRCNN("inference", cfg, "logs", stage4_blocks=blocks)
+    inf2.set_weights(Wt)
+    res2 = inf2.generate_captions([inputs[0][0], inputs[0][1]], return_probabilities=False)
+    _, cfg1, _ = make_joint(S, V, T, blocks)
+    cfg1.POST_NMS_ROIS_INFERENCE, cfg1.DETECTION_MAX_INSTANCES = 40, 10
+    inf1 = DenseImageCapRCNN("inference", cfg1, "logs", stage4_blocks=blocks)
+    inf1.set_weights(Wt)
+    assert len(res2) == 2
+    for b in range(2):                                        # (a batch of two may pick other conv tiles than a batch of one: last-bit differences)
+        r1 = inf1.generate_captions([inputs[0][b]], return_probabilities=False)[0]
+        assert abs(len(r1["rois"]) - len(res2[b]["rois"])) <= 1 and len(r1["rois"]) > 0
+        same = sum(1 for box, ids in zip(r1["rois"], r1["ids"])
+                   if any(np.abs(box - bx).max() <= 1 and np.array_equal(ids, ix) for bx, ix in zip(res2[b]["rois"], res2[b]["ids"])))
+        assert same >= 0.8 * len(r1["rois"]), (same, len(r1["rois"]))
+    # train(): the generator's batches of two images through fit's loop, one checkpoint
+    cfg.STEPS_PER_EPOCH, cfg.MAX_GT_INSTANCES = 2, 6
+
+    class Toy(utils.Dataset):
+        def load_image(self, image_id):
+            return np.random.RandomState(image_id).randint(0, 255, (S, S, 3)).astype(np.uint8)
+
+        def load_captions_and_rois(self, image_id):
+            r = np.random.RandomState(100 + image_id)
+            n = 2 + image_id % 3
+            y, x = r.randint(0, 60, n), r.randint(0, 60, n)
+            boxes = np.stack([y, x, y + r.randint(20, 60, n), x + r.randint(20, 60, n)], axis=1)
+            caps = np.zeros((n, T), np.float32)
+            caps[:, 0], caps[:, 1:3], caps[:, 3] = 1, r.randint(3, V, (n, 2)), 2
+            return boxes, caps
+    train, val = Toy(), Toy()
+    for ds, ids in ((train, range(4)), (val, range(4, 6))):
+        for i in ids:
+            ds.add_image("toy", image_id=i, path=None)
+        ds.prepare()
+    tm = DenseImageCapRCNN("training", cfg, str(tmp_path / "logs"), stage4_blocks=blocks)
+    tm.set_weights(Wt)
+    hist = tm.train(train, val, learning_rate=1e-5, epochs=1, layers="no_backbone")
+    assert len(hist) == 1 and all(np.isfinite(v) for v in hist[0].values())
+    assert not np.array_equal(tm.get_weights_dict()['fpn_p2/kernel'], np.asarray(Wt['fpn_p2/kernel'], np.float32))
