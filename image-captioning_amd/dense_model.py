@@ -955,8 +955,7 @@ class DenseImageCapRCNN(object):
         # large kernels) needs only the encoder's outputs and the step's RPN targets, while the chain proposals -> top-k -> NMS scan ->
         # detection targets -> RoIAlign -> head + LSTM forward is a string of small, latency-bound launches (the NMS scan alone is one
         # wave for 0.28 ms).  They run side by side: the RPN backward on a second stream, forked here and joined before the RoIAlign
-        # backward adds into dP.  (Captured: two branches of the step's hipGraph.  Data parallel: serial as before -- the RPN ranges'
-        # all-reduce is issued from Python right behind their backward.)
+        # backward adds into dP.  (Captured: two branches of the step's hipGraph.)
         overlap_dp = self.grad_sync is not None and hasattr(self.grad_sync, "ready") and getattr(self.grad_sync, "world", 1) > 1
         # Data parallel (round 6): the same fork.  The RPN ranges' regulariser pass and their all-reduce are issued from INSIDE the side
         # stream's context right behind the RPN backward -- torch.distributed orders a collective behind the stream that is current when
