@@ -30,8 +30,12 @@ def close(got, want, tol=3e-5):
     want = np.asarray(want, np.float64)
     assert got.shape == want.shape, (got.shape, want.shape)
     scale = max(1.0, float(np.abs(want).max()))
-    err = float(np.abs(got - want).max()) / scale
-    assert err < tol, "max err %.3e (scaled) exceeds %.1e" % (err, tol)
+    diff = np.abs(got - want)
+    err = float(diff.max()) / scale
+    if not err < tol:                                          # where, and how many: a lone entry reads differently from a spread-out excess
+        at = np.unravel_index(int(diff.argmax()), diff.shape)
+        raise AssertionError("max err %.3e (scaled) exceeds %.1e at %s: got %.9g want %.9g; %d of %d entries above the tolerance"
+                             % (err, tol, at, got[at], want[at], int((diff > tol * scale).sum()), diff.size))
 
 
 def test_cast_is_round_to_nearest_even(ops):
