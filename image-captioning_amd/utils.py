@@ -198,3 +198,11 @@ def trim_zeros(x):
     """Rows that are not all zero (utils.py:410-417)."""
     assert len(x.shape) == 2
     return x[~np.all(x == 0, axis=1)]
+
+
+def compute_recall(pred_boxes, gt_boxes, iou):
+    """(share of GT boxes that are some prediction's best match at IoU >= iou, indices of those predictions) (utils.py:420-436)."""
+    overlaps = compute_overlaps(pred_boxes, gt_boxes)
+    best, arg = np.max(overlaps, axis=1), np.argmax(overlaps, axis=1)
+    positive_ids = np.where(best >= iou)[0]
+    return len(set(arg[positive_ids])) / gt_boxes.shape[0], positive_ids

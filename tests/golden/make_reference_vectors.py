@@ -326,7 +326,10 @@ def main():
     out["v2_seq/image_roi_next"] = np.asarray([[s_[0], s_[1], s_[3]] for s_ in seqs])
     out["v2_seq/prefix_flat"] = np.asarray([w for s_ in seqs for w in list(s_[2]) + [-1]])
 
-    USEP = functions_from(os.path.join(SEP, "utils.py"), ["compute_iou", "compute_overlaps", "box_refinement"])
+    USEP = functions_from(os.path.join(SEP, "utils.py"), ["compute_iou", "compute_overlaps", "box_refinement", "compute_recall"])
+    for thr in (0.3, 0.5):
+        rec, pos = USEP.compute_recall(b1, b2, thr)
+        out["sep/recall_%02d" % int(thr * 10)], out["sep/recall_pos_%02d" % int(thr * 10)] = np.asarray(rec), pos
     out["sep/overlaps"] = USEP.compute_overlaps(b1, b2)
     out["sep/refine"] = USEP.box_refinement(b1.copy(), g)
     ib2 = np.round(b1).astype(np.int32)

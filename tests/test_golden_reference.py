@@ -268,6 +268,10 @@ def test_utils_namespace_box_helpers_match_reference():
         assert got.dtype == want.dtype == np.float32
         np.testing.assert_array_equal(got, want)
     np.testing.assert_array_equal(U.trim_zeros(G["trim/in"]), G["trim/out"])
+    for thr in (0.3, 0.5):
+        rec, pos = U.compute_recall(b1, b2, thr)
+        assert rec == float(G["sep/recall_%02d" % int(thr * 10)])
+        np.testing.assert_array_equal(pos, G["sep/recall_pos_%02d" % int(thr * 10)])
 
 
 def _evaluator():
