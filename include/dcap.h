@@ -536,7 +536,9 @@ int dc_scatter2_add_f32(const float* coarse, float* fine, int N, int Hc, int Wc,
  * non-deterministic, this one is reproducible from (seed, offset).  offset_dev (optional): a device word added to `offset`, so that a
  * captured hipGraph draws a fresh sample every replay.
  * Writes rois [n_rois][4] (positives, then negatives, zero padded), captions [n_rois][T] (the best GT box's caption for positives,
- * zeros otherwise) and counts = {n_pos, n_neg}.  Limits: n_proposals <= 4096, n_gt <= 512.  One workgroup; no workspace. */
+ * zeros otherwise) and counts = {n_pos, n_neg}.  Limits: n_proposals <= 4096, n_gt <= 512.  ceil(n_proposals / 256) workgroups, each
+ * building the same class / key table in its LDS and ranking its own 256 proposals (outputs are disjoint rows); one image per call (a batch:
+ * one call per image, dense_img_cap/utils.py batch_slice); no workspace. */
 typedef struct {
     int n_proposals, n_gt, n_rois, T;
     const float*   proposals;
