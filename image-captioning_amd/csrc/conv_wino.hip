@@ -22,10 +22,11 @@
 //   The first version (round 3: thread (tile, channel quad) loads its 4 x 4 patch into registers, transforms it and writes a V image,
 //     two blocks per CU) asked L2 for 128 KB per 1.05 MFLOP-chunk and block: 810 us on fpn_p2, where the MFMAs alone need 437; it
 //     was removed in round 5 (profiles/r03_winograd_bench.txt keeps its numbers).
-//   wino64_kernel / wino32_kernel = wino_body<2 / 1> (DESIGN.md section 5 has the measurements that led here): 64 / 32 tiles per
+//   wino64_kernel / wino32_kernel = wino_body<2 / 1> (HISTORY.md section 5 has the measurements that led here): 64 / 32 tiles per
 //     item, the input patch staged ONCE per 32 channels by LDS-DMA, no V image -- every wave makes its own MFMA fragments straight
-//     from the patch --, persistent blocks, vector-memory instructions issued one per MFMA: 639 us.  64-tile items (512 threads,
-//     one block per CU) where every CU gets one, 32-tile items (256 threads, two blocks per CU) for the small layers.
+//     from the patch --, persistent blocks, vector-memory instructions issued one per MFMA: 639 us.  fp32 products: 64-tile items
+//     (512 threads, one block per CU) where every CU gets one, 32-tile items (256 threads, two blocks per CU) for the small layers;
+//     split-bf16 products (the default plan): 32-tile items everywhere since round 6 (conv_winograd_tiles below).
 #include "igemm_bf16s.h"
 #include <algorithm>
 
@@ -526,6 +527,12 @@ static int persistent_cus() {
 int conv_winograd_tiles(const dc_conv_desc* d) {
     const int force = wino_force();
     if (force == 32 || force == 64) return force;
+    // Split-bf16 products (round 6): 32-tile items on every layer.  Alone on the chip the two item sizes are within 0 - 4 % of each other
+    // (tools/conv_bench.py: res2_2b 51.3 -> 48.9 us, fpn_p3 138.5 -> 132.5, res4_2b 39.7 -> 39.5), but in the training pipeline two
+    // 256-thread blocks per CU hide each other's fixed cost per item (7.5 us: first patch, U prefetch, output transform) and leave
+    // the decoder stream's small kernels a place beside them: whole encoder pass 5.76 -> 5.41 ms, headline 10 440 -> 10 930 captions/s
+    // (profiles/r06_wino_tiles.txt).  The fp32-product kernels keep the item-count rule they were measured with (rounds 3 - 4).
+    if (wino_b3(d)) return 32;
     const int th = (d->H + 1) / 2, tw = (d->W + 1) / 2;
     const long items64 = (long)d->N * ((th + 7) / 8) * ((tw + 7) / 8) * (d->Cout / 32);
     return items64 >= kNumCU ? 64 : 32;

@@ -195,7 +195,8 @@ def test_conv2d_winograd_matches_oracle_and_direct(ops, case, products):
     got = ops.conv2d(*args, out=out, **kw)
     th, tw = (H + 1) // 2, (W + 1) // 2
     big = N * ((th + 7) // 8) * ((tw + 7) // 8) * (Cout // 32) >= 256
-    assert ops.conv2d_kernel_name(*args, **kw) == ("wino64" if big else "wino32") + ("b" if products == "b3" else "") + "_kernel"
+    # fp32 products: 64-tile items where every CU gets one; split-bf16 products: 32-tile items everywhere (round 6, conv_winograd_tiles)
+    assert ops.conv2d_kernel_name(*args, **kw) == ("wino32b_kernel" if products == "b3" else ("wino64_kernel" if big else "wino32_kernel"))
     close(got, y, 2e-5)
     direct = ops.conv2d(*args)
     assert not ops.conv2d_kernel_name(*args).startswith("wino")
@@ -214,22 +215,23 @@ WINO_PERSISTENT_CASES = [
 ]
 
 
-def _wino_items_per_block(N, H, W, Cout):
+def _wino_items_per_block(N, H, W, Cout, tiles=64):
+    """Work items of a layer and items per persistent block: 64-tile items on 256 blocks (one per CU), 32-tile items (8 x 4 tiles) on 512."""
     th, tw = (H + 1) // 2, (W + 1) // 2
-    items = N * ((th + 7) // 8) * ((tw + 7) // 8) * (Cout // 32)
-    return items, items / 256.0
+    items = N * ((th + (7 if tiles == 64 else 3)) // (8 if tiles == 64 else 4)) * ((tw + 7) // 8) * (Cout // 32)
+    return items, items / (256.0 if tiles == 64 else 512.0)
 
 
 @pytest.mark.parametrize("products", ["b3", "f32"])
 @pytest.mark.parametrize("case", WINO_PERSISTENT_CASES)
 def test_conv2d_winograd_persistent_multi_item_blocks_at_benchmark_shapes(ops, case, products):
-    """The kernel behind the headline number on the code path the headline runs (products = 'b3': wino64b_kernel, the split-bf16
-    products the encoder plan uses by default since round 5; 'f32': wino64_kernel): >= 2 work items per persistent
-    block (next-item patch prefetch, M image in buffer 1 while buffer 0 refills, even / odd KP).  Whole tensor against the direct
+    """The kernel behind the headline number on the code path the headline runs (products = 'b3': wino32b_kernel since round 6 -- the
+    split-bf16 products of the default plan on 32-tile items, two persistent blocks per CU; 'f32': wino64_kernel): >= 2 work items per
+    persistent block (next-item patch prefetch, M image in buffer 1 while buffer 0 refills, even / odd KP).  Whole tensor against the direct
     implicit-GEMM kernel (2e-5), and against the float64 oracle on windows that straddle image corners, image edges, the
     16-pixel item boundaries and the image-0 / image-1 seam, over ALL output channels (every slice of every sampled item)."""
     N, H, W, Cin, Cout = case
-    items, per_block = _wino_items_per_block(N, H, W, Cout)
+    items, per_block = _wino_items_per_block(N, H, W, Cout, 32 if products == "b3" else 64)
     assert items >= 256 and per_block > 1.0, "case does not reach the multi-item loop: %d items" % items
     g = torch.Generator(device="cuda").manual_seed(N * 1000003 + H * 1009 + Cin * 31 + Cout)
     x = torch.randn(N, H, W, Cin, device="cuda", generator=g)
@@ -238,7 +240,7 @@ def test_conv2d_winograd_persistent_multi_item_blocks_at_benchmark_shapes(ops, c
     sh = torch.randn(Cout, device="cuda", generator=g)
     kw = dict(w_wino_b3=ops.winograd_pack_b3(w, Cin, Cout)) if products == "b3" else dict(w_wino=ops.winograd_pack(w, Cin, Cout))
     args = (x, w, 3, 3, 1, 1, 1, H, W, sc, sh, None, 0, True)
-    assert ops.conv2d_kernel_name(*args, **kw) == ("wino64b_kernel" if products == "b3" else "wino64_kernel")
+    assert ops.conv2d_kernel_name(*args, **kw) == ("wino32b_kernel" if products == "b3" else "wino64_kernel")
     out = torch.full((N, H, W, Cout), float("nan"), device="cuda")
     got = ops.conv2d(*args, out=out, **kw)
     assert bool(torch.isfinite(got).all())
@@ -269,28 +271,30 @@ def test_conv2d_winograd_persistent_multi_item_blocks_at_benchmark_shapes(ops, c
 
 @pytest.mark.parametrize("force", ["32", "64"])
 def test_conv2d_winograd_forced_kernels_in_a_child_process(ops, force):
-    """DCAP_WINO_TILES (read once per process) forces the 32- / 64-tile items whatever the layer's size.  Each against the direct kernel."""
+    """DCAP_WINO_TILES (read once per process) forces the 32- / 64-tile items whatever the layer's size and product form (the 64-tile
+    split-bf16 kernel wino64b runs only when forced since round 6: it incl. its multi-item loop is covered here).  Each against the
+    direct kernel."""
     import subprocess
     import sys
     code = (
         "import numpy as np, torch\n"
         "from image_captioning_amd import ops\n"
         "torch.manual_seed(0)\n"
-        "for (N, H, W, Cin, Cout) in ((1, 12, 20, 64, 64), (2, 33, 17, 32, 96)):\n"
+        "for (N, H, W, Cin, Cout) in ((1, 12, 20, 64, 64), (2, 33, 17, 32, 96), (2, 128, 128, 128, 128)):\n"
         "    x = torch.randn(N, H, W, Cin, device='cuda'); w = torch.randn(Cout, 9 * Cin, device='cuda') / (9 * Cin) ** 0.5\n"
         "    sh = torch.randn(Cout, device='cuda')\n"
-        "    u = ops.winograd_pack(w, Cin, Cout)\n"
-        "    a = ops.conv2d(x, w, 3, 3, 1, 1, 1, H, W, None, sh, None, 0, True, w_wino=u)\n"
         "    b = ops.conv2d(x, w, 3, 3, 1, 1, 1, H, W, None, sh, None, 0, True)\n"
-        "    name = ops.conv2d_kernel_name(x, w, 3, 3, 1, 1, 1, H, W, None, sh, None, 0, True, w_wino=u)\n"
-        "    err = float((a - b).abs().max() / b.abs().max())\n"
-        "    assert err < 2e-5, (name, err)\n"
-        "    print(name, err)\n")
+        "    for kw in (dict(w_wino=ops.winograd_pack(w, Cin, Cout)), dict(w_wino_b3=ops.winograd_pack_b3(w, Cin, Cout))):\n"
+        "        a = ops.conv2d(x, w, 3, 3, 1, 1, 1, H, W, None, sh, None, 0, True, **kw)\n"
+        "        name = ops.conv2d_kernel_name(x, w, 3, 3, 1, 1, 1, H, W, None, sh, None, 0, True, **kw)\n"
+        "        err = float((a - b).abs().max() / b.abs().max())\n"
+        "        assert err < 2e-5, (name, err)\n"
+        "        print(name, err)\n")
     env = dict(os.environ, DCAP_WINO_TILES=force)
     r = subprocess.run([sys.executable, "-c", code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert ("wino64_kernel" if force == "64" else "wino32_kernel") in r.stdout
+    assert ("wino64_kernel" if force == "64" else "wino32_kernel") in r.stdout and ("wino64b_kernel" if force == "64" else "wino32b_kernel") in r.stdout
 
 
 @pytest.mark.parametrize("products", ["b3", "f32"])
