@@ -18,8 +18,11 @@ class CaptionTrainPipeline(object):
         # layers, which lose 0.3 ms per pass beside them: 6.18 / 6.15 ms against 6.18 / 6.14 without, profiles/r06_decoder_behind.txt)
         self.plan, self.dec = plan, decoder
         dev = plan.device
+        # equal stream priorities (round 6): the decoder's short kernels fill what the encoder's launches leave; with the decoder stream at
+        # high priority (rounds 2 - 5) they were served first and cost the encoder pass -- the critical path -- 0.6 % (10 882 / 10 967 against
+        # 10 953 / 11 037 captions/s, alternating runs on one box; encoder high / decoder normal: 10 870 / 10 860)
         self.s_enc = torch.cuda.Stream(device=dev)
-        self.s_dec = torch.cuda.Stream(device=dev, priority=-1)      # its short kernels slot in between the convs
+        self.s_dec = torch.cuda.Stream(device=dev)
         B = plan.B
         self.fc = fc = getattr(plan, "feat_channels", 256)
         self.feat = [torch.empty((B, rois_per_image, 7, 7, fc), dtype=torch.float32, device=dev) for _ in range(2)]
