@@ -20,7 +20,7 @@ The line's `dtype` says so.  Inputs are resident in HBM before the timed region.
 Rank 0 prints ONE JSON line (see the driver contract) with extra objects:
   roofline      -- the dominant kernel (the conv instantiation with the largest time share): the FLOPs the matrix pipe EXECUTES per
                    launch / mean launch time against the peak OF THE PIPE THE KERNEL RUNS ON (`peak`: 2500 TFLOP/s dense bf16 for the
-                   split-bf16 kernels wino64b / wino32b / pw_chain<..., true> / igemm_bs, 157.3 TFLOP/s for the fp32-MFMA kernels);
+                   split-bf16 kernels wino32b (wino64b when forced) / pw_chain<..., true> / igemm_bs, 157.3 TFLOP/s for the fp32-MFMA kernels);
                    `frac` <= 1 by construction.  For the Winograd F(2x2,3x3) kernels executed = direct-form FLOPs / 2.25
                    (x 6 when split), and the direct-form rate is reported beside it as `achieved_direct_form` with
                    `frac_algorithmic` = direct-form rate / the same pipe's peak (SURVEY 8d's definition).  `target` states
