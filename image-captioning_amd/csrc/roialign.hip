@@ -8,6 +8,11 @@
 #include <math.h>
 #include <algorithm>
 
+// Every float operation of this file is rounded on its own, as the TF float32 kernels it mirrors round theirs: the decisions taken on the
+// results (a sample inside the map or not, floor/ceil, IoU > threshold, sort order) are discontinuous, and a multiply fused into the
+// following add moves them (HIP's __fmul_rn / __fadd_rn are plain operators: without this the compiler is free to contract them).
+#pragma clang fp contract(off)
+
 namespace dcap {
 
 __device__ __forceinline__ int roi_level(float y1, float x1, float y2, float x2, float image_area) {

@@ -32,3 +32,10 @@ def test_ops_refuse_cpu_tensors():
     from image_captioning_amd import ops, _lib
     with pytest.raises(_lib.DcapError):
         ops.gemm(torch.zeros(8, 8), torch.zeros(8, 8))
+
+
+def test_device_code_is_built_without_compiler_packed_f32():
+    """The build keeps -fno-slp-vectorize: with the compiler's v_pk_*_f32 packing dc_vocab_ce's gradient was not reproducible from call to
+    call on MI355X (tests/test_gpu_bf16.py::test_vocab_ce_is_bit_identical_from_call_to_call; DESIGN.md section 8)."""
+    import __graft_entry__ as entry
+    assert "-fno-slp-vectorize" in entry.FLAGS and "-O3" in entry.FLAGS

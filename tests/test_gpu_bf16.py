@@ -259,6 +259,34 @@ def test_vocab_ce_masked_keras_sparse(ops, bf16, M, V, K):
     assert torch.equal(only_loss, loss)
 
 
+@pytest.mark.parametrize("bf16,M,V,K,calls", [(True, 130, 50000, 1024, 300), (False, 130, 10000, 256, 100), (True, 600, 50000, 1024, 60)])
+def test_vocab_ce_is_bit_identical_from_call_to_call(ops, bf16, M, V, K, calls):
+    """Identical inputs, identical bits, every call.  The (130, 50000, 1024, bf16) case is the one that did NOT hold this in round 6 while
+    the library was built with the compiler's packed-f32 (v_pk_*_f32) vectorisation: about one call in fifteen -- and the first call of a
+    process more often than not -- returned 16 wrong gradient entries (one row, one float4 component, lanes 48-63 of a wave) and the
+    bias-gradient sums over them; nothing in the kernel is order-dependent (no atomics, fixed-order partial sums), so every call must
+    equal the first (tools/determinism_vocab_ce.py prints the differing entries)."""
+    rng = np.random.default_rng(V + K)
+    X, W, b, t, _ = _ce_case(rng, M, V, K, bf16)
+    b[t[0]] -= 80.0
+    X[1] = 0
+    w = rng.random(M)
+    w[2] = 0.0
+    Xd, Wd = dev(X), dev(W)
+    if bf16:
+        Xd, Wd = ops.to_bf16(Xd), ops.to_bf16(Wd)
+    bd, td, wd = dev(b), dev(t, torch.int32), dev(w)
+    first = None
+    for call in range(calls):
+        out = (torch.empty(M, device="cuda"), torch.empty((M, V), device="cuda"), torch.empty(V, device="cuda"))
+        ops.vocab_ce(Xd, Wd, bd, td, loss_rows=out[0], dlogits=out[1], dbias=out[2], grad_scale=1.0, row_weights=wd, keras_sparse=True)
+        if first is None:
+            first = out
+            continue
+        for name, a, r in zip(("loss", "dlogits", "dbias"), out, first):
+            assert torch.equal(a, r), "call %d: %s differs from the first call's in %d entries" % (call, name, int((a != r).sum()))
+
+
 @pytest.mark.parametrize("bf16,M,V,K", [(False, 300, 1000, 64), (True, 300, 1000, 64), (True, 1500, 8200, 512)])
 def test_vocab_ce_keras_sparse_clip_pass_runs_only_where_a_row_needs_it(ops, bf16, M, V, K):
     """The lazy CLIP pass (round 5): the STATS pass keeps every row's smallest logit, the row kernel marks the rows with a probability

@@ -433,6 +433,26 @@ def test_roi_align_pyramid(ops):
     close(got, want, 1e-5)
 
 
+def test_roi_align_boxes_clipped_to_the_image_border(ops):
+    """Boxes that the ProposalLayer clipped to the image (y2 or x2 exactly 1): the last sample row/column lands ON the last pixel when
+    every float operation is rounded on its own, as TF's kernel does -- y1*(H-1) + 6*((1-y1)*(H-1)/6) -- and for about one such box in
+    twenty-five just OUTSIDE (extrapolation value 0) when the multiply is fused into the add.  Round 6 met exactly that on the box
+    below once the build flags changed which multiplies the compiler fused; the file now forbids the fusion (csrc/roialign.hip)."""
+    rng = np.random.default_rng(11)
+    B, R, C, S = 1, 600, 256, 128
+    maps = [rng.standard_normal((B, S // s, S // s, C)) + 3.0 for s in (4, 8, 16, 32)]       # far from 0: an extrapolated sample shows
+    boxes = np.zeros((B, R, 4), np.float32)
+    y1, x1 = rng.random(R) * 0.7, rng.random(R) * 0.7
+    boxes[0, :, 0], boxes[0, :, 1] = y1, x1
+    boxes[0, :, 2] = np.where(np.arange(R) % 3 != 1, 1.0, y1 + 0.05 + rng.random(R) * 0.25)
+    boxes[0, :, 3] = np.where(np.arange(R) % 3 != 0, 1.0, x1 + 0.05 + rng.random(R) * 0.25)
+    boxes[0, 0] = np.array([float.fromhex('0x1.c84c6ap-2'), float.fromhex('0x1.17b2bcp-3'), 1.0, float.fromhex('0x1.de575ep-2')], np.float32)
+    want = O.pyramid_roi_align(boxes, maps, (S, S, 3), 7)
+    got = ops.roi_align_pyramid([dev(m) for m in maps], dev(boxes), S * S, 7)
+    close(got, want, 1e-5)
+    assert float(np.abs(want[0, 0, 6]).min()) > 0        # the box of round 6: its last row is inside the map
+
+
 @pytest.mark.parametrize("B,T,I,U,masked", [(3, 4, 8, 4, True), (64, 10, 300, 128, True), (8, 15, 64, 512, False), (5, 1, 2048, 256, False),
                                             (70, 6, 32, 512, True), (200, 4, 16, 256, True), (37, 3, 16, 16, True), (300, 3, 16, 512, False),
                                             (64, 15, 300, 1024, True),      # the headline's word-LSTM (64 captions x 15 tokens, 300 -> 1024)
