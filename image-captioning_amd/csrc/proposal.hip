@@ -9,8 +9,15 @@
 
 // Every float operation of this file is rounded on its own, as the TF float32 kernels it mirrors round theirs: the decisions taken on the
 // results (a sample inside the map or not, floor/ceil, IoU > threshold, sort order) are discontinuous, and a multiply fused into the
-// following add moves them (HIP's __fmul_rn / __fadd_rn are plain operators: without this the compiler is free to contract them).
+// following add moves them.  HIP's __fmul_rn / __fadd_rn do not prevent that: they are plain operators in a header parsed before this
+// pragma, so their operations stay fusable after inlining -- the helpers below are compiled under it.
 #pragma clang fp contract(off)
+namespace dcap {
+__device__ __forceinline__ float mul_rn(float a, float b) { return a * b; }
+__device__ __forceinline__ float add_rn(float a, float b) { return a + b; }
+__device__ __forceinline__ float sub_rn(float a, float b) { return a - b; }
+__device__ __forceinline__ float div_rn(float a, float b) { return a / b; }      // correctly rounded: hipcc's default for fp32 division
+}
 
 namespace dcap {
 
@@ -33,8 +40,8 @@ __global__ __launch_bounds__(256) void rpn_score_kernel(dc_proposal_desc d, int 
         const long o = (long)b * d.A_total + level_off + r;
         scores[o] = e1 / (e0 + e1);
         const float* bb = h + A * 2 + a * 4;
-        float4 dl = make_float4(__fmul_rn(bb[0], d.std_dev[0]), __fmul_rn(bb[1], d.std_dev[1]), __fmul_rn(bb[2], d.std_dev[2]),
-                                __fmul_rn(bb[3], d.std_dev[3]));
+        float4 dl = make_float4(mul_rn(bb[0], d.std_dev[0]), mul_rn(bb[1], d.std_dev[1]), mul_rn(bb[2], d.std_dev[2]),
+                                mul_rn(bb[3], d.std_dev[3]));
         reinterpret_cast<float4*>(deltas)[o] = dl;
         if (b == 0) iota[level_off + r] = level_off + r;
     }
@@ -50,29 +57,29 @@ __global__ __launch_bounds__(256) void decode_kernel(dc_proposal_desc d, const i
     const int a = order[(long)b * d.A_total + i];
     const float4 an = reinterpret_cast<const float4*>(d.anchors)[a];
     const float4 dl = reinterpret_cast<const float4*>(deltas)[(long)b * d.A_total + a];
-    float h = __fsub_rn(an.z, an.x), w = __fsub_rn(an.w, an.y);
-    float cy = __fadd_rn(an.x, __fmul_rn(0.5f, h)), cx = __fadd_rn(an.y, __fmul_rn(0.5f, w));
-    cy = __fadd_rn(cy, __fmul_rn(dl.x, h));
-    cx = __fadd_rn(cx, __fmul_rn(dl.y, w));
-    h = __fmul_rn(h, expf(dl.z));
-    w = __fmul_rn(w, expf(dl.w));
-    float y1 = __fsub_rn(cy, __fmul_rn(0.5f, h)), x1 = __fsub_rn(cx, __fmul_rn(0.5f, w));
-    float y2 = __fadd_rn(y1, h), x2 = __fadd_rn(x1, w);
+    float h = sub_rn(an.z, an.x), w = sub_rn(an.w, an.y);
+    float cy = add_rn(an.x, mul_rn(0.5f, h)), cx = add_rn(an.y, mul_rn(0.5f, w));
+    cy = add_rn(cy, mul_rn(dl.x, h));
+    cx = add_rn(cx, mul_rn(dl.y, w));
+    h = mul_rn(h, expf(dl.z));
+    w = mul_rn(w, expf(dl.w));
+    float y1 = sub_rn(cy, mul_rn(0.5f, h)), x1 = sub_rn(cx, mul_rn(0.5f, w));
+    float y2 = add_rn(y1, h), x2 = add_rn(x1, w);
     y1 = fmaxf(fminf(y1, d.image_h), 0.f); x1 = fmaxf(fminf(x1, d.image_w), 0.f);
     y2 = fmaxf(fminf(y2, d.image_h), 0.f); x2 = fmaxf(fminf(x2, d.image_w), 0.f);
-    boxes[idx] = make_float4(__fdiv_rn(y1, d.image_h), __fdiv_rn(x1, d.image_w), __fdiv_rn(y2, d.image_h), __fdiv_rn(x2, d.image_w));
+    boxes[idx] = make_float4(div_rn(y1, d.image_h), div_rn(x1, d.image_w), div_rn(y2, d.image_h), div_rn(x2, d.image_w));
 }
 
 __device__ __forceinline__ bool iou_exceeds(const float4 a, const float4 b, float thr) {
     const float ay0 = fminf(a.x, a.z), ay1 = fmaxf(a.x, a.z), ax0 = fminf(a.y, a.w), ax1 = fmaxf(a.y, a.w);
     const float by0 = fminf(b.x, b.z), by1 = fmaxf(b.x, b.z), bx0 = fminf(b.y, b.w), bx1 = fmaxf(b.y, b.w);
-    const float area_a = __fmul_rn(__fsub_rn(ay1, ay0), __fsub_rn(ax1, ax0));
-    const float area_b = __fmul_rn(__fsub_rn(by1, by0), __fsub_rn(bx1, bx0));
+    const float area_a = mul_rn(sub_rn(ay1, ay0), sub_rn(ax1, ax0));
+    const float area_b = mul_rn(sub_rn(by1, by0), sub_rn(bx1, bx0));
     if (area_a <= 0.f || area_b <= 0.f) return false;
-    const float ih = fmaxf(__fsub_rn(fminf(ay1, by1), fmaxf(ay0, by0)), 0.f);
-    const float iw = fmaxf(__fsub_rn(fminf(ax1, bx1), fmaxf(ax0, bx0)), 0.f);
-    const float inter = __fmul_rn(ih, iw);
-    return __fdiv_rn(inter, __fsub_rn(__fadd_rn(area_a, area_b), inter)) > thr;
+    const float ih = fmaxf(sub_rn(fminf(ay1, by1), fmaxf(ay0, by0)), 0.f);
+    const float iw = fmaxf(sub_rn(fminf(ax1, bx1), fmaxf(ax0, bx0)), 0.f);
+    const float inter = mul_rn(ih, iw);
+    return div_rn(inter, sub_rn(add_rn(area_a, area_b), inter)) > thr;
 }
 
 // mask[b][i][w] bit j: candidate 64*w + j (ranked after i) overlaps candidate i by more than the threshold

@@ -10,15 +10,22 @@
 
 // Every float operation of this file is rounded on its own, as the TF float32 kernels it mirrors round theirs: the decisions taken on the
 // results (a sample inside the map or not, floor/ceil, IoU > threshold, sort order) are discontinuous, and a multiply fused into the
-// following add moves them (HIP's __fmul_rn / __fadd_rn are plain operators: without this the compiler is free to contract them).
+// following add moves them.  HIP's __fmul_rn / __fadd_rn do not prevent that: they are plain operators in a header parsed before this
+// pragma, so their operations stay fusable after inlining -- the helpers below are compiled under it.
 #pragma clang fp contract(off)
+namespace dcap {
+__device__ __forceinline__ float mul_rn(float a, float b) { return a * b; }
+__device__ __forceinline__ float add_rn(float a, float b) { return a + b; }
+__device__ __forceinline__ float sub_rn(float a, float b) { return a - b; }
+__device__ __forceinline__ float div_rn(float a, float b) { return a / b; }      // correctly rounded: hipcc's default for fp32 division
+}
 
 namespace dcap {
 
 __device__ __forceinline__ int roi_level(float y1, float x1, float y2, float x2, float image_area) {
-    const float h = __fsub_rn(y2, y1), w = __fsub_rn(x2, x1);
-    const float ratio = __fdiv_rn(__fsqrt_rn(__fmul_rn(h, w)), __fdiv_rn(224.0f, __fsqrt_rn(image_area)));
-    const float lvl = __fdiv_rn(logf(ratio), logf(2.0f));
+    const float h = sub_rn(y2, y1), w = sub_rn(x2, x1);
+    const float ratio = div_rn(__fsqrt_rn(mul_rn(h, w)), div_rn(224.0f, __fsqrt_rn(image_area)));
+    const float lvl = div_rn(logf(ratio), logf(2.0f));
     if (!(lvl > -100.f)) return 2;          // log(0) = -inf, NaN: TF's int cast underflows, the clamp gives 2
     const int r = (int)rintf(lvl);          // round half to even, like tf.round
     return min(5, max(2, 4 + r));
@@ -39,12 +46,12 @@ __global__ __launch_bounds__(256) void roi_align_kernel(dc_roialign_desc d) {
     const float* fm = d.maps[li] + (long)(box / d.R) * H * W * d.C;
     float4* out = reinterpret_cast<float4*>(d.out) + (long)wave * C4;
 
-    const float hs = (d.pool > 1) ? __fdiv_rn(__fmul_rn(__fsub_rn(bx.z, bx.x), (float)(H - 1)), (float)(d.pool - 1)) : 0.f;
-    const float ws = (d.pool > 1) ? __fdiv_rn(__fmul_rn(__fsub_rn(bx.w, bx.y), (float)(W - 1)), (float)(d.pool - 1)) : 0.f;
-    const float in_y = (d.pool > 1) ? __fadd_rn(__fmul_rn(bx.x, (float)(H - 1)), __fmul_rn((float)py, hs))
-                                    : __fmul_rn(__fmul_rn(0.5f, __fadd_rn(bx.x, bx.z)), (float)(H - 1));
-    const float in_x = (d.pool > 1) ? __fadd_rn(__fmul_rn(bx.y, (float)(W - 1)), __fmul_rn((float)px, ws))
-                                    : __fmul_rn(__fmul_rn(0.5f, __fadd_rn(bx.y, bx.w)), (float)(W - 1));
+    const float hs = (d.pool > 1) ? div_rn(mul_rn(sub_rn(bx.z, bx.x), (float)(H - 1)), (float)(d.pool - 1)) : 0.f;
+    const float ws = (d.pool > 1) ? div_rn(mul_rn(sub_rn(bx.w, bx.y), (float)(W - 1)), (float)(d.pool - 1)) : 0.f;
+    const float in_y = (d.pool > 1) ? add_rn(mul_rn(bx.x, (float)(H - 1)), mul_rn((float)py, hs))
+                                    : mul_rn(mul_rn(0.5f, add_rn(bx.x, bx.z)), (float)(H - 1));
+    const float in_x = (d.pool > 1) ? add_rn(mul_rn(bx.y, (float)(W - 1)), mul_rn((float)px, ws))
+                                    : mul_rn(mul_rn(0.5f, add_rn(bx.y, bx.w)), (float)(W - 1));
     const bool ok = (in_y >= 0.f) && (in_y <= (float)(H - 1)) && (in_x >= 0.f) && (in_x <= (float)(W - 1));
     if (!ok) {
         for (int c = lane; c < C4; c += 64) out[c] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -73,10 +80,10 @@ __global__ __launch_bounds__(256) void roi_align_kernel(dc_roialign_desc d) {
 // Sample coordinates of bin row / column `p` of a box on a map of extent n (TF's operation order, as in the forward kernel).
 __device__ __forceinline__ float roi_sample(float lo, float hi, int p, int n, int pool) {
     if (pool > 1) {
-        const float step = __fdiv_rn(__fmul_rn(__fsub_rn(hi, lo), (float)(n - 1)), (float)(pool - 1));
-        return __fadd_rn(__fmul_rn(lo, (float)(n - 1)), __fmul_rn((float)p, step));
+        const float step = div_rn(mul_rn(sub_rn(hi, lo), (float)(n - 1)), (float)(pool - 1));
+        return add_rn(mul_rn(lo, (float)(n - 1)), mul_rn((float)p, step));
     }
-    return __fmul_rn(__fmul_rn(0.5f, __fadd_rn(lo, hi)), (float)(n - 1));
+    return mul_rn(mul_rn(0.5f, add_rn(lo, hi)), (float)(n - 1));
 }
 
 // backward, DETERMINISTIC (round 3): gather per destination pixel instead of an atomic scatter per bin.  One wave per pixel of
