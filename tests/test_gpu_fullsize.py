@@ -43,11 +43,12 @@ def test_full_size_encoder_graph_replay_is_bit_identical_and_finite(ops):
     img = torch.tensor(synth.images(5, 2), device="cuda")
     img[1] = 97                                                                    # constant image
     outs = []
-    for rep in range(3):                                                            # eager, capture, replay
+    for rep in range(12):                                                           # eager, capture, ten replays: the same bits every time
         P = plan.forward(img)
         outs.append([p.clone() for p in P])
-    for a, b in zip(outs[0], outs[2]):
-        assert torch.equal(a, b)
+    for rep in range(1, 12):
+        for a, b in zip(outs[0], outs[rep]):
+            assert torch.equal(a, b), rep
     for p in outs[0]:
         assert bool(torch.isfinite(p).all())
     P4 = outs[0][2][1]                                                              # [64,64,256] of the constant image
