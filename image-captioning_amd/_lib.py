@@ -256,6 +256,11 @@ def load():
     if not os.path.exists(path):
         raise DcapError("%s is missing: build it with `python __graft_entry__.py` "
                         "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    # torch first: its wheel bundles the HIP / HSA runtime it was built with, and the library must bind to THAT copy (same soname as the
+    # system's /opt/rocm one).  Loaded before torch, the library maps the system runtime, torch then brings its own, and the process
+    # holds two HSA runtimes -- the library's launches fail with "no ROCm-capable device is detected" (build() followed by smoke() in one
+    # process did exactly that).
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported

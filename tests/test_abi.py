@@ -39,3 +39,36 @@ def test_device_code_is_built_without_compiler_packed_f32():
     call on MI355X (tests/test_gpu_bf16.py::test_vocab_ce_is_bit_identical_from_call_to_call; DESIGN.md section 8)."""
     import __graft_entry__ as entry
     assert "-fno-slp-vectorize" in entry.FLAGS and "-O3" in entry.FLAGS
+
+
+def test_library_binds_to_the_hip_runtime_torch_brought(repo_root):
+    """One HIP / HSA runtime per process: loaded before torch, the library would map /opt/rocm's copy and torch then its own bundled
+    one (same soname) -- on a GPU box the library's launches then fail with "no ROCm-capable device is detected" (round 6: build()
+    followed by smoke() in one process).  _lib.load() imports torch first; checked in a fresh interpreter that has not imported it."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from image_captioning_amd import _lib\n"
+            "assert 'torch' not in sys.modules\n"
+            "_lib.load()\n"
+            "libs = sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l or 'libhsa-runtime64' in l))\n"
+            "print('\\n'.join(libs))\n") % repo_root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    libs = out.stdout.split()
+    assert len([l for l in libs if "libamdhip64" in l]) == 1 and len([l for l in libs if "libhsa-runtime64" in l]) == 1, libs
+    assert all(os.sep + "torch" + os.sep in l for l in libs), libs
+
+
+@pytest.mark.gpu
+def test_build_then_smoke_in_one_process(repo_root):
+    """What a driver may do on the GPU box: __graft_entry__.build() (loads the library before anything touched torch.cuda) and then
+    smoke() in the same interpreter."""
+    import subprocess
+    import sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=repo_root, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "smoke ok" in out.stdout, (out.stdout[-1000:], out.stderr[-2000:])
