@@ -776,6 +776,31 @@ def test_roi_align_backward_is_the_adjoint_of_forward(ops):
         close(d, w, 2e-5)
 
 
+def test_roi_align_backward_of_boxes_clipped_to_the_image_border(ops):
+    """The backward's sample coordinates take the same decisions as the forward's (test_roi_align_boxes_clipped_to_the_image_border):
+    300 boxes whose far edge is the image border -- the last sample row / column lands ON the last pixel, or just outside, exactly as the
+    oracle's float32 arithmetic says -- scattered against the oracle's loop, and <forward, g> = <maps, backward>."""
+    rng = np.random.default_rng(12)
+    B, R, C, S = 1, 300, 64, 128
+    maps = [rng.standard_normal((B, S // s, S // s, C)) for s in (4, 8, 16, 32)]
+    boxes = np.zeros((B, R, 4), np.float32)
+    y1, x1 = rng.random(R) * 0.7, rng.random(R) * 0.7
+    boxes[0, :, 0], boxes[0, :, 1] = y1, x1
+    boxes[0, :, 2] = np.where(np.arange(R) % 3 != 1, 1.0, y1 + 0.05 + rng.random(R) * 0.25)
+    boxes[0, :, 3] = np.where(np.arange(R) % 3 != 0, 1.0, x1 + 0.05 + rng.random(R) * 0.25)
+    boxes[0, 0] = np.array([float.fromhex('0x1.c84c6ap-2'), float.fromhex('0x1.17b2bcp-3'), 1.0, float.fromhex('0x1.de575ep-2')], np.float32)
+    g = rng.standard_normal((B, R, 7, 7, C))
+    fwd = ops.roi_align_pyramid([dev(m) for m in maps], dev(boxes), S * S, 7).cpu().numpy().astype(np.float64)
+    dm = [torch.zeros(m.shape, device="cuda") for m in maps]
+    ops.roi_align_pyramid_bwd(dm, dev(boxes), S * S, dev(g), 7)
+    lhs = float((fwd * g).sum())
+    rhs = sum(float((d.cpu().numpy().astype(np.float64) * m).sum()) for d, m in zip(dm, maps))
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
+    want = O.pyramid_roi_align_backward(boxes, [m.shape for m in maps], (S, S), g)
+    for d, w in zip(dm, want):
+        close(d, w, 2e-5)
+
+
 def test_roi_align_backward_is_deterministic_and_accumulates(ops):
     """The backward gathers per destination pixel in a fixed (RoI, bin) order -- no float atomics: two runs are bit-identical even
     with hundreds of overlapping RoIs (incl. boxes that leave the image, degenerate and duplicate boxes, two images), and it ADDS to
