@@ -714,18 +714,48 @@ def run_joint(args, dev, rank, world, barrier):
     if world > 1 and getattr(inner, "grad_sync", None) is not None and hasattr(inner.grad_sync, "exposed_ms"):
         inner.grad_sync.exposed_ms()
         inner.grad_sync.timing = True
+    # The timed schedule (round 6): the frozen backbone of batch i + 1 on a second stream beside the rest of batch i's step
+    # (pipeline.JointTrainPipeline: two encoder plans alternate; bit-equal to the serial steps, tests/test_gpu_models.py).  --no-pipeline, or a
+    # trainable ResNet stage: the serial step.
+    pipe = None
+    if not args.no_pipeline and inner.backbone_from is None:
+        from image_captioning_amd.pipeline import JointTrainPipeline
+        pipe = JointTrainPipeline(model)
+        for _ in range(6):                                # both plans: eager pass, capture, replay of the backbone and FPN / RPN graphs
+            pipe.step(inputs)
+        pipe.flush()
+        if world > 1 and getattr(inner, "grad_sync", None) is not None and hasattr(inner.grad_sync, "exposed_ms"):
+            inner.grad_sync.exposed_ms()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        # per-rank image: every rank steps its own shard (weak scaling).  The losses stay on the device (train_on_batch_device, what the
-        # model's own train() loop calls): no host synchronisation inside the timed region, one read-back after it
-        out_dev = inner.train_on_batch_device(inputs)
+    if pipe is not None:
+        for _ in range(args.steps):
+            pipe.step(inputs)
+        out_dev = pipe.flush()                            # every one of the K steps is complete inside the timed region
+    else:
+        for _ in range(args.steps):
+            # per-rank image: every rank steps its own shard (weak scaling).  The losses stay on the device (train_on_batch_device, what the
+            # model's own train() loop calls): no host synchronisation inside the timed region, one read-back after it
+            out_dev = inner.train_on_batch_device(inputs)
     barrier()
     dt = time.perf_counter() - t0
     out = inner._losses_to_api(out_dev.cpu().numpy())
     R = cfg.TRAIN_ROIS_PER_IMAGE * args.joint_images_per_gpu          # captions (RoIs with their targets) per step and GPU
     inner.other_path_ms_per_step = None
-    if world == 1:
+    inner.pipelined = pipe is not None
+    inner.serial_ms_per_step = None
+    if world == 1 and pipe is not None:
+        # the serial step (eager launches, the path the model's own measurement kept on this pool's boxes) over the same K steps, beside it
+        inner.timed_path = "pipelined"
+        for _ in range(3):
+            inner.train_on_batch(inputs)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            inner.train_on_batch_device(inputs)
+        torch.cuda.synchronize()
+        inner.serial_ms_per_step = 1e3 * (time.perf_counter() - t1) / args.steps
+    elif world == 1:
         # what the data-parallel step gives up (or gains) by issuing its launches from Python (its collectives cannot
         # sit inside a capture): the SAME step with the same two-stream fork on the OTHER path -- eager when the timed region replayed the
         # captured graph, the graph when the model's measured choice was eager -- timed after the headline region, reported beside it
@@ -963,10 +993,14 @@ def main():
                        "other_path_ms_per_step": None if getattr(inner, "other_path_ms_per_step", None) is None else
                        {("eager" if getattr(inner, "timed_path", "") == "graph" else "graph"): round(inner.other_path_ms_per_step, 4)},
                        "step_path_choice": getattr(inner, "step_path_choice", None),
+                       "pipeline": ("backbone(i+1) || rest of step i (FPN, RPN, proposals .. AMSGrad), 2 encoder plans, 2 HIP streams + the RPN-backward branch"
+                                    if getattr(inner, "pipelined", False) else "serial step"),
+                       "serial_ms_per_step": None if getattr(inner, "serial_ms_per_step", None) is None else round(inner.serial_ms_per_step, 4),
                        "step_path": ("eager, data-parallel: RPN backward + its ranges' all-reduce on a second stream beside the proposals -> decoder chain; "
                                      "per-layer-group all-reduce issued from Python behind each group's backward"
                                      if world > 1 else ("captured hipGraph + RPN backward on a second branch" if getattr(inner, "timed_path", "graph") == "graph"
-                                                        else "eager launches (the model's measured choice over the captured graph) + RPN backward on a second stream")),
+                                                        else "eager launches" + (" (the model's measured choice over the captured graph)" if getattr(inner, "timed_path", "") == "eager" else "")
+                                                        + " + RPN backward on a second stream")),
                        "step_graph_fallback": inner.step_graph_fallback,
                        "grad_wire_dtype": getattr(getattr(inner, "grad_sync", None), "dtype", None) if world > 1 else None},
         }

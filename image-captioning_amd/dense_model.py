@@ -389,7 +389,8 @@ class DenseImageCapRCNN(object):
         self.caption_model.recurrent_dropout = float(getattr(cfg, "RECURRENT_DROPOUT", 0.2))    # dense_img_cap/dense_model.py:769-770: recurrent_dropout=0.2
         self.caption_model.dropout_rows = str(getattr(cfg, "DROPOUT_ROWS", "roi"))
         self.store = self.caption_model.store
-        self._plan = None
+        self._plan = None                                    # the encoder plan the step runs on
+        self._plans = []                                     # ... and its siblings (pipeline.JointTrainPipeline alternates between two)
         self._reg_coef = None
         self._bufs = {}
         self._bf16_cache = {}
@@ -416,25 +417,42 @@ class DenseImageCapRCNN(object):
 
     def plan(self):
         if self._plan is None:
-            cfg, w = self.config, self.store.w
-            ext = {name: (w[name + "/kernel"], None, w[name + "/bias"]) for name, _, _ in FPN_CONVS}
-            ext["rpn_conv_shared"] = (w["rpn_conv_shared/kernel"], None, w["rpn_conv_shared/bias"])
-            ext["rpn_head"] = (w["rpn_head/kernel"], None, w["rpn_head/bias"])
-            count = cfg.POST_NMS_ROIS_TRAINING if self.mode == "training" else cfg.POST_NMS_ROIS_INFERENCE
-            rpn = dict(scales=cfg.RPN_ANCHOR_SCALES, ratios=cfg.RPN_ANCHOR_RATIOS, strides=cfg.BACKBONE_STRIDES,
-                       anchor_stride=cfg.RPN_ANCHOR_STRIDE, bbox_std=[float(v) for v in cfg.RPN_BBOX_STD_DEV],
-                       nms_threshold=cfg.RPN_NMS_THRESHOLD, proposal_count=count, head_channels=HEAD_PAD)
-            h, wd = [int(v) for v in cfg.IMAGE_SHAPE[:2]]
-            ext_bn = {}
-            for sp in self._trunk_specs():             # trainable ResNet layers: kernel in place, BN folded on the device every forward
-                ext[sp.name] = (w[sp.name + "/kernel"], None, None)
-                ext_bn[sp.name] = dict(gamma=w[sp.bn + "/gamma"], beta=w[sp.bn + "/beta"], bias=w[sp.name + "/bias"],
-                                       mean=w[sp.bn + "/moving_mean"], var=w[sp.bn + "/moving_variance"])
-            stages = () if self.backbone_from is None else tuple(range(max(self.backbone_from, 2), 6))
-            # the FPN/RPN weights change every step: the plan reads them in place from the parameter bucket
-            self._plan = EncoderPlan(self._backbone, self.images_per_gpu, h, wd, self.device, self.stage4_blocks, cfg.MEAN_PIXEL, rpn=rpn, external=ext,
-                                     math=self.conv_math, external_bn=ext_bn, train_stages=stages)
+            self._plan = self._new_plan()
+            self._plans = [self._plan]
         return self._plan
+
+    def plan_pair(self):
+        """Two encoder plans on the same weights (frozen backbone packed per plan, FPN / RPN weights read in place from the parameter
+        bucket by both), each with its own activation buffers: batch i + 1's backbone pass may write one while batch i's step still
+        reads the other (pipeline.JointTrainPipeline).  use_plan(j) makes one of them the plan the step runs on."""
+        self.plan()
+        while len(self._plans) < 2:
+            self._plans.append(self._new_plan())
+        return self._plans
+
+    def use_plan(self, j):
+        self._plan = self._plans[j]
+        return self._plan
+
+    def _new_plan(self):
+        cfg, w = self.config, self.store.w
+        ext = {name: (w[name + "/kernel"], None, w[name + "/bias"]) for name, _, _ in FPN_CONVS}
+        ext["rpn_conv_shared"] = (w["rpn_conv_shared/kernel"], None, w["rpn_conv_shared/bias"])
+        ext["rpn_head"] = (w["rpn_head/kernel"], None, w["rpn_head/bias"])
+        count = cfg.POST_NMS_ROIS_TRAINING if self.mode == "training" else cfg.POST_NMS_ROIS_INFERENCE
+        rpn = dict(scales=cfg.RPN_ANCHOR_SCALES, ratios=cfg.RPN_ANCHOR_RATIOS, strides=cfg.BACKBONE_STRIDES,
+                   anchor_stride=cfg.RPN_ANCHOR_STRIDE, bbox_std=[float(v) for v in cfg.RPN_BBOX_STD_DEV],
+                   nms_threshold=cfg.RPN_NMS_THRESHOLD, proposal_count=count, head_channels=HEAD_PAD)
+        h, wd = [int(v) for v in cfg.IMAGE_SHAPE[:2]]
+        ext_bn = {}
+        for sp in self._trunk_specs():             # trainable ResNet layers: kernel in place, BN folded on the device every forward
+            ext[sp.name] = (w[sp.name + "/kernel"], None, None)
+            ext_bn[sp.name] = dict(gamma=w[sp.bn + "/gamma"], beta=w[sp.bn + "/beta"], bias=w[sp.name + "/bias"],
+                                   mean=w[sp.bn + "/moving_mean"], var=w[sp.bn + "/moving_variance"])
+        stages = () if self.backbone_from is None else tuple(range(max(self.backbone_from, 2), 6))
+        # the FPN/RPN weights change every step: the plan reads them in place from the parameter bucket
+        return EncoderPlan(self._backbone, self.images_per_gpu, h, wd, self.device, self.stage4_blocks, cfg.MEAN_PIXEL, rpn=rpn, external=ext,
+                           math=self.conv_math, external_bn=ext_bn, train_stages=stages)
 
     # ---- weights ----------------------------------------------------------------------------
     def _unpacked(self, name, packed):
@@ -488,7 +506,7 @@ class DenseImageCapRCNN(object):
                 self._backbone[k] = np.asarray(v, np.float32)
                 backbone_changed = True
         if backbone_changed:
-            self._plan = None
+            self._plan, self._plans = None, []
             self._invalidate_graphs()
         st.refresh_shadow()                  # the bf16 operand copies: once per call, not once per weight
 
@@ -907,7 +925,7 @@ class DenseImageCapRCNN(object):
             return dict(rois=r[0], caps=k[0], npos=int(c[0, 0]), nneg=int(c[0, 1]))
         return dict(rois=r, caps=k, npos=c[:, 0].astype(int), nneg=c[:, 1].astype(int))
 
-    def forward_backward(self, inputs, shuffle="rng", backward=True, targets=None):
+    def forward_backward(self, inputs, shuffle="rng", backward=True, targets=None, trunk_done=False):
         """Losses and gradients of one step's IMAGES_PER_GPU images into the flat gradient bucket (no optimizer step).
         Returns the device tensor [rpn_class_loss, rpn_bbox_loss, imgcap_loss, reg_loss].
         backward=False: the forward graph only (validation, Keras' test_on_batch): no gradient is computed, the gradient bucket is
@@ -924,7 +942,10 @@ class DenseImageCapRCNN(object):
         rpn_up = self._step_uploads(p, rpn_match, rpn_bbox, gt_norm, gt_caps, backward)
 
         # ---- forward: backbone + FPN + RPN (the plan's hipGraph), then everything behind the encoder
-        p.forward(self._images_u8(images))
+        if trunk_done:                                       # the backbone pass of these images has run on this plan (JointTrainPipeline)
+            p.forward_top()
+        else:
+            p.forward(self._images_u8(images))
         return self._after_encoder(p, rpn_up, shuffle, backward, gt_caps, gt_norm)
 
     def _check_batch(self, p, images, gt_boxes):
@@ -1148,9 +1169,10 @@ class DenseImageCapRCNN(object):
         self.last_losses = d = self._loss_list(v)
         return [d["loss"], d["rpn_class_loss"], d["rpn_bbox_loss"], d["imgcap_loss"]]
 
-    def train_on_batch_device(self, inputs, targets=None):
+    def train_on_batch_device(self, inputs, targets=None, trunk_done=False):
         """One optimizer step; the raw loss terms as a float32 device tensor [4] (the loss all-reduce of ParallelModel and the
-        epoch sums of train() work on it; _losses_to_api makes the Keras return value from its host copy)."""
+        epoch sums of train() work on it; _losses_to_api makes the Keras return value from its host copy).
+        trunk_done: plan().forward_trunk() has already run on these images (pipeline.JointTrainPipeline): the step starts at the FPN."""
         assert self.mode == "training", "Create model in training mode."
         if self.optimizer is None:
             raise RuntimeError("compile(learning_rate) first")
@@ -1159,7 +1181,7 @@ class DenseImageCapRCNN(object):
         cm = self.caption_model
         if world != 1 or cm._prefix_rows(True):
             # eager, serial: the data-parallel step (its collectives are issued from Python as layer groups finish), DROPOUT_ROWS='prefix'
-            losses = self.forward_backward(inputs)
+            losses = self.forward_backward(inputs, trunk_done=trunk_done)
             scale = self.grad_sync(self.store.flat_grad) if self.grad_sync is not None else 1.0
             self.optimizer.apply(self.store, grad_scale=scale)
             return losses
@@ -1174,7 +1196,10 @@ class DenseImageCapRCNN(object):
         if timing:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        p.forward(self._images_u8(images))
+        if trunk_done:
+            p.forward_top()
+        else:
+            p.forward(self._images_u8(images))
         opt = self.optimizer
 
         def timed(kind, out):

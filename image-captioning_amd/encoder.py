@@ -102,6 +102,7 @@ class EncoderPlan:
         self.stage4_blocks = stage4_blocks
         self.use_graph = bool(use_graph)
         self._graph = None
+        self._part_graphs, self._part_warm = {}, set()
         self._warm = False
         self._specs = {s.name: s for s in resnet_fpn_convs(stage4_blocks)}
         self.rpn = rpn
@@ -349,6 +350,7 @@ class EncoderPlan:
         C4 = stage(4, ["a"] + [chr(98 + i) for i in range(self.stage4_blocks)], 256, 1024, 2, C3)
         C5 = stage(5, "abc", 512, 2048, 2, C4)
         self.C = (C2, C3, C4, C5)
+        self._n_trunk = len(self._ops)                     # ops [0, _n_trunk): image -> C2..C5; the rest: FPN (+ RPN)  (forward_trunk / forward_top)
         self.pre = None
         t5, t4 = self._buf(H // 32, W // 32, 256), self._buf(H // 16, W // 16, 256)
         t3, t2 = self._buf(H // 8, W // 8, 256), self._buf(H // 4, W // 4, 256)
@@ -549,6 +551,39 @@ class EncoderPlan:
                 self._run_ops()
             self._graph = g
             g.replay()
+        return self.P
+
+    # The pass in two halves, for a caller that runs the frozen backbone of the NEXT batch beside the rest of this batch's step
+    # (pipeline.JointTrainPipeline): forward_trunk() = image -> C2..C5 (reads nothing a train step changes when no ResNet stage is
+    # trainable), forward_top() = the FPN and the RPN on the C maps of the last forward_trunk().  Each half is its own hipGraph;
+    # forward_trunk(); forward_top() enqueues exactly the launches of forward().
+    def _run_part(self, part, lo, hi):
+        if not self.use_graph:
+            self._run_ops(lo, hi)
+            return
+        g = self._part_graphs.get(part)
+        if g is not None:
+            g.replay()
+        elif part not in self._part_warm:
+            self._run_ops(lo, hi)                           # first call: eager (kernel attributes, workspace sizes)
+            self._part_warm.add(part)
+        else:
+            g = torch.cuda.CUDAGraph()
+            with ops.no_gc_during_capture(), torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self._run_ops(lo, hi)
+            self._part_graphs[part] = g
+            g.replay()
+
+    def forward_trunk(self, images_u8=None):
+        if self._external_bn:
+            raise RuntimeError("forward_trunk: this plan folds trainable BatchNorm layers inside the backbone pass; use forward()")
+        if images_u8 is not None:
+            self.images.copy_(images_u8, non_blocking=bool(images_u8.is_cuda or images_u8.is_pinned()))
+        self._run_part("trunk", 0, self._n_trunk)
+        return self.C
+
+    def forward_top(self):
+        self._run_part("top", self._n_trunk, None)
         return self.P
 
     def proposals(self, debug=False):

@@ -95,3 +95,75 @@ class CaptionTrainPipeline(object):
         cur.wait_stream(self.s_enc)
         cur.wait_stream(self.s_dec)
         return loss
+
+
+class JointTrainPipeline(object):
+    """The joint model's train step (dense_model.DenseImageCapRCNN, BASELINE configs[4]) with the frozen backbone of batch i + 1 running
+    beside the rest of batch i's step.
+
+    Behind the backbone the step is a long chain of small, latency-bound launches (proposal selection, the single-wave NMS scan,
+    detection targets, two LSTMs step by step, ~170 launches of under 10 us) that leave most of the chip idle; the backbone pass
+    (ResNet-101, frozen: it reads nothing a train step changes) is ~100 convolution launches that fill it.  Two encoder plans with their
+    own activation buffers alternate: step(batch k) enqueues plan[k % 2].forward_trunk() on a second stream and, on the caller's stream,
+    the rest of batch k - 1's step (FPN, RPN, proposals ... AMSGrad) on the other plan.  Semantics are unchanged -- batch k's update uses
+    batch k's C2..C5 and the weights after update k - 1; every kernel and every reduction order is the serial step's, so the weights after
+    N steps are bit-equal to N calls of train_on_batch_device (tests/test_gpu_models.py) -- the result is just returned one call late,
+    like CaptionTrainPipeline's.  Only when no ResNet stage is trainable (layers 'heads'-like sets; a trainable stage makes the backbone
+    pass depend on the previous update and the model falls back to the serial step)."""
+
+    def __init__(self, model):
+        inner = getattr(model, "inner_model", model)
+        if inner.backbone_from is not None:
+            raise ValueError("JointTrainPipeline: ResNet stages are trainable (backbone_from = %r): the backbone pass of the next batch depends on "
+                             "this batch's update" % (inner.backbone_from,))
+        self.model, self.inner = model, inner
+        self.plans = inner.plan_pair()
+        dev = inner.device
+        # (tried: the rest of the step on a HIGH-priority stream of its own, the backbone pass at normal priority -- 11.9 - 12.3 ms per step
+        # against 6.89 - 6.93 with both at the default priority, same box, alternating runs)
+        self.s_trunk = torch.cuda.Stream(device=dev)
+        self.ev_trunk = [torch.cuda.Event(), torch.cuda.Event()]     # C2..C5 of plan j are complete
+        self.pending = None                                          # (inputs, plan index) awaiting the rest of its step
+        self.n = 0
+        self._hold = []                                              # image tensors of the batches in flight (allocated on the caller's stream)
+        inner.use_step_graph = False                                 # the rest of the step alternates between two plans' buffers: eager launches
+
+    def _trunk(self, j, images):
+        dev = self.inner.device
+        cur = torch.cuda.current_stream(dev)
+        # everything the caller's stream holds so far -- the rest of batch k - 2's step, the last reader of plan j's buffers, and whatever
+        # produced `images` -- comes first
+        self.s_trunk.wait_stream(cur)
+        with torch.cuda.stream(self.s_trunk):
+            self.plans[j].forward_trunk(self.inner._images_u8(images))
+            self.ev_trunk[j].record(self.s_trunk)
+
+    def _rest(self, inputs, j):
+        torch.cuda.current_stream(self.inner.device).wait_event(self.ev_trunk[j])
+        self.inner.use_plan(j)
+        losses = self.inner.train_on_batch_device(inputs, trunk_done=True)
+        return self.model.mean_over_towers(losses) if self.model is not self.inner else losses      # (ParallelModel: the towers' mean)
+
+    def step(self, inputs):
+        """Enqueue the backbone pass of `inputs` and the rest of the previous batch's step.  Returns the previous batch's raw loss terms
+        (device tensor [4]) or None on the first call."""
+        j = self.n & 1
+        if self.model is not self.inner:
+            inputs = self.model.shard_inputs(inputs)                 # ParallelModel: this rank's share of the global batch (tf.split)
+        self._hold = self._hold[-2:] + [inputs[0]]
+        self._trunk(j, inputs[0])
+        losses = None
+        if self.pending is not None:
+            losses = self._rest(*self.pending)
+        self.pending = (inputs, j)
+        self.n += 1
+        return losses
+
+    def flush(self):
+        """The rest of the last enqueued batch's step; joins the backbone stream into the caller's."""
+        losses = None
+        if self.pending is not None:
+            losses = self._rest(*self.pending)
+            self.pending = None
+        torch.cuda.current_stream(self.inner.device).wait_stream(self.s_trunk)
+        return losses

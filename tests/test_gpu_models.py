@@ -1229,3 +1229,47 @@ def test_joint_model_two_images_per_gpu_small(gpu, tmp_path):
     hist = tm.train(train, val, learning_rate=1e-5, epochs=1, layers="no_backbone")
     assert len(hist) == 1 and all(np.isfinite(v) for v in hist[0].values())
     assert not np.array_equal(tm.get_weights_dict()['fpn_p2/kernel'], np.asarray(Wt['fpn_p2/kernel'], np.float32))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_joint_train_pipeline_equals_the_serial_steps(gpu, dtype):
+    """pipeline.JointTrainPipeline -- the frozen backbone of batch k + 1 on a second stream beside the rest of batch k's step, two encoder
+    plans alternating -- against train_on_batch_device called batch after batch: six different batches, every loss term and every
+    weight afterwards equal bit for bit (same kernels, same reduction orders, batch k still updated from batch k's features and the
+    weights after update k - 1); the losses arrive one call late.  A model with a trainable ResNet stage is refused."""
+    from image_captioning_amd import synth
+    from image_captioning_amd.pipeline import JointTrainPipeline
+    S, V, T, blocks = 128, 24, 5, 1
+    batches = []
+    for s in range(6):
+        inp = joint_inputs(S, V, T, seed=8 + s)
+        if s & 1:                                                   # another image (its GT boxes then match no proposal: no caption loss);
+            inp[0] = synth.images(20 + s, 1, S, S)                  # the even batches keep the image the GT boxes were made for
+        batches.append(inp)
+    runs = []
+    for piped in (False, True):
+        model, cfg, Wt = make_joint(S, V, T, blocks, compute_dtype=dtype, conv_math="bf16" if dtype == "bf16" else None)
+        model.compile(1e-5)
+        model.use_step_graph = False
+        losses = []
+        if piped:
+            pipe = JointTrainPipeline(model)
+            for b in batches:
+                l = pipe.step(b)
+                if l is not None:
+                    losses.append(l.clone())
+            losses.append(pipe.flush().clone())
+            assert len(model._plans) == 2 and model._plans[0] is not model._plans[1]
+        else:
+            for b in batches:
+                losses.append(model.train_on_batch_device(b).clone())
+        torch.cuda.synchronize()
+        runs.append((torch.stack(losses).cpu().numpy(), model.store.flat.clone(), model.optimizer.iterations))
+    assert runs[0][2] == runs[1][2] == 6
+    assert np.array_equal(runs[0][0], runs[1][0]), (runs[0][0], runs[1][0])
+    assert torch.equal(runs[0][1], runs[1][1])
+    assert len(np.unique(runs[0][0], axis=0)) == 6 and (runs[0][0][:, 2] > 0).any()          # six different batches, positive RoIs (a caption loss) in at least one
+    trainable_trunk, _, _ = make_joint(S, V, T, blocks)
+    trainable_trunk.set_trainable(trainable_trunk.LAYER_REGEX["5+"])
+    with pytest.raises(ValueError):
+        JointTrainPipeline(trainable_trunk)
