@@ -720,8 +720,8 @@ def run_joint(args, dev, rank, world, barrier):
     pipe = None
     if not args.no_pipeline and inner.backbone_from is None:
         from image_captioning_amd.pipeline import JointTrainPipeline
-        pipe = JointTrainPipeline(model)
-        for _ in range(6):                                # both plans: eager pass, capture, replay of the backbone and FPN / RPN graphs
+        pipe = JointTrainPipeline(inner)                  # `inputs` is this rank's own batch (weak scaling), as in the serial leg below: the tower, not
+        for _ in range(6):                                # the ParallelModel (whose step() would tf.split a global batch); grad_sync lives on the tower
             pipe.step(inputs)
         pipe.flush()
         if world > 1 and getattr(inner, "grad_sync", None) is not None and hasattr(inner.grad_sync, "exposed_ms"):

@@ -1316,11 +1316,23 @@ class DenseImageCapRCNN(object):
         val_batch = next(val_generator)[0]
         names = ("loss",) + self.LOSS_NAMES
         history = []
+        # Frozen ResNet (the script's layers: 'heads'-like sets): the backbone pass of batch i + 1 runs beside the rest of batch i's step
+        # (pipeline.JointTrainPipeline: same updates bit for bit, tests/test_gpu_models.py; DCAP_JOINT_PIPELINE=0 keeps the serial loop).
+        pipe = None
+        if self.backbone_from is None and os.environ.get("DCAP_JOINT_PIPELINE", "1") != "0":
+            from .pipeline import JointTrainPipeline
+            pipe = JointTrainPipeline(self._outer)
         for epoch in range(self.epoch, epochs):
             acc = None                                           # raw loss terms summed on the device: one host copy per epoch
-            for _ in range(cfg.STEPS_PER_EPOCH):
-                step = self._outer.train_on_batch_device(next(train_generator)[0])
-                acc = step.clone() if acc is None else acc.add_(step)
+            for i in range(cfg.STEPS_PER_EPOCH + (1 if pipe is not None else 0)):
+                if pipe is None:
+                    step = self._outer.train_on_batch_device(next(train_generator)[0])
+                elif i < cfg.STEPS_PER_EPOCH:
+                    step = pipe.step(next(train_generator)[0])   # the losses of the batch before (None on the epoch's first call)
+                else:
+                    step = pipe.flush()                          # the epoch's last batch: every update is in before validation and checkpoint
+                if step is not None:
+                    acc = step.clone() if acc is None else acc.add_(step)
             logs = dict(zip(names, self._losses_to_api((acc / cfg.STEPS_PER_EPOCH).cpu().numpy())))
             # the reference validates on ONE fixed batch too: validation_data=next(val_generator) (:1878)
             logs.update({"val_" + n: v for n, v in zip(names, self._outer.test_on_batch(val_batch))})

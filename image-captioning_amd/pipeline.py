@@ -122,6 +122,7 @@ class JointTrainPipeline(object):
         # (tried: the rest of the step on a HIGH-priority stream of its own, the backbone pass at normal priority -- 11.9 - 12.3 ms per step
         # against 6.89 - 6.93 with both at the default priority, same box, alternating runs)
         self.s_trunk = torch.cuda.Stream(device=dev)
+        self.s_copy = torch.cuda.Stream(device=dev)                  # host images: uploaded on a stream that never waits for a step
         self.ev_trunk = [torch.cuda.Event(), torch.cuda.Event()]     # C2..C5 of plan j are complete
         self.pending = None                                          # (inputs, plan index) awaiting the rest of its step
         self.n = 0
@@ -131,11 +132,22 @@ class JointTrainPipeline(object):
     def _trunk(self, j, images):
         dev = self.inner.device
         cur = torch.cuda.current_stream(dev)
+        u8 = self.inner._images_u8(images)
+        if not u8.is_cuda:
+            # A host batch (the data generator's): a copy from pageable memory blocks the host until the stream it is issued on has drained.
+            # On the backbone stream that would be the end of batch k - 2's step -- the host could never run ahead of the GPU.  The copy goes
+            # to a device tensor of its own on a stream with nothing else in it (the host waits for the 3 MB per image only); the backbone
+            # stream then waits for that stream.  The tensor is kept in _hold until two more batches have been enqueued.
+            with torch.cuda.stream(self.s_copy):
+                u8 = u8.to(dev)
+            self.s_trunk.wait_stream(self.s_copy)
+            u8.record_stream(self.s_trunk)                 # (allocated on the copy stream, read on the backbone stream)
+            self._hold.append(u8)
         # everything the caller's stream holds so far -- the rest of batch k - 2's step, the last reader of plan j's buffers, and whatever
         # produced `images` -- comes first
         self.s_trunk.wait_stream(cur)
         with torch.cuda.stream(self.s_trunk):
-            self.plans[j].forward_trunk(self.inner._images_u8(images))
+            self.plans[j].forward_trunk(u8)
             self.ev_trunk[j].record(self.s_trunk)
 
     def _rest(self, inputs, j):
@@ -150,7 +162,7 @@ class JointTrainPipeline(object):
         j = self.n & 1
         if self.model is not self.inner:
             inputs = self.model.shard_inputs(inputs)                 # ParallelModel: this rank's share of the global batch (tf.split)
-        self._hold = self._hold[-2:] + [inputs[0]]
+        self._hold = self._hold[-4:] + [inputs[0]]                   # (a host batch adds its device copy in _trunk: two entries per batch)
         self._trunk(j, inputs[0])
         losses = None
         if self.pending is not None:

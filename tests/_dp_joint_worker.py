@@ -39,9 +39,21 @@ def main():
     pm = ParallelModel(model, world)
     assert model.grad_sync.dtype == os.environ.get("DCAP_GRAD_DTYPE", "f32")        # the wire format the test asked for
     inputs, _ = global_inputs(world)
-    losses = [pm.train_on_batch(inputs) for _ in range(steps)]
+    mode = sys.argv[3] if len(sys.argv) > 3 else "serial"
+    tag = "" if mode == "serial" else "_" + mode
+    if mode == "pipeline":
+        # pipeline.JointTrainPipeline over the ParallelModel: GLOBAL batches in (tf.split inside step()), the towers' mean losses one call late
+        from image_captioning_amd.pipeline import JointTrainPipeline
+        model.use_step_graph = False
+        pipe = JointTrainPipeline(pm)
+        raw = [pipe.step(inputs) for _ in range(steps)][1:] + [pipe.flush()]
+        losses = [model._losses_to_api(l.cpu().numpy()) for l in raw]
+    else:
+        if mode == "serial_eager":
+            model.use_step_graph = False
+        losses = [pm.train_on_batch(inputs) for _ in range(steps)]
     torch.cuda.synchronize()
-    np.savez(os.path.join(out_dir, "joint_rank%d.npz" % rank), flat=model.store.flat.cpu().numpy(), losses=np.array(losses))
+    np.savez(os.path.join(out_dir, "joint%s_rank%d.npz" % (tag, rank)), flat=model.store.flat.cpu().numpy(), losses=np.array(losses))
     dist.barrier()
     dist.destroy_process_group()
 

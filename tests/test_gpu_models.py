@@ -1226,9 +1226,24 @@ def test_joint_model_two_images_per_gpu_small(gpu, tmp_path):
         ds.prepare()
     tm = DenseImageCapRCNN("training", cfg, str(tmp_path / "logs"), stage4_blocks=blocks)
     tm.set_weights(Wt)
+    np.random.seed(5)                                         # (the generator's shuffle and the RPN-target sampling draw from np.random)
     hist = tm.train(train, val, learning_rate=1e-5, epochs=1, layers="no_backbone")
     assert len(hist) == 1 and all(np.isfinite(v) for v in hist[0].values())
     assert not np.array_equal(tm.get_weights_dict()['fpn_p2/kernel'], np.asarray(Wt['fpn_p2/kernel'], np.float32))
+    # train() ran the frozen backbone of batch i + 1 beside the rest of batch i's step (pipeline.JointTrainPipeline, host batches uploaded on
+    # their own stream); the serial loop (DCAP_JOINT_PIPELINE=0) gives the same epoch bit for bit: weights, epoch means, validation losses
+    assert len(tm._plans) == 2
+    ts = DenseImageCapRCNN("training", cfg, str(tmp_path / "logs_serial"), stage4_blocks=blocks)
+    ts.set_weights(Wt)
+    np.random.seed(5)
+    os.environ["DCAP_JOINT_PIPELINE"] = "0"
+    try:
+        hist_s = ts.train(train, val, learning_rate=1e-5, epochs=1, layers="no_backbone")
+    finally:
+        del os.environ["DCAP_JOINT_PIPELINE"]
+    assert len(ts._plans) == 1
+    assert hist_s == hist, (hist_s, hist)
+    assert torch.equal(ts.store.flat, tm.store.flat)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])

@@ -140,3 +140,30 @@ def test_joint_model_two_ranks_average_the_tower_gradients(tmp_path, grad_dtype)
         assert moved > 0 and dl2 < 2e-2 and diff < 0.5 * moved, (dl2, diff, moved)
         return
     assert moved > 0 and diff == 0.0      # bit-equal (round 2: 2e-3 of the update -- RoIAlign's backward was an atomic scatter then; it is a fixed-order gather now)
+
+
+def test_joint_train_pipeline_under_parallel_model_two_ranks(tmp_path):
+    """pipeline.JointTrainPipeline wrapped around the ParallelModel (global batches in, tf.split inside step(), the towers' mean losses
+    one call late): three steps on two ranks leave both replicas with the same weights, bit for bit the weights and losses of three
+    serial ParallelModel.train_on_batch calls on the same global batches."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    world, steps = 2, 3
+    backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
+    for mode in ("serial_eager", "pipeline"):
+        port = _free_port()
+        procs = []
+        for rank in range(world):
+            env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       DCAP_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0", DCAP_GRAD_DTYPE="f32")
+            procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dp_joint_worker.py"), str(tmp_path), str(steps), mode],
+                                          env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        outs = [p.communicate(timeout=600)[0] for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
+    ser = [np.load(tmp_path / ("joint_serial_eager_rank%d.npz" % k)) for k in range(world)]
+    pip = [np.load(tmp_path / ("joint_pipeline_rank%d.npz" % k)) for k in range(world)]
+    np.testing.assert_array_equal(pip[0]["flat"], pip[1]["flat"])            # replicas stay bit-identical
+    np.testing.assert_array_equal(pip[0]["losses"], pip[1]["losses"])
+    assert pip[0]["losses"].shape == ser[0]["losses"].shape == (steps, 4)
+    np.testing.assert_array_equal(pip[0]["losses"], ser[0]["losses"])
+    np.testing.assert_array_equal(pip[0]["flat"], ser[0]["flat"])
