@@ -120,7 +120,9 @@ class JointTrainPipeline(object):
         self.plans = inner.plan_pair()
         dev = inner.device
         # (tried: the rest of the step on a HIGH-priority stream of its own, the backbone pass at normal priority -- 11.9 - 12.3 ms per step
-        # against 6.89 - 6.93 with both at the default priority, same box, alternating runs)
+        # against 6.89 - 6.93 with both at the default priority, same box, alternating runs; the backbone stream restricted to 30 / 28 / 24 / 20 of
+        # the 32 CUs of every XCD (hipExtStreamCreateWithCUMask), to leave the chain's small kernels CUs of their own: 23.3 / 23.8 / 24.1 / 25.0 ms
+        # against 6.75 -- profiles/r06_joint_pipeline_cumask.txt.  Queues that are not plain streams lose their concurrency on this runtime.)
         self.s_trunk = torch.cuda.Stream(device=dev)
         self.s_copy = torch.cuda.Stream(device=dev)                  # host images: uploaded on a stream that never waits for a step
         self.ev_trunk = [torch.cuda.Event(), torch.cuda.Event()]     # C2..C5 of plan j are complete
