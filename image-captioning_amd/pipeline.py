@@ -123,6 +123,9 @@ class JointTrainPipeline(object):
         # against 6.89 - 6.93 with both at the default priority, same box, alternating runs; the backbone stream restricted to 30 / 28 / 24 / 20 of
         # the 32 CUs of every XCD (hipExtStreamCreateWithCUMask), to leave the chain's small kernels CUs of their own: 23.3 / 23.8 / 24.1 / 25.0 ms
         # against 6.75 -- profiles/r06_joint_pipeline_cumask.txt.  Queues that are not plain streams lose their concurrency on this runtime.)
+        # (tried: the backbone pass enqueued LATER in the other batch's step instead of at its start -- behind the FPN / RPN forward 7.00 - 7.06 ms,
+        # behind the decoder's forward 7.15 - 7.19, behind its backward or behind the FPN backward 7.73 - 7.77 = the serial step; at the start
+        # 6.75 - 6.83: profiles/r06_joint_pipeline_phase.txt)
         self.s_trunk = torch.cuda.Stream(device=dev)
         self.s_copy = torch.cuda.Stream(device=dev)                  # host images: uploaded on a stream that never waits for a step
         self.ev_trunk = [torch.cuda.Event(), torch.cuda.Event()]     # C2..C5 of plan j are complete
