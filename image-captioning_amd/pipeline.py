@@ -126,6 +126,11 @@ class JointTrainPipeline(object):
         # (tried: the backbone pass enqueued LATER in the other batch's step instead of at its start -- behind the FPN / RPN forward 7.00 - 7.06 ms,
         # behind the decoder's forward 7.15 - 7.19, behind its backward or behind the FPN backward 7.73 - 7.77 = the serial step; at the start
         # 6.75 - 6.83: profiles/r06_joint_pipeline_phase.txt)
+        # (tried: the backbone pass waiting only for an event behind the FPN backward of the step that last ran on its plan instead of for the
+        # whole caller's stream, so that its first layers run beside that step's HBM-bound regulariser / optimizer passes: 6.75 - 6.78 ms
+        # against 6.75 - 6.83, i.e. nothing -- the backbone pass has a whole step to finish in, where it starts inside it moves the contention,
+        # it does not remove it; the only stream priority this runtime offers besides the default is "high": 13.7 ms with it on this stream.
+        # The host is 5 steps ahead of the GPU after 20: 4.95 ms of enqueueing per 6.80 ms step, tools/joint_host_time.py)
         self.s_trunk = torch.cuda.Stream(device=dev)
         self.s_copy = torch.cuda.Stream(device=dev)                  # host images: uploaded on a stream that never waits for a step
         self.ev_trunk = [torch.cuda.Event(), torch.cuda.Event()]     # C2..C5 of plan j are complete
