@@ -870,7 +870,7 @@ def joint_roofline(args, dev, inner):
     traffic, traffic_src = None, None
     for tname in ("r06_joint_pmc_traffic.json", "r05_joint_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
-        if os.path.exists(tpath):
+        if traffic is None and os.path.exists(tpath):       # the newest round's passes that hold the kernel
             for name, rec in json.load(open(tpath)).items():
                 if ("::" + dom + "(") in name or name.startswith("dcap::" + dom) or name.startswith("void dcap::" + dom):
                     traffic, traffic_src = rec["hbm_bytes_per_launch_corrected"], "profiles/" + tname
