@@ -33,8 +33,9 @@ tail -1 $out/joint_bench_2img.log > $out/joint_bench_2img.json
 DCAP_VOCAB_MATERIALIZE=0 python3 $root/bench.py --config joint --steps 10 --no-roofline > $out/joint_bench_recompute_logits.log 2>&1
 tail -1 $out/joint_bench_recompute_logits.log > $out/joint_bench_recompute_logits.json
 rocprofv3 --kernel-trace --stats -d $out/joint -o joint -- python3 $root/bench.py --config joint --steps 10 --no-roofline > $out/joint.log 2>&1
-python3 $root/tools/prof_summary.py $out/joint/joint_results.db $out/joint_kernels.csv 32   # 8 warm-up + 10 timed + 4 + 10 steps on the other path
-python3 $root/tools/prof_timeline.py $out/joint/joint_results.db $out/joint_timeline.tsv || true
+python3 $root/tools/prof_summary.py $out/joint/joint_results.db $out/joint_kernels.csv 37   # 8 warm-up + 6 pipeline warm-up + 10 timed (pipelined) + 3 + 10 serial steps beside them
+python3 $root/tools/prof_timeline.py $out/joint/joint_results.db $out/joint_timeline.tsv amsgrad 15 || true          # a step of the pipelined leg (the 13 serial steps run behind it)
+python3 $root/tools/prof_timeline.py $out/joint/joint_results.db $out/joint_timeline_serial.tsv || true
 rm -rf $out/joint
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/jf -- python3 $root/bench.py --config joint --steps 3 --warmup 2 --no-roofline > $out/joint_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/jw -- python3 $root/bench.py --config joint --steps 3 --warmup 2 --no-roofline > $out/joint_pmc_write.log 2>&1

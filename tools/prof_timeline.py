@@ -1,7 +1,7 @@
 """One steady-state step of a rocprofv3 --kernel-trace run (rocpd .db) as a timeline: every kernel between the ends of the last two
 launches of a marker kernel (default: amsgrad), with its start offset, duration and queue / stream -- what runs beside what, where the
 chip idles, which chain is the critical one.
-Usage: python tools/prof_timeline.py results.db out.tsv [marker substring]"""
+Usage: python tools/prof_timeline.py results.db out.tsv [marker substring [marker launches to skip at the end]]"""
 import sqlite3
 import sys
 
@@ -16,7 +16,10 @@ def main():
     ends = [r[2] for r in rows if marker in r[0]]
     if len(ends) < 3:
         raise SystemExit("fewer than three %r launches in the trace" % marker)
-    t0, t1 = ends[-3], ends[-2]                              # (the last step may be followed by teardown work: take the one before)
+    skip = int(sys.argv[4]) if len(sys.argv) > 4 else 0       # (e.g. the steps of a second leg timed behind the one of interest)
+    if len(ends) < 3 + skip:
+        raise SystemExit("fewer than %d %r launches in the trace" % (3 + skip, marker))
+    t0, t1 = ends[-3 - skip], ends[-2 - skip]                # (the last step may be followed by teardown work: take the one before)
     step = [r for r in rows if t0 <= r[1] < t1]
     busy, cur_end = 0, t0
     with open(sys.argv[2], "w") as f:
