@@ -15,7 +15,11 @@ The line's `dtype` says so.  Inputs are resident in HBM before the timed region.
   (N > 1: either under python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ..., or plainly:
    without WORLD_SIZE in the environment this process starts the N ranks itself as child processes, see self_launch)
   python bench.py --config joint      BASELINE configs[4]: the joint model (bf16 decoder / head / vocabulary GEMMs), one
-                                      1024x1024 image per GPU and step, 2000 proposals -> 200 RoIs, V = 50 000
+                                      1024x1024 image per GPU and step, 2000 proposals -> 200 RoIs, V = 50 000.  The timed schedule is the one
+                                      DenseImageCapRCNN.train() runs with a frozen ResNet: the backbone pass of batch i + 1 on a second stream
+                                      beside the rest of batch i's step (pipeline.JointTrainPipeline; K step() calls + flush() inside the timed
+                                      region, bit-equal to K serial steps); `config.serial_ms_per_step` = the serial step in the same process,
+                                      --no-pipeline times that one alone
 
 Rank 0 prints ONE JSON line (see the driver contract) with extra objects:
   roofline      -- the dominant kernel (the conv instantiation with the largest time share): the FLOPs the matrix pipe EXECUTES per
@@ -1112,20 +1116,23 @@ def main():
             other["configs4_joint"] = {"workload": jt["config"]["workload"], "value": jt["value"], "unit": "captions/s", "ms_per_step": jt["ms_per_step"],
                                        "steps": jt["steps"], "dtype": jt["dtype"], "positive_rois": jt["config"]["positive_rois"],
                                        "rois_per_image": jt["config"]["rois_per_image"], "recurrent_dropout": jt["config"]["recurrent_dropout"],
+                                       "schedule": jt["config"].get("pipeline"), "serial_ms_per_step": jt["config"].get("serial_ms_per_step"),
                                        "roofline": jt.get("roofline")}
             # the same step with the reference's recurrent_dropout = 0.2 on both LSTMs (dense_img_cap/dense_model.py:769-770): device-side
             # Philox masks, one fused launch per LSTM timestep in both directions (round 4)
             rd = subprocess.run(cmdj + ["--joint-dropout", "0.2", "--no-roofline"], capture_output=True, text=True, timeout=400)
             jd = json.loads(rd.stdout.strip().splitlines()[-1])
             other["configs4_joint_reference_dropout"] = {"value": jd["value"], "unit": "captions/s", "ms_per_step": jd["ms_per_step"], "steps": jd["steps"],
-                                                         "recurrent_dropout": jd["config"]["recurrent_dropout"]}
+                                                         "recurrent_dropout": jd["config"]["recurrent_dropout"],
+                                                         "serial_ms_per_step": jd["config"].get("serial_ms_per_step")}
             # IMAGES_PER_GPU = 2 (the reference's batched graph, config.py:35): every latency-bound trunk layer sees twice the pixels
             r2 = subprocess.run(cmdj + ["--joint-images-per-gpu", "2", "--no-roofline"], capture_output=True, text=True, timeout=400)
             j2 = json.loads(r2.stdout.strip().splitlines()[-1])
             other["configs4_joint_2img"] = {"value": j2["value"], "unit": "captions/s", "captions_per_s_per_gpu": j2["value"] / max(1, j2["n_gpus"]),
                                             "ms_per_step": j2["ms_per_step"], "steps": j2["steps"], "images_per_gpu": j2["config"]["images_per_gpu"],
                                             "rois_per_image": j2["config"]["rois_per_image"], "positive_rois": j2["config"]["positive_rois"],
-                                            "step_path": j2["config"]["step_path"]}
+                                            "step_path": j2["config"]["step_path"], "schedule": j2["config"].get("pipeline"),
+                                            "serial_ms_per_step": j2["config"].get("serial_ms_per_step")}
         except Exception as e:
             other["error_joint"] = repr(e)[:300]
         if not args.no_cpu_baseline:
