@@ -677,7 +677,7 @@ extern "C" int dc_lstm_seq_fwd_f32(const dc_lstm_fwd_desc* d, void* workspace, s
 }
 
 extern "C" int dc_lstm_seq_bwd_f32(const dc_lstm_bwd_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
-    DC_REQUIRE(d && d->z && d->U_rec && d->h_seq && d->c_seq && d->dz && d->dU_rec, DC_EINVAL, "dc_lstm_seq_bwd: null pointer");
+    DC_REQUIRE(d && d->z && d->U_rec && d->h_seq && d->c_seq && d->dz, DC_EINVAL, "dc_lstm_seq_bwd: null pointer");
     DC_REQUIRE(d->B > 0 && d->T > 0 && d->U > 0 && (d->U & 3) == 0, DC_EINVAL, "dc_lstm_seq_bwd: bad B/T/U (U %% 4 == 0)");
     DC_REQUIRE(workspace && workspace_bytes >= dc_lstm_seq_workspace_bytes(d->B, d->T, d->U), DC_EWORKSPACE,
                "dc_lstm_seq_bwd: workspace too small");
@@ -745,6 +745,7 @@ extern "C" int dc_lstm_seq_bwd_f32(const dc_lstm_bwd_desc* d, void* workspace, s
             if (rc) return rc;
         }
     }
+    if (!d->dU_rec) return DC_OK;                               // the caller forms dU_rec itself (e.g. on the bf16 pipe from its bf16 copies of h_seq and dz)
     if (T > 1 && d->rec_masks) {                                // dU_g = sum_t (h_{t-1} * m_g)^T dz_{t,g}
         const long rows = (long)(T - 1) * B;
         hipLaunchKernelGGL(lstm_mask_rows_kernel, dim3((int)std::min<long>((rows * U + 255) / 256, (long)kNumCU * 8)), dim3(256), 0, s, d->h_seq,

@@ -630,6 +630,8 @@ def lstm_seq_bwd(z, U_rec, mask, h_seq, c_seq, B, T, dh_seq=None, dh_last=None, 
         dz = torch.empty((T * B, 4 * U), dtype=torch.float32, device=z.device)
     if dU is None:
         dU = torch.empty((U, 4 * U), dtype=torch.float32, device=z.device)
+    elif dU is False:                                  # the caller forms the recurrent kernel's gradient itself (returns (dz, None))
+        dU = None
     d = LstmBwdDesc()
     d.B, d.T, d.U = B, T, U
     d.z, d.U_rec = _chk(z, name="z").data_ptr(), _chk(U_rec, name="U_rec").data_ptr()
@@ -640,7 +642,7 @@ def lstm_seq_bwd(z, U_rec, mask, h_seq, c_seq, B, T, dh_seq=None, dh_last=None, 
             raise _lib.DcapError("lstm_seq_bwd: %s must be contiguous" % name)
     d.dh_seq = None if dh_seq is None else dh_seq.data_ptr()
     d.dh_last = None if dh_last is None else dh_last.data_ptr()
-    d.dz, d.dU_rec, d.accumulate_dU = dz.data_ptr(), _chk(dU, name="dU").data_ptr(), int(accumulate_dU)
+    d.dz, d.dU_rec, d.accumulate_dU = dz.data_ptr(), (None if dU is None else _chk(dU, name="dU").data_ptr()), int(accumulate_dU)
     d.rec_masks = _rec_masks(rec_masks, B, U)
     ws, wsb = WORKSPACE.get(lib.dc_lstm_seq_workspace_bytes(B, T, U), z.device)
     check(lib.dc_lstm_seq_bwd_f32(C.byref(d), _ptr(ws), wsb, _stream()), "dc_lstm_seq_bwd_f32")

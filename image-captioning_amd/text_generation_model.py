@@ -438,18 +438,29 @@ class CaptionModelV1(KerasLikeModel):
         df = self._mm(dzd_f, self._wview('imgcap_lstm_d1/kernel', (u, u + self.FEAT)), key='df', b_trans=True).f
         dh2 = self._mm(dz_d1, self._wview('imgcap_lstm_d1/kernel', (0, u)), key='dh2', b_trans=True).f
         # lstm2
+        # bf16 model without recurrent-dropout masks: the recurrent kernels' gradients dU = h[0 .. T-1)^T dz[1 .. T) on the bf16 pipe from the
+        # bf16 copies, like every other weight gradient of this model (fp32: 62 us each at 3000 x 512 x 2048 on the step's critical chain)
+        du_b = (dl.f is None and self.compute_dtype == "bf16" and T > 1 and self._rec_masks[0] is None and self._rec_masks[1] is None
+                and ((T - 1) * Bl) % 8 == 0 and u % 8 == 0)
+
+        def dU_bf16(h, dz, name):
+            ops.gemm_bf16(h.b[:(T - 1) * Bl], dz.b[Bl:], a_trans=True, out=g[name])
         # (prefix rows: only the last -- carried -- state of each padded prefix feeds the dense layers: Keras' lstm2 without return_sequences)
         dz2, _ = ops.lstm_seq_bwd(bf['z2'], w['imgcap_lstm2/recurrent_kernel'], mask, self._h2.f, bf['c2'], Bl, T,
                                   dh_seq=dh2 if Bl == B else None, dh_last=None if Bl == B else dh2,
-                                  dz=self._buf('dz2', (NL, 4 * u)), dU=g['imgcap_lstm2/recurrent_kernel'], rec_masks=self._rec_masks[1])
+                                  dz=self._buf('dz2', (NL, 4 * u)), dU=False if du_b else g['imgcap_lstm2/recurrent_kernel'], rec_masks=self._rec_masks[1])
         dz2 = self._act('dz2', dz2)
+        if du_b:
+            dU_bf16(self._h2, dz2, 'imgcap_lstm2/recurrent_kernel')
         self._mm(h1, dz2, a_trans=True, out=g['imgcap_lstm2/kernel'])
         ops.colsum(dz2.f, out=g['imgcap_lstm2/bias'])
         self._grads_ready('imgcap_lstm2')
         dh1 = self._mm(dz2, self._wview('imgcap_lstm2/kernel'), key='dh1', b_trans=True).f
         # lstm1
         dz1, _ = ops.lstm_seq_bwd(bf['z1'], w['imgcap_lstm1/recurrent_kernel'], mask, h1.f, bf['c1'], Bl, T, dh_seq=dh1,
-                                  dz=self._buf('dz1', (NL, 4 * u)), dU=g['imgcap_lstm1/recurrent_kernel'], rec_masks=self._rec_masks[0])
+                                  dz=self._buf('dz1', (NL, 4 * u)), dU=False if du_b else g['imgcap_lstm1/recurrent_kernel'], rec_masks=self._rec_masks[0])
+        if du_b:
+            dU_bf16(h1, self._act('dz1', dz1), 'imgcap_lstm1/recurrent_kernel')
         gW1 = g['imgcap_lstm1/kernel']
         ops.gemm(w['imgcap_embedding_layer/embeddings'], dz1, a_trans=True, gather=ids_tm, out=gW1[:self.E])
         ops.colsum(dz1, out=g['imgcap_lstm1/bias'])

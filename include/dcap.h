@@ -389,7 +389,9 @@ int    dc_lstm_seq_fwd_f32(const dc_lstm_fwd_desc* d, void* workspace, size_t wo
 /* Backward of the recurrence.  dh_seq [T*B][U] (may be NULL) is the gradient w.r.t. every step's
  * output, dh_last [B][U] (may be NULL) an extra gradient on the last step's output.
  * Outputs: dz [T*B][4U] (caller derives dkernel = x^T dz, dbias = colsum dz, dx = dz kernel^T with
- * dc_gemm_f32 / dc_colsum_f32) and dU_rec [U][4U] (written, or accumulated if accumulate_dU). */
+ * dc_gemm_f32 / dc_colsum_f32) and dU_rec [U][4U] (written, or accumulated if accumulate_dU).  dU_rec may be NULL: the
+ * caller then forms it itself, dU_rec = h_seq[0 .. (T-1)B)^T dz[B .. TB) (with rec_masks: per gate g from h_seq * m_g) -- the
+ * bf16 joint model does, on the bf16 matrix pipe from the bf16 copies it already holds. */
 typedef struct {
     int B, T, U;
     const float* z;
