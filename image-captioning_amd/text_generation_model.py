@@ -325,8 +325,15 @@ class CaptionModelV1(KerasLikeModel):
         w, u = self.store.w, self.units
         Bl = B if Bl is None else Bl
         zf = self._mm(f, self._wview('imgcap_lstm1/kernel', (self.E, self.E + self.FEAT)), key='zf').f        # per-RoI half of x.W
-        z1 = ops.gemm(w['imgcap_embedding_layer/embeddings'], w['imgcap_lstm1/kernel'][:self.E], gather=ids_tm, shift=w['imgcap_lstm1/bias'],
-                      residual=zf, res_rows=B, out=self._buf('z1', (T * Bl, 4 * u)))
+        emb_b = self._emb_bf16()
+        if emb_b is not None:
+            # bf16 model: the embedding half of x.W on the bf16 pipe like the other half.  The table's bf16 copy is zero-padded to a multiple of
+            # 8 columns (E = 300 -> 304): the kernel rows 300 .. 303 it then also reads (the feature half's first rows) meet zeros
+            z1 = ops.gemm_bf16(emb_b, self.store.wb['imgcap_lstm1/kernel'][:emb_b.shape[1]], gather=ids_tm, shift=w['imgcap_lstm1/bias'],
+                               residual=zf, res_rows=B, out=self._buf('z1', (T * Bl, 4 * u)))
+        else:
+            z1 = ops.gemm(w['imgcap_embedding_layer/embeddings'], w['imgcap_lstm1/kernel'][:self.E], gather=ids_tm, shift=w['imgcap_lstm1/bias'],
+                          residual=zf, res_rows=B, out=self._buf('z1', (T * Bl, 4 * u)))
         h1, c1 = ops.lstm_seq_fwd(z1, w['imgcap_lstm1/recurrent_kernel'], mask, Bl, T, self._buf('h1', (T * Bl, u)),
                                   self._buf('c1', (T * Bl, u)), rec_masks=self._rec_masks[0])
         self._h1 = self._act('h1', h1)
@@ -338,6 +345,24 @@ class CaptionModelV1(KerasLikeModel):
         zdf = self._mm(f, self._wview('imgcap_lstm_d1/kernel', (u, u + self.FEAT)), key='zdf').f
         return self._mm(self._h2_out, self._wview('imgcap_lstm_d1/kernel', (0, u)), key='a1', shift=w['imgcap_lstm_d1/bias'], residual=zdf,
                         res_rows=B, relu=True, want_b=True)
+
+    def _emb_bf16(self):
+        """bf16 copy of the (frozen) embedding table, zero-padded to a multiple of 8 columns -- the bf16 GEMMs' operand granularity -- or None
+        when this model computes in fp32.  Made once per table content (the tensor's version counter), outside the timed / captured steps."""
+        wb1 = self.store.wb.get('imgcap_lstm1/kernel')
+        if self.compute_dtype != "bf16" or wb1 is None:
+            return None
+        emb = self.store.w['imgcap_embedding_layer/embeddings']
+        Ep = (self.E + 7) // 8 * 8
+        if Ep > wb1.shape[0]:
+            return None
+        key = (emb.data_ptr(), emb._version)
+        cached = getattr(self, '_emb_b', None)
+        if cached is None or cached[0] != key:
+            t = torch.zeros((emb.shape[0], Ep), dtype=torch.bfloat16, device=emb.device)
+            t[:, :self.E] = emb.to(torch.bfloat16)           # (round to nearest even, as the library's cast)
+            self._emb_b = cached = (key, t)
+        return cached[1]
 
     def _word_model(self, f, ids_tm, mask, B, T):
         """Logits [T*B, V] of the whole word model (inference / predict path; training never materialises them)."""
@@ -459,10 +484,16 @@ class CaptionModelV1(KerasLikeModel):
         # lstm1
         dz1, _ = ops.lstm_seq_bwd(bf['z1'], w['imgcap_lstm1/recurrent_kernel'], mask, h1.f, bf['c1'], Bl, T, dh_seq=dh1,
                                   dz=self._buf('dz1', (NL, 4 * u)), dU=False if du_b else g['imgcap_lstm1/recurrent_kernel'], rec_masks=self._rec_masks[0])
+        emb_b = self._emb_bf16() if dl.f is None else None
+        dz1a = self._act('dz1', dz1) if (du_b or emb_b is not None) else None
         if du_b:
-            dU_bf16(h1, self._act('dz1', dz1), 'imgcap_lstm1/recurrent_kernel')
+            dU_bf16(h1, dz1a, 'imgcap_lstm1/recurrent_kernel')
         gW1 = g['imgcap_lstm1/kernel']
-        ops.gemm(w['imgcap_embedding_layer/embeddings'], dz1, a_trans=True, gather=ids_tm, out=gW1[:self.E])
+        if emb_b is not None and NL % 8 == 0:
+            # (rows E .. Ep of the result are the padded columns' zeros; the feature half's gradient below writes those rows)
+            ops.gemm_bf16(emb_b, dz1a.b, a_trans=True, gather=ids_tm, out=gW1[:emb_b.shape[1]])
+        else:
+            ops.gemm(w['imgcap_embedding_layer/embeddings'], dz1, a_trans=True, gather=ids_tm, out=gW1[:self.E])
         ops.colsum(dz1, out=g['imgcap_lstm1/bias'])
         dzf = self._act('dzf', ops.fold_time(dz1, NL // B, B, self._buf('dzf', (B, 4 * u))))      # rows (t*Bl + j*B + b) -> RoI b
         self._mm(f, dzf, a_trans=True, out=gW1[self.E:])
