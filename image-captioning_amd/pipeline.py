@@ -8,6 +8,8 @@ them instead of serialising behind them.  Semantics are unchanged: batch i's upd
 i's features and the weights after update i-1 (no staleness); the two RoI-feature buffers are handed over
 with HIP events.
 """
+import os
+
 import torch
 
 
@@ -43,9 +45,15 @@ class CaptionTrainPipeline(object):
 
     def _encode(self, slot, images, boxes):
         with torch.cuda.stream(self.s_enc):
-            if self.n >= 2:
+            if self.n >= 2 and os.environ.get("DCAP_PIPE_LATE_WAIT", "1") == "0":
                 self.s_enc.wait_event(self.ev_free[slot])
             self.plan.forward(images)
+            # Only the RoIAlign launch writes the slot the decoder pass of two batches ago read: the ~100 convolution launches in front of it
+            # wait for nothing but the previous encoder pass.  (Rounds 2 - 6 waited HERE, in front of the whole pass: the encoder stream then
+            # stood still from the end of each pass until the decoder step running beside it -- starved of CUs by the pass's persistent grids --
+            # had finished: 0.69 ms of every 5.87 ms step in profiles/r06_headline_timeline.tsv.)
+            if self.n >= 2 and os.environ.get("DCAP_PIPE_LATE_WAIT", "1") != "0":
+                self.s_enc.wait_event(self.ev_free[slot])
             self.plan.roi_features(boxes_norm=boxes, out=self.feat[slot])
             self.ev_feat[slot].record(self.s_enc)
 
