@@ -32,6 +32,7 @@ class CaptionTrainPipeline(object):
         self.ev_free = [torch.cuda.Event() for _ in range(2)]       # decoder done reading slot
         self.pending = None                                          # (slot, tables) awaiting its decoder pass
         self.n = 0
+        self.late_wait = os.environ.get("DCAP_PIPE_LATE_WAIT", "1") != "0"      # the slot event gates the RoIAlign launch only (see _encode)
         # inputs of the steps in flight, each with the event recorded behind its decoder pass (which itself waits for its encoder
         # pass): their memory -- allocated on the PRODUCER's stream -- must not go back to the allocator, and from there into the next
         # upload, while a kernel that reads them is still queued.  Lifetime follows the GPU, not a host step count: an entry is
@@ -45,14 +46,14 @@ class CaptionTrainPipeline(object):
 
     def _encode(self, slot, images, boxes):
         with torch.cuda.stream(self.s_enc):
-            if self.n >= 2 and os.environ.get("DCAP_PIPE_LATE_WAIT", "1") == "0":
+            if self.n >= 2 and not self.late_wait:
                 self.s_enc.wait_event(self.ev_free[slot])
             self.plan.forward(images)
             # Only the RoIAlign launch writes the slot the decoder pass of two batches ago read: the ~100 convolution launches in front of it
             # wait for nothing but the previous encoder pass.  (Rounds 2 - 6 waited HERE, in front of the whole pass: the encoder stream then
             # stood still from the end of each pass until the decoder step running beside it -- starved of CUs by the pass's persistent grids --
             # had finished: 0.69 ms of every 5.87 ms step in profiles/r06_headline_timeline.tsv.)
-            if self.n >= 2 and os.environ.get("DCAP_PIPE_LATE_WAIT", "1") != "0":
+            if self.n >= 2 and self.late_wait:
                 self.s_enc.wait_event(self.ev_free[slot])
             self.plan.roi_features(boxes_norm=boxes, out=self.feat[slot])
             self.ev_feat[slot].record(self.s_enc)
